@@ -1,0 +1,133 @@
+"""``_C`` of the drop-in ``diff_gaussian_rasterization`` package: the three functions the upstream pybind
+module exports (rasterize_points.h / ext.cpp), same positional signatures, same return
+tuples, same error strings -- implemented over the C ABI of libgsr_hip.so (include/gsr.h).
+
+Caller: ``_RasterizeGaussians`` in :mod:`gsworld_amd.rasterizer`, which GSWorld reaches through
+``gaussian_renderer.render`` (/root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:266-267).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (GsrBuffers, GsrFrameStats, GsrInputs, GsrOutputs, GsrSettings, RESIZE_FN, check, lib)
+
+# GSWorld's edit of cuda_rasterizer/auxiliary.h (/root/reference/README.md:33).  Module-level so that a stock
+# 3DGS caller can restore 0.2 without touching the ABI.
+NEAR_PLANE = _lib.GSR_NEAR_PLANE
+
+
+def _ptr(t: torch.Tensor | None):
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, device, what: str) -> torch.Tensor:
+    if t.numel() == 0:
+        return t
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what} must be float32")
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def _resizer(t: torch.Tensor):
+    def fn(_user, nbytes):
+        t.resize_(int(nbytes))
+        return t.data_ptr()
+
+    return RESIZE_FN(fn)
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: the MI355X rasterizer has no CPU path (tensors must live on a HIP device)")
+
+
+def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
+                viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
+                imgBuffer, r_capacity: int = 0, want_stats: bool = True):
+    """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here)."""
+    dev = means3D.device
+    inp = GsrInputs(
+        P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
+        colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),
+        cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix), projmatrix=_ptr(projmatrix),
+        campos=_ptr(campos))
+    out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii))
+    cbs = (_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer))
+    buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
+    stats = GsrFrameStats()
+    with torch.cuda.device(dev):
+        check(lib().gsr_forward(C.byref(settings), C.byref(inp), C.byref(out), C.byref(buf), C.c_int64(r_capacity),
+                                C.byref(stats) if want_stats else None, _stream(dev)))
+    return stats
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, antialiasing, debug):
+    """-> (num_rendered, out_color (3,H,W), radii (P,), geomBuffer, binningBuffer, imgBuffer, out_invdepth (1,H,W))."""
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(image_height), int(image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out_color = torch.zeros((3, H, W), **f32)
+    out_invdepth = torch.zeros((1, H, W), **f32)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geomBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    binningBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    imgBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    rendered = 0
+    if P != 0:
+        M = sh.size(1) if sh.numel() != 0 else 0
+        st = GsrSettings(H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M),
+                         int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug)), float(NEAR_PLANE))
+        stats = forward_raw(
+            st, _f32(background, dev, "background"), _f32(means3D, dev, "means3D"), _f32(colors, dev, "colors"),
+            _f32(opacity, dev, "opacity"), _f32(scales, dev, "scales"), _f32(rotations, dev, "rotations"),
+            _f32(cov3D_precomp, dev, "cov3D_precomp"), _f32(viewmatrix, dev, "viewmatrix"),
+            _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"), _f32(campos, dev, "campos"),
+            out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer, r_capacity=0)
+        rendered = int(stats.num_rendered)
+    return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_invdepth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                 antialiasing, debug):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    from . import _backward
+
+    return _backward.rasterize_gaussians_backward(
+        background, means3D, radii, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
+        binningBuffer, imageBuffer, antialiasing, debug, NEAR_PLANE)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool (P,): Gaussians in front of the near plane (upstream markVisible; projmatrix is unused there too)."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m3 = _f32(means3D, dev, "means3D")
+        vm = _f32(viewmatrix, dev, "viewmatrix")
+        with torch.cuda.device(dev):
+            check(lib().gsr_mark_visible(P, _ptr(m3), _ptr(vm), C.c_float(NEAR_PLANE), C.c_void_p(present.data_ptr()),
+                                         _stream(dev)))
+    return present

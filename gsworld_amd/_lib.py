@@ -1,0 +1,135 @@
+"""ctypes binding of libgsr_hip.so -- the C ABI declared in include/gsr.h.
+
+The library is built in-tree (``gsworld_amd/libgsr_hip.so``) by ``gsworld_amd.build`` / ``__graft_entry__.build()``.
+There is NO fallback: if the shared object is missing or a symbol cannot be resolved, importing the binding
+raises, and every operator that needs it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+GSR_OK = 0
+GSR_E_INVALID = -1
+GSR_E_HIP = -2
+GSR_E_ALLOC = -3
+GSR_E_OVERFLOW = -4
+GSR_NEAR_PLANE = 0.05  # /root/reference/README.md:33
+
+
+class GsrSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("prefiltered", C.c_int32), ("antialiasing", C.c_int32), ("debug", C.c_int32),
+        ("near_plane", C.c_float),
+    ]
+
+
+class GsrInputs(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+        ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+        ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+        ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class GsrOutputs(C.Structure):
+    _fields_ = [("out_color", C.c_void_p), ("out_invdepth", C.c_void_p), ("radii", C.c_void_p)]
+
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class GsrBuffers(C.Structure):
+    _fields_ = [
+        ("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p),
+        ("binning_resize", RESIZE_FN), ("binning_user", C.c_void_p),
+        ("image_resize", RESIZE_FN), ("image_user", C.c_void_p),
+    ]
+
+
+class GsrFrameStats(C.Structure):
+    _fields_ = [("num_visible", C.c_int64), ("num_rendered", C.c_int64), ("overflow", C.c_int32)]
+
+
+class GsrStateView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "splat", "cov3D", "clamped", "tiles_touched", "rects", "depth_order", "point_list", "point_tiles",
+        "ranges", "final_T", "n_contrib")]
+
+
+class GsrProfile(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("stage_ms", C.c_double * 5)]
+
+
+PROFILE_STAGES = ("preprocess", "compact+depth_sort", "tile_offsets", "emit+tile_sort+ranges", "render")
+
+
+class GsrError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libgsr_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgsr_hip.so (once).  Raises ``RuntimeError`` if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gsworld_amd/csrc`). "
+            "There is no CPU fallback for the rasterizer.")
+    L = C.CDLL(LIB_PATH)
+    L.gsr_last_error.restype = C.c_char_p
+    L.gsr_version.restype = C.c_char_p
+    L.gsr_geom_bytes.restype = C.c_size_t
+    L.gsr_geom_bytes.argtypes = [C.c_int32]
+    L.gsr_binning_bytes.restype = C.c_size_t
+    L.gsr_binning_bytes.argtypes = [C.c_int64]
+    L.gsr_image_bytes.restype = C.c_size_t
+    L.gsr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.gsr_forward.restype = C.c_int
+    L.gsr_forward.argtypes = [C.POINTER(GsrSettings), C.POINTER(GsrInputs), C.POINTER(GsrOutputs),
+                              C.POINTER(GsrBuffers), C.c_int64, C.POINTER(GsrFrameStats), C.c_void_p]
+    L.gsr_frame_stats.restype = C.c_int
+    L.gsr_frame_stats.argtypes = [C.c_void_p, C.POINTER(GsrFrameStats), C.c_void_p]
+    L.gsr_state_view.restype = C.c_int
+    L.gsr_state_view.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(GsrStateView)]
+    L.gsr_mark_visible.restype = C.c_int
+    L.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    L.gsr_pack_rgb8.restype = C.c_int
+    L.gsr_pack_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.gsr_profile_enable.restype = C.c_int
+    L.gsr_profile_enable.argtypes = [C.c_int]
+    L.gsr_profile_collect.restype = C.c_int
+    L.gsr_profile_collect.argtypes = [C.POINTER(GsrProfile)]
+    _lib = L
+    return L
+
+
+def check(code: int) -> None:
+    if code != GSR_OK:
+        raise GsrError(code, lib().gsr_last_error().decode("utf-8", "replace"))
+
+
+def exported_symbols() -> list[str]:
+    """Names declared in include/gsr.h (parsed from the header) -- used by the CPU test-suite."""
+    import re
+
+    header = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)) - {"gsr_resize_fn"})

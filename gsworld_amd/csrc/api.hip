@@ -1,0 +1,280 @@
+// api.hip -- C-ABI entry points of libgsr_hip.so (include/gsr.h) and the forward-pass orchestration
+// (upstream rasterize_points.cu RasterizeGaussiansCUDA + rasterizer_impl.cu Rasterizer::forward).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "gsr_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+// ---- optional stage timing with HIP events on the caller's stream (bench / profiling only) ----------------
+constexpr int kStages = GSR_PROFILE_STAGES;
+constexpr int kMaxFrames = 4096;
+struct Profiler {
+    int mode = 0;  // 0 off, 1 render kernel only, 2 every stage
+    int frames = 0;
+    std::vector<hipEvent_t> ev;  // (kStages + 1) events per frame
+    hipEvent_t &at(int frame, int k) { return ev[(size_t)frame * (kStages + 1) + k]; }
+};
+Profiler g_prof;
+
+inline void prof_mark(int k, hipStream_t stream) {
+    if (g_prof.mode == 0 || g_prof.frames >= kMaxFrames) return;
+    if (g_prof.mode == 1 && k < kStages - 1) return;
+    (void)hipEventRecord(g_prof.at(g_prof.frames, k), stream);
+}
+inline void prof_end_frame() {
+    if (g_prof.mode != 0 && g_prof.frames < kMaxFrames) g_prof.frames++;
+}
+}  // namespace
+
+void gsr_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int gsr_check_launch(const char *what, bool debug, hipStream_t stream) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        gsr_set_error("%s: %s", what, hipGetErrorString(e));
+        return GSR_E_HIP;
+    }
+    return GSR_OK;
+}
+
+extern "C" {
+
+const char *gsr_last_error(void) { return g_err; }
+const char *gsr_version(void) { return "gsworld_amd-gsr 0.1 (gfx950)"; }
+
+size_t gsr_geom_bytes(int32_t P) { return GeomState::required(P); }
+size_t gsr_binning_bytes(int64_t r_capacity) { return BinningState::required(r_capacity); }
+size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageState::required(width, height); }
+
+static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out, const GsrBuffers *buf) {
+    if (!st || !in || !out || !buf) {
+        gsr_set_error("gsr_forward: null argument struct");
+        return GSR_E_INVALID;
+    }
+    if (st->image_width <= 0 || st->image_height <= 0) {
+        gsr_set_error("gsr_forward: image size must be positive");
+        return GSR_E_INVALID;
+    }
+    if (gsr_div_up(st->image_width, GSR_TILE) > 65535 || gsr_div_up(st->image_height, GSR_TILE) > 65535) {
+        gsr_set_error("gsr_forward: image too large for 16-bit tile rects");
+        return GSR_E_INVALID;
+    }
+    if (in->P < 0) {
+        gsr_set_error("gsr_forward: negative P");
+        return GSR_E_INVALID;
+    }
+    if (!out->out_color || !out->out_invdepth || !in->background) {
+        gsr_set_error("gsr_forward: out_color, out_invdepth and background are required");
+        return GSR_E_INVALID;
+    }
+    if (in->P > 0) {
+        if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->campos || !out->radii) {
+            gsr_set_error("gsr_forward: means3D, opacities, viewmatrix, projmatrix, campos and radii are required");
+            return GSR_E_INVALID;
+        }
+        if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
+            gsr_set_error("Please provide excatly one of either SHs or precomputed colors!");
+            return GSR_E_INVALID;
+        }
+        const bool have_sr = in->scales != nullptr && in->rotations != nullptr;
+        if (have_sr == (in->cov3D_precomp != nullptr) || (in->scales != nullptr) != (in->rotations != nullptr)) {
+            gsr_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+            return GSR_E_INVALID;
+        }
+        if (in->shs) {
+            if (st->sh_degree < 0 || st->sh_degree > 3 || st->sh_coeffs < (st->sh_degree + 1) * (st->sh_degree + 1)) {
+                gsr_set_error("gsr_forward: sh_degree must be 0..3 and sh_coeffs >= (degree+1)^2");
+                return GSR_E_INVALID;
+            }
+        }
+    }
+    if (!buf->geom_resize || !buf->binning_resize || !buf->image_resize) {
+        gsr_set_error("gsr_forward: resize callbacks are required");
+        return GSR_E_INVALID;
+    }
+    return GSR_OK;
+}
+
+int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out, const GsrBuffers *buf,
+                int64_t r_capacity, GsrFrameStats *stats, void *stream_) {
+    if (int e = validate(st, in, out, buf)) return e;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool debug = st->debug != 0;
+    const int W = st->image_width, H = st->image_height;
+    if (stats) memset(stats, 0, sizeof(*stats));
+
+    if (in->P == 0) {
+        // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
+        const size_t n = (size_t)W * H;
+        if (hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess ||
+            hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess) {
+            gsr_set_error("gsr_forward: hipMemsetAsync(outputs) failed");
+            return GSR_E_HIP;
+        }
+        return GSR_OK;
+    }
+    if (r_capacity > 0xFFFFFFFFll) {
+        gsr_set_error("gsr_forward: r_capacity exceeds 32-bit instance offsets");
+        return GSR_E_INVALID;
+    }
+
+    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P));
+    char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
+    if (!geom_mem || !img_mem) {
+        gsr_set_error("gsr_forward: resize callback returned NULL");
+        return GSR_E_ALLOC;
+    }
+    const GeomState g = GeomState::carve(geom_mem, in->P);
+    const ImageState img = ImageState::carve(img_mem, W, H);
+
+    if (hipMemsetAsync(g.hdr, 0, sizeof(GsrHeader), stream) != hipSuccess) {
+        gsr_set_error("hipMemsetAsync(header) failed");
+        return GSR_E_HIP;
+    }
+    prof_mark(0, stream);
+    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, stream)) return e;
+    if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
+    prof_mark(1, stream);
+    if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+    prof_mark(2, stream);
+
+    const bool exact = r_capacity <= 0;
+    // exact mode first scans with an unlimited capacity, reads R back, then sizes the binning state exactly
+    if (int e = gsr_launch_tile_offsets(in->P, g, exact ? 0xFFFFFFFFu : (uint32_t)r_capacity, debug, stream)) return e;
+    prof_mark(3, stream);
+    int64_t cap = r_capacity;
+    if (exact) {
+        GsrHeader h;
+        if (hipMemcpyAsync(&h, g.hdr, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            gsr_set_error("gsr_forward: header read-back failed: %s", hipGetErrorString(hipGetLastError()));
+            return GSR_E_HIP;
+        }
+        cap = h.R_raw;
+        if (stats) {
+            stats->num_visible = h.V;
+            stats->num_rendered = h.R_raw;
+            stats->overflow = 0;
+        }
+    }
+    char *bin_mem = buf->binning_resize(buf->binning_user, BinningState::required(cap));
+    if (!bin_mem) {
+        gsr_set_error("gsr_forward: binning resize callback returned NULL");
+        return GSR_E_ALLOC;
+    }
+    const BinningState b = BinningState::carve(bin_mem, cap);
+    if (int e = gsr_launch_emit_and_tile_sort(*st, in->P, g, b, img, cap, debug, stream)) return e;
+    const int side = BinningState::tile_passes(gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE)) & 1;
+    prof_mark(4, stream);
+    if (int e = gsr_launch_render(*st, g, b.gidx[side], img, in->background, out->out_color, out->out_invdepth, stream))
+        return e;
+    prof_mark(5, stream);
+    prof_end_frame();
+    return gsr_check_launch("render", debug, stream);
+}
+
+int gsr_profile_enable(int mode) {
+    if (mode < 0 || mode > 2) {
+        gsr_set_error("gsr_profile_enable: mode must be 0, 1 or 2");
+        return GSR_E_INVALID;
+    }
+    if (mode != 0 && g_prof.ev.empty()) {
+        g_prof.ev.resize((size_t)kMaxFrames * (kStages + 1));
+        for (auto &e : g_prof.ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                gsr_set_error("gsr_profile_enable: hipEventCreate failed");
+                return GSR_E_HIP;
+            }
+    }
+    g_prof.mode = mode;
+    g_prof.frames = 0;
+    return GSR_OK;
+}
+
+int gsr_profile_collect(GsrProfile *out) {
+    if (!out) {
+        gsr_set_error("gsr_profile_collect: null output");
+        return GSR_E_INVALID;
+    }
+    memset(out, 0, sizeof(*out));
+    out->frames = g_prof.frames;
+    for (int f = 0; f < g_prof.frames; f++) {
+        for (int k = (g_prof.mode == 1 ? kStages - 1 : 0); k < kStages; k++) {
+            if (hipEventSynchronize(g_prof.at(f, k + 1)) != hipSuccess) {
+                gsr_set_error("gsr_profile_collect: hipEventSynchronize failed");
+                return GSR_E_HIP;
+            }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_prof.at(f, k), g_prof.at(f, k + 1)) != hipSuccess) {
+                gsr_set_error("gsr_profile_collect: hipEventElapsedTime failed");
+                return GSR_E_HIP;
+            }
+            out->stage_ms[k] += (double)ms;
+        }
+    }
+    g_prof.frames = 0;
+    return GSR_OK;
+}
+
+int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream_) {
+    if (!geom || !stats) {
+        gsr_set_error("gsr_frame_stats: null argument");
+        return GSR_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    GsrHeader h;
+    if (hipMemcpyAsync(&h, geom, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        gsr_set_error("gsr_frame_stats: read-back failed: %s", hipGetErrorString(hipGetLastError()));
+        return GSR_E_HIP;
+    }
+    stats->num_visible = h.V;
+    stats->num_rendered = h.R_raw;
+    stats->overflow = (int32_t)h.overflow;
+    return h.overflow ? GSR_E_OVERFLOW : GSR_OK;
+}
+
+int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity, const void *geom, const void *binning,
+                   const void *image, GsrStateView *v) {
+    if (!v) {
+        gsr_set_error("gsr_state_view: null view");
+        return GSR_E_INVALID;
+    }
+    memset(v, 0, sizeof(*v));
+    if (geom) {
+        const GeomState g = GeomState::carve((char *)geom, P);
+        v->splat = reinterpret_cast<const float *>(g.splat);
+        v->cov3D = g.cov3D;
+        v->clamped = reinterpret_cast<const uint8_t *>(g.clamped);
+        v->tiles_touched = g.tiles_touched;
+        v->rects = reinterpret_cast<const uint16_t *>(g.rects);
+        v->depth_order = g.idx[0];
+    }
+    if (binning) {
+        const BinningState b = BinningState::carve((char *)binning, r_capacity);
+        const int side = BinningState::tile_passes(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) & 1;
+        v->point_list = b.gidx[side];
+        v->point_tiles = b.tile[side];
+    }
+    if (image) {
+        const ImageState s = ImageState::carve((char *)image, width, height);
+        v->ranges = reinterpret_cast<const uint32_t *>(s.ranges);
+        v->final_T = s.final_T;
+        v->n_contrib = s.n_contrib;
+    }
+    return GSR_OK;
+}
+
+}  // extern "C"

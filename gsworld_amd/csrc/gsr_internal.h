@@ -1,0 +1,191 @@
+// gsr_internal.h -- state layout and wave64 helpers shared by the HIP translation units of libgsr_hip.so.
+// gfx950 (MI355X) only: 64-wide wavefronts are assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/gsr.h"
+
+#define GSR_WAVE 64
+#define GSR_BLOCK 256                 // threads per workgroup for every streaming kernel (4 waves)
+#define GSR_SORT_ITEMS 8              // keys per thread per radix block
+#define GSR_SORT_CHUNK (GSR_BLOCK * GSR_SORT_ITEMS)
+#define GSR_RADIX_BITS 8
+#define GSR_RADIX_BINS 256
+
+// Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
+// depends on a value the host would have to read back.
+struct GsrHeader {
+    uint32_t V;           // visible Gaussians (radii > 0)
+    uint32_t R;           // rendered instances actually binned (0 when overflowed)
+    uint32_t overflow;    // R_raw > r_capacity
+    uint32_t r_capacity;
+    uint32_t R_raw;       // sum of tiles touched, even when it overflowed
+    uint32_t pad[59];
+};
+static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
+
+static inline size_t gsr_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int gsr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- geometry state (per Gaussian) -------------------------------------------------------------------
+struct GeomState {
+    GsrHeader *hdr;
+    float4 *splat;            // [3P]  rec0 = (px, py, depth, 1/depth) rec1 = (conic.x, conic.y, conic.z, opacity)
+                              //       rec2 = (r, g, b, radius as float)
+    float *cov3D;             // [6P]
+    uint32_t *clamped;        // [P]   byte c = SH clamp flag of channel c
+    uint32_t *tiles_touched;  // [P]
+    uint2 *rects;             // [P]   x = min.x | min.y<<16, y = max.x | max.y<<16
+    uint32_t *block_counts;   // [ceil(P/256)+1]  visible per preprocess block -> exclusive offsets
+    uint32_t *key[2];         // [P]   depth-sort ping-pong keys (float bits of depth)
+    uint32_t *idx[2];         // [P]   depth-sort ping-pong values (Gaussian index)
+    uint32_t *sort_table;     // [256 * nb]  per-block digit histograms (digit-major)
+    uint32_t *sort_totals;    // [256]
+    uint32_t *tile_bsum;      // [nb+1] tiles touched per 2048 depth-ordered Gaussians -> exclusive offsets
+
+    static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
+    static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
+
+    template <typename T>
+    static T *take(char *&p, size_t count) {
+        T *r = reinterpret_cast<T *>(p);
+        p += gsr_align_up(count * sizeof(T));
+        return r;
+    }
+    static GeomState carve(char *base, int32_t P, size_t *bytes = nullptr) {
+        GeomState g;
+        char *p = base;
+        const size_t n = (size_t)(P > 0 ? P : 1);
+        g.hdr = take<GsrHeader>(p, 1);
+        g.splat = take<float4>(p, 3 * n);
+        g.cov3D = take<float>(p, 6 * n);
+        g.clamped = take<uint32_t>(p, n);
+        g.tiles_touched = take<uint32_t>(p, n);
+        g.rects = take<uint2>(p, n);
+        g.block_counts = take<uint32_t>(p, (size_t)prep_blocks(P) + 1);
+        g.key[0] = take<uint32_t>(p, n);
+        g.key[1] = take<uint32_t>(p, n);
+        g.idx[0] = take<uint32_t>(p, n);
+        g.idx[1] = take<uint32_t>(p, n);
+        g.sort_table = take<uint32_t>(p, (size_t)GSR_RADIX_BINS * sort_blocks(P));
+        g.sort_totals = take<uint32_t>(p, GSR_RADIX_BINS);
+        g.tile_bsum = take<uint32_t>(p, (size_t)sort_blocks(P) + 1);
+        if (bytes) *bytes = (size_t)(p - base);
+        return g;
+    }
+    static size_t required(int32_t P) {
+        size_t bytes = 0;
+        carve(nullptr, P, &bytes);
+        return bytes;
+    }
+};
+
+// ---- binning state (per rendered instance) -------------------------------------------------------------
+struct BinningState {
+    uint32_t *tile[2];     // [Rcap] tile id per instance, ping-pong
+    uint32_t *gidx[2];     // [Rcap] Gaussian index per instance, ping-pong
+    uint32_t *sort_table;  // [256 * nb]
+    uint32_t *sort_totals; // [256]
+
+    static int sort_blocks(int64_t rcap) { return gsr_div_up(rcap > 0 ? rcap : 1, GSR_SORT_CHUNK); }
+    static BinningState carve(char *base, int64_t rcap, size_t *bytes = nullptr) {
+        BinningState b;
+        char *p = base;
+        const size_t n = (size_t)(rcap > 0 ? rcap : 1);
+        b.tile[0] = GeomState::take<uint32_t>(p, n);
+        b.tile[1] = GeomState::take<uint32_t>(p, n);
+        b.gidx[0] = GeomState::take<uint32_t>(p, n);
+        b.gidx[1] = GeomState::take<uint32_t>(p, n);
+        b.sort_table = GeomState::take<uint32_t>(p, (size_t)GSR_RADIX_BINS * sort_blocks(rcap));
+        b.sort_totals = GeomState::take<uint32_t>(p, GSR_RADIX_BINS);
+        if (bytes) *bytes = (size_t)(p - base);
+        return b;
+    }
+    static size_t required(int64_t rcap) {
+        size_t bytes = 0;
+        carve(nullptr, rcap, &bytes);
+        return bytes;
+    }
+    // number of tile-sort passes and therefore which ping-pong side holds the sorted result
+    static int tile_bits(int num_tiles) {
+        int bits = 1;
+        while ((1 << bits) < num_tiles) bits++;
+        return bits;
+    }
+    static int tile_passes(int num_tiles) { return (tile_bits(num_tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS; }
+};
+
+// ---- image state (per pixel / per tile) ----------------------------------------------------------------
+struct ImageState {
+    uint2 *ranges;       // [tiles]
+    float *final_T;      // [W*H]
+    uint32_t *n_contrib; // [W*H]
+    static ImageState carve(char *base, int32_t W, int32_t H, size_t *bytes = nullptr) {
+        ImageState s;
+        char *p = base;
+        const size_t tiles = (size_t)gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE);
+        s.ranges = GeomState::take<uint2>(p, tiles);
+        s.final_T = GeomState::take<float>(p, (size_t)W * H);
+        s.n_contrib = GeomState::take<uint32_t>(p, (size_t)W * H);
+        if (bytes) *bytes = (size_t)(p - base);
+        return s;
+    }
+    static size_t required(int32_t W, int32_t H) {
+        size_t bytes = 0;
+        carve(nullptr, W, H, &bytes);
+        return bytes;
+    }
+};
+
+// ---- error plumbing ------------------------------------------------------------------------------------
+void gsr_set_error(const char *fmt, ...);
+int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
+
+// ---- launchers implemented in the kernel files -----------------------------------------------------------
+int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
+                          hipStream_t stream);
+int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
+int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                                  const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
+int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
+                      const ImageState &img, const float *background, float *out_color, float *out_invdepth,
+                      hipStream_t stream);
+int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr, int64_t n_max, int bits,
+                       uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream);
+
+#ifdef __HIPCC__
+// ---- wave64 / block primitives ---------------------------------------------------------------------------
+__device__ __forceinline__ int gsr_lane() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int gsr_wave() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ uint64_t gsr_lanemask_lt() { return (1ull << gsr_lane()) - 1ull; }
+
+__device__ __forceinline__ uint32_t gsr_wave_incl_scan(uint32_t v) {
+    const int lane = gsr_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Inclusive scan over the 256 threads of a block.  s_w must hold 4 uint32 in LDS.  Two barriers.
+__device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
+    const uint32_t incl = gsr_wave_incl_scan(v);
+    const int lane = gsr_lane(), wave = gsr_wave();
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    uint32_t add = 0;
+    if (wave > 0) add += w0;
+    if (wave > 1) add += w1;
+    if (wave > 2) add += w2;
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return incl + add;
+}
+#endif  // __HIPCC__

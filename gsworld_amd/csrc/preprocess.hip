@@ -1,0 +1,306 @@
+// preprocess.hip -- per-Gaussian projection stage (upstream forward.cu preprocessCUDA + auxiliary.h helpers;
+// SURVEY.md 8a rows A3/A4/A9).  One thread per Gaussian, 256-thread workgroups.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; every fused multiply-add below is an explicit
+// __builtin_fmaf, division and sqrtf are the correctly rounded forms (hipcc default), so the depth keys, radii
+// and tile rects are bit-identical to the canonical order fixed by oracle/gs_oracle.c.
+//
+// HBM traffic per Gaussian: 12 B xyz always; +28 B scale/quat, +4 B opacity once the near cull passed;
+// +192 B of SH and 88 B of state written only for Gaussians that survive to a non-empty tile rect.
+#include "gsr_internal.h"
+
+namespace {
+
+struct PreprocessArgs {
+    int P, D, M;
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy, scale_modifier, near_plane;
+    int antialiasing;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *view, *proj, *campos;
+    int32_t *radii;
+    float4 *splat;
+    float *cov3D;
+    uint32_t *clamped;
+    uint32_t *tiles_touched;
+    uint2 *rects;
+    uint32_t *block_counts;
+};
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+constexpr float kC0 = 0.28209479177387814f;
+constexpr float kC1 = 0.4886025119029199f;
+constexpr float kC2_0 = 1.0925484305920792f, kC2_1 = -1.0925484305920792f, kC2_2 = 0.31539156525252005f,
+                kC2_3 = -1.0925484305920792f, kC2_4 = 0.5462742152960396f;
+constexpr float kC3_0 = -0.5900435899266435f, kC3_1 = 2.890611442640554f, kC3_2 = -0.4570457994644658f,
+                kC3_3 = 0.3731763325901154f, kC3_4 = -0.4570457994644658f, kC3_5 = 1.445305721320277f,
+                kC3_6 = -0.5900435899266435f;
+
+// real SH basis of a unit direction (coefficient signs of forward.cu computeColorFromSH)
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float *b) {
+    b[0] = kC0;
+    if (deg > 0) {
+        b[1] = -(kC1 * y);
+        b[2] = kC1 * z;
+        b[3] = -(kC1 * x);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = kC2_0 * xy;
+            b[5] = kC2_1 * yz;
+            b[6] = kC2_2 * (fma_(2.f, zz, -xx) - yy);
+            b[7] = kC2_3 * xz;
+            b[8] = kC2_4 * (xx - yy);
+            if (deg > 2) {
+                b[9] = (kC3_0 * y) * fma_(3.f, xx, -yy);
+                b[10] = (kC3_1 * xy) * z;
+                b[11] = (kC3_2 * y) * (fma_(4.f, zz, -xx) - yy);
+                b[12] = (kC3_3 * z) * fma_(-3.f, yy, fma_(-3.f, xx, 2.f * zz));
+                b[13] = (kC3_4 * x) * (fma_(4.f, zz, -xx) - yy);
+                b[14] = (kC3_5 * z) * (xx - yy);
+                b[15] = (kC3_6 * x) * fma_(-3.f, yy, xx);
+            }
+        }
+    }
+}
+
+template <bool FAST_SH16>
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    bool visible = false;
+    if (i < a.P) {
+        const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1],
+                    pz = a.means3D[3 * (size_t)i + 2];
+        const float *m = a.view;
+        // transformPoint4x3: M[r][c] = m[c*4+r]
+        const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
+        const float vy = fma_(m[9], pz, fma_(m[5], py, m[1] * px)) + m[13];
+        const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
+        int radius = 0;
+        uint32_t touched = 0;
+        if (vz > a.near_plane) {  // in_frustum with GSWorld's near plane
+            const float *q = a.proj;
+            const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
+            const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
+            const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+            // ---- 3D covariance: Sigma = R diag((mod*s)^2) R^T ------------------------------------------------
+            float c0, c1, c2, c3, c4, c5;
+            if (a.cov3D_precomp) {
+                const float *c = a.cov3D_precomp + 6 * (size_t)i;
+                c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+            } else {
+                const float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+                const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
+                const float s0 = a.scale_modifier * a.scales[3 * (size_t)i];
+                const float s1 = a.scale_modifier * a.scales[3 * (size_t)i + 1];
+                const float s2 = a.scale_modifier * a.scales[3 * (size_t)i + 2];
+                const float R00 = fma_(-2.f, fma_(z, z, y * y), 1.f);
+                const float R01 = 2.f * fma_(-r, z, x * y);
+                const float R02 = 2.f * fma_(r, y, x * z);
+                const float R10 = 2.f * fma_(r, z, x * y);
+                const float R11 = fma_(-2.f, fma_(z, z, x * x), 1.f);
+                const float R12 = 2.f * fma_(-r, x, y * z);
+                const float R20 = 2.f * fma_(-r, y, x * z);
+                const float R21 = 2.f * fma_(r, x, y * z);
+                const float R22 = fma_(-2.f, fma_(y, y, x * x), 1.f);
+                // M[k][j] = s_k * R[j][k]
+                const float M00 = s0 * R00, M01 = s0 * R10, M02 = s0 * R20;
+                const float M10 = s1 * R01, M11 = s1 * R11, M12 = s1 * R21;
+                const float M20 = s2 * R02, M21 = s2 * R12, M22 = s2 * R22;
+                c0 = fma_(M20, M20, fma_(M10, M10, M00 * M00));
+                c1 = fma_(M20, M21, fma_(M10, M11, M00 * M01));
+                c2 = fma_(M20, M22, fma_(M10, M12, M00 * M02));
+                c3 = fma_(M21, M21, fma_(M11, M11, M01 * M01));
+                c4 = fma_(M21, M22, fma_(M11, M12, M01 * M02));
+                c5 = fma_(M22, M22, fma_(M12, M12, M02 * M02));
+            }
+
+            // ---- EWA 2D covariance: (J W) Sigma (J W)^T ---------------------------------------------------------
+            const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+            const float txtz = vx / vz, tytz = vy / vz;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+            const float J00 = a.fx / vz, J02 = -(a.fx * tx) / (vz * vz);
+            const float J11 = a.fy / vz, J12 = -(a.fy * ty) / (vz * vz);
+            // A = J W with W[i][j] = m[j*4+i]
+            const float A00 = fma_(J02, m[2], J00 * m[0]);
+            const float A01 = fma_(J02, m[6], J00 * m[4]);
+            const float A02 = fma_(J02, m[10], J00 * m[8]);
+            const float A10 = fma_(J12, m[2], J11 * m[1]);
+            const float A11 = fma_(J12, m[6], J11 * m[5]);
+            const float A12 = fma_(J12, m[10], J11 * m[9]);
+            // B = A Sigma
+            const float B00 = fma_(A02, c2, fma_(A01, c1, A00 * c0));
+            const float B01 = fma_(A02, c4, fma_(A01, c3, A00 * c1));
+            const float B02 = fma_(A02, c5, fma_(A01, c4, A00 * c2));
+            const float B10 = fma_(A12, c2, fma_(A11, c1, A10 * c0));
+            const float B11 = fma_(A12, c4, fma_(A11, c3, A10 * c1));
+            const float B12 = fma_(A12, c5, fma_(A11, c4, A10 * c2));
+            float cxx = fma_(B02, A02, fma_(B01, A01, B00 * A00));
+            const float cxy = fma_(B02, A12, fma_(B01, A11, B00 * A10));
+            float cyy = fma_(B12, A12, fma_(B11, A11, B10 * A10));
+
+            const float det_cov = fma_(-cxy, cxy, cxx * cyy);
+            cxx += 0.3f;
+            cyy += 0.3f;
+            const float det = fma_(-cxy, cxy, cxx * cyy);
+            float h_scale = 1.0f;
+            if (a.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float conic_x = cyy * det_inv, conic_y = -cxy * det_inv, conic_z = cxx * det_inv;
+                const float mid = 0.5f * (cxx + cyy);
+                const float root = sqrtf(fmaxf(0.1f, fma_(mid, mid, -det)));
+                const float lambda1 = mid + root, lambda2 = mid - root;
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                // ndc2Pix is binary64 upstream (double literals)
+                const float pix_x = (float)((((double)ndc_x + 1.0) * (double)a.W - 1.0) * 0.5);
+                const float pix_y = (float)((((double)ndc_y + 1.0) * (double)a.H - 1.0) * 0.5);
+                const int ir = (int)my_radius;
+                const float fr = (float)ir;
+                int rminx = (int)((pix_x - fr) / (float)GSR_TILE);
+                int rminy = (int)((pix_y - fr) / (float)GSR_TILE);
+                int rmaxx = (int)((pix_x + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
+                int rmaxy = (int)((pix_y + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
+                rminx = min(a.gx, max(0, rminx));
+                rminy = min(a.gy, max(0, rminy));
+                rmaxx = min(a.gx, max(0, rmaxx));
+                rmaxy = min(a.gy, max(0, rmaxy));
+                const int area = (rmaxx - rminx) * (rmaxy - rminy);
+                if (area != 0) {
+                    // ---- colour ---------------------------------------------------------------------------
+                    float cr, cg, cb;
+                    uint32_t clamp_bits = 0;
+                    if (a.colors_precomp) {
+                        cr = a.colors_precomp[3 * (size_t)i];
+                        cg = a.colors_precomp[3 * (size_t)i + 1];
+                        cb = a.colors_precomp[3 * (size_t)i + 2];
+                    } else {
+                        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+                        const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+                        dx = dx / len; dy = dy / len; dz = dz / len;
+                        float b[16];
+                        sh_basis(a.D, dx, dy, dz, b);
+                        if (FAST_SH16) {
+                            // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
+                            const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)i * 48);
+                            float4 v[12];
+#pragma unroll
+                            for (int k = 0; k < 12; k++) v[k] = sh4[k];
+                            const float *f = reinterpret_cast<const float *>(v);
+                            cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
+#pragma unroll
+                            for (int k = 1; k < 16; k++) {
+                                cr = fma_(b[k], f[3 * k], cr);
+                                cg = fma_(b[k], f[3 * k + 1], cg);
+                                cb = fma_(b[k], f[3 * k + 2], cb);
+                            }
+                        } else {
+                            const float *sh = a.shs + (size_t)i * a.M * 3;
+                            const int nb = (a.D + 1) * (a.D + 1);
+                            cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
+                            for (int k = 1; k < nb; k++) {
+                                cr = fma_(b[k], sh[3 * k], cr);
+                                cg = fma_(b[k], sh[3 * k + 1], cg);
+                                cb = fma_(b[k], sh[3 * k + 2], cb);
+                            }
+                        }
+                        cr += 0.5f; cg += 0.5f; cb += 0.5f;
+                        clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
+                        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+                    }
+                    const float opacity = a.opacities[i] * h_scale;
+                    float4 *rec = a.splat + 3 * (size_t)i;
+                    rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
+                    rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
+                    rec[2] = make_float4(cr, cg, cb, fr);
+                    float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
+                    cv[0] = make_float2(c0, c1);
+                    cv[1] = make_float2(c2, c3);
+                    cv[2] = make_float2(c4, c5);
+                    a.clamped[i] = clamp_bits;
+                    a.rects[i] = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
+                                            (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+                    radius = ir;
+                    touched = (uint32_t)area;
+                    visible = true;
+                }
+            }
+        }
+        a.radii[i] = radius;
+        a.tiles_touched[i] = touched;
+    }
+    // visible Gaussians of this block, consumed by the index-ordered compaction
+    const int cnt = __syncthreads_count(visible ? 1 : 0);
+    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = (uint32_t)cnt;
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float *means3D, const float *m,
+                                                                 float near_plane, uint8_t *present) {
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+    const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
+    present[i] = vz > near_plane ? 1 : 0;
+}
+
+}  // namespace
+
+int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
+                          hipStream_t stream) {
+    PreprocessArgs a;
+    a.P = in.P;
+    a.D = st.sh_degree;
+    a.M = st.sh_coeffs;
+    a.W = st.image_width;
+    a.H = st.image_height;
+    a.gx = gsr_div_up(a.W, GSR_TILE);
+    a.gy = gsr_div_up(a.H, GSR_TILE);
+    a.tanfovx = st.tanfovx;
+    a.tanfovy = st.tanfovy;
+    a.fx = (float)a.W / (2.0f * st.tanfovx);
+    a.fy = (float)a.H / (2.0f * st.tanfovy);
+    a.scale_modifier = st.scale_modifier;
+    a.near_plane = st.near_plane;
+    a.antialiasing = st.antialiasing;
+    a.means3D = in.means3D;
+    a.shs = in.shs;
+    a.colors_precomp = in.colors_precomp;
+    a.opacities = in.opacities;
+    a.scales = in.scales;
+    a.rotations = in.rotations;
+    a.cov3D_precomp = in.cov3D_precomp;
+    a.view = in.viewmatrix;
+    a.proj = in.projmatrix;
+    a.campos = in.campos;
+    a.radii = radii;
+    a.splat = g.splat;
+    a.cov3D = g.cov3D;
+    a.clamped = g.clamped;
+    a.tiles_touched = g.tiles_touched;
+    a.rects = g.rects;
+    a.block_counts = g.block_counts;
+    const int blocks = GeomState::prep_blocks(in.P);
+    const bool fast = (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
+                      ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
+    if (fast)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+    return GSR_OK;
+}
+
+extern "C" int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, float near_plane,
+                                uint8_t *present, void *stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+        gsr_set_error("gsr_mark_visible: null pointer or negative P");
+        return GSR_E_INVALID;
+    }
+    if (P == 0) return GSR_OK;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(gsr_div_up(P, GSR_BLOCK)), dim3(GSR_BLOCK), 0,
+                       (hipStream_t)stream, P, means3D, viewmatrix, near_plane, present);
+    return gsr_check_launch("mark_visible", false, (hipStream_t)stream);
+}

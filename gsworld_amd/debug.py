@@ -1,0 +1,50 @@
+"""Typed views into the opaque state buffers of a forward pass (tools / tests; not on the hot path)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import GsrStateView, check, lib
+
+
+def _view(buf: torch.Tensor, ptr, count: int, dtype: torch.dtype) -> torch.Tensor:
+    off = int(ptr) - buf.data_ptr()
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    assert 0 <= off and off + nbytes <= buf.numel(), "state view outside its buffer"
+    return buf[off:off + nbytes].view(dtype)
+
+
+def state_view(P: int, width: int, height: int, num_rendered: int, num_visible: int, geomBuffer: torch.Tensor,
+               binningBuffer: torch.Tensor | None, imgBuffer: torch.Tensor | None, r_capacity: int | None = None):
+    """Returns a dict of tensors aliasing the state buffers (see GsrStateView in include/gsr.h).
+
+    ``r_capacity`` must be the capacity the forward pass used (``num_rendered`` in exact mode).
+    """
+    v = GsrStateView()
+    cap = num_rendered if r_capacity is None else r_capacity
+    check(lib().gsr_state_view(P, width, height, C.c_int64(cap), C.c_void_p(geomBuffer.data_ptr()),
+                               C.c_void_p(binningBuffer.data_ptr()) if binningBuffer is not None else None,
+                               C.c_void_p(imgBuffer.data_ptr()) if imgBuffer is not None else None, C.byref(v)))
+    gx, gy = (width + 15) // 16, (height + 15) // 16
+    out = {}
+    splat = _view(geomBuffer, v.splat, 12 * P, torch.float32).view(P, 12)
+    out["splat"] = splat
+    out["means2D"] = splat[:, 0:2]
+    out["depths"] = splat[:, 2]
+    out["invdepths"] = splat[:, 3]
+    out["conic_opacity"] = splat[:, 4:8]
+    out["rgb"] = splat[:, 8:11]
+    out["cov3D"] = _view(geomBuffer, v.cov3D, 6 * P, torch.float32).view(P, 6)
+    out["clamped"] = _view(geomBuffer, v.clamped, 4 * P, torch.uint8).view(P, 4)[:, :3]
+    out["tiles_touched"] = _view(geomBuffer, v.tiles_touched, P, torch.int32)
+    out["rects"] = _view(geomBuffer, v.rects, 4 * P, torch.int16).view(P, 4)
+    out["depth_order"] = _view(geomBuffer, v.depth_order, max(num_visible, 0), torch.int32)
+    if binningBuffer is not None and num_rendered > 0:
+        out["point_list"] = _view(binningBuffer, v.point_list, num_rendered, torch.int32)
+        out["point_tiles"] = _view(binningBuffer, v.point_tiles, num_rendered, torch.int32)
+    if imgBuffer is not None:
+        out["ranges"] = _view(imgBuffer, v.ranges, 2 * gx * gy, torch.int32).view(gx * gy, 2)
+        out["final_T"] = _view(imgBuffer, v.final_T, width * height, torch.float32).view(height, width)
+        out["n_contrib"] = _view(imgBuffer, v.n_contrib, width * height, torch.int32).view(height, width)
+    return out

@@ -1,0 +1,160 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native 3D-Gaussian-Splatting rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary under the Python packages GSWorld imports
+ * (/root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:11-13,22-26,266-267).  Each entry
+ * point names the upstream pybind function of the un-vendored CUDA extension it replaces:
+ *
+ *   gsr_forward            <->  diff_gaussian_rasterization._C.rasterize_gaussians
+ *   gsr_backward           <->  diff_gaussian_rasterization._C.rasterize_gaussians_backward
+ *   gsr_mark_visible       <->  diff_gaussian_rasterization._C.mark_visible
+ *   gsr_knn_dist2          <->  simple_knn._C.distCUDA2
+ *   gsr_ssim_forward       <->  fused_ssim_cuda.fusedssim
+ *   gsr_ssim_backward      <->  fused_ssim_cuda.fusedssim_backward
+ *   gsr_transform_gaussians<->  the per-step rigid transform of GSWorld itself
+ *                               (gs_world_wrapper.py:110-162,244-265 + gsworld/utils/gs_utils.py:283-385)
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every data pointer is DEVICE memory on the
+ * current HIP device unless marked [host]; all inputs are borrowed, contiguous, float32; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Functions return 0 on success or a negative
+ * GSR_E_* code; gsr_last_error() returns a human-readable message for the calling thread.
+ * Work buffers are caller-owned and grown through a resize callback -- the same contract as upstream's
+ * std::function<char*(size_t)> lambdas that resize_ a torch byte tensor and hand back its data_ptr.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_E_INVALID (-1)   /* bad argument (shape / null / unsupported value) */
+#define GSR_E_HIP (-2)       /* a HIP runtime call or kernel failed (debug mode checks every launch) */
+#define GSR_E_ALLOC (-3)     /* a resize callback returned NULL */
+#define GSR_E_OVERFLOW (-4)  /* num_rendered exceeded the binning capacity in no-sync mode */
+
+#define GSR_TILE 16          /* BLOCK_X = BLOCK_Y of cuda_rasterizer/config.h */
+#define GSR_NEAR_PLANE 0.05f /* /root/reference/README.md:33 (stock upstream 0.2f) */
+
+/* GaussianRasterizationSettings (the 13-field NamedTuple) minus the tensors, plus GSWorld's near plane. */
+typedef struct GsrSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;    /* active degree D, 0..3 */
+    int32_t sh_coeffs;    /* M = coefficients stored per Gaussian (shs is (P, M, 3)) */
+    int32_t prefiltered;
+    int32_t antialiasing;
+    int32_t debug;        /* sync + error check after every kernel */
+    float near_plane;     /* cull p_view.z <= near_plane; GSR_NEAR_PLANE for GSWorld */
+} GsrSettings;
+
+typedef struct GsrInputs {
+    int32_t P;                   /* number of Gaussians */
+    const float *background;     /* (3) */
+    const float *means3D;        /* (P,3) */
+    const float *shs;            /* (P,M,3) or NULL when colors_precomp is given */
+    const float *colors_precomp; /* (P,3) or NULL */
+    const float *opacities;      /* (P) */
+    const float *scales;         /* (P,3) or NULL when cov3D_precomp is given */
+    const float *rotations;      /* (P,4) (r,x,y,z), used un-normalised */
+    const float *cov3D_precomp;  /* (P,6) or NULL */
+    const float *viewmatrix;     /* (16) world->view, element [r][c] at m[c*4+r] */
+    const float *projmatrix;     /* (16) full projection, same layout */
+    const float *campos;         /* (3) */
+} GsrInputs;
+
+typedef struct GsrOutputs {
+    float *out_color;    /* (3,H,W) */
+    float *out_invdepth; /* (1,H,W) */
+    int32_t *radii;      /* (P) */
+} GsrOutputs;
+
+/* resize callback: must return a device pointer to at least `bytes` bytes (256-byte aligned), or NULL. */
+typedef char *(*gsr_resize_fn)(void *user, size_t bytes);
+
+typedef struct GsrBuffers {
+    gsr_resize_fn geom_resize;    void *geom_user;    /* geometry state   (per Gaussian) */
+    gsr_resize_fn binning_resize; void *binning_user; /* binning state    (per rendered instance) */
+    gsr_resize_fn image_resize;   void *image_user;   /* image state      (per pixel / per tile) */
+} GsrBuffers;
+
+/* Frame statistics, all produced by the pipeline itself (N, V, R). */
+typedef struct GsrFrameStats {
+    int64_t num_visible;  /* V: Gaussians with radii > 0 */
+    int64_t num_rendered; /* R: sum of tiles touched */
+    int32_t overflow;     /* 1 if R exceeded the binning capacity (no-sync mode only) */
+} GsrFrameStats;
+
+const char *gsr_last_error(void);
+const char *gsr_version(void);
+
+/* Bytes needed for each state buffer. */
+size_t gsr_geom_bytes(int32_t P);
+size_t gsr_binning_bytes(int64_t r_capacity);
+size_t gsr_image_bytes(int32_t width, int32_t height);
+
+/*
+ * Forward rasterization (upstream RasterizeGaussiansCUDA -> CudaRasterizer::Rasterizer::forward).
+ *
+ * r_capacity <= 0 : exact mode.  One host read-back of num_rendered in the middle of the frame (what
+ *                   upstream does), binning state sized exactly; `stats` (may be NULL) is filled.
+ * r_capacity  > 0 : no-sync mode.  Binning state sized for r_capacity instances, nothing is read back and the
+ *                   call returns as soon as the work is enqueued.  Call gsr_frame_stats() later to learn
+ *                   V, R and whether R overflowed the capacity (then the image is invalid: re-run bigger).
+ */
+int gsr_forward(const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
+                const GsrBuffers *buffers, int64_t r_capacity, GsrFrameStats *stats, void *stream);
+
+/* Reads V / R / overflow of the frame whose geometry state is `geom` (synchronises `stream`). */
+int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream);
+
+/* Views into the opaque state, for tests and tools (device pointers into the caller's buffers). */
+typedef struct GsrStateView {
+    const float *splat;           /* (P,12): xy, depth, 1/depth | conic xyz, opacity | rgb, radius */
+    const float *cov3D;           /* (P,6) */
+    const uint8_t *clamped;       /* (P,4) */
+    const uint32_t *tiles_touched;/* (P) */
+    const uint16_t *rects;        /* (P,4) min.x min.y max.x max.y */
+    const uint32_t *depth_order;  /* (V) Gaussian indices, ascending (depth bits, index) */
+    const uint32_t *point_list;   /* (R) Gaussian index per instance, tile-major / depth / index order */
+    const uint32_t *point_tiles;  /* (R) tile id per instance (sorted) */
+    const uint32_t *ranges;       /* (tiles,2) */
+    const float *final_T;         /* (H*W) */
+    const uint32_t *n_contrib;    /* (H*W) */
+} GsrStateView;
+int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity_or_R, const void *geom,
+                   const void *binning, const void *image, GsrStateView *view);
+
+/*
+ * Optional stage timing with HIP events recorded on the caller's stream (what bench.py's roofline uses).
+ * mode 0 = off, 1 = the compositing kernel only (2 events / frame), 2 = every stage (6 events / frame).
+ * Stages: 0 preprocess, 1 compaction + depth sort, 2 tile offsets (scan), 3 emit + tile sort + ranges, 4 render.
+ * Not thread-safe; at most 4096 frames are recorded between two collects.
+ */
+#define GSR_PROFILE_STAGES 5
+typedef struct GsrProfile {
+    int32_t frames;
+    double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
+} GsrProfile;
+int gsr_profile_enable(int mode);
+int gsr_profile_collect(GsrProfile *out);
+
+/* GSWorld's frame conversion (gs_world_wrapper.py:268-270): (3,H,W) float -> (H,W,3) uint8 with
+ * (x*255).clamp(0,255) and a truncating cast.  `out` must be 4-byte aligned. */
+int gsr_pack_rgb8(const float *color, int32_t width, int32_t height, uint8_t *out, void *stream);
+
+/* upstream markVisible / checkFrustum: present[i] = p_view.z > near_plane. */
+int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, float near_plane,
+                     uint8_t *present, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

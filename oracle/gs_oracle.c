@@ -1,0 +1,497 @@
+/*
+ * gs_oracle.c -- CPU restatement of the 3D-Gaussian-Splatting rasterizer GSWorld renders through.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product path (gsworld_amd/) never does.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in third-party CUDA code that is NOT under
+ * /root/reference (empty submodule, /root/reference/.gitmodules:1-3 ->
+ * graphdeco-inria/gaussian-splatting -> diff-gaussian-rasterization (branch dr_aa), simple-knn,
+ * fused-ssim; no commit pins recoverable; GSWorld's only edit is the near-plane constant,
+ * /root/reference/README.md:33 "from 0.2f to 0.05f in cuda_rasterizer/auxiliary.h").
+ * The reference has no tests or golden vectors for this path.  What follows
+ * restates the *published* algorithm of those packages, by upstream file name:
+ *   cuda_rasterizer/auxiliary.h   in_frustum, getRect, ndc2Pix, transformPoint4x3/4x4, SH constants
+ *   cuda_rasterizer/forward.cu    computeCov3D, computeCov2D, computeColorFromSH, preprocessCUDA, renderCUDA
+ *   cuda_rasterizer/rasterizer_impl.cu  getHigherMsb, duplicateWithKeys, identifyTileRanges, sort range
+ *   cuda_rasterizer/backward.cu   renderCUDA (bwd), computeCov2DCUDA, preprocessCUDA (bwd)
+ *   simple-knn/simple_knn.cu      distCUDA2  (exact 3-NN mean squared distance)
+ *   fused-ssim/ssim.cu            fusedssim / fusedssim_backward
+ * and is anchored on the reference's call sites:
+ *   /root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:232-275 (render call, bg=0,
+ *   uint8 conversion) and :277-325 (camera construction).
+ *
+ * Canonical floating-point order.  Where bit-exactness matters (depth keys, radii, tile rects) the
+ * result depends on FMA contraction choices nvcc made, which cannot be known here.  This file therefore
+ * DEFINES the canonical order: every fused multiply-add is an explicit fmaf(), everything else is a
+ * single IEEE-754 binary32 operation, and the file must be compiled with -ffp-contract=off.  The HIP
+ * kernels follow the same order and are tested bit-for-bit against this file.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define GSO_BLOCK_X 16
+#define GSO_BLOCK_Y 16
+#define GSO_NEAR_DEFAULT 0.05f /* /root/reference/README.md:33 (stock upstream: 0.2f) */
+
+typedef struct {
+    int32_t image_height, image_width;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* active degree D (0..3) */
+    int32_t sh_coeffs;   /* M: coefficients stored per Gaussian (16 for GSWorld) */
+    int32_t prefiltered;
+    int32_t antialiasing;
+    float near_plane;    /* 0.05f for GSWorld */
+} GsoSettings;
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+void gso_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int gso_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* rasterizer_impl.cu getHigherMsb: smallest msb with (n >> msb) == 0, found by bisection from 16. */
+uint32_t gso_higher_msb(uint32_t n) {
+    uint32_t msb = 32u / 2u, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* auxiliary.h transformPoint4x3 / 4x4; matrices are stored so that M[r][c] = m[c*4+r]. */
+static inline void xform4x3(const float *m, float px, float py, float pz, float *o) {
+    o[0] = fmaf(m[8], pz, fmaf(m[4], py, m[0] * px)) + m[12];
+    o[1] = fmaf(m[9], pz, fmaf(m[5], py, m[1] * px)) + m[13];
+    o[2] = fmaf(m[10], pz, fmaf(m[6], py, m[2] * px)) + m[14];
+}
+static inline void xform4x4(const float *m, float px, float py, float pz, float *o) {
+    xform4x3(m, px, py, pz, o);
+    o[3] = fmaf(m[11], pz, fmaf(m[7], py, m[3] * px)) + m[15];
+}
+
+/* auxiliary.h ndc2Pix: the upstream expression mixes double literals with a float argument, so the
+ * arithmetic is binary64 and only the result is rounded to float. */
+static inline float ndc2pix(float v, int S) {
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+/* forward.cu computeCov3D: Sigma = R diag((mod*s)^2) R^T, quaternion (r,x,y,z) used as given. */
+static void cov3d_from_scale_rot(const float *scale, float mod, const float *q, float *cov6) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    float R[3][3];
+    R[0][0] = fmaf(-2.f, fmaf(z, z, y * y), 1.f);
+    R[0][1] = 2.f * fmaf(-r, z, x * y);
+    R[0][2] = 2.f * fmaf(r, y, x * z);
+    R[1][0] = 2.f * fmaf(r, z, x * y);
+    R[1][1] = fmaf(-2.f, fmaf(z, z, x * x), 1.f);
+    R[1][2] = 2.f * fmaf(-r, x, y * z);
+    R[2][0] = 2.f * fmaf(-r, y, x * z);
+    R[2][1] = 2.f * fmaf(r, x, y * z);
+    R[2][2] = fmaf(-2.f, fmaf(y, y, x * x), 1.f);
+    float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    float M[3][3]; /* M[k][j] = s_k * R[j][k]  (S * R^T) */
+    for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 3; j++) M[k][j] = s[k] * R[j][k];
+#define SIG(i, j) fmaf(M[2][i], M[2][j], fmaf(M[1][i], M[1][j], M[0][i] * M[0][j]))
+    cov6[0] = SIG(0, 0); cov6[1] = SIG(0, 1); cov6[2] = SIG(0, 2);
+    cov6[3] = SIG(1, 1); cov6[4] = SIG(1, 2); cov6[5] = SIG(2, 2);
+#undef SIG
+}
+
+/* forward.cu computeCov2D (EWA splatting): cov = (J W) Sigma (J W)^T, returns xx, xy, yy. */
+static void cov2d_ewa(const float *t_in, float fx, float fy, float tanfovx, float tanfovy,
+                      const float *c6, const float *view, float *out3) {
+    float tx = t_in[0], ty = t_in[1];
+    const float tz = t_in[2];
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+    const float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+    float A[2][3];
+    for (int j = 0; j < 3; j++) {
+        /* W[i][j] = view[j*4+i] */
+        A[0][j] = fmaf(J02, view[j * 4 + 2], J00 * view[j * 4 + 0]);
+        A[1][j] = fmaf(J12, view[j * 4 + 2], J11 * view[j * 4 + 1]);
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float B[2][3];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++)
+            B[i][j] = fmaf(A[i][2], S[2][j], fmaf(A[i][1], S[1][j], A[i][0] * S[0][j]));
+    out3[0] = fmaf(B[0][2], A[0][2], fmaf(B[0][1], A[0][1], B[0][0] * A[0][0]));
+    out3[1] = fmaf(B[0][2], A[1][2], fmaf(B[0][1], A[1][1], B[0][0] * A[1][0]));
+    out3[2] = fmaf(B[1][2], A[1][2], fmaf(B[1][1], A[1][1], B[1][0] * A[1][0]));
+}
+
+/* SH basis for a unit direction: b[0..(deg+1)^2).  forward.cu computeColorFromSH coefficient signs. */
+static void sh_basis(int deg, float x, float y, float z, float *b) {
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -(SH_C1 * y);
+        b[2] = SH_C1 * z;
+        b[3] = -(SH_C1 * x);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy;
+            b[5] = SH_C2[1] * yz;
+            b[6] = SH_C2[2] * (fmaf(2.f, zz, -xx) - yy);
+            b[7] = SH_C2[3] * xz;
+            b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = (SH_C3[0] * y) * fmaf(3.f, xx, -yy);
+                b[10] = (SH_C3[1] * xy) * z;
+                b[11] = (SH_C3[2] * y) * (fmaf(4.f, zz, -xx) - yy);
+                b[12] = (SH_C3[3] * z) * fmaf(-3.f, yy, fmaf(-3.f, xx, 2.f * zz));
+                b[13] = (SH_C3[4] * x) * (fmaf(4.f, zz, -xx) - yy);
+                b[14] = (SH_C3[5] * z) * (xx - yy);
+                b[15] = (SH_C3[6] * x) * fmaf(-3.f, yy, xx);
+            }
+        }
+    }
+}
+
+/* forward.cu preprocessCUDA (forward).  All per-Gaussian outputs are written for every index; culled
+ * Gaussians get radii = 0 and tiles_touched = 0 (other fields are left as passed in / zero).
+ * rects: (min.x, min.y, max.x, max.y) per Gaussian, the getRect result (int32). */
+void gso_preprocess(const GsoSettings *st, int P, const float *means3D, const float *shs,
+                    const float *colors_precomp, const float *opacities, const float *scales,
+                    const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                    const float *projmatrix, const float *campos,
+                    /* outputs */ float *depths, int32_t *radii, float *means2D, float *cov3D,
+                    float *conic_opacity, float *rgb, uint8_t *clamped, uint32_t *tiles_touched,
+                    int32_t *rects) {
+    const int W = st->image_width, H = st->image_height;
+    const int gx = (W + GSO_BLOCK_X - 1) / GSO_BLOCK_X, gy = (H + GSO_BLOCK_Y - 1) / GSO_BLOCK_Y;
+    const float fx = (float)W / (2.0f * st->tanfovx), fy = (float)H / (2.0f * st->tanfovy);
+    const int D = st->sh_degree, M = st->sh_coeffs;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        radii[i] = 0;
+        tiles_touched[i] = 0;
+        rects[4 * i + 0] = rects[4 * i + 1] = rects[4 * i + 2] = rects[4 * i + 3] = 0;
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        float pv[3];
+        xform4x3(viewmatrix, px, py, pz, pv);
+        if (pv[2] <= st->near_plane) continue; /* in_frustum (prefiltered trap not restated) */
+        float ph[4];
+        xform4x4(projmatrix, px, py, pz, ph);
+        const float p_w = 1.0f / (ph[3] + 0.0000001f);
+        const float pprx = ph[0] * p_w, ppry = ph[1] * p_w;
+        float c6_local[6];
+        const float *c6;
+        if (cov3D_precomp) {
+            c6 = cov3D_precomp + 6 * (size_t)i;
+        } else {
+            cov3d_from_scale_rot(scales + 3 * (size_t)i, st->scale_modifier, rotations + 4 * (size_t)i,
+                                 c6_local);
+            c6 = c6_local;
+        }
+        for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = c6[k];
+        float cov[3];
+        cov2d_ewa(pv, fx, fy, st->tanfovx, st->tanfovy, c6, viewmatrix, cov);
+        const float h_var = 0.3f;
+        const float det_cov = fmaf(-cov[1], cov[1], cov[0] * cov[2]);
+        cov[0] += h_var;
+        cov[2] += h_var;
+        const float det = fmaf(-cov[1], cov[1], cov[0] * cov[2]);
+        float h_scale = 1.0f;
+        if (st->antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
+        if (det == 0.0f) continue;
+        const float det_inv = 1.f / det;
+        const float conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
+        const float mid = 0.5f * (cov[0] + cov[2]);
+        const float root = sqrtf(fmaxf(0.1f, fmaf(mid, mid, -det)));
+        const float lambda1 = mid + root, lambda2 = mid - root;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix_x = ndc2pix(pprx, W), pix_y = ndc2pix(ppry, H);
+        const int ir = (int)my_radius; /* getRect takes the radius as int */
+        int rminx = (int)((pix_x - (float)ir) / (float)GSO_BLOCK_X);
+        int rminy = (int)((pix_y - (float)ir) / (float)GSO_BLOCK_Y);
+        int rmaxx = (int)((pix_x + (float)ir + (float)(GSO_BLOCK_X - 1)) / (float)GSO_BLOCK_X);
+        int rmaxy = (int)((pix_y + (float)ir + (float)(GSO_BLOCK_Y - 1)) / (float)GSO_BLOCK_Y);
+        rminx = rminx < 0 ? 0 : (rminx > gx ? gx : rminx);
+        rminy = rminy < 0 ? 0 : (rminy > gy ? gy : rminy);
+        rmaxx = rmaxx < 0 ? 0 : (rmaxx > gx ? gx : rmaxx);
+        rmaxy = rmaxy < 0 ? 0 : (rmaxy > gy ? gy : rmaxy);
+        if ((rmaxx - rminx) * (rmaxy - rminy) == 0) continue;
+        if (colors_precomp) {
+            for (int ch = 0; ch < 3; ch++) {
+                rgb[3 * (size_t)i + ch] = colors_precomp[3 * (size_t)i + ch];
+                clamped[3 * (size_t)i + ch] = 0;
+            }
+        } else {
+            float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+            const float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            float b[16];
+            sh_basis(D, dx, dy, dz, b);
+            const int nb = (D + 1) * (D + 1);
+            const float *sh = shs + (size_t)i * M * 3;
+            for (int ch = 0; ch < 3; ch++) {
+                float c = b[0] * sh[ch];
+                for (int k = 1; k < nb; k++) c = fmaf(b[k], sh[3 * k + ch], c);
+                c += 0.5f;
+                clamped[3 * (size_t)i + ch] = (c < 0.f);
+                rgb[3 * (size_t)i + ch] = fmaxf(c, 0.f);
+            }
+        }
+        depths[i] = pv[2];
+        radii[i] = ir;
+        means2D[2 * (size_t)i] = pix_x;
+        means2D[2 * (size_t)i + 1] = pix_y;
+        conic_opacity[4 * (size_t)i + 0] = conic[0];
+        conic_opacity[4 * (size_t)i + 1] = conic[1];
+        conic_opacity[4 * (size_t)i + 2] = conic[2];
+        conic_opacity[4 * (size_t)i + 3] = opacities[i] * h_scale;
+        tiles_touched[i] = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+        rects[4 * i + 0] = rminx; rects[4 * i + 1] = rminy;
+        rects[4 * i + 2] = rmaxx; rects[4 * i + 3] = rmaxy;
+    }
+}
+
+/* auxiliary.h in_frustum via rasterizer_impl.cu checkFrustum (markVisible). */
+void gso_mark_visible(int P, const float *means3D, const float *viewmatrix, float near_plane,
+                      uint8_t *present) {
+    for (int i = 0; i < P; i++) {
+        float pv[3];
+        xform4x3(viewmatrix, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], pv);
+        present[i] = pv[2] > near_plane;
+    }
+}
+
+/* rasterizer_impl.cu: InclusiveSum over tiles_touched (uint32); returns num_rendered. */
+int64_t gso_inclusive_sum(int P, const uint32_t *tiles_touched, uint32_t *offsets) {
+    uint32_t acc = 0;
+    for (int i = 0; i < P; i++) {
+        acc += tiles_touched[i];
+        offsets[i] = acc;
+    }
+    return P ? (int64_t)acc : 0;
+}
+
+/* stable LSD radix sort of (u64 key, u32 value) on the low `bits` bits -- what SortPairs does. */
+static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int bits) {
+    if (n <= 1) return;
+    uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    uint32_t *v2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    uint64_t *ks = keys, *kd = k2;
+    uint32_t *vs = vals, *vd = v2;
+    for (int shift = 0; shift < bits; shift += 8) {
+        int64_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        const int nb = (bits - shift) < 8 ? (bits - shift) : 8;
+        const uint64_t mask = ((uint64_t)1 << nb) - 1;
+        for (int64_t i = 0; i < n; i++) hist[((ks[i] >> shift) & mask) + 1]++;
+        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t p = hist[(ks[i] >> shift) & mask]++;
+            kd[p] = ks[i];
+            vd[p] = vs[i];
+        }
+        uint64_t *tk = ks; ks = kd; kd = tk;
+        uint32_t *tv = vs; vs = vd; vd = tv;
+    }
+    if (ks != keys) {
+        memcpy(keys, ks, sizeof(uint64_t) * (size_t)n);
+        memcpy(vals, vs, sizeof(uint32_t) * (size_t)n);
+    }
+    free(k2);
+    free(v2);
+}
+
+/* rasterizer_impl.cu duplicateWithKeys + SortPairs + identifyTileRanges.
+ * keys/values have num_rendered entries; ranges has 2*tiles entries (start,end), zero when empty.
+ * keys_unsorted (optional, may be NULL) receives the emission-order keys. */
+void gso_bin(const GsoSettings *st, int P, const float *depths, const int32_t *radii,
+             const int32_t *rects, const uint32_t *offsets, int64_t num_rendered,
+             uint64_t *keys, uint32_t *values, uint64_t *keys_unsorted, uint32_t *ranges) {
+    const int W = st->image_width, H = st->image_height;
+    const int gx = (W + GSO_BLOCK_X - 1) / GSO_BLOCK_X, gy = (H + GSO_BLOCK_Y - 1) / GSO_BLOCK_Y;
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        uint32_t off = (i == 0) ? 0 : offsets[i - 1];
+        uint32_t dbits;
+        memcpy(&dbits, &depths[i], 4);
+        for (int y = rects[4 * i + 1]; y < rects[4 * i + 3]; y++)
+            for (int x = rects[4 * i + 0]; x < rects[4 * i + 2]; x++) {
+                uint64_t key = (uint64_t)(y * gx + x);
+                key <<= 32;
+                key |= dbits;
+                keys[off] = key;
+                values[off] = (uint32_t)i;
+                off++;
+            }
+    }
+    if (keys_unsorted) memcpy(keys_unsorted, keys, sizeof(uint64_t) * (size_t)num_rendered);
+    const int bits = 32 + (int)gso_higher_msb((uint32_t)(gx * gy));
+    radix_sort_pairs(keys, values, num_rendered, bits);
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)(gx * gy));
+    for (int64_t i = 0; i < num_rendered; i++) {
+        const uint32_t tile = (uint32_t)(keys[i] >> 32);
+        if (i == 0) ranges[2 * tile] = 0;
+        else {
+            const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+            if (tile != prev) {
+                ranges[2 * prev + 1] = (uint32_t)i;
+                ranges[2 * tile] = (uint32_t)i;
+            }
+        }
+        if (i == num_rendered - 1) ranges[2 * tile + 1] = (uint32_t)num_rendered;
+    }
+}
+
+/* forward.cu renderCUDA: front-to-back alpha compositing per pixel.  The tile-cooperative batching of
+ * the CUDA kernel has no arithmetic effect, so each pixel simply walks its tile's range.
+ * exp() is libm expf.  The borderline map (optional) counts, per pixel, decisions that sit within a relative
+ * band of a threshold (`border_eps` around alpha = 1/255, `border_eps_T` around T = 1e-4) and could therefore
+ * flip under an exp() that differs in the last ulps (the GPU uses the hardware exp2 unit). */
+void gso_render(const GsoSettings *st, const uint32_t *ranges, const uint32_t *point_list,
+                const float *means2D, const float *conic_opacity, const float *rgb,
+                const float *depths, const float *bg, float *out_color, float *out_invdepth,
+                float *final_T, uint32_t *n_contrib, float border_eps, float border_eps_T,
+                uint32_t *borderline) {
+    const int W = st->image_width, H = st->image_height;
+    const int gx = (W + GSO_BLOCK_X - 1) / GSO_BLOCK_X;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < H; py++) {
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / GSO_BLOCK_Y) * gx + (px / GSO_BLOCK_X);
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            const float pfx = (float)px, pfy = (float)py;
+            float T = 1.0f, C[3] = {0.f, 0.f, 0.f}, Dacc = 0.f;
+            uint32_t contributor = 0, last = 0, nborder = 0;
+            for (uint32_t j = r0; j < r1; j++) {
+                contributor++;
+                const uint32_t g = point_list[j];
+                const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
+                const float *co = conic_opacity + 4 * (size_t)g;
+                const float q = fmaf(co[2] * dy, dy, (co[0] * dx) * dx);
+                const float power = fmaf(-(co[1] * dx), dy, -0.5f * q);
+                if (power > 0.0f) continue;
+                const float a_raw = co[3] * expf(power);
+                const float alpha = fminf(0.99f, a_raw);
+                if (borderline && fabsf(a_raw - (1.0f / 255.0f)) <= border_eps * (1.0f / 255.0f)) nborder++;
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1.0f - alpha);
+                if (borderline && fabsf(test_T - 0.0001f) <= border_eps_T * 0.0001f) nborder++;
+                if (test_T < 0.0001f) break; /* done: this instance is NOT added */
+                const float w = alpha * T;
+                C[0] = fmaf(rgb[3 * (size_t)g + 0], w, C[0]);
+                C[1] = fmaf(rgb[3 * (size_t)g + 1], w, C[1]);
+                C[2] = fmaf(rgb[3 * (size_t)g + 2], w, C[2]);
+                Dacc = fmaf(1.0f / depths[g], w, Dacc);
+                T = test_T;
+                last = contributor;
+            }
+            const size_t pid = (size_t)py * W + px;
+            final_T[pid] = T;
+            n_contrib[pid] = last;
+            for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = fmaf(T, bg[ch], C[ch]);
+            out_invdepth[pid] = Dacc;
+            if (borderline) borderline[pid] = nborder;
+        }
+    }
+}
+
+/* Brute-force cross-check (SURVEY.md 8c KAT 8): per pixel, ALL Gaussians that pass preprocess and whose
+ * tile rect contains the pixel's tile, ordered by (depth bits, index), composited in binary64. */
+typedef struct { uint32_t d; uint32_t g; } GsoDG;
+static int cmp_dg(const void *a, const void *b) {
+    const GsoDG *x = (const GsoDG *)a, *y = (const GsoDG *)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return x->g < y->g ? -1 : (x->g > y->g);
+}
+void gso_render_bruteforce(const GsoSettings *st, int P, const int32_t *radii, const int32_t *rects,
+                           const float *means2D, const float *conic_opacity, const float *rgb,
+                           const float *depths, const float *bg, double *out_color,
+                           double *out_invdepth) {
+    const int W = st->image_width, H = st->image_height;
+    GsoDG *order = (GsoDG *)malloc(sizeof(GsoDG) * (size_t)(P > 0 ? P : 1));
+    int n = 0;
+    for (int i = 0; i < P; i++)
+        if (radii[i] > 0) {
+            memcpy(&order[n].d, &depths[i], 4);
+            order[n].g = (uint32_t)i;
+            n++;
+        }
+    qsort(order, (size_t)n, sizeof(GsoDG), cmp_dg);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tx = px / GSO_BLOCK_X, ty = py / GSO_BLOCK_Y;
+            double T = 1.0, C[3] = {0, 0, 0}, Dacc = 0;
+            for (int k = 0; k < n; k++) {
+                const uint32_t g = order[k].g;
+                if (tx < rects[4 * g] || tx >= rects[4 * g + 2] || ty < rects[4 * g + 1] ||
+                    ty >= rects[4 * g + 3])
+                    continue;
+                const double dx = (double)means2D[2 * g] - px, dy = (double)means2D[2 * g + 1] - py;
+                const float *co = conic_opacity + 4 * (size_t)g;
+                const double power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0) continue;
+                double alpha = co[3] * exp(power);
+                if (alpha > 0.99) alpha = 0.99;
+                if (alpha < 1.0 / 255.0) continue;
+                const double test_T = T * (1 - alpha);
+                if (test_T < 0.0001) break;
+                for (int ch = 0; ch < 3; ch++) C[ch] += rgb[3 * (size_t)g + ch] * alpha * T;
+                Dacc += alpha * T / depths[g];
+                T = test_T;
+            }
+            const size_t pid = (size_t)py * W + px;
+            for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch] + T * bg[ch];
+            out_invdepth[pid] = Dacc;
+        }
+    free(order);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * simple-knn distCUDA2: mean of the squared distances to the 3 nearest OTHER points (self excluded by
+ * index, duplicates give 0).  The Morton/box machinery upstream only accelerates the search; the
+ * result is the exact 3-NN, so the restatement is the O(N^2) definition with the same float
+ * expression for the distance and the same ascending 3-best accumulation.
+ * ------------------------------------------------------------------------------------------------ */
+void gso_knn_dist2(int P, const float *pts, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            const float dx = x - pts[3 * j], dy = y - pts[3 * j + 1], dz = z - pts[3 * j + 2];
+            float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            for (int k = 0; k < 3; k++)
+                if (best[k] > d) { float t = best[k]; best[k] = d; d = t; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+}
