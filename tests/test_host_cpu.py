@@ -1,0 +1,175 @@
+"""CPU suite (-m "not gpu"): golden vectors captured from the reference's own Python (tools/make_golden.py), the
+host-side mirrors of the reference interface, and the C-ABI library's exported symbols (no compute calls)."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gsworld_amd import _lib, camera, scenes, transform
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _lib.exported_symbols()
+    assert "gsr_forward" in names and "gsr_mark_visible" in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert b"gfx950" in lib.gsr_version()
+    # sizes are pure host arithmetic: monotone and 256-byte aligned
+    g1, g2 = lib.gsr_geom_bytes(1000), lib.gsr_geom_bytes(2000)
+    assert 0 < g1 < g2 and g1 % 256 == 0
+    assert lib.gsr_binning_bytes(10_000) % 256 == 0 and lib.gsr_image_bytes(640, 480) % 256 == 0
+    # argument validation never touches the GPU
+    assert lib.gsr_forward(None, None, None, None, 0, None, None) == _lib.GSR_E_INVALID
+    assert b"null" in lib.gsr_last_error()
+    assert lib.gsr_profile_enable(7) == _lib.GSR_E_INVALID
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgsr_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_rasterizer_rejects_cpu_tensors():
+    from gsworld_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    cam = scenes.identity_camera(32, 32)
+    rs = GaussianRasterizationSettings(32, 32, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
+                                       False, False, False)
+    r = GaussianRasterizer(rs)
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1))
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), colors_precomp=m)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=m)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=m,
+          rotations=torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        r(means3D=torch.zeros(4, 2), means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=m,
+          rotations=torch.ones(4, 4))
+    # GSWorld probes this name to choose the separate_sh call path (gs_world_wrapper.py:22-26): must be absent
+    import gsworld_amd.rasterizer as rz
+    assert not hasattr(rz, "SparseGaussianAdam")
+
+
+def test_constants_match_reference_capture():
+    ref = np.load(os.path.join(GOLD, "reference_constants.npz"))
+    np.testing.assert_array_equal(scenes.SIM2GS_ARM_TRANS, ref["sim2gs_arm_trans"])
+    np.testing.assert_array_equal(scenes.SIM2GS_XARM_TRANS, ref["sim2gs_xarm_trans"])
+    np.testing.assert_array_equal(scenes.RS_D435I_RGB_K, ref["rs_d435i_rgb_k"])
+    np.testing.assert_array_equal(scenes.RIGHT2BASE, ref["right2base"])
+    np.testing.assert_array_equal(scenes.XARM_RIGHT2BASE, ref["xarm_right2base"])
+
+
+def test_extract_rigid_transform_golden():
+    ref = np.load(os.path.join(GOLD, "extract_rigid_transform.npz"))
+    for i in range(3):
+        rigid, scale, R, t = camera.extract_rigid_transform(torch.from_numpy(ref["single_in"][i]))
+        np.testing.assert_allclose(rigid.numpy(), ref["single_rigid"][i], atol=1e-6)
+        np.testing.assert_allclose(scale.numpy(), ref["single_scale"][i], atol=1e-6)
+    # scale of sim2gs_xarm_trans = 1.0016118, first rigid row (-0.9685, 0.2244, 0.1082, 0.3279)
+    rigid, scale, _, _ = camera.extract_rigid_transform(torch.tensor(scenes.SIM2GS_XARM_TRANS))
+    assert abs(float(scale) - 1.0016118) < 1e-6
+    np.testing.assert_allclose(rigid[0].numpy(), [-0.9685, 0.2244, 0.1082, 0.3279], atol=1e-4)
+    rigid, scale, R, t = camera.extract_rigid_transform(torch.from_numpy(ref["batch_in"]))
+    np.testing.assert_allclose(rigid.numpy(), ref["batch_rigid"], atol=1e-5)
+    np.testing.assert_allclose(scale.numpy(), ref["batch_scale"], atol=1e-6)
+    np.testing.assert_allclose(R.numpy(), ref["batch_R"], atol=1e-5)
+    np.testing.assert_allclose(t.numpy(), ref["batch_t"], atol=0)
+    with pytest.raises(ValueError):
+        camera.extract_rigid_transform(torch.zeros(3, 3))
+
+
+def test_transform_gaussians_golden():
+    ref = np.load(os.path.join(GOLD, "transform_gaussians.npz"))
+    import types
+    g = types.SimpleNamespace(_xyz=torch.from_numpy(ref["xyz"]), _scaling=torch.from_numpy(ref["scaling"]),
+                              _rotation=torch.from_numpy(ref["rotation"]), _opacity=torch.from_numpy(ref["opacity"]))
+    sel = torch.from_numpy(ref["selected"])
+    cases = sorted({k.split(".")[0] for k in ref.files if ".out." in k})
+    assert cases == ["actor_env1", "actor_env2", "link_env1", "link_env3", "translate_vec3"]
+    for c in cases:
+        kw = {k: (torch.from_numpy(ref[f"{c}.in.{k}"]) if f"{c}.in.{k}" in ref.files else None)
+              for k in ("scale", "rot_mat", "translation")}
+        out = transform.transform_gaussians(g, sel, **kw)
+        for name, got in zip(("xyz", "scaling", "rotation", "opacity"), out):
+            want = ref[f"{c}.out.{name}"]
+            assert tuple(got.shape) == want.shape, (c, name, got.shape, want.shape)
+            np.testing.assert_allclose(got.numpy(), want, atol=2e-6, rtol=1e-6, err_msg=f"{c}.{name}")
+    # the shapes the wrapper's `shape[0] == num_envs` tests depend on (gs_world_wrapper.py:246-265), num_envs = 1
+    assert ref["link_env1.out.xyz"].shape == (1, 300, 3) and ref["link_env1.out.rotation"].shape == (1, 300, 4)
+    assert ref["link_env1.out.scaling"].shape == (300, 3)
+    np.testing.assert_allclose(transform.inverse_sigmoid(torch.from_numpy(ref["inverse_sigmoid.in"])).numpy(),
+                               ref["inverse_sigmoid.out"], atol=1e-6)
+
+
+def test_quaternion_helpers_roundtrip():
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn(64, 4, generator=gen)
+    q = transform.standardize_quaternion(q / q.norm(dim=1, keepdim=True))
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    np.testing.assert_allclose(transform.matrix_to_quaternion(R).numpy(), q.numpy(), atol=1e-5)
+    ident = torch.tensor([[1.0, 0, 0, 0]]).expand(64, 4)
+    np.testing.assert_allclose(transform.quaternion_multiply(ident, q).numpy(), q.numpy(), atol=1e-7)
+
+
+def test_sensor_camera_matches_survey_values():
+    """cam_maniskill2gs math (gs_world_wrapper.py:280-301) on the right_cam calibration: FoVs of SURVEY.md 8c."""
+    cam = scenes.sensor_camera("xarm6_align")
+    assert abs(cam.FoVx - 0.9715089) < 1e-6 and abs(cam.FoVy - 0.7551448) < 1e-6
+    assert abs(cam.tanfovx - 0.527947) < 1e-6 and abs(cam.tanfovy - 0.3966005) < 1e-6
+    assert (cam.image_width, cam.image_height) == (640, 480)
+    V = cam.world_view_transform  # W2C^T
+    W2C = V.T
+    np.testing.assert_allclose((W2C[:3, :3] @ W2C[:3, :3].T).numpy(), np.eye(3), atol=1e-5)
+    assert abs(float(torch.det(W2C[:3, :3])) - 1.0) < 1e-5
+    # camera centre = -R^T t and equals the calibrated pose pushed through scale + rigid sim->GS
+    c = -(W2C[:3, :3].T @ W2C[:3, 3])
+    np.testing.assert_allclose(cam.camera_center.numpy(), c.numpy(), atol=1e-5)
+    rigid, scale, _, _ = camera.extract_rigid_transform(torch.tensor(scenes.SIM2GS_XARM_TRANS))
+    p_sim = torch.tensor(scenes.XARM_RIGHT2BASE[:3, 3]) + torch.tensor([0.0, 0.0, 0.03])
+    want = rigid[:3, :3] @ (p_sim * scale) + rigid[:3, 3]
+    np.testing.assert_allclose(cam.camera_center.numpy(), want.numpy(), atol=1e-5)
+    # projection: P[0,0] = 1/tanfovx, P[1,1] = 1/tanfovy, w = z; full = view @ proj
+    P = camera.get_projection_matrix(0.01, 100.0, cam.FoVx, cam.FoVy)
+    assert abs(float(P[0, 0]) - 1 / cam.tanfovx) < 1e-5 and abs(float(P[1, 1]) - 1 / cam.tanfovy) < 1e-5
+    assert float(P[3, 2]) == 1.0 and abs(float(P[2, 2]) - 100.0 / 99.99) < 1e-6
+    np.testing.assert_allclose(cam.full_proj_transform.numpy(), (V @ P.T).numpy(), atol=1e-6)
+
+
+def test_scene_generators_are_seeded_and_shaped():
+    a = scenes.tabletop_scene("xarm6_align", n=5000, seed=1)
+    b = scenes.tabletop_scene("xarm6_align", n=5000, seed=1)
+    c = scenes.tabletop_scene("fr3_align", n=5000, seed=2)
+    assert torch.equal(a.xyz, b.xyz) and not torch.equal(a.xyz[:, 0], c.xyz[:, 0])
+    assert a.features_dc.shape == (5000, 1, 3) and a.features_rest.shape == (5000, 15, 3)
+    assert a.opacity.shape == (5000, 1) and a.scaling.shape == (5000, 3) and a.rotation.shape == (5000, 4)
+    means, shs, op, sc, rot = a.activated()
+    assert shs.shape == (5000, 16, 3) and shs.is_contiguous()
+    assert float(op.min()) > 0 and float(op.max()) < 1 and float(sc.min()) > 0
+    np.testing.assert_allclose(rot.norm(dim=1).numpy(), 1.0, atol=1e-5)
+    assert scenes.XARM6_ALIGN_NUM_GAUSSIANS == 1_468_850 and len(scenes.SCENE_NAMES) == 8
+    r = scenes.random_scene_camera_frame(1000, seed=0)
+    assert int(((r.xyz[:, 2] > 0.05) & (r.xyz[:, 2] < 0.2)).sum()) == 10  # the 1 % that exercises the 0.05f cull
+
+
+def test_frame_stats_algorithmic_bytes():
+    from gsworld_amd.renderer import FrameStats
+
+    s = FrameStats(1_468_850, 881_310, 3_525_240, False)
+    # SURVEY.md 8d worked example: 70.5 + 246.8 + 225.6 + 4.9 = 548 MB
+    assert abs(s.algorithmic_bytes(640, 480) / 1e6 - 547.8) < 0.5
