@@ -1,0 +1,96 @@
+"""Python side of ``_C.rasterize_gaussians_backward`` (upstream rasterize_points.cu
+RasterizeGaussiansBackwardCUDA) over gsr_backward of the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import GsrInputs, GsrSettings, check, lib
+
+
+class GsrBackwardInputs(C.Structure):
+    _fields_ = [("dL_dout_color", C.c_void_p), ("dL_dout_invdepth", C.c_void_p), ("radii", C.c_void_p),
+                ("num_rendered", C.c_int64), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p)]
+
+
+class GsrGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
+                                          "dL_dsh", "dL_dscales", "dL_drots", "dL_dconic", "dL_dinvdepths")]
+
+
+def _bind():
+    L = lib()
+    if not getattr(L, "_bwd_bound", False):
+        L.gsr_backward.restype = C.c_int
+        L.gsr_backward.argtypes = [C.POINTER(GsrSettings), C.POINTER(GsrInputs), C.POINTER(GsrBackwardInputs),
+                                   C.POINTER(GsrGrads), C.c_void_p]
+        L.gsr_selftest_wave_sum.restype = C.c_int
+        L.gsr_selftest_wave_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L._bwd_bound = True
+    return L
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, dev):
+    if t.numel() == 0:
+        return t
+    if t.dtype != torch.float32:
+        raise RuntimeError("rasterizer tensors must be float32")
+    return (t.to(dev) if t.device != dev else t).contiguous()
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_invdepth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                 antialiasing, debug, near_plane):
+    L = _bind()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    # allocated uninitialised: gsr_backward zeroes every gradient buffer on the stream
+    dL_dmeans3D = torch.empty((P, 3), **f32)
+    dL_dmeans2D = torch.empty((P, 3), **f32)
+    dL_dcolors = torch.empty((P, 3), **f32)
+    dL_dconic = torch.empty((P, 2, 2), **f32)
+    dL_dopacity = torch.empty((P, 1), **f32)
+    dL_dcov3D = torch.empty((P, 6), **f32)
+    dL_dsh = torch.empty((P, M, 3), **f32)
+    dL_dscales = torch.empty((P, 3), **f32)
+    dL_drotations = torch.empty((P, 4), **f32)
+    dL_dinvdepths = torch.empty((P, 1), **f32)
+    if P != 0:
+        tensors = [_f32(t, dev) for t in (background, means3D, colors, opacities, scales, rotations, cov3D_precomp,
+                                          viewmatrix, projmatrix, sh, campos, dL_dout_color)]
+        (background, means3D, colors, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, campos,
+         dL_dout_color) = tensors
+        dLd = None
+        if dL_dout_invdepth is not None and dL_dout_invdepth.numel() != 0:
+            dLd = _f32(dL_dout_invdepth, dev)
+        st = GsrSettings(H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M), 0,
+                         int(bool(antialiasing)), int(bool(debug)), float(near_plane))
+        inp = GsrInputs(P=P, background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
+                        colors_precomp=_ptr(colors), opacities=_ptr(opacities), scales=_ptr(scales),
+                        rotations=_ptr(rotations), cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix),
+                        projmatrix=_ptr(projmatrix), campos=_ptr(campos))
+        bw = GsrBackwardInputs(_ptr(dL_dout_color), _ptr(dLd), _ptr(radii), int(R), _ptr(geomBuffer),
+                               _ptr(binningBuffer), _ptr(imageBuffer))
+        gr = GsrGrads(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                      _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dconic), _ptr(dL_dinvdepths))
+        with torch.cuda.device(dev):
+            check(L.gsr_backward(C.byref(st), C.byref(inp), C.byref(bw), C.byref(gr),
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def selftest_wave_sum(x256: torch.Tensor) -> torch.Tensor:
+    L = _bind()
+    out = torch.zeros(4, dtype=torch.float32, device=x256.device)
+    with torch.cuda.device(x256.device):
+        check(L.gsr_selftest_wave_sum(_ptr(x256), _ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out

@@ -146,6 +146,38 @@ typedef struct GsrProfile {
 int gsr_profile_enable(int mode);
 int gsr_profile_collect(GsrProfile *out);
 
+/*
+ * Backward rasterization (upstream RasterizeGaussiansBackwardCUDA -> Rasterizer::backward).
+ * `settings` / `in` are the forward's; the three state pointers are the buffers the forward filled (exact mode:
+ * binning state carved for num_rendered instances).  Every gradient buffer is zeroed by the call.
+ */
+typedef struct GsrBackwardInputs {
+    const float *dL_dout_color;    /* (3,H,W) */
+    const float *dL_dout_invdepth; /* (1,H,W) or NULL */
+    const int32_t *radii;          /* (P) from the forward */
+    int64_t num_rendered;          /* R from the forward */
+    const void *geom, *binning, *image;
+} GsrBackwardInputs;
+
+typedef struct GsrGrads {
+    float *dL_dmeans2D;   /* (P,3)  pixel-NDC units, z unused */
+    float *dL_dcolors;    /* (P,3) */
+    float *dL_dopacity;   /* (P) */
+    float *dL_dmeans3D;   /* (P,3) */
+    float *dL_dcov3D;     /* (P,6) */
+    float *dL_dsh;        /* (P,M,3) or NULL with colors_precomp */
+    float *dL_dscales;    /* (P,3) or NULL with cov3D_precomp */
+    float *dL_drots;      /* (P,4) or NULL with cov3D_precomp */
+    float *dL_dconic;     /* (P,4) scratch: xx, xy (half, upstream convention), -, yy */
+    float *dL_dinvdepths; /* (P)   scratch */
+} GsrGrads;
+
+int gsr_backward(const GsrSettings *settings, const GsrInputs *in, const GsrBackwardInputs *bw,
+                 const GsrGrads *grads, void *stream);
+
+/* Self-test of the DPP wave reduction used by the backward: out4[w] = sum(in256[64w .. 64w+63]). */
+int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream);
+
 /* GSWorld's frame conversion (gs_world_wrapper.py:268-270): (3,H,W) float -> (H,W,3) uint8 with
  * (x*255).clamp(0,255) and a truncating cast.  `out` must be 4-byte aligned. */
 int gsr_pack_rgb8(const float *color, int32_t width, int32_t height, uint8_t *out, void *stream);

@@ -495,3 +495,299 @@ void gso_knn_dist2(int P, const float *pts, float *out) {
         out[i] = (best[0] + best[1] + best[2]) / 3.0f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward pass (backward.cu: renderCUDA, computeCov2DCUDA, preprocessCUDA).
+ * The CUDA kernels accumulate with float atomics in a non-deterministic order; this restatement keeps the
+ * same per-(pixel, instance) float32 expressions and sums them in binary64, so it is the order-free value
+ * the HIP path is compared against (tolerance stated in tests/test_backward_gpu.py).
+ * Conventions kept from upstream: dL_dconic.y holds HALF of the off-diagonal derivative (the 2D-covariance
+ * stage multiplies it back); the 0.99 alpha cap is transparent to the gradient; dL_dscale is the derivative
+ * w.r.t. (scale_modifier * scale) and is not multiplied by scale_modifier.
+ * ------------------------------------------------------------------------------------------------ */
+void gso_render_backward(const GsoSettings *st, int P, const uint32_t *ranges, const uint32_t *point_list,
+                         const float *means2D, const float *conic_opacity, const float *rgb,
+                         const float *depths, const float *bg, const float *final_T,
+                         const uint32_t *n_contrib, const float *dL_dpix, const float *dL_dinvdepth_pix,
+                         /* out, all zero-initialised here */ double *dL_dmean2D /*2P*/,
+                         double *dL_dconic /*3P: xx, xy(half), yy*/, double *dL_dopacity /*P*/,
+                         double *dL_dcolors /*3P*/, double *dL_dinvdepths /*P*/) {
+    const int W = st->image_width, H = st->image_height;
+    const int gx = (W + GSO_BLOCK_X - 1) / GSO_BLOCK_X;
+    memset(dL_dmean2D, 0, sizeof(double) * 2 * (size_t)P);
+    memset(dL_dconic, 0, sizeof(double) * 3 * (size_t)P);
+    memset(dL_dopacity, 0, sizeof(double) * (size_t)P);
+    memset(dL_dcolors, 0, sizeof(double) * 3 * (size_t)P);
+    memset(dL_dinvdepths, 0, sizeof(double) * (size_t)P);
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / GSO_BLOCK_Y) * gx + (px / GSO_BLOCK_X);
+            const uint32_t r0 = ranges[2 * tile];
+            const size_t pid = (size_t)py * W + px;
+            const float T_final = final_T[pid];
+            float T = T_final;
+            const uint32_t last_contributor = n_contrib[pid];
+            float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
+            float accum_invd = 0.f, last_invd = 0.f, last_alpha = 0.f;
+            float dLp[3];
+            for (int ch = 0; ch < 3; ch++) dLp[ch] = dL_dpix[(size_t)ch * H * W + pid];
+            const float dLd = dL_dinvdepth_pix ? dL_dinvdepth_pix[pid] : 0.f;
+            const float bg_dot = fmaf(bg[2], dLp[2], fmaf(bg[1], dLp[1], bg[0] * dLp[0]));
+            const float pfx = (float)px, pfy = (float)py;
+            /* instances [r0, r0 + last_contributor) were examined before the pixel finished; walk them back to front */
+            for (uint32_t k = last_contributor; k-- > 0;) {
+                const uint32_t g = point_list[r0 + k];
+                const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
+                const float *co = conic_opacity + 4 * (size_t)g;
+                const float q = fmaf(co[2] * dy, dy, (co[0] * dx) * dx);
+                const float power = fmaf(-(co[1] * dx), dy, -0.5f * q);
+                if (power > 0.0f) continue;
+                const float G = expf(power);
+                const float alpha = fminf(0.99f, co[3] * G);
+                if (alpha < 1.0f / 255.0f) continue;
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                float dL_dalpha = 0.f;
+                for (int ch = 0; ch < 3; ch++) {
+                    const float c = rgb[3 * (size_t)g + ch];
+                    accum_rec[ch] = fmaf(last_alpha, last_color[ch], (1.f - last_alpha) * accum_rec[ch]);
+                    last_color[ch] = c;
+                    dL_dalpha = fmaf(c - accum_rec[ch], dLp[ch], dL_dalpha);
+                    dL_dcolors[3 * (size_t)g + ch] += (double)(dchannel_dcolor * dLp[ch]);
+                }
+                if (dL_dinvdepth_pix) {
+                    const float invd = 1.f / depths[g];
+                    accum_invd = fmaf(last_alpha, last_invd, (1.f - last_alpha) * accum_invd);
+                    last_invd = invd;
+                    dL_dalpha = fmaf(invd - accum_invd, dLd, dL_dalpha);
+                    dL_dinvdepths[g] += (double)(dchannel_dcolor * dLd);
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha = fmaf(-T_final / (1.f - alpha), bg_dot, dL_dalpha);
+                const float dL_dG = co[3] * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = fmaf(-gdy, co[1], -gdx * co[0]);
+                const float dG_ddely = fmaf(-gdx, co[1], -gdy * co[2]);
+                dL_dmean2D[2 * (size_t)g] += (double)((dL_dG * dG_ddelx) * ddelx_dx);
+                dL_dmean2D[2 * (size_t)g + 1] += (double)((dL_dG * dG_ddely) * ddely_dy);
+                dL_dconic[3 * (size_t)g] += (double)((-0.5f * gdx) * dx * dL_dG);
+                dL_dconic[3 * (size_t)g + 1] += (double)((-0.5f * gdx) * dy * dL_dG);
+                dL_dconic[3 * (size_t)g + 2] += (double)((-0.5f * gdy) * dy * dL_dG);
+                dL_dopacity[g] += (double)(G * dL_dalpha);
+            }
+        }
+}
+
+/* Per-Gaussian chain: conic -> 2D covariance -> (3D covariance, view-space mean), projected-mean and
+ * inverse-depth gradients, SH -> dL_dsh and view direction, 3D covariance -> scale and quaternion.
+ * Inputs are the double accumulators of gso_render_backward rounded to float (what the atomics produce). */
+void gso_preprocess_backward(const GsoSettings *st, int P, const float *means3D, const int32_t *radii,
+                             const float *shs, const uint8_t *clamped, const float *opacities,
+                             const float *scales, const float *rotations, const float *cov3D,
+                             int cov3D_is_precomp, int colors_are_precomp, const float *viewmatrix,
+                             const float *projmatrix, const float *campos, const float *dL_dmean2D,
+                             const float *dL_dconic, float *dL_dopacity /* in/out */,
+                             const float *dL_dcolors, const float *dL_dinvdepths,
+                             /* out */ float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales,
+                             float *dL_drots) {
+    const int W = st->image_width, H = st->image_height;
+    const float fx = (float)W / (2.0f * st->tanfovx), fy = (float)H / (2.0f * st->tanfovy);
+    const int D = st->sh_degree, M = st->sh_coeffs;
+    memset(dL_dmeans3D, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dcov3D, 0, sizeof(float) * 6 * (size_t)P);
+    if (dL_dsh) memset(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * (size_t)P);
+    if (dL_dscales) memset(dL_dscales, 0, sizeof(float) * 3 * (size_t)P);
+    if (dL_drots) memset(dL_drots, 0, sizeof(float) * 4 * (size_t)P);
+    const float *m = viewmatrix;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        const float *c6 = cov3D + 6 * (size_t)i;
+        /* ---- computeCov2DCUDA ---------------------------------------------------------------- */
+        float t[3];
+        xform4x3(m, px, py, pz, t);
+        const float limx = 1.3f * st->tanfovx, limy = 1.3f * st->tanfovy;
+        const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float tz = t[2];
+        const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+        float A[2][3], Wm[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Wm[r][c] = m[c * 4 + r];
+        for (int j = 0; j < 3; j++) {
+            A[0][j] = fmaf(J02, Wm[2][j], J00 * Wm[0][j]);
+            A[1][j] = fmaf(J12, Wm[2][j], J11 * Wm[1][j]);
+        }
+        const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float B[2][3];
+        for (int r = 0; r < 2; r++)
+            for (int j = 0; j < 3; j++)
+                B[r][j] = fmaf(A[r][2], S[2][j], fmaf(A[r][1], S[1][j], A[r][0] * S[0][j]));
+        float a = fmaf(B[0][2], A[0][2], fmaf(B[0][1], A[0][1], B[0][0] * A[0][0]));
+        const float b = fmaf(B[0][2], A[1][2], fmaf(B[0][1], A[1][1], B[0][0] * A[1][0]));
+        float c = fmaf(B[1][2], A[1][2], fmaf(B[1][1], A[1][1], B[1][0] * A[1][0]));
+        const float h_var = 0.3f;
+        float dL_da_aa = 0.f, dL_db_aa = 0.f, dL_dc_aa = 0.f;
+        if (st->antialiasing) {
+            const float det_cov = fmaf(-b, b, a * c);
+            a += h_var;
+            c += h_var;
+            const float det_plus = fmaf(-b, b, a * c);
+            const float ratio = det_cov / det_plus;
+            const float h_scale = sqrtf(fmaxf(0.000025f, ratio));
+            const float dL_dop = dL_dopacity[i];
+            const float d_h = dL_dop * opacities[i];
+            dL_dopacity[i] = dL_dop * h_scale;
+            const float d_root = ratio <= 0.000025f ? 0.f : d_h / (2.f * h_scale);
+            /* ratio = ((a-h)(c-h) - b^2) / (a c - b^2) with a, c the post-filter entries */
+            const float inv2 = 1.f / (det_plus * det_plus);
+            dL_da_aa = d_root * ((c - h_var) * det_plus - det_cov * c) * inv2;
+            dL_dc_aa = d_root * ((a - h_var) * det_plus - det_cov * a) * inv2;
+            dL_db_aa = d_root * (-2.f * b * det_plus + 2.f * b * det_cov) * inv2;
+        } else {
+            a += h_var;
+            c += h_var;
+        }
+        const float Lx = dL_dconic[3 * (size_t)i], Ly = dL_dconic[3 * (size_t)i + 1], Lz = dL_dconic[3 * (size_t)i + 2];
+        const float denom = fmaf(-b, b, a * c);
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * Lx + 2.f * b * c * Ly + (denom - a * c) * Lz);
+            dL_dc = denom2inv * (-a * a * Lz + 2.f * a * b * Ly + (denom - a * c) * Lx);
+            dL_db = denom2inv * 2.f * (b * c * Lx - (denom + 2.f * b * b) * Ly + a * b * Lz);
+        }
+        dL_da += dL_da_aa;
+        dL_db += dL_db_aa;
+        dL_dc += dL_dc_aa;
+        float dS[6]; /* gradient w.r.t. the 6 stored entries (off-diagonals count twice) */
+        dS[0] = A[0][0] * A[0][0] * dL_da + A[0][0] * A[1][0] * dL_db + A[1][0] * A[1][0] * dL_dc;
+        dS[3] = A[0][1] * A[0][1] * dL_da + A[0][1] * A[1][1] * dL_db + A[1][1] * A[1][1] * dL_dc;
+        dS[5] = A[0][2] * A[0][2] * dL_da + A[0][2] * A[1][2] * dL_db + A[1][2] * A[1][2] * dL_dc;
+        dS[1] = 2.f * A[0][0] * A[0][1] * dL_da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * dL_db +
+                2.f * A[1][0] * A[1][1] * dL_dc;
+        dS[2] = 2.f * A[0][0] * A[0][2] * dL_da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * dL_db +
+                2.f * A[1][0] * A[1][2] * dL_dc;
+        dS[4] = 2.f * A[0][2] * A[0][1] * dL_da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * dL_db +
+                2.f * A[1][1] * A[1][2] * dL_dc;
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+        /* dL/dA = 2 G (A Sigma), G = [[da, db/2],[db/2, dc]] */
+        float dA[2][3];
+        for (int j = 0; j < 3; j++) {
+            dA[0][j] = 2.f * B[0][j] * dL_da + B[1][j] * dL_db;
+            dA[1][j] = 2.f * B[1][j] * dL_dc + B[0][j] * dL_db;
+        }
+        const float dJ00 = Wm[0][0] * dA[0][0] + Wm[0][1] * dA[0][1] + Wm[0][2] * dA[0][2];
+        const float dJ02 = Wm[2][0] * dA[0][0] + Wm[2][1] * dA[0][1] + Wm[2][2] * dA[0][2];
+        const float dJ11 = Wm[1][0] * dA[1][0] + Wm[1][1] * dA[1][1] + Wm[1][2] * dA[1][2];
+        const float dJ12 = Wm[2][0] * dA[1][0] + Wm[2][1] * dA[1][1] + Wm[2][2] * dA[1][2];
+        const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float dtx = x_grad_mul * -fx * itz2 * dJ02;
+        const float dty = y_grad_mul * -fy * itz2 * dJ12;
+        float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.f * fx * tx) * itz3 * dJ02 + (2.f * fy * ty) * itz3 * dJ12;
+        if (dL_dinvdepths) dtz -= dL_dinvdepths[i] / (tz * tz);
+        float dmean[3];
+        for (int j = 0; j < 3; j++) dmean[j] = m[j * 4 + 0] * dtx + m[j * 4 + 1] * dty + m[j * 4 + 2] * dtz;
+        /* ---- projected mean (preprocessCUDA bwd) ----------------------------------------------- */
+        const float *q = projmatrix;
+        float ph[4];
+        xform4x4(q, px, py, pz, ph);
+        const float m_w = 1.0f / (ph[3] + 0.0000001f);
+        const float mul1 = ph[0] * m_w * m_w, mul2 = ph[1] * m_w * m_w;
+        const float g2x = dL_dmean2D[2 * (size_t)i], g2y = dL_dmean2D[2 * (size_t)i + 1];
+        dmean[0] += (q[0] * m_w - q[3] * mul1) * g2x + (q[1] * m_w - q[3] * mul2) * g2y;
+        dmean[1] += (q[4] * m_w - q[7] * mul1) * g2x + (q[5] * m_w - q[7] * mul2) * g2y;
+        dmean[2] += (q[8] * m_w - q[11] * mul1) * g2x + (q[9] * m_w - q[11] * mul2) * g2y;
+        /* ---- SH -> colour (computeColorFromSH bwd) ------------------------------------------------ */
+        if (!colors_are_precomp && dL_dsh) {
+            const float ox = px - campos[0], oy = py - campos[1], oz = pz - campos[2];
+            const float len = sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+            const float x = ox / len, y = oy / len, z = oz / len;
+            float dRGB[3];
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = clamped[3 * (size_t)i + ch] ? 0.f : dL_dcolors[3 * (size_t)i + ch];
+            float bas[16], bx[16], by[16], bz[16];
+            sh_basis(D, x, y, z, bas);
+            for (int k = 0; k < 16; k++) bx[k] = by[k] = bz[k] = 0.f;
+            if (D > 0) {
+                by[1] = -SH_C1; bz[2] = SH_C1; bx[3] = -SH_C1;
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    bx[4] = SH_C2[0] * y; by[4] = SH_C2[0] * x;
+                    by[5] = SH_C2[1] * z; bz[5] = SH_C2[1] * y;
+                    bx[6] = SH_C2[2] * -2.f * x; by[6] = SH_C2[2] * -2.f * y; bz[6] = SH_C2[2] * 4.f * z;
+                    bx[7] = SH_C2[3] * z; bz[7] = SH_C2[3] * x;
+                    bx[8] = SH_C2[4] * 2.f * x; by[8] = SH_C2[4] * -2.f * y;
+                    if (D > 2) {
+                        bx[9] = SH_C3[0] * 6.f * x * y; by[9] = SH_C3[0] * (3.f * xx - 3.f * yy);
+                        bx[10] = SH_C3[1] * y * z; by[10] = SH_C3[1] * x * z; bz[10] = SH_C3[1] * x * y;
+                        bx[11] = SH_C3[2] * -2.f * x * y; by[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy);
+                        bz[11] = SH_C3[2] * 8.f * y * z;
+                        bx[12] = SH_C3[3] * -6.f * x * z; by[12] = SH_C3[3] * -6.f * y * z;
+                        bz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                        bx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); by[13] = SH_C3[4] * -2.f * x * y;
+                        bz[13] = SH_C3[4] * 8.f * x * z;
+                        bx[14] = SH_C3[5] * 2.f * x * z; by[14] = SH_C3[5] * -2.f * y * z; bz[14] = SH_C3[5] * (xx - yy);
+                        bx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); by[15] = SH_C3[6] * -6.f * x * y;
+                    }
+                }
+            }
+            const int nb = (D + 1) * (D + 1);
+            const float *sh = shs + (size_t)i * M * 3;
+            float ddir[3] = {0, 0, 0};
+            for (int k = 0; k < nb; k++)
+                for (int ch = 0; ch < 3; ch++) {
+                    dL_dsh[((size_t)i * M + k) * 3 + ch] = bas[k] * dRGB[ch];
+                    ddir[0] += bx[k] * sh[3 * k + ch] * dRGB[ch];
+                    ddir[1] += by[k] * sh[3 * k + ch] * dRGB[ch];
+                    ddir[2] += bz[k] * sh[3 * k + ch] * dRGB[ch];
+                }
+            /* through the normalisation dir = o / |o| */
+            const float sum2 = ox * ox + oy * oy + oz * oz;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((sum2 - ox * ox) * ddir[0] - oy * ox * ddir[1] - oz * ox * ddir[2]) * inv32;
+            dmean[1] += (-ox * oy * ddir[0] + (sum2 - oy * oy) * ddir[1] - oz * oy * ddir[2]) * inv32;
+            dmean[2] += (-ox * oz * ddir[0] - oy * oz * ddir[1] + (sum2 - oz * oz) * ddir[2]) * inv32;
+        }
+        for (int j = 0; j < 3; j++) dL_dmeans3D[3 * (size_t)i + j] = dmean[j];
+        /* ---- 3D covariance -> scale, quaternion (computeCov3D bwd) -------------------------------- */
+        if (!cov3D_is_precomp && dL_dscales && dL_drots) {
+            const float *rq = rotations + 4 * (size_t)i;
+            const float r = rq[0], x = rq[1], y = rq[2], z = rq[3];
+            float R[3][3];
+            R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+            R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+            R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+            float s[3];
+            for (int k = 0; k < 3; k++) s[k] = st->scale_modifier * scales[3 * (size_t)i + k];
+            float Mm[3][3];
+            for (int k = 0; k < 3; k++)
+                for (int j = 0; j < 3; j++) Mm[k][j] = s[k] * R[j][k];
+            const float Gs[3][3] = {{dS[0], 0.5f * dS[1], 0.5f * dS[2]},
+                                    {0.5f * dS[1], dS[3], 0.5f * dS[4]},
+                                    {0.5f * dS[2], 0.5f * dS[4], dS[5]}};
+            float dM[3][3]; /* dL/dM = 2 M G */
+            for (int k = 0; k < 3; k++)
+                for (int j = 0; j < 3; j++)
+                    dM[k][j] = 2.f * (Mm[k][0] * Gs[0][j] + Mm[k][1] * Gs[1][j] + Mm[k][2] * Gs[2][j]);
+            float dR[3][3]; /* dL/dR[j][k] = s_k dM[k][j] */
+            for (int k = 0; k < 3; k++) {
+                dL_dscales[3 * (size_t)i + k] = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
+                for (int j = 0; j < 3; j++) dR[j][k] = s[k] * dM[k][j];
+            }
+            float *dq = dL_drots + 4 * (size_t)i;
+            dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] +
+                           z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] -
+                           r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] +
+                           y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    }
+}

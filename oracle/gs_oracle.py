@@ -189,6 +189,55 @@ def render_bruteforce(st: Settings, geom, bg):
     return out_color, out_invdepth
 
 
+def backward(st: Settings, fwd, inp, bg, dL_dcolor, dL_dinvdepth=None, colors_precomp=None, cov3D_precomp=None):
+    """Backward pass on top of a ``forward`` result.  ``inp`` is the dict of forward inputs (numpy).
+    Returns the 8 gradients of upstream's rasterize_gaussians_backward, same order and shapes:
+    (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
+     dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4))."""
+    geom, binning = fwd["geom"], fwd["binning"]
+    P = geom["depths"].shape[0]
+    H, W = st.image_height, st.image_width
+    bg = _f32(bg)
+    dL_dcolor = _f32(dL_dcolor).reshape(3, H, W)
+    dLd = None if dL_dinvdepth is None else _f32(dL_dinvdepth).reshape(H, W)
+    d_mean2D = np.zeros((P, 2), np.float64)
+    d_conic = np.zeros((P, 3), np.float64)
+    d_opac = np.zeros(P, np.float64)
+    d_colors = np.zeros((P, 3), np.float64)
+    d_invd = np.zeros(P, np.float64)
+    cs = st.c()
+    pl = np.ascontiguousarray(binning["point_list"] if binning["num_rendered"] > 0 else np.zeros(1), np.uint32)
+    lib().gso_render_backward(
+        C.byref(cs), C.c_int(P), _p(binning["ranges"]), _p(pl), _p(geom["means2D"]), _p(geom["conic_opacity"]),
+        _p(geom["rgb"]), _p(geom["depths"]), _p(bg), _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor),
+        _p(dLd), _p(d_mean2D), _p(d_conic), _p(d_opac), _p(d_colors), _p(d_invd))
+    M = st.sh_coeffs
+    f_mean2D, f_conic = d_mean2D.astype(np.float32), d_conic.astype(np.float32)
+    f_opac, f_colors, f_invd = d_opac.astype(np.float32), d_colors.astype(np.float32), d_invd.astype(np.float32)
+    d_means3D = np.zeros((P, 3), np.float32)
+    d_cov3D = np.zeros((P, 6), np.float32)
+    d_sh = np.zeros((P, max(M, 1), 3), np.float32)
+    d_scales = np.zeros((P, 3), np.float32)
+    d_rots = np.zeros((P, 4), np.float32)
+    cov = _f32(cov3D_precomp) if cov3D_precomp is not None else geom["cov3D"]
+    shs = None if colors_precomp is not None else _f32(inp["shs"])
+    scales = None if cov3D_precomp is not None else _f32(inp["scales"])
+    rots = None if cov3D_precomp is not None else _f32(inp["rotations"])
+    lib().gso_preprocess_backward(
+        C.byref(cs), C.c_int(P), _p(_f32(inp["means3D"])), _p(geom["radii"]), _p(shs), _p(geom["clamped"]),
+        _p(_f32(inp["opacities"])), _p(scales), _p(rots), _p(cov), C.c_int(cov3D_precomp is not None),
+        C.c_int(colors_precomp is not None), _p(_f32(inp["viewmatrix"])), _p(_f32(inp["projmatrix"])),
+        _p(_f32(inp["campos"])), _p(f_mean2D), _p(f_conic), _p(f_opac), _p(f_colors),
+        _p(f_invd) if dLd is not None else None, _p(d_means3D), _p(d_cov3D),
+        _p(d_sh) if colors_precomp is None else None, _p(d_scales) if cov3D_precomp is None else None,
+        _p(d_rots) if cov3D_precomp is None else None)
+    d_means2D3 = np.zeros((P, 3), np.float32)
+    d_means2D3[:, :2] = f_mean2D
+    return dict(dL_dmeans2D=d_means2D3, dL_dcolors=f_colors, dL_dopacity=f_opac.reshape(P, 1),
+                dL_dmeans3D=d_means3D, dL_dcov3D=d_cov3D, dL_dsh=d_sh, dL_dscales=d_scales, dL_drotations=d_rots,
+                dL_dconic=f_conic, dL_dinvdepths=f_invd)
+
+
 def knn_dist2(points):
     points = _f32(points)
     P = points.shape[0]

@@ -40,12 +40,27 @@ def _sh_to_rgb(deg, sh, dirs):
     return torch.clamp_min(res, 0.0), res < 0
 
 
-@torch.no_grad()
 def render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, campos, bg, H, W, tanfovx, tanfovy,
            sh_degree=3, scale_modifier=1.0, near_plane=0.05, antialiasing=False):
-    """All arguments are float32 CPU tensors laid out as the rasterizer takes them (viewmatrix/projmatrix are the
-    transposed 4x4s).  Returns dict(color (3,H,W), invdepth (1,H,W), radii, n_contrib, final_T, num_rendered)."""
+    """All arguments are CPU tensors of one floating dtype (float32 for the numerics gate, float64 for the
+    autograd check of the backward oracle) laid out as the rasterizer takes them (viewmatrix/projmatrix are the
+    transposed 4x4s).  Differentiable w.r.t. means3D, shs, opacities, scales, rotations (piecewise: the cull /
+    sort / threshold decisions are constants).  Returns dict(color (3,H,W), invdepth (1,H,W), radii, ...)."""
     P = means3D.shape[0]
+    dt = means3D.dtype
+    _default = torch.get_default_dtype()
+    torch.set_default_dtype(dt)
+    try:
+        return _render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, campos, bg, H, W, tanfovx,
+                       tanfovy, sh_degree, scale_modifier, near_plane, antialiasing)
+    finally:
+        torch.set_default_dtype(_default)
+
+
+def _render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, campos, bg, H, W, tanfovx, tanfovy,
+            sh_degree, scale_modifier, near_plane, antialiasing):
+    P = means3D.shape[0]
+    dt = means3D.dtype
     V = viewmatrix.reshape(4, 4)  # row-vector convention: p_view = [p,1] @ V
     Pm = projmatrix.reshape(4, 4)
     ones = torch.ones(P, 1)
@@ -91,12 +106,12 @@ def render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, c
     root = torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
     radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + root, mid - root)))
     pix = torch.stack((((ndc[:, 0].double() + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1].double() + 1.0) * H - 1.0) * 0.5),
-                      1).float()
+                      1).to(dt)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    ir = radius.nan_to_num(0.0).to(torch.int32).float()
+    ir = radius.detach().nan_to_num(0.0).to(torch.int32).to(dt)
 
     def tile(v, g):
-        return torch.clamp(torch.trunc(v / 16.0).nan_to_num(0.0).to(torch.int64), 0, g)
+        return torch.clamp(torch.trunc(v.detach() / 16.0).nan_to_num(0.0).to(torch.int64), 0, g)
 
     rminx, rminy = tile(pix[:, 0] - ir, gx), tile(pix[:, 1] - ir, gy)
     rmaxx, rmaxy = tile(pix[:, 0] + ir + 15.0, gx), tile(pix[:, 1] + ir + 15.0, gy)
@@ -121,23 +136,22 @@ def render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, c
     ty_ = rminy[g_rep] + local // wdt
     tx_ = rminx[g_rep] + local % wdt
     tile_id = ty_ * gx + tx_
-    dbits = depth.view(torch.int32).to(torch.int64)[g_rep]
+    dbits = depth.detach().float().view(torch.int32).to(torch.int64)[g_rep]
     keys = (tile_id << 32) | dbits
     order = torch.sort(keys, stable=True).indices
     keys_s, g_s = keys[order], g_rep[order]
     tiles_s = keys_s >> 32
     bounds = torch.searchsorted(tiles_s, torch.arange(gx * gy + 1))
 
-    color = torch.zeros(3, H, W)
-    invdepth = torch.zeros(1, H, W)
+    color_tiles, invd_tiles = {}, {}
     final_T = torch.ones(H, W)
     n_contrib = torch.zeros(H, W, dtype=torch.int32)
     ys, xs = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
     for t in range(gx * gy):
         a, b = int(bounds[t]), int(bounds[t + 1])
         x0, y0 = (t % gx) * 16, (t // gx) * 16
-        pxs = (x0 + xs).reshape(-1).float()
-        pys = (y0 + ys).reshape(-1).float()
+        pxs = (x0 + xs).reshape(-1).to(dt)
+        pys = (y0 + ys).reshape(-1).to(dt)
         n = b - a
         T = torch.ones(256)
         C = torch.zeros(256, 3)
@@ -154,7 +168,7 @@ def render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, c
             a_eff = torch.where(valid, alpha, torch.zeros(()))
             Tcum = torch.cumprod(1.0 - a_eff, 0)
             T_before = torch.cat((torch.ones(1, 256), Tcum[:-1]), 0)
-            stop = valid & (T_before * (1.0 - a_eff) < 0.0001)
+            stop = valid & ((T_before * (1.0 - a_eff)).detach() < 0.0001)
             alive = torch.cumsum(stop.to(torch.int32), 0) == 0  # strictly before the terminating instance
             contrib = valid & alive
             w = torch.where(contrib, a_eff * T_before, torch.zeros(()))
@@ -169,11 +183,18 @@ def render(means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, c
         hh, ww = min(16, H - y0), min(16, W - x0)
         sel = (ys < hh) & (xs < ww)
         col = (C + T[:, None] * bg[None, :]).reshape(16, 16, 3)
-        color[:, y0:y0 + hh, x0:x0 + ww] = col[:hh, :ww].permute(2, 0, 1)
-        invdepth[0, y0:y0 + hh, x0:x0 + ww] = D.reshape(16, 16)[:hh, :ww]
-        final_T[y0:y0 + hh, x0:x0 + ww] = T.reshape(16, 16)[:hh, :ww]
+        color_tiles[t] = col.permute(2, 0, 1)
+        invd_tiles[t] = D.reshape(16, 16)
+        final_T[y0:y0 + hh, x0:x0 + ww] = T.detach().reshape(16, 16)[:hh, :ww]
         n_contrib[y0:y0 + hh, x0:x0 + ww] = last.reshape(16, 16)[:hh, :ww]
         del sel
+    # assemble the image from the tiles without in-place writes (keeps autograd intact)
+    rows_c, rows_d = [], []
+    for ty in range(gy):
+        rows_c.append(torch.cat([color_tiles[ty * gx + tx] for tx in range(gx)], dim=2))
+        rows_d.append(torch.cat([invd_tiles[ty * gx + tx] for tx in range(gx)], dim=1))
+    color = torch.cat(rows_c, dim=1)[:, :H, :W]
+    invdepth = torch.cat(rows_d, dim=0)[None, :H, :W]
     return dict(color=color, invdepth=invdepth, radii=radii, final_T=final_T, n_contrib=n_contrib,
                 num_rendered=R_total, point_list=g_s, keys=keys_s, means2D=pix, depths=depth, rgb=rgb,
                 conic=conic, opacity=opac, tiles_touched=torch.where(visible, touched, torch.zeros(())).long())

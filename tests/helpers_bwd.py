@@ -1,0 +1,83 @@
+"""Backward parity helpers: HIP path (through the C ABI / the autograd Function) vs the backward oracle."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from gsworld_amd import scenes
+from oracle import gs_oracle as go
+from tests import helpers as hp
+
+GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+              "dL_drotations")
+
+
+def gpu_forward_backward(inp, st, bg, dL_dcolor, dL_dinvdepth, device="cuda", colors_precomp=None,
+                         cov3D_precomp=None):
+    from gsworld_amd import _C
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    empty = torch.empty(0, device=device)
+    sh = empty if colors_precomp is not None else t(inp["shs"])
+    colors = t(colors_precomp) if colors_precomp is not None else empty
+    scales = empty if cov3D_precomp is not None else t(inp["scales"])
+    rots = empty if cov3D_precomp is not None else t(inp["rotations"])
+    cov = t(cov3D_precomp) if cov3D_precomp is not None else empty
+    args = dict(bg=t(np.asarray(bg, np.float32)), means=t(inp["means3D"]), op=t(inp["opacities"]).reshape(-1, 1),
+                view=t(inp["viewmatrix"]).reshape(4, 4), proj=t(inp["projmatrix"]).reshape(4, 4), campos=t(inp["campos"]))
+    old = _C.NEAR_PLANE
+    _C.NEAR_PLANE = st.near_plane
+    try:
+        R, color, radii, gB, bB, iB, invd = _C.rasterize_gaussians(
+            args["bg"], args["means"], colors, args["op"], scales, rots, st.scale_modifier, cov, args["view"],
+            args["proj"], st.tanfovx, st.tanfovy, st.image_height, st.image_width, sh, st.sh_degree, args["campos"],
+            False, st.antialiasing, False)
+        grads = _C.rasterize_gaussians_backward(
+            args["bg"], args["means"], radii, colors, args["op"], scales, rots, st.scale_modifier, cov, args["view"],
+            args["proj"], st.tanfovx, st.tanfovy, t(dL_dcolor), None if dL_dinvdepth is None else t(dL_dinvdepth), sh,
+            st.sh_degree, args["campos"], gB, R, bB, iB, st.antialiasing, False)
+    finally:
+        _C.NEAR_PLANE = old
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in zip(GRAD_NAMES, grads)}, color.cpu().numpy()
+
+
+def compare_grads(ref: dict, got: dict, names=GRAD_NAMES, rtol=2e-3, frac_ok=0.999, max_norm_err=2e-2):
+    rep = {}
+    for k in names:
+        a, b = ref[k], got[k].reshape(ref[k].shape)
+        if a.size == 0:
+            continue
+        scale = float(np.abs(a).max())
+        if scale == 0.0:
+            assert float(np.abs(b).max()) == 0.0, f"{k}: expected all-zero gradient"
+            continue
+        err = np.abs(a - b) / (np.abs(a) + 1e-3 * scale)
+        rep[k] = dict(max_norm_err=float(err.max()), frac_within=float((err <= rtol).mean()), scale=scale)
+        assert np.isfinite(b).all(), f"{k}: non-finite gradient"
+        assert rep[k]["frac_within"] >= frac_ok, (k, rep[k])
+        assert rep[k]["max_norm_err"] <= max_norm_err, (k, rep[k])
+    return rep
+
+
+def run_case(n, W, H, seed, device="cuda", aa=False, deg=3, bg=(0.3, 0.1, 0.6), scale_boost=0.5, with_invdepth=True,
+             raw=None, cam=None):
+    raw = raw if raw is not None else scenes.random_scene_camera_frame(n, seed=seed)
+    if scale_boost:
+        raw.scaling += scale_boost
+    cam = cam if cam is not None else scenes.identity_camera(W, H, 60.0)
+    inp = hp.np_inputs(raw, cam)
+    st = hp.oracle_settings(cam, antialiasing=aa, sh_degree=deg)
+    bg = np.asarray(bg, np.float32)
+    fwd = hp.oracle_forward(inp, st, bg, border_eps=0.0)
+    rng = np.random.default_rng(seed)
+    dLc = rng.standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    dLd = rng.standard_normal((1, cam.image_height, cam.image_width)).astype(np.float32) if with_invdepth else None
+    ref = go.backward(st, fwd, inp, bg, dLc, dLd)
+    got, color = gpu_forward_backward(inp, st, bg, dLc, dLd, device=device)
+    assert np.abs(color - fwd["color"]).max() < 1e-3
+    return compare_grads(ref, got)
+
+
+def smoke_backward(device="cuda:0"):
+    return run_case(5000, 96, 64, seed=41, device=device)
