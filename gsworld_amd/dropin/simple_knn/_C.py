@@ -1,0 +1,1 @@
+from gsworld_amd.knn import distCUDA2  # noqa: F401

@@ -175,6 +175,26 @@ typedef struct GsrGrads {
 int gsr_backward(const GsrSettings *settings, const GsrInputs *in, const GsrBackwardInputs *bw,
                  const GsrGrads *grads, void *stream);
 
+/*
+ * simple_knn._C.distCUDA2(points (P,3)) -> (P): mean of the squared distances to the 3 nearest OTHER points
+ * (exact; self excluded by index, duplicates give 0).  `workspace` needs gsr_knn_workspace_bytes(P) bytes.
+ */
+size_t gsr_knn_workspace_bytes(int32_t P);
+int gsr_knn_dist2(int32_t P, const float *points, float *mean_dist2, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/*
+ * fused_ssim_cuda.fusedssim / fusedssim_backward: images are (B,CH,H,W) contiguous; 11x11 Gaussian window
+ * (sigma 1.5), zero "same" padding.  With train != 0 the three partial maps needed by the backward are stored.
+ * The backward differentiates w.r.t. img1 only (as upstream).
+ */
+int gsr_ssim_forward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float *img1,
+                     const float *img2, int32_t train, float *ssim_map, float *dm_dmu1, float *dm_dsigma1_sq,
+                     float *dm_dsigma12, void *stream);
+int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, float C2, const float *img1,
+                      const float *img2, const float *dL_dmap, const float *dm_dmu1, const float *dm_dsigma1_sq,
+                      const float *dm_dsigma12, float *dL_dimg1, void *stream);
+
 /* Self-test of the DPP wave reduction used by the backward: out4[w] = sum(in256[64w .. 64w+63]). */
 int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream);
 
