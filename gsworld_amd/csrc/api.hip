@@ -10,6 +10,7 @@
 
 namespace {
 thread_local char g_err[512] = "";
+bool g_force_radix_binning = false;  // tests: exercise the large-grid fallback on small images
 
 // ---- optional stage timing with HIP events on the caller's stream (bench / profiling only) ----------------
 constexpr int kStages = GSR_PROFILE_STAGES;
@@ -54,7 +55,9 @@ extern "C" {
 const char *gsr_last_error(void) { return g_err; }
 const char *gsr_version(void) { return "gsworld_amd-gsr 0.1 (gfx950)"; }
 
-size_t gsr_geom_bytes(int32_t P) { return GeomState::required(P); }
+size_t gsr_geom_bytes(int32_t P, int32_t width, int32_t height) {
+    return GeomState::required(P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE));
+}
 size_t gsr_binning_bytes(int64_t r_capacity) { return BinningState::required(r_capacity); }
 size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageState::required(width, height); }
 
@@ -114,6 +117,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const bool debug = st->debug != 0;
     const int W = st->image_width, H = st->image_height;
     if (stats) memset(stats, 0, sizeof(*stats));
+    const int tiles = gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE);
 
     if (in->P == 0) {
         // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
@@ -130,13 +134,13 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         return GSR_E_INVALID;
     }
 
-    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P));
+    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles));
     char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
     if (!geom_mem || !img_mem) {
         gsr_set_error("gsr_forward: resize callback returned NULL");
         return GSR_E_ALLOC;
     }
-    const GeomState g = GeomState::carve(geom_mem, in->P);
+    const GeomState g = GeomState::carve(geom_mem, in->P, tiles);
     const ImageState img = ImageState::carve(img_mem, W, H);
 
     if (hipMemsetAsync(g.hdr, 0, sizeof(GsrHeader), stream) != hipSuccess) {
@@ -151,8 +155,14 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(2, stream);
 
     const bool exact = r_capacity <= 0;
-    // exact mode first scans with an unlimited capacity, reads R back, then sizes the binning state exactly
-    if (int e = gsr_launch_tile_offsets(in->P, g, exact ? 0xFFFFFFFFu : (uint32_t)r_capacity, debug, stream)) return e;
+    const bool counting = GeomState::counting(tiles) && !g_force_radix_binning;
+    // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
+    const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
+    if (counting) {
+        if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
+    } else {
+        if (int e = gsr_launch_tile_offsets(in->P, g, cap32, debug, stream)) return e;
+    }
     prof_mark(3, stream);
     int64_t cap = r_capacity;
     if (exact) {
@@ -175,14 +185,23 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         return GSR_E_ALLOC;
     }
     const BinningState b = BinningState::carve(bin_mem, cap);
-    if (int e = gsr_launch_emit_and_tile_sort(*st, in->P, g, b, img, cap, debug, stream)) return e;
-    const int side = BinningState::tile_passes(gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE)) & 1;
+    if (counting) {
+        if (int e = gsr_launch_tile_place(*st, in->P, g, b, img, debug, stream)) return e;
+    } else {
+        if (int e = gsr_launch_emit_and_tile_sort(*st, in->P, g, b, img, cap, debug, stream)) return e;
+    }
     prof_mark(4, stream);
-    if (int e = gsr_launch_render(*st, g, b.gidx[side], img, in->background, out->out_color, out->out_invdepth, stream))
+    // both binning paths leave the point list in gidx[0]
+    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();
     return gsr_check_launch("render", debug, stream);
+}
+
+int gsr_debug_force_radix_binning(int enable) {
+    g_force_radix_binning = enable != 0;
+    return GSR_OK;
 }
 
 int gsr_profile_enable(int mode) {
@@ -254,7 +273,7 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity,
     }
     memset(v, 0, sizeof(*v));
     if (geom) {
-        const GeomState g = GeomState::carve((char *)geom, P);
+        const GeomState g = GeomState::carve((char *)geom, P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE));
         v->splat = reinterpret_cast<const float *>(g.splat);
         v->cov3D = g.cov3D;
         v->clamped = reinterpret_cast<const uint8_t *>(g.clamped);
@@ -264,9 +283,8 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity,
     }
     if (binning) {
         const BinningState b = BinningState::carve((char *)binning, r_capacity);
-        const int side = BinningState::tile_passes(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) & 1;
-        v->point_list = b.gidx[side];
-        v->point_tiles = b.tile[side];
+        v->point_list = b.gidx[0];  // both binning paths finish in side 0
+        v->point_tiles = nullptr;   // tile ids follow from `ranges` (the counting path never materialises them)
     }
     if (image) {
         const ImageState s = ImageState::carve((char *)image, width, height);

@@ -495,12 +495,11 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: forward state / dL_dout_color / radii missing");
         return GSR_E_INVALID;
     }
-    const GeomState g = GeomState::carve((char *)bw->geom, P);
+    const GeomState g = GeomState::carve((char *)bw->geom, P, gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE));
     const BinningState b = BinningState::carve((char *)bw->binning, bw->num_rendered);
     const ImageState img = ImageState::carve((char *)bw->image, W, H);
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
-    const int side = BinningState::tile_passes(gx * gy) & 1;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, b.gidx[side],
+    hipLaunchKernelGGL(render_backward_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, b.gidx[0],
                        g.splat, W, H, gx, in->background, img.final_T, img.n_contrib, bw->dL_dout_color,
                        bw->dL_dout_invdepth, gr->dL_dmeans2D, gr->dL_dconic, gr->dL_dopacity, gr->dL_dcolors,
                        gr->dL_dinvdepths);

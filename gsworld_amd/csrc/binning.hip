@@ -88,7 +88,163 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t *
     if (i == R - 1u) ranges[t].y = R;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Counting placement (default path, tile grids up to GSR_MAX_COUNT_TILES).
+//
+// The Gaussians arrive depth-sorted, and every Gaussian touches DISTINCT tiles.  The final slot of instance
+// (g, t) is therefore  tile_start[t] + #{Gaussians earlier in depth order that touch t}.  A workgroup owns 256
+// consecutive depth ranks (64 per wave); a wave walks its Gaussians one at a time with its 64 lanes spread over
+// that Gaussian's tiles, so one LDS counter per (wave, tile) ranks instances in depth order without any key
+// material: ds_add_rtn from one wave retires in issue order and lanes of one instruction never collide.
+//   tile_count  : per-workgroup tile histogram  -> table[t][workgroup]
+//   row scan    : exclusive scan of each tile's row over the workgroups, row total -> totals[t]   (sort.hip)
+//   tile_starts : exclusive scan of totals -> ranges[t] = [start, start+total), R, overflow check
+//   tile_place  : recount per wave, turn the counters into running cursors, write the point list
+// This replaces emit + a 2-pass radix sort of R (tile, index) pairs + identifyTileRanges.
+// ---------------------------------------------------------------------------------------------------------
+template <bool PLACE>
+__device__ __forceinline__ void walk_wave(const uint32_t *__restrict__ order, const uint32_t *__restrict__ tiles_touched,
+                                          const uint2 *__restrict__ rects, uint32_t V, uint32_t rank0, int gx,
+                                          uint32_t *cnt, uint32_t *__restrict__ out) {
+    const int lane = gsr_lane();
+    const uint32_t rank = rank0 + (uint32_t)lane;
+    const bool valid = rank < V;
+    const uint32_t g = valid ? order[rank] : 0u;
+    const uint32_t t = valid ? tiles_touched[g] : 0u;
+    uint2 rc = make_uint2(0u, 0u);
+    if (valid) rc = rects[g];
+    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16, width = (rc.y & 0xffffu) - minx;
+    uint64_t todo = __ballot(t > 0u);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)t, src);
+        const uint32_t bg = (uint32_t)__builtin_amdgcn_readlane((int)g, src);
+        const uint32_t bminx = (uint32_t)__builtin_amdgcn_readlane((int)minx, src);
+        const uint32_t bminy = (uint32_t)__builtin_amdgcn_readlane((int)miny, src);
+        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)width, src);
+        for (uint32_t j = (uint32_t)lane; j < bt; j += 64u) {
+            const uint32_t yy = j / bw, xx = j - yy * bw;
+            const uint32_t tile = (bminy + yy) * (uint32_t)gx + (bminx + xx);
+            if (PLACE) {
+                const uint32_t pos = atomicAdd(&cnt[tile], 1u);
+                out[pos] = bg;
+            } else {
+                atomicAdd(&cnt[tile], 1u);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_count_kernel(const uint32_t *__restrict__ order,
+                                                               const uint32_t *__restrict__ tiles_touched,
+                                                               const uint2 *__restrict__ rects,
+                                                               const GsrHeader *__restrict__ hdr, int gx, int T,
+                                                               uint32_t *__restrict__ table, int nb_stride) {
+    extern __shared__ uint32_t s_cnt[];  // [4][T]
+    const uint32_t V = hdr->V;
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
+    if (base >= V) return;
+    for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
+    __syncthreads();
+    walk_wave<false>(order, tiles_touched, rects, V, base + (uint32_t)gsr_wave() * 64u, gx, s_cnt + gsr_wave() * T,
+                     nullptr);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK)
+        table[(size_t)t * nb_stride + blockIdx.x] = s_cnt[t] + s_cnt[T + t] + s_cnt[2 * T + t] + s_cnt[3 * T + t];
+}
+
+// one workgroup: totals[T] -> ranges, R; untouched tiles keep (0,0) like the reference's memset
+__global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *__restrict__ totals, int T,
+                                                                GsrHeader *hdr, uint32_t r_capacity,
+                                                                uint2 *__restrict__ ranges) {
+    __shared__ uint32_t s_w[4];
+    uint32_t sum = 0;
+    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) sum += totals[t];
+    uint32_t grand;
+    gsr_block_incl_scan(sum, s_w, grand);
+    const bool overflow = grand > r_capacity;
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += GSR_BLOCK) {
+        const int t = base + (int)threadIdx.x;
+        const uint32_t v = t < T ? totals[t] : 0u;
+        uint32_t total;
+        const uint32_t incl = gsr_block_incl_scan(v, s_w, total);
+        if (t < T) {
+            const uint32_t start = carry + incl - v;
+            ranges[t] = (v == 0u || overflow) ? make_uint2(0u, 0u) : make_uint2(start, start + v);
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        hdr->R_raw = grand;
+        hdr->r_capacity = r_capacity;
+        hdr->overflow = overflow ? 1u : 0u;
+        hdr->R = overflow ? 0u : grand;
+    }
+}
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *__restrict__ order,
+                                                               const uint32_t *__restrict__ tiles_touched,
+                                                               const uint2 *__restrict__ rects,
+                                                               const GsrHeader *__restrict__ hdr, int gx, int T,
+                                                               const uint32_t *__restrict__ table, int nb_stride,
+                                                               const uint2 *__restrict__ ranges,
+                                                               uint32_t *__restrict__ point_list) {
+    extern __shared__ uint32_t s_cnt[];  // [4][T]: counts, then running cursors
+    const uint32_t V = hdr->V;
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
+    if (base >= V || hdr->overflow) return;
+    for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
+    __syncthreads();
+    const int wave = gsr_wave();
+    walk_wave<false>(order, tiles_touched, rects, V, base + (uint32_t)wave * 64u, gx, s_cnt + wave * T, nullptr);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) {
+        const uint32_t c0 = s_cnt[t], c1 = s_cnt[T + t], c2 = s_cnt[2 * T + t];
+        const uint32_t c3 = s_cnt[3 * T + t];
+        if ((c0 | c1 | c2 | c3) != 0u) {
+            const uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + blockIdx.x];
+            s_cnt[t] = s;
+            s_cnt[T + t] = s + c0;
+            s_cnt[2 * T + t] = s + c0 + c1;
+            s_cnt[3 * T + t] = s + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
+    walk_wave<true>(order, tiles_touched, rects, V, base + (uint32_t)wave * 64u, gx, s_cnt + wave * T, point_list);
+}
+
 }  // namespace
+
+// default path, part 1: per-tile instance counts -> ranges and R (no instance buffer needed yet)
+int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
+                          uint32_t r_capacity, bool debug, hipStream_t stream) {
+    const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
+    const int T = gx * gy;
+    const int nb = GeomState::prep_blocks(P);
+    const size_t lds = (size_t)4 * T * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
+                       g.hdr, gx, T, g.tile_table, nb);
+    if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
+    if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
+                       img.ranges);
+    return gsr_check_launch("tile_starts", debug, stream);
+}
+
+// default path, part 2: write the point list (tile-major, depth order, index order on ties)
+int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                          const ImageState &img, bool debug, hipStream_t stream) {
+    const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
+    const int T = gx * gy;
+    const int nb = GeomState::prep_blocks(P);
+    const size_t lds = (size_t)4 * T * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_place_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
+                       g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
+    return gsr_check_launch("tile_place", debug, stream);
+}
 
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream) {
@@ -108,5 +264,14 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
     const int side = BinningState::tile_passes(tiles) & 1;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(r_capacity > 0 ? r_capacity : 1, GSR_BLOCK)),
                        dim3(GSR_BLOCK), 0, stream, b.tile[side], g.hdr, img.ranges);
-    return gsr_check_launch("tile_ranges", debug, stream);
+    if (int e = gsr_check_launch("tile_ranges", debug, stream)) return e;
+    if (side == 1) {
+        // the point list always ends in side 0 (what render / backward / state views read)
+        const size_t n = (size_t)(r_capacity > 0 ? r_capacity : 1) * sizeof(uint32_t);
+        if (hipMemcpyAsync(b.gidx[0], b.gidx[1], n, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+            gsr_set_error("tile sort: result copy failed");
+            return GSR_E_HIP;
+        }
+    }
+    return GSR_OK;
 }

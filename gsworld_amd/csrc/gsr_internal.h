@@ -14,6 +14,7 @@
 #define GSR_SORT_CHUNK (GSR_BLOCK * GSR_SORT_ITEMS)
 #define GSR_RADIX_BITS 8
 #define GSR_RADIX_BINS 256
+#define GSR_MAX_COUNT_TILES 3840         // counting placement keeps 4 x tiles LDS counters per workgroup (<= 60 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
 // depends on a value the host would have to read back.
@@ -45,6 +46,8 @@ struct GeomState {
     uint32_t *sort_table;     // [256 * nb]  per-block digit histograms (digit-major)
     uint32_t *sort_totals;    // [256]
     uint32_t *tile_bsum;      // [nb+1] tiles touched per 2048 depth-ordered Gaussians -> exclusive offsets
+    uint32_t *tile_table;     // [tiles * prep_blocks]  per-workgroup tile histograms (counting placement)
+    uint32_t *tile_totals;    // [tiles]
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -55,7 +58,8 @@ struct GeomState {
         p += gsr_align_up(count * sizeof(T));
         return r;
     }
-    static GeomState carve(char *base, int32_t P, size_t *bytes = nullptr) {
+    static bool counting(int tiles) { return tiles <= GSR_MAX_COUNT_TILES; }
+    static GeomState carve(char *base, int32_t P, int tiles, size_t *bytes = nullptr) {
         GeomState g;
         char *p = base;
         const size_t n = (size_t)(P > 0 ? P : 1);
@@ -73,12 +77,15 @@ struct GeomState {
         g.sort_table = take<uint32_t>(p, (size_t)GSR_RADIX_BINS * sort_blocks(P));
         g.sort_totals = take<uint32_t>(p, GSR_RADIX_BINS);
         g.tile_bsum = take<uint32_t>(p, (size_t)sort_blocks(P) + 1);
+        const size_t tt = counting(tiles) ? (size_t)tiles : 0;
+        g.tile_table = take<uint32_t>(p, tt * prep_blocks(P) + 1);
+        g.tile_totals = take<uint32_t>(p, tt + 1);
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
-    static size_t required(int32_t P) {
+    static size_t required(int32_t P, int tiles) {
         size_t bytes = 0;
-        carve(nullptr, P, &bytes);
+        carve(nullptr, P, tiles, &bytes);
         return bytes;
     }
 };
@@ -116,6 +123,8 @@ struct BinningState {
         return bits;
     }
     static int tile_passes(int num_tiles) { return (tile_bits(num_tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS; }
+    // which ping-pong side holds the final point list
+    static int result_side(int num_tiles) { return num_tiles <= GSR_MAX_COUNT_TILES ? 0 : (tile_passes(num_tiles) & 1); }
 };
 
 // ---- image state (per pixel / per tile) ----------------------------------------------------------------
@@ -154,6 +163,12 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
                       hipStream_t stream);
+int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
+                          uint32_t r_capacity, bool debug, hipStream_t stream);
+int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                          const ImageState &img, bool debug, hipStream_t stream);
+int gsr_launch_rowscan(uint32_t *table, const uint32_t *n_ptr, int nb_stride, int chunk, int rows, uint32_t *totals,
+                       bool debug, hipStream_t stream);
 int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr, int64_t n_max, int bits,
                        uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream);
 

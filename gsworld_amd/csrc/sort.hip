@@ -93,10 +93,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t *_
 // one workgroup per digit: exclusive scan of its row over the live blocks, row total -> totals[d]
 __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__restrict__ table,
                                                                   const uint32_t *__restrict__ n_ptr, int nb_stride,
-                                                                  uint32_t *__restrict__ totals) {
+                                                                  uint32_t *__restrict__ totals, int chunk) {
     __shared__ uint32_t s_w[4];
     const uint32_t n = *n_ptr;
-    const int nb = (int)((n + (uint32_t)GSR_SORT_CHUNK - 1u) / (uint32_t)GSR_SORT_CHUNK);
+    const int nb = (int)((n + (uint32_t)chunk - 1u) / (uint32_t)chunk);
     uint32_t *row = table + (size_t)blockIdx.x * nb_stride;
     uint32_t carry = 0;
     for (int base = 0; base < nb; base += GSR_BLOCK) {
@@ -184,6 +184,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_blocksum_kernel(const uint32_t
 
 }  // namespace
 
+// Exclusive scan of each of `rows` table rows over its live entries (ceil(*n_ptr / chunk)); row totals -> totals.
+int gsr_launch_rowscan(uint32_t *table, const uint32_t *n_ptr, int nb_stride, int chunk, int rows, uint32_t *totals,
+                       bool debug, hipStream_t stream) {
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(rows), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb_stride, totals,
+                       chunk);
+    return gsr_check_launch("rowscan", debug, stream);
+}
+
 // Stable LSD radix sort of (key, val) pairs on the low `bits` bits.  Result lands in key[passes & 1].
 int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr, int64_t n_max, int bits,
                        uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream) {
@@ -196,7 +204,7 @@ int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr
                            mask);
         if (int e = gsr_check_launch("radix_hist", debug, stream)) return e;
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(GSR_RADIX_BINS), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb,
-                           totals);
+                           totals, GSR_SORT_CHUNK);
         if (int e = gsr_check_launch("radix_rowscan", debug, stream)) return e;
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(GSR_BLOCK), 0, stream, key[src], val[src],
                            key[src ^ 1], val[src ^ 1], n_ptr, table, totals, nb, shift, mask, nbits);

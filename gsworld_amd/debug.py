@@ -42,7 +42,13 @@ def state_view(P: int, width: int, height: int, num_rendered: int, num_visible: 
     out["depth_order"] = _view(geomBuffer, v.depth_order, max(num_visible, 0), torch.int32)
     if binningBuffer is not None and num_rendered > 0:
         out["point_list"] = _view(binningBuffer, v.point_list, num_rendered, torch.int32)
-        out["point_tiles"] = _view(binningBuffer, v.point_tiles, num_rendered, torch.int32)
+    if imgBuffer is not None and "point_list" in out:
+        # tile id of every slot of the point list, reconstructed from the ranges
+        r = _view(imgBuffer, v.ranges, 2 * gx * gy, torch.int32).view(gx * gy, 2).to(torch.int64)
+        tiles = torch.zeros(num_rendered, dtype=torch.int64, device=r.device)
+        nonempty = r[:, 1] > r[:, 0]
+        tiles[r[nonempty, 0]] = torch.nonzero(nonempty).squeeze(1)
+        out["point_tiles"] = torch.cummax(tiles, 0).values.to(torch.int32)
     if imgBuffer is not None:
         out["ranges"] = _view(imgBuffer, v.ranges, 2 * gx * gy, torch.int32).view(gx * gy, 2)
         out["final_T"] = _view(imgBuffer, v.final_T, width * height, torch.float32).view(height, width)

@@ -96,7 +96,7 @@ const char *gsr_last_error(void);
 const char *gsr_version(void);
 
 /* Bytes needed for each state buffer. */
-size_t gsr_geom_bytes(int32_t P);
+size_t gsr_geom_bytes(int32_t P, int32_t width, int32_t height);
 size_t gsr_binning_bytes(int64_t r_capacity);
 size_t gsr_image_bytes(int32_t width, int32_t height);
 
@@ -124,7 +124,7 @@ typedef struct GsrStateView {
     const uint16_t *rects;        /* (P,4) min.x min.y max.x max.y */
     const uint32_t *depth_order;  /* (V) Gaussian indices, ascending (depth bits, index) */
     const uint32_t *point_list;   /* (R) Gaussian index per instance, tile-major / depth / index order */
-    const uint32_t *point_tiles;  /* (R) tile id per instance (sorted) */
+    const uint32_t *point_tiles;  /* always NULL: tile ids follow from `ranges` */
     const uint32_t *ranges;       /* (tiles,2) */
     const float *final_T;         /* (H*W) */
     const uint32_t *n_contrib;    /* (H*W) */
@@ -144,6 +144,8 @@ typedef struct GsrProfile {
     double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
 } GsrProfile;
 int gsr_profile_enable(int mode);
+/* Tests only: route binning through the radix-sort fallback used for tile grids above 3840 tiles. */
+int gsr_debug_force_radix_binning(int enable);
 int gsr_profile_collect(GsrProfile *out);
 
 /*

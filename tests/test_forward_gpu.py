@@ -102,6 +102,22 @@ def test_tabletop_config2_full(cuda_device):
     assert rep["P"] == scenes.XARM6_ALIGN_NUM_GAUSSIANS
 
 
+def test_radix_fallback_binning_matches_too(cuda_device):
+    """Tile grids above 3840 tiles use emit + radix sort instead of the counting placement: same point list."""
+    from gsworld_amd._lib import lib
+
+    raw = scenes.random_scene_camera_frame(30_000, seed=14)
+    lib().gsr_debug_force_radix_binning(1)
+    try:
+        _run(raw, scenes.identity_camera(200, 120, 60.0))   # 104 tiles: 1 radix pass (result side 1 -> copied)
+        _run(raw, scenes.identity_camera(640, 480, 60.0))   # 1200 tiles: 2 passes
+    finally:
+        lib().gsr_debug_force_radix_binning(0)
+    # a grid that is natively above the counting limit (120 x 68 = 8160 tiles)
+    rep = _run(scenes.random_scene_camera_frame(30_000, seed=15), scenes.identity_camera(1920, 1080, 60.0))
+    assert rep["R"] > 0
+
+
 def test_mark_visible(cuda_device):
     from oracle import gs_oracle as go
     from gsworld_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer

@@ -21,7 +21,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert not missing, missing
     assert b"gfx950" in lib.gsr_version()
     # sizes are pure host arithmetic: monotone and 256-byte aligned
-    g1, g2 = lib.gsr_geom_bytes(1000), lib.gsr_geom_bytes(2000)
+    g1, g2 = lib.gsr_geom_bytes(1000, 640, 480), lib.gsr_geom_bytes(2000, 640, 480)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.gsr_binning_bytes(10_000) % 256 == 0 and lib.gsr_image_bytes(640, 480) % 256 == 0
     # argument validation never touches the GPU
