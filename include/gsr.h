@@ -144,6 +144,8 @@ typedef struct GsrProfile {
     double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
 } GsrProfile;
 int gsr_profile_enable(int mode);
+/* A/B measurements: 0 = LDS-staged compositing kernel, 1 = wave-independent kernel (default). */
+int gsr_debug_set_render_variant(int variant);
 /* Tests only: route binning through the radix-sort fallback used for tile grids above 3840 tiles. */
 int gsr_debug_force_radix_binning(int enable);
 int gsr_profile_collect(GsrProfile *out);
