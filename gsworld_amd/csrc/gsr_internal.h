@@ -24,7 +24,8 @@ struct GsrHeader {
     uint32_t overflow;    // R_raw > r_capacity
     uint32_t r_capacity;
     uint32_t R_raw;       // sum of tiles touched, even when it overflowed
-    uint32_t pad[59];
+    uint32_t tile_queue;  // ticket counter of the compositing kernel's tile queue (zeroed with the header)
+    uint32_t pad[58];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -132,11 +133,13 @@ struct ImageState {
     uint2 *ranges;       // [tiles]
     float *final_T;      // [W*H]
     uint32_t *n_contrib; // [W*H]
+    uint32_t *tile_order; // [tiles] tile ids, longest instance list first (compositing queue order)
     static ImageState carve(char *base, int32_t W, int32_t H, size_t *bytes = nullptr) {
         ImageState s;
         char *p = base;
         const size_t tiles = (size_t)gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE);
         s.ranges = GeomState::take<uint2>(p, tiles);
+        s.tile_order = GeomState::take<uint32_t>(p, tiles);
         s.final_T = GeomState::take<float>(p, (size_t)W * H);
         s.n_contrib = GeomState::take<uint32_t>(p, (size_t)W * H);
         if (bytes) *bytes = (size_t)(p - base);

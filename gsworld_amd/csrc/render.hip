@@ -12,7 +12,8 @@
 
 namespace {
 
-int g_render_variant = 1;
+int g_render_variant = 2;
+int g_render_blocks_per_cu = 5;
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -213,6 +214,165 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_wave_kernel(const uint2 *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2: LDS-staged, 4 instances per step, predicated, persistent workgroups on a longest-first tile queue.
+//
+// What the counters of variant 0 showed (profiles/round1): half of the wave time parked on lgkmcnt / barriers,
+// as many SALU (exec-mask) instructions as VALU, and an average wave lifetime of half the kernel (tile lists
+// differ 3x in length while every tile is resident from t = 0).  Hence:
+//  * the per-pixel test (power, alpha, thresholds) of FOUR instances is evaluated back to back on operands that
+//    were all fetched from LDS by one batch of ds_reads -> one lgkmcnt wait per 4 instances and 4-way ILP for a
+//    wave that is alone on its SIMD at the tail;
+//  * no divergent control flow: lane state is updated with selects, branches are wave-uniform (ballot);
+//    n_contrib needs no per-lane counter because a live lane has examined exactly (position + 1) instances;
+//  * workgroups are persistent and pull tiles from a queue ordered by descending list length, so the chip
+//    drains evenly instead of waiting for the CU that happened to receive the long tiles.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBatch = 4;
+
+__global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__restrict__ ranges,
+                                                                 const uint32_t *__restrict__ point_list,
+                                                                 const float4 *__restrict__ splat, int W, int H, int gx,
+                                                                 int num_tiles, const uint32_t *__restrict__ tile_order,
+                                                                 uint32_t *__restrict__ queue_head,
+                                                                 const float *__restrict__ bg,
+                                                                 float *__restrict__ out_color,
+                                                                 float *__restrict__ out_invdepth,
+                                                                 float *__restrict__ final_T,
+                                                                 uint32_t *__restrict__ n_contrib) {
+    __shared__ float4 s_rec0[GSR_BLOCK + kBatch];
+    __shared__ float4 s_rec1[GSR_BLOCK + kBatch];
+    __shared__ float4 s_rec2[GSR_BLOCK + kBatch];
+    __shared__ uint32_t s_ticket;
+    const int lane = gsr_lane(), wave = gsr_wave();
+    const int lx = ((wave & 1) << 3) | (lane & 7);
+    const int ly = ((wave >> 1) << 3) | (lane >> 3);
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    if (threadIdx.x < kBatch) {  // padding entries: alpha = 0 -> never valid
+        s_rec0[GSR_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rec1[GSR_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rec2[GSR_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (;;) {
+        __syncthreads();  // previous tile fully consumed (LDS records and the ticket)
+        if (threadIdx.x == 0) s_ticket = atomicAdd(queue_head, 1u);
+        __syncthreads();
+        const uint32_t ticket = s_ticket;
+        if (ticket >= (uint32_t)num_tiles) break;
+        const int tile = tile_order ? (int)tile_order[ticket] : (int)ticket;
+        const int tile_x = tile % gx, tile_y = tile / gx;
+        const int px = tile_x * GSR_TILE + lx, py = tile_y * GSR_TILE + ly;
+        const bool inside = px < W && py < H;
+        const float pfx = (float)px, pfy = (float)py;
+        const uint2 range = ranges[tile];
+        const int n_inst = (int)(range.y - range.x);
+        const int rounds = (n_inst + GSR_BLOCK - 1) / GSR_BLOCK;
+
+        bool done = !inside;
+        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
+        uint32_t last_contributor = 0;
+
+        for (int rd = 0; rd < rounds; rd++) {
+            if (__syncthreads_count(done ? 1 : 0) == GSR_BLOCK) break;
+            const int fetch = rd * GSR_BLOCK + (int)threadIdx.x;
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
+            if (fetch < n_inst) {
+                const uint32_t g = point_list[range.x + (uint32_t)fetch];
+                const float4 *rec = splat + 3 * (size_t)g;
+                f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
+            }
+            s_rec0[threadIdx.x] = f0;
+            s_rec1[threadIdx.x] = f1;
+            s_rec2[threadIdx.x] = f2;
+            __syncthreads();
+            const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
+            const uint32_t pos0 = (uint32_t)(rd * GSR_BLOCK);
+            for (int j = 0; j < cnt; j += kBatch) {
+                if (__ballot(!done) == 0ull) break;
+                float alpha[kBatch];
+                bool valid[kBatch];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const float4 r0 = s_rec0[j + k];
+                    const float4 r1 = s_rec1[j + k];
+                    const float dx = r0.x - pfx, dy = r0.y - pfy;
+                    const float q = fma_(r1.z * dy, dy, (r1.x * dx) * dx);
+                    const float power = fma_(-(r1.y * dx), dy, -0.5f * q);
+                    alpha[k] = fminf(0.99f, r1.w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+                    valid[k] = power <= 0.0f && alpha[k] >= 1.0f / 255.0f;
+                    any = any || valid[k];
+                }
+                if (__ballot(any && !done) == 0ull) continue;
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const bool hit = valid[k] && !done;
+                    if (__ballot(hit) == 0ull) continue;
+                    const float4 r2 = s_rec2[j + k];
+                    const float invd = s_rec0[j + k].w;
+                    const float test_T = T * (1.0f - alpha[k]);
+                    const bool stop = hit && test_T < 0.0001f;
+                    const bool blend = hit && !stop;
+                    const float w = blend ? alpha[k] * T : 0.0f;
+                    C0 = blend ? fma_(r2.x, w, C0) : C0;
+                    C1 = blend ? fma_(r2.y, w, C1) : C1;
+                    C2 = blend ? fma_(r2.z, w, C2) : C2;
+                    Dacc = blend ? fma_(invd, w, Dacc) : Dacc;
+                    T = blend ? test_T : T;
+                    last_contributor = blend ? pos0 + (uint32_t)(j + k) + 1u : last_contributor;
+                    done = done || stop;
+                }
+            }
+        }
+        if (inside) {
+            const size_t pid = (size_t)py * W + px;
+            const size_t plane = (size_t)H * W;
+            final_T[pid] = T;
+            n_contrib[pid] = last_contributor;
+            out_color[pid] = fma_(T, bg0, C0);
+            out_color[plane + pid] = fma_(T, bg1, C1);
+            out_color[2 * plane + pid] = fma_(T, bg2, C2);
+            out_invdepth[pid] = Dacc;
+        }
+    }
+}
+
+// Longest-first tile order for the queue: a 64-bucket counting sort of the tile list lengths (one workgroup).
+__global__ __launch_bounds__(GSR_BLOCK) void tile_order_kernel(const uint2 *__restrict__ ranges, int num_tiles,
+                                                               uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_bins[64];
+    __shared__ uint32_t s_red[4];
+    uint32_t mx = 0;
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) mx = max(mx, ranges[t].y - ranges[t].x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (gsr_lane() == 0) s_red[gsr_wave()] = mx;
+    if (threadIdx.x < 64) s_bins[threadIdx.x] = 0u;
+    __syncthreads();
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
+    // bucket 0 = longest lists
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        atomicAdd(&s_bins[63 - (int)((float)len * scale)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 64; b++) {
+            const uint32_t c = s_bins[b];
+            s_bins[b] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)len * scale)], 1u);
+        order[pos] = (uint32_t)t;
+    }
+}
+
 // GSWorld's frame conversion (gs_world_wrapper.py:268-270): CHW float -> HWC uint8, (x*255).clamp(0,255) then a
 // truncating cast.  4 pixels (12 output bytes) per thread so that stores are three aligned dwords.
 __global__ __launch_bounds__(GSR_BLOCK) void pack_rgb8_kernel(const float *__restrict__ color, int n_pix,
@@ -258,7 +418,24 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
                       const float *background, float *out_color, float *out_invdepth, hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
-    if (g_render_variant == 0)
+    if (g_render_variant == 2) {
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                gsr_set_error("render: hipGetDeviceProperties failed");
+                return GSR_E_HIP;
+            }
+            num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int T = gx * gy;
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
+        const int blocks = min(T, num_cus * g_render_blocks_per_cu);
+        hipLaunchKernelGGL(render_queue_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
+                           g.splat, W, H, gx, T, img.tile_order, &g.hdr->tile_queue, background, out_color,
+                           out_invdepth, img.final_T, img.n_contrib);
+    } else if (g_render_variant == 0)
         hipLaunchKernelGGL(render_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list, g.splat,
                            W, H, gx, background, out_color, out_invdepth, img.final_T, img.n_contrib);
     else
@@ -268,12 +445,14 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     return GSR_OK;
 }
 
-// 0 = LDS-staged tile kernel (kept for A/B measurements), 1 = wave-independent kernel (default)
-extern "C" int gsr_debug_set_render_variant(int variant) {
-    if (variant < 0 || variant > 1) {
-        gsr_set_error("gsr_debug_set_render_variant: variant must be 0 or 1");
+// 0 = LDS-staged tile kernel, 1 = wave-independent readlane kernel, 2 = batched / queued kernel (default);
+// variants 0 and 1 are kept for within-process A/B measurements.  blocks_per_cu sizes variant 2's persistent grid.
+extern "C" int gsr_debug_set_render_variant(int variant, int blocks_per_cu) {
+    if (variant < 0 || variant > 2 || blocks_per_cu < 0 || blocks_per_cu > 8) {
+        gsr_set_error("gsr_debug_set_render_variant: variant must be 0..2, blocks_per_cu 0..8");
         return GSR_E_INVALID;
     }
     g_render_variant = variant;
+    if (blocks_per_cu > 0) g_render_blocks_per_cu = blocks_per_cu;
     return GSR_OK;
 }

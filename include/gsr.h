@@ -144,8 +144,10 @@ typedef struct GsrProfile {
     double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
 } GsrProfile;
 int gsr_profile_enable(int mode);
-/* A/B measurements: 0 = LDS-staged compositing kernel, 1 = wave-independent kernel (default). */
-int gsr_debug_set_render_variant(int variant);
+/* A/B measurements: compositing kernel 0 = LDS-staged per tile, 1 = wave-independent (readlane broadcast),
+ * 2 = batched + persistent workgroups on a longest-first tile queue (default).  blocks_per_cu (1..8, 0 = keep)
+ * sizes variant 2's grid. */
+int gsr_debug_set_render_variant(int variant, int blocks_per_cu);
 /* Tests only: route binning through the radix-sort fallback used for tile grids above 3840 tiles. */
 int gsr_debug_force_radix_binning(int enable);
 int gsr_profile_collect(GsrProfile *out);

@@ -1,0 +1,28 @@
+"""Renders a few config-2 frames (for rocprofv3 --pmc runs).  Usage: pmc_frames.py [variant] [frames] [blocks_per_cu]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd._lib import check, lib  # noqa: E402
+from gsworld_amd.renderer import FrameRenderer  # noqa: E402
+
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+bpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+dev = torch.device("cuda:0")
+raw = scenes.tabletop_scene("xarm6_align")
+cam = scenes.sensor_camera("xarm6_align").to(dev)
+means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+r = FrameRenderer(dev)
+L = lib()
+L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
+check(L.gsr_debug_set_render_variant(variant, bpc))
+for _ in range(frames):
+    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot)
+torch.cuda.synchronize()
+print("stats", r.stats())
