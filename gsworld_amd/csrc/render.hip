@@ -272,55 +272,86 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
         float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
         uint32_t last_contributor = 0;
 
+        // global -> register pipeline, one round (256 instances) ahead of the LDS image: the records of round rd
+        // are already in (f0,f1,f2) when the round starts and the Gaussian index of round rd+1 is in g_next
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 f0 = zero4, f1 = zero4, f2 = zero4;
+        uint32_t g_next = 0;
+        if ((int)threadIdx.x < n_inst) {
+            const uint32_t g = point_list[range.x + threadIdx.x];
+            const float4 *rec = splat + 3 * (size_t)g;
+            f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
+        }
+        if (GSR_BLOCK + (int)threadIdx.x < n_inst) g_next = point_list[range.x + GSR_BLOCK + threadIdx.x];
+
         for (int rd = 0; rd < rounds; rd++) {
             if (__syncthreads_count(done ? 1 : 0) == GSR_BLOCK) break;
-            const int fetch = rd * GSR_BLOCK + (int)threadIdx.x;
-            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
-            if (fetch < n_inst) {
-                const uint32_t g = point_list[range.x + (uint32_t)fetch];
-                const float4 *rec = splat + 3 * (size_t)g;
-                f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
-            }
-            s_rec0[threadIdx.x] = f0;
+            s_rec0[threadIdx.x] = f0;  // zero records past the end of the list: alpha = 0, never valid
             s_rec1[threadIdx.x] = f1;
             s_rec2[threadIdx.x] = f2;
             __syncthreads();
+            {
+                const int nf = (rd + 1) * GSR_BLOCK + (int)threadIdx.x;
+                f0 = zero4; f1 = zero4; f2 = zero4;
+                if (nf < n_inst) {
+                    const float4 *rec = splat + 3 * (size_t)g_next;
+                    f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
+                }
+                if (nf + GSR_BLOCK < n_inst) g_next = point_list[range.x + (uint32_t)(nf + GSR_BLOCK)];
+            }
             const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
             const uint32_t pos0 = (uint32_t)(rd * GSR_BLOCK);
+            // LDS -> register pipeline, one batch ahead
+            float4 c0[kBatch], c1[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                c0[k] = s_rec0[k];
+                c1[k] = s_rec1[k];
+            }
             for (int j = 0; j < cnt; j += kBatch) {
-                if (__ballot(!done) == 0ull) break;
+                float4 n0[kBatch], n1[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {  // entries up to 256 + kBatch - 1 exist (zero padding)
+                    n0[k] = s_rec0[j + kBatch + k];
+                    n1[k] = s_rec1[j + kBatch + k];
+                }
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
                 float alpha[kBatch];
                 bool valid[kBatch];
-                bool any = false;
+                uint64_t any = 0ull;
 #pragma unroll
                 for (int k = 0; k < kBatch; k++) {
-                    const float4 r0 = s_rec0[j + k];
-                    const float4 r1 = s_rec1[j + k];
-                    const float dx = r0.x - pfx, dy = r0.y - pfy;
-                    const float q = fma_(r1.z * dy, dy, (r1.x * dx) * dx);
-                    const float power = fma_(-(r1.y * dx), dy, -0.5f * q);
-                    alpha[k] = fminf(0.99f, r1.w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+                    const float dx = c0[k].x - pfx, dy = c0[k].y - pfy;
+                    const float q = fma_(c1[k].z * dy, dy, (c1[k].x * dx) * dx);
+                    const float power = fma_(-(c1[k].y * dx), dy, -0.5f * q);
+                    alpha[k] = fminf(0.99f, c1[k].w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
                     valid[k] = power <= 0.0f && alpha[k] >= 1.0f / 255.0f;
-                    any = any || valid[k];
+                    any |= __builtin_amdgcn_ballot_w64(valid[k]);
                 }
-                if (__ballot(any && !done) == 0ull) continue;
+                if ((any & __builtin_amdgcn_ballot_w64(!done)) != 0ull) {
+#pragma unroll
+                    for (int k = 0; k < kBatch; k++) {
+                        const bool hit = valid[k] && !done;
+                        if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
+                        const float4 r2 = s_rec2[j + k];
+                        // non-hit lanes run with alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0
+                        const float a_eff = hit ? alpha[k] : 0.0f;
+                        const float test_T = T * (1.0f - a_eff);
+                        const bool stop = test_T < 0.0001f;
+                        const float w = stop ? 0.0f : a_eff * T;
+                        C0 = fma_(r2.x, w, C0);
+                        C1 = fma_(r2.y, w, C1);
+                        C2 = fma_(r2.z, w, C2);
+                        Dacc = fma_(c0[k].w, w, Dacc);
+                        T = stop ? T : test_T;
+                        last_contributor = (hit && !stop) ? pos0 + (uint32_t)(j + k) + 1u : last_contributor;
+                        done = done || stop;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < kBatch; k++) {
-                    const bool hit = valid[k] && !done;
-                    if (__ballot(hit) == 0ull) continue;
-                    const float4 r2 = s_rec2[j + k];
-                    const float invd = s_rec0[j + k].w;
-                    const float test_T = T * (1.0f - alpha[k]);
-                    const bool stop = hit && test_T < 0.0001f;
-                    const bool blend = hit && !stop;
-                    const float w = blend ? alpha[k] * T : 0.0f;
-                    C0 = blend ? fma_(r2.x, w, C0) : C0;
-                    C1 = blend ? fma_(r2.y, w, C1) : C1;
-                    C2 = blend ? fma_(r2.z, w, C2) : C2;
-                    Dacc = blend ? fma_(invd, w, Dacc) : Dacc;
-                    T = blend ? test_T : T;
-                    last_contributor = blend ? pos0 + (uint32_t)(j + k) + 1u : last_contributor;
-                    done = done || stop;
+                    c0[k] = n0[k];
+                    c1[k] = n1[k];
                 }
             }
         }
