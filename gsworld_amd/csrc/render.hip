@@ -301,21 +301,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
             }
             const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
             const uint32_t pos0 = (uint32_t)(rd * GSR_BLOCK);
-            // LDS -> register pipeline, one batch ahead
-            float4 c0[kBatch], c1[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                c0[k] = s_rec0[k];
-                c1[k] = s_rec1[k];
-            }
             for (int j = 0; j < cnt; j += kBatch) {
-                float4 n0[kBatch], n1[kBatch];
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {  // entries up to 256 + kBatch - 1 exist (zero padding)
-                    n0[k] = s_rec0[j + kBatch + k];
-                    n1[k] = s_rec1[j + kBatch + k];
-                }
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                float4 c0[kBatch], c1[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {  // one batch of ds_reads, one lgkmcnt wait
+                    c0[k] = s_rec0[j + k];
+                    c1[k] = s_rec1[j + k];
+                }
                 float alpha[kBatch];
                 bool valid[kBatch];
                 uint64_t any = 0ull;
@@ -347,11 +340,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
                         last_contributor = (hit && !stop) ? pos0 + (uint32_t)(j + k) + 1u : last_contributor;
                         done = done || stop;
                     }
-                }
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    c0[k] = n0[k];
-                    c1[k] = n1[k];
                 }
             }
         }
