@@ -143,10 +143,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const GeomState g = GeomState::carve(geom_mem, in->P, tiles);
     const ImageState img = ImageState::carve(img_mem, W, H);
 
-    if (hipMemsetAsync(g.hdr, 0, sizeof(GsrHeader), stream) != hipSuccess) {
-        gsr_set_error("hipMemsetAsync(header) failed");
-        return GSR_E_HIP;
-    }
+    // the frame header is reset by the first kernel that writes it (scan of the block counts)
     prof_mark(0, stream);
     if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, stream)) return e;
     if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
@@ -192,7 +189,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     }
     prof_mark(4, stream);
     // both binning paths leave the point list in gidx[0]
-    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, stream))
+    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, counting, stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();

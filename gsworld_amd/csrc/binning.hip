@@ -114,8 +114,25 @@ __device__ __forceinline__ void walk_wave(const uint32_t *__restrict__ order, co
     const uint32_t t = valid ? tiles_touched[g] : 0u;
     uint2 rc = make_uint2(0u, 0u);
     if (valid) rc = rects[g];
-    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16, width = (rc.y & 0xffffu) - minx;
-    uint64_t todo = __ballot(t > 0u);
+    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16, maxx = rc.y & 0xffffu, width = maxx - minx;
+    uint64_t todo;
+    if (!PLACE) {
+        // counting does not care about order: a lane walks a short tile list itself (LDS atomics resolve any
+        // collisions between lanes), only long lists are spread over the wave
+        if (t > 0u && t <= 32u) {
+            uint32_t x = minx, tile_row = miny * (uint32_t)gx;
+            for (uint32_t j = 0; j < t; j++) {
+                atomicAdd(&cnt[tile_row + x], 1u);
+                if (++x == maxx) { x = minx; tile_row += (uint32_t)gx; }
+            }
+        }
+        todo = __ballot(t > 32u);
+    } else {
+        todo = __ballot(t > 0u);
+    }
+    // j / width without an integer division: (j + 0.5) * (1 / width) truncates to the exact quotient for every
+    // j below 2^21 (the margin 0.5 / width dwarfs the 2^-23 relative error of the product)
+    const float inv_w = 1.0f / (float)(width > 0u ? width : 1u);
     while (todo) {
         const int src = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1ull;
@@ -124,8 +141,9 @@ __device__ __forceinline__ void walk_wave(const uint32_t *__restrict__ order, co
         const uint32_t bminx = (uint32_t)__builtin_amdgcn_readlane((int)minx, src);
         const uint32_t bminy = (uint32_t)__builtin_amdgcn_readlane((int)miny, src);
         const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)width, src);
+        const float binv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), src));
         for (uint32_t j = (uint32_t)lane; j < bt; j += 64u) {
-            const uint32_t yy = j / bw, xx = j - yy * bw;
+            const uint32_t yy = (uint32_t)(((float)j + 0.5f) * binv), xx = j - yy * bw;
             const uint32_t tile = (bminy + yy) * (uint32_t)gx + (bminx + xx);
             if (PLACE) {
                 const uint32_t pos = atomicAdd(&cnt[tile], 1u);
@@ -158,8 +176,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_count_kernel(const uint32_t *_
 // one workgroup: totals[T] -> ranges, R; untouched tiles keep (0,0) like the reference's memset
 __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *__restrict__ totals, int T,
                                                                 GsrHeader *hdr, uint32_t r_capacity,
-                                                                uint2 *__restrict__ ranges) {
+                                                                uint2 *__restrict__ ranges,
+                                                                uint32_t *__restrict__ tile_order) {
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_bins[64];
     uint32_t sum = 0;
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) sum += totals[t];
     uint32_t grand;
@@ -183,6 +203,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
         hdr->overflow = overflow ? 1u : 0u;
         hdr->R = overflow ? 0u : grand;
     }
+    __syncthreads();  // this workgroup's range stores are visible to all of its threads
+    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *__restrict__ order,
@@ -230,7 +252,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
-                       img.ranges);
+                       img.ranges, img.tile_order);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

@@ -165,7 +165,7 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
-                      hipStream_t stream);
+                      bool order_ready, hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
@@ -205,5 +205,36 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t *s_
     total = w0 + w1 + w2 + w3;
     __syncthreads();
     return incl + add;
+}
+// Longest-first tile order for the compositing queue: a 64-bucket counting sort of the tile list lengths, run by
+// ONE workgroup (callers: tile_starts_kernel on the counting path, tile_order_kernel on the radix fallback).
+// s_bins: 64 uint32 in LDS, s_red: 4 uint32 in LDS.  The ranges must be visible to the whole workgroup.
+__device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int num_tiles, uint32_t *order,
+                                                     uint32_t *s_bins, uint32_t *s_red) {
+    uint32_t mx = 0;
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) mx = max(mx, ranges[t].y - ranges[t].x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (gsr_lane() == 0) s_red[gsr_wave()] = mx;
+    if (threadIdx.x < 64) s_bins[threadIdx.x] = 0u;
+    __syncthreads();
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK)  // bucket 0 = longest lists
+        atomicAdd(&s_bins[63 - (int)((float)(ranges[t].y - ranges[t].x) * scale)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 64; b++) {
+            const uint32_t c = s_bins[b];
+            s_bins[b] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
+        const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)(ranges[t].y - ranges[t].x) * scale)], 1u);
+        order[pos] = (uint32_t)t;
+    }
 }
 #endif  // __HIPCC__

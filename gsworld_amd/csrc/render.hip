@@ -356,40 +356,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
     }
 }
 
-// Longest-first tile order for the queue: a 64-bucket counting sort of the tile list lengths (one workgroup).
+// Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
 __global__ __launch_bounds__(GSR_BLOCK) void tile_order_kernel(const uint2 *__restrict__ ranges, int num_tiles,
                                                                uint32_t *__restrict__ order) {
     __shared__ uint32_t s_bins[64];
     __shared__ uint32_t s_red[4];
-    uint32_t mx = 0;
-    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) mx = max(mx, ranges[t].y - ranges[t].x);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    if (gsr_lane() == 0) s_red[gsr_wave()] = mx;
-    if (threadIdx.x < 64) s_bins[threadIdx.x] = 0u;
-    __syncthreads();
-    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
-    const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
-    // bucket 0 = longest lists
-    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
-        const uint32_t len = ranges[t].y - ranges[t].x;
-        atomicAdd(&s_bins[63 - (int)((float)len * scale)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int b = 0; b < 64; b++) {
-            const uint32_t c = s_bins[b];
-            s_bins[b] = acc;
-            acc += c;
-        }
-    }
-    __syncthreads();
-    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
-        const uint32_t len = ranges[t].y - ranges[t].x;
-        const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)len * scale)], 1u);
-        order[pos] = (uint32_t)t;
-    }
+    gsr_tile_order_block(ranges, num_tiles, order, s_bins, s_red);
 }
 
 // GSWorld's frame conversion (gs_world_wrapper.py:268-270): CHW float -> HWC uint8, (x*255).clamp(0,255) then a
@@ -434,7 +406,8 @@ extern "C" int gsr_pack_rgb8(const float *color, int32_t width, int32_t height, 
 }
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
-                      const float *background, float *out_color, float *out_invdepth, hipStream_t stream) {
+                      const float *background, float *out_color, float *out_invdepth, bool order_ready,
+                      hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     if (g_render_variant == 2) {
@@ -449,7 +422,8 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
             num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const int T = gx * gy;
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
+        if (!order_ready)
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
         const int blocks = min(T, num_cus * g_render_blocks_per_cu);
         hipLaunchKernelGGL(render_queue_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
                            g.splat, W, H, gx, T, img.tile_order, &g.hdr->tile_queue, background, out_color,

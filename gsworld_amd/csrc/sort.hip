@@ -19,19 +19,29 @@ __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, i
     __shared__ uint32_t s_w[4];
     int n = n_static;
     if (n_items_ptr) n = (int)((*n_items_ptr + (uint32_t)chunk - 1u) / (uint32_t)chunk);
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += GSR_BLOCK) {
-        const int i = base + (int)threadIdx.x;
-        const uint32_t v = i < n ? data[i] : 0u;
-        uint32_t total;
-        const uint32_t incl = gsr_block_incl_scan(v, s_w, total);
-        if (i < n) data[i] = carry + incl - v;
-        carry += total;
+    // each thread owns a contiguous slice: one pass to sum it, ONE block scan of the 256 slice sums, one pass to
+    // write the exclusive offsets (2 barriers in total instead of 2 per 256 elements)
+    const int per = (n + GSR_BLOCK - 1) / GSR_BLOCK;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t mine = 0;
+    for (int i = lo; i < hi; i++) mine += data[i];
+    uint32_t carry;
+    uint32_t run = gsr_block_incl_scan(mine, s_w, carry) - mine;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t v = data[i];
+        data[i] = run;
+        run += v;
     }
     if (threadIdx.x == 0) {
         data[n] = carry;  // arrays carry one spare slot: exclusive offsets have n+1 entries
         if (mode == 0) {
+            // first kernel of the frame that touches the header: reset it here (saves a memset launch)
             hdr->V = carry;
+            hdr->R = 0u;
+            hdr->overflow = 0u;
+            hdr->r_capacity = 0u;
+            hdr->R_raw = 0u;
+            hdr->tile_queue = 0u;
         } else {
             hdr->R_raw = carry;
             hdr->r_capacity = r_capacity;
