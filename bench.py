@@ -49,21 +49,19 @@ def main():
     from gsworld_amd._lib import GsrProfile, PROFILE_STAGES, check, lib
     from gsworld_amd.renderer import FrameRenderer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from gsworld_amd import distributed as gd
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, _ = gd.init_from_env(dev)  # RCCL ("nccl" backend on ROCm) when WORLD_SIZE > 1
 
     # ---- scene: one per rank (weak scaling over independent scenes) ---------------------------------------------
-    name = scenes.SCENE_NAMES[rank % len(scenes.SCENE_NAMES)]
+    name, seed = gd.scene_for_rank(rank, scenes.SCENE_NAMES)
     n = args.num_gaussians or scenes.XARM6_ALIGN_NUM_GAUSSIANS
-    raw = scenes.tabletop_scene(name, n=n, seed=1 + rank)
+    raw = scenes.tabletop_scene(name, n=n, seed=seed)
     cam_cpu = scenes.sensor_camera(name, args.width, args.height)
     means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
     cam = cam_cpu.to(dev)
@@ -72,13 +70,11 @@ def main():
 
     r = FrameRenderer(dev)
     K_g = max(1, args.gather_every)
-    frames_u8 = torch.empty((K_g, H, W, 3), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * K_g, H, W, 3), dtype=torch.uint8, device=dev) if world > 1 else None
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world)
 
     def frame(slot):
         color, _radii, _invd = r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg)
-        r.pack_rgb8(color, frames_u8[slot])
+        r.pack_rgb8(color, fg.frames[slot])
 
     # exact-mode frame sizes the binning capacity from the real R; then check the no-sync path is valid
     frame(0)
@@ -114,12 +110,7 @@ def main():
             graph[slot].replay()
         else:
             frame(slot)
-        if world > 1 and slot == K_g - 1:
-            comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(gathered, frames_u8)
-            # the next batch overwrites frames_u8: order it after the gather has read it
-            torch.cuda.current_stream().wait_stream(comm_stream)
+        fg.step_done(i)  # RCCL all_gather of the batch of finished frames on a side stream (N > 1)
 
     def barrier():
         if world > 1:
