@@ -281,7 +281,8 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
     uint32_t *key[2] = {b.tile[0], b.tile[1]};
     uint32_t *val[2] = {b.gidx[0], b.gidx[1]};
     const int bits = BinningState::tile_bits(tiles);
-    if (int e = gsr_radix_sort_u32(key, val, &g.hdr->R, r_capacity, bits, b.sort_table, b.sort_totals, debug, stream))
+    if (int e = gsr_radix_sort_u32(key, val, &g.hdr->R, r_capacity, bits, GSR_RADIX_BITS, 0, b.sort_table,
+                                   b.sort_totals, debug, stream))
         return e;
     const int side = BinningState::tile_passes(tiles) & 1;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(r_capacity > 0 ? r_capacity : 1, GSR_BLOCK)),

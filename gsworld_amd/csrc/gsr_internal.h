@@ -12,8 +12,10 @@
 #define GSR_BLOCK 256                 // threads per workgroup for every streaming kernel (4 waves)
 #define GSR_SORT_ITEMS 8              // keys per thread per radix block
 #define GSR_SORT_CHUNK (GSR_BLOCK * GSR_SORT_ITEMS)
-#define GSR_RADIX_BITS 8
+#define GSR_RADIX_BITS 8              // digit width of the tile-id sort (large-grid fallback)
 #define GSR_RADIX_BINS 256
+#define GSR_DEPTH_RADIX_BITS 11       // digit width of the 32-bit depth sort and the 30-bit Morton sort: 3 passes
+#define GSR_DEPTH_RADIX_BINS 2048
 #define GSR_MAX_COUNT_TILES 3840         // counting placement keeps 4 x tiles LDS counters per workgroup (<= 60 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
@@ -75,8 +77,8 @@ struct GeomState {
         g.key[1] = take<uint32_t>(p, n);
         g.idx[0] = take<uint32_t>(p, n);
         g.idx[1] = take<uint32_t>(p, n);
-        g.sort_table = take<uint32_t>(p, (size_t)GSR_RADIX_BINS * sort_blocks(P));
-        g.sort_totals = take<uint32_t>(p, GSR_RADIX_BINS);
+        g.sort_table = take<uint32_t>(p, (size_t)GSR_DEPTH_RADIX_BINS * sort_blocks(P));
+        g.sort_totals = take<uint32_t>(p, GSR_DEPTH_RADIX_BINS);
         g.tile_bsum = take<uint32_t>(p, (size_t)sort_blocks(P) + 1);
         const size_t tt = counting(tiles) ? (size_t)tiles : 0;
         g.tile_table = take<uint32_t>(p, tt * prep_blocks(P) + 1);
@@ -172,8 +174,10 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
                           const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_rowscan(uint32_t *table, const uint32_t *n_ptr, int nb_stride, int chunk, int rows, uint32_t *totals,
                        bool debug, hipStream_t stream);
+int gsr_radix_passes(int bits, int bits_per_pass);
 int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr, int64_t n_max, int bits,
-                       uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream);
+                       int bits_per_pass, int start_side, uint32_t *table, uint32_t *totals, bool debug,
+                       hipStream_t stream);
 
 #ifdef __HIPCC__
 // ---- wave64 / block primitives ---------------------------------------------------------------------------

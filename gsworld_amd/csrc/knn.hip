@@ -39,8 +39,8 @@ struct KnnState {
         s.key[1] = GeomState::take<uint32_t>(p, n);
         s.idx[0] = GeomState::take<uint32_t>(p, n);
         s.idx[1] = GeomState::take<uint32_t>(p, n);
-        s.sort_table = GeomState::take<uint32_t>(p, (size_t)GSR_RADIX_BINS * GeomState::sort_blocks(P));
-        s.sort_totals = GeomState::take<uint32_t>(p, GSR_RADIX_BINS);
+        s.sort_table = GeomState::take<uint32_t>(p, (size_t)GSR_DEPTH_RADIX_BINS * GeomState::sort_blocks(P));
+        s.sort_totals = GeomState::take<uint32_t>(p, GSR_DEPTH_RADIX_BINS);
         s.sorted_pts = GeomState::take<float>(p, 3 * n);
         s.boxes = GeomState::take<float>(p, 6 * (size_t)gsr_div_up(n, kBox));
         if (bytes) *bytes = (size_t)(p - base);
@@ -245,13 +245,16 @@ extern "C" int gsr_knn_dist2(int32_t P, const float *points, float *mean_dist2, 
     hipLaunchKernelGGL(knn_minmax_partial_kernel, dim3(nred), dim3(GSR_BLOCK), 0, stream, P, points, s.minmax_partial);
     hipLaunchKernelGGL(knn_minmax_final_kernel, dim3(1), dim3(64), 0, stream, nred, s.minmax_partial, s.minmax, s.n_dev,
                        (uint32_t)P);
+    // 30-bit codes, 11 bits per pass = 3 passes: start in side 1 so that the sorted order ends in idx[0]
+    const int start = gsr_radix_passes(30, GSR_DEPTH_RADIX_BITS) & 1;
     hipLaunchKernelGGL(knn_morton_kernel, dim3(gsr_div_up(P, GSR_BLOCK)), dim3(GSR_BLOCK), 0, stream, P, points,
-                       s.minmax, s.key[0], s.idx[0]);
+                       s.minmax, s.key[start], s.idx[start]);
     if (int e = gsr_check_launch("knn_morton", false, stream)) return e;
     uint32_t *key[2] = {s.key[0], s.key[1]};
     uint32_t *val[2] = {s.idx[0], s.idx[1]};
-    if (int e = gsr_radix_sort_u32(key, val, s.n_dev, P, 30, s.sort_table, s.sort_totals, false, stream)) return e;
-    // 30 bits = 4 passes: the sorted order is back in idx[0]
+    if (int e = gsr_radix_sort_u32(key, val, s.n_dev, P, 30, GSR_DEPTH_RADIX_BITS, start, s.sort_table, s.sort_totals,
+                                   false, stream))
+        return e;
     const int nbox = gsr_div_up(P, kBox);
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nbox), dim3(GSR_BLOCK), 0, stream, P, points, s.idx[0],
                        s.sorted_pts, s.boxes);

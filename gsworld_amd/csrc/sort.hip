@@ -9,8 +9,9 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
-// Exclusive scan (in place) of a small array by ONE workgroup; writes the grand total to *total_out.
-// mode 0: plain.  mode 1: the total is num_rendered -- record R_raw, clamp against the binning capacity.
+// Exclusive scan (in place) of a small array by ONE workgroup; writes the grand total to data[n].
+// mode 0: the total is V (and the frame header is reset).  mode 1: the total is num_rendered -- record R_raw,
+// clamp against the binning capacity.
 // `n_items_ptr`/`chunk` (optional): the live length is ceil(*n_items_ptr / chunk) instead of n_static.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, int n_static,
@@ -78,18 +79,21 @@ __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Radix sort, one pass = histogram -> per-digit row scan -> stable scatter.
-// table[d * nb_stride + b] = number of keys with digit d in block b (block = GSR_SORT_CHUNK consecutive keys).
+// Radix sort, one pass = histogram -> per-digit row scan -> stable scatter; BITS = digit width (8 or 11).
+// A workgroup owns GSR_SORT_CHUNK consecutive keys; wave w owns the contiguous quarter [w*512, w*512+512).
+// table[d * nb_stride + b] = number of keys with digit d in workgroup b.
 // ---------------------------------------------------------------------------------------------------------
+template <int BITS>
 __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t *__restrict__ keys,
                                                                const uint32_t *__restrict__ n_ptr,
                                                                uint32_t *__restrict__ table, int nb_stride, int shift,
                                                                uint32_t mask) {
+    constexpr int BINS = 1 << BITS;
     const uint32_t n = *n_ptr;
     const uint32_t base = blockIdx.x * (uint32_t)GSR_SORT_CHUNK;
     if (base >= n) return;
-    __shared__ uint32_t s_h[GSR_RADIX_BINS];
-    s_h[threadIdx.x] = 0u;
+    __shared__ uint32_t s_h[BINS];
+    for (int i = (int)threadIdx.x; i < BINS; i += GSR_BLOCK) s_h[i] = 0u;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < GSR_SORT_ITEMS; r++) {
@@ -97,10 +101,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t *_
         if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    table[(size_t)threadIdx.x * nb_stride + blockIdx.x] = s_h[threadIdx.x];
+    for (int d = (int)threadIdx.x; d < BINS; d += GSR_BLOCK) table[(size_t)d * nb_stride + blockIdx.x] = s_h[d];
 }
 
-// one workgroup per digit: exclusive scan of its row over the live blocks, row total -> totals[d]
+// one workgroup per row: exclusive scan of the row over its live entries, row total -> totals[row]
 __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__restrict__ table,
                                                                   const uint32_t *__restrict__ n_ptr, int nb_stride,
                                                                   uint32_t *__restrict__ totals, int chunk) {
@@ -120,59 +124,85 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__re
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Stable scatter.  Each wave first counts the digits of ITS quarter (LDS atomics), the counts become per-wave
+// running cursors (global digit start + earlier workgroups + earlier waves), and the ranking loop then runs
+// without any workgroup barrier: lanes holding the same digit find each other with BITS ballots, the rank inside
+// the group is a popcount of the lanes below, the group's first lane advances the cursor.  LDS operations of one
+// wave retire in order, so round r+1 sees the cursors round r left behind.
+template <int BITS>
 __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ table,
     const uint32_t *__restrict__ totals, int nb_stride, int shift, uint32_t mask, int nbits) {
+    constexpr int BINS = 1 << BITS;
+    constexpr int PER = BINS / GSR_BLOCK;        // bins owned by one thread when sweeping the digit space
+    constexpr int WAVE_ITEMS = GSR_SORT_CHUNK / 4;  // 512 keys per wave, 8 rounds of 64
     const uint32_t n = *n_ptr;
     const uint32_t base = blockIdx.x * (uint32_t)GSR_SORT_CHUNK;
     if (base >= n) return;
-    __shared__ uint32_t s_base[GSR_RADIX_BINS];
-    __shared__ uint32_t s_wcnt[4][GSR_RADIX_BINS];
+    __shared__ uint32_t s_cur[4][BINS];
     __shared__ uint32_t s_w[4];
-    const int tid = (int)threadIdx.x, wave = gsr_wave();
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint64_t lt = gsr_lanemask_lt();
-    {
-        // global start of digit `tid` for this block = (keys with a smaller digit) + (same digit, earlier blocks)
-        const uint32_t tot = totals[tid];
-        uint32_t all;
-        const uint32_t incl = gsr_block_incl_scan(tot, s_w, all);
-        s_base[tid] = incl - tot + table[(size_t)tid * nb_stride + blockIdx.x];
-        s_wcnt[0][tid] = 0u; s_wcnt[1][tid] = 0u; s_wcnt[2][tid] = 0u; s_wcnt[3][tid] = 0u;
+    for (int i = tid; i < 4 * BINS; i += GSR_BLOCK) (&s_cur[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t wbase = base + (uint32_t)wave * WAVE_ITEMS;
+#pragma unroll
+    for (int r = 0; r < WAVE_ITEMS / 64; r++) {
+        const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+        if (i < n) atomicAdd(&s_cur[wave][(keys_in[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (int r = 0; r < GSR_SORT_ITEMS; r++) {
-        const uint32_t i = base + (uint32_t)r * GSR_BLOCK + (uint32_t)tid;
+    {
+        // start of digit d for this workgroup = (keys with a smaller digit) + (digit d in earlier workgroups);
+        // thread `tid` owns the PER consecutive digits tid*PER .. tid*PER+PER-1
+        uint32_t t[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            t[k] = totals[tid * PER + k];
+            sum += t[k];
+        }
+        uint32_t all;
+        uint32_t run = gsr_block_incl_scan(sum, s_w, all) - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int d = tid * PER + k;
+            const uint32_t c0 = s_cur[0][d], c1 = s_cur[1][d], c2 = s_cur[2][d];
+            const uint32_t start = run + table[(size_t)d * nb_stride + blockIdx.x];
+            s_cur[0][d] = start;
+            s_cur[1][d] = start + c0;
+            s_cur[2][d] = start + c0 + c1;
+            s_cur[3][d] = start + c0 + c1 + c2;
+            run += t[k];
+        }
+    }
+    __syncthreads();
+    uint32_t *cur = s_cur[wave];
+    for (int r = 0; r < WAVE_ITEMS / 64; r++) {
+        const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
         const bool valid = i < n;
         const uint32_t key = valid ? keys_in[i] : 0u;
         const uint32_t val = valid ? vals_in[i] : 0u;
         const uint32_t d = (key >> shift) & mask;
-        // lanes of this wave holding the same digit (wave64 "match any" from nbits ballots)
-        uint64_t same = __ballot(valid);
+        uint64_t same = __builtin_amdgcn_ballot_w64(valid);
         for (int b = 0; b < nbits; b++) {
             const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
             same &= bit ? bal : ~bal;
         }
         const uint32_t rank = (uint32_t)__popcll(same & lt);
-        if (valid && rank == 0u) s_wcnt[wave][d] = (uint32_t)__popcll(same);
-        __syncthreads();
         if (valid) {
-            uint32_t pos = s_base[d] + rank;
-            if (wave > 0) pos += s_wcnt[0][d];
-            if (wave > 1) pos += s_wcnt[1][d];
-            if (wave > 2) pos += s_wcnt[2][d];
+            const uint32_t pos = cur[d] + rank;
             keys_out[pos] = key;
             vals_out[pos] = val;
         }
-        __syncthreads();
-        s_base[tid] += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
-        s_wcnt[0][tid] = 0u; s_wcnt[1][tid] = 0u; s_wcnt[2][tid] = 0u; s_wcnt[3][tid] = 0u;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // every lane has read its cursor before the group leader moves it
+        if (valid && rank == 0u) cur[d] += (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// tiles touched by each chunk of GSR_SORT_CHUNK depth-ordered Gaussians
+// tiles touched by each chunk of GSR_SORT_CHUNK depth-ordered Gaussians (large-grid fallback path)
 __global__ __launch_bounds__(GSR_BLOCK) void tile_blocksum_kernel(const uint32_t *__restrict__ order,
                                                                   const uint32_t *__restrict__ tiles_touched,
                                                                   const GsrHeader *__restrict__ hdr,
@@ -192,6 +222,21 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_blocksum_kernel(const uint32_t
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 
+template <int BITS>
+int radix_pass(uint32_t *kin, uint32_t *vin, uint32_t *kout, uint32_t *vout, const uint32_t *n_ptr, int nb, int shift,
+               int nbits, uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream) {
+    const uint32_t mask = (1u << nbits) - 1u;
+    hipLaunchKernelGGL(radix_hist_kernel<BITS>, dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, n_ptr, table, nb, shift,
+                       mask);
+    if (int e = gsr_check_launch("radix_hist", debug, stream)) return e;
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb, totals,
+                       GSR_SORT_CHUNK);
+    if (int e = gsr_check_launch("radix_rowscan", debug, stream)) return e;
+    hipLaunchKernelGGL(radix_scatter_kernel<BITS>, dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, vin, kout, vout, n_ptr,
+                       table, totals, nb, shift, mask, nbits);
+    return gsr_check_launch("radix_scatter", debug, stream);
+}
+
 }  // namespace
 
 // Exclusive scan of each of `rows` table rows over its live entries (ceil(*n_ptr / chunk)); row totals -> totals.
@@ -202,41 +247,50 @@ int gsr_launch_rowscan(uint32_t *table, const uint32_t *n_ptr, int nb_stride, in
     return gsr_check_launch("rowscan", debug, stream);
 }
 
-// Stable LSD radix sort of (key, val) pairs on the low `bits` bits.  Result lands in key[passes & 1].
+int gsr_radix_passes(int bits, int bits_per_pass) { return (bits + bits_per_pass - 1) / bits_per_pass; }
+
+// Stable LSD radix sort of (key, val) pairs on the low `bits` bits, `bits_per_pass` (8 or 11) bits at a time.
+// Input in side `start_side`; the result lands in side start_side ^ (passes & 1).  The table needs
+// (1 << bits_per_pass) * ceil(n_max / GSR_SORT_CHUNK) entries, totals (1 << bits_per_pass).
 int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr, int64_t n_max, int bits,
-                       uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream) {
+                       int bits_per_pass, int start_side, uint32_t *table, uint32_t *totals, bool debug,
+                       hipStream_t stream) {
+    if (bits_per_pass != 8 && bits_per_pass != 11) {
+        gsr_set_error("radix sort: bits_per_pass must be 8 or 11");
+        return GSR_E_INVALID;
+    }
     const int nb = gsr_div_up(n_max > 0 ? n_max : 1, GSR_SORT_CHUNK);
-    int src = 0;
-    for (int shift = 0; shift < bits; shift += GSR_RADIX_BITS) {
-        const int nbits = (bits - shift) < GSR_RADIX_BITS ? (bits - shift) : GSR_RADIX_BITS;
-        const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(GSR_BLOCK), 0, stream, key[src], n_ptr, table, nb, shift,
-                           mask);
-        if (int e = gsr_check_launch("radix_hist", debug, stream)) return e;
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(GSR_RADIX_BINS), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb,
-                           totals, GSR_SORT_CHUNK);
-        if (int e = gsr_check_launch("radix_rowscan", debug, stream)) return e;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(GSR_BLOCK), 0, stream, key[src], val[src],
-                           key[src ^ 1], val[src ^ 1], n_ptr, table, totals, nb, shift, mask, nbits);
-        if (int e = gsr_check_launch("radix_scatter", debug, stream)) return e;
+    int src = start_side;
+    for (int shift = 0; shift < bits; shift += bits_per_pass) {
+        const int nbits = (bits - shift) < bits_per_pass ? (bits - shift) : bits_per_pass;
+        int e;
+        if (bits_per_pass == 8)
+            e = radix_pass<8>(key[src], val[src], key[src ^ 1], val[src ^ 1], n_ptr, nb, shift, nbits, table, totals,
+                              debug, stream);
+        else
+            e = radix_pass<11>(key[src], val[src], key[src ^ 1], val[src ^ 1], n_ptr, nb, shift, nbits, table, totals,
+                               debug, stream);
+        if (e) return e;
         src ^= 1;
     }
     return GSR_OK;
 }
 
-// block_counts -> exclusive offsets + V; index-ordered compaction; depth sort (32-bit float keys).
-// Leaves the depth order in g.idx[0] (4 passes, even).
+// block_counts -> exclusive offsets + V; index-ordered compaction; depth sort (32-bit float keys, 3 passes of
+// 11 bits).  The compaction writes into side 1 so that the sorted depth order ends in g.idx[0].
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.block_counts, nb1,
                        (const uint32_t *)nullptr, 1, g.hdr, 0, 0u);
     if (int e = gsr_check_launch("scan_block_counts", debug, stream)) return e;
+    const int start = gsr_radix_passes(32, GSR_DEPTH_RADIX_BITS) & 1;
     hipLaunchKernelGGL(compact_kernel, dim3(nb1), dim3(GSR_BLOCK), 0, stream, P, g.tiles_touched, g.splat,
-                       g.block_counts, g.key[0], g.idx[0]);
+                       g.block_counts, g.key[start], g.idx[start]);
     if (int e = gsr_check_launch("compact", debug, stream)) return e;
     uint32_t *key[2] = {g.key[0], g.key[1]};
     uint32_t *val[2] = {g.idx[0], g.idx[1]};
-    return gsr_radix_sort_u32(key, val, &g.hdr->V, P, 32, g.sort_table, g.sort_totals, debug, stream);
+    return gsr_radix_sort_u32(key, val, &g.hdr->V, P, 32, GSR_DEPTH_RADIX_BITS, start, g.sort_table, g.sort_totals,
+                              debug, stream);
 }
 
 // per-chunk tile counts in depth order -> exclusive chunk offsets, R (clamped against the capacity)
