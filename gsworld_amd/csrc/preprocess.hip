@@ -68,6 +68,7 @@ template <bool FAST_SH16>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
     bool visible = false;
+    float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);  // xyz + radius, handed to the colour phase
     if (i < a.P) {
         const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1],
                     pz = a.means3D[3 * (size_t)i + 2];
@@ -171,71 +172,86 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                 rmaxy = min(a.gy, max(0, rmaxy));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
-                    // ---- colour ---------------------------------------------------------------------------
-                    float cr, cg, cb;
-                    uint32_t clamp_bits = 0;
-                    if (a.colors_precomp) {
-                        cr = a.colors_precomp[3 * (size_t)i];
-                        cg = a.colors_precomp[3 * (size_t)i + 1];
-                        cb = a.colors_precomp[3 * (size_t)i + 2];
-                    } else {
-                        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
-                        const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
-                        dx = dx / len; dy = dy / len; dz = dz / len;
-                        float b[16];
-                        sh_basis(a.D, dx, dy, dz, b);
-                        if (FAST_SH16) {
-                            // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
-                            const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)i * 48);
-                            float4 v[12];
-#pragma unroll
-                            for (int k = 0; k < 12; k++) v[k] = sh4[k];
-                            const float *f = reinterpret_cast<const float *>(v);
-                            cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
-#pragma unroll
-                            for (int k = 1; k < 16; k++) {
-                                cr = fma_(b[k], f[3 * k], cr);
-                                cg = fma_(b[k], f[3 * k + 1], cg);
-                                cb = fma_(b[k], f[3 * k + 2], cb);
-                            }
-                        } else {
-                            const float *sh = a.shs + (size_t)i * a.M * 3;
-                            const int nb = (a.D + 1) * (a.D + 1);
-                            cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
-                            for (int k = 1; k < nb; k++) {
-                                cr = fma_(b[k], sh[3 * k], cr);
-                                cg = fma_(b[k], sh[3 * k + 1], cg);
-                                cb = fma_(b[k], sh[3 * k + 2], cb);
-                            }
-                        }
-                        cr += 0.5f; cg += 0.5f; cb += 0.5f;
-                        clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
-                        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
-                    }
                     const float opacity = a.opacities[i] * h_scale;
                     float4 *rec = a.splat + 3 * (size_t)i;
                     rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
                     rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
-                    rec[2] = make_float4(cr, cg, cb, fr);
                     float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
                     cv[0] = make_float2(c0, c1);
                     cv[1] = make_float2(c2, c3);
                     cv[2] = make_float2(c4, c5);
-                    a.clamped[i] = clamp_bits;
                     a.rects[i] = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
                                             (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                     radius = ir;
                     touched = (uint32_t)area;
                     visible = true;
+                    mypos = make_float4(px, py, pz, fr);
                 }
             }
         }
         a.radii[i] = radius;
         a.tiles_touched[i] = touched;
     }
-    // visible Gaussians of this block, consumed by the index-ordered compaction
-    const int cnt = __syncthreads_count(visible ? 1 : 0);
-    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = (uint32_t)cnt;
+    // ---- phase 2: colour, on the block-compacted list of survivors ------------------------------------------
+    // Typically only a fraction of the 256 lanes survive cull + rect; evaluating the SH (48 loads + ~110 VALU per
+    // Gaussian) in place would run all 4 waves at that fraction of their lanes.  Dense lanes instead.
+    __shared__ uint32_t s_w[4];
+    __shared__ float4 s_pos[GSR_BLOCK];
+    __shared__ int s_idx[GSR_BLOCK];
+    uint32_t cnt;
+    const uint32_t incl = gsr_block_incl_scan(visible ? 1u : 0u, s_w, cnt);
+    if (visible) {
+        s_pos[incl - 1u] = mypos;
+        s_idx[incl - 1u] = i;
+    }
+    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = cnt;  // consumed by the index-ordered compaction
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+        const int g = s_idx[threadIdx.x];
+        const float4 pp = s_pos[threadIdx.x];
+        float cr, cg, cb;
+        uint32_t clamp_bits = 0;
+        if (a.colors_precomp) {
+            cr = a.colors_precomp[3 * (size_t)g];
+            cg = a.colors_precomp[3 * (size_t)g + 1];
+            cb = a.colors_precomp[3 * (size_t)g + 2];
+        } else {
+            float dx = pp.x - a.campos[0], dy = pp.y - a.campos[1], dz = pp.z - a.campos[2];
+            const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            float b[16];
+            sh_basis(a.D, dx, dy, dz, b);
+            if (FAST_SH16) {
+                // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
+                const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
+                float4 v[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) v[k] = sh4[k];
+                const float *f = reinterpret_cast<const float *>(v);
+                cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    cr = fma_(b[k], f[3 * k], cr);
+                    cg = fma_(b[k], f[3 * k + 1], cg);
+                    cb = fma_(b[k], f[3 * k + 2], cb);
+                }
+            } else {
+                const float *sh = a.shs + (size_t)g * a.M * 3;
+                const int nb = (a.D + 1) * (a.D + 1);
+                cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
+                for (int k = 1; k < nb; k++) {
+                    cr = fma_(b[k], sh[3 * k], cr);
+                    cg = fma_(b[k], sh[3 * k + 1], cg);
+                    cb = fma_(b[k], sh[3 * k + 2], cb);
+                }
+            }
+            cr += 0.5f; cg += 0.5f; cb += 0.5f;
+            clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
+            cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+        }
+        a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, pp.w);
+        a.clamped[g] = clamp_bits;
+    }
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float *means3D, const float *m,
