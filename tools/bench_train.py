@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: forward + backward (dL/dmeans, dscales/drot -> dcov, dSH, dopacity) on 500k Gaussians
+at 800x800 with the 3DGS training loss 0.8 * L1 + 0.2 * (1 - fused_ssim) (lambda_dssim = 0.2,
+/root/reference/gsworld/utils/gs_utils.py:96), through the drop-in modules exactly as upstream train.py calls them
+(GaussianRasterizer autograd Function + fused_ssim).  Prints one JSON line (secondary metric; bench.py carries the
+headline).  Usage: bench_train.py [--steps K] [--warmup W] [--num-gaussians N]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gsworld_amd", "dropin"))
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
+from fused_ssim import fused_ssim  # noqa: E402
+from gsworld_amd import scenes  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--num-gaussians", type=int, default=500_000)
+    ap.add_argument("--size", type=int, default=800)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    S = args.size
+    cam = scenes.training_camera(S, S, 60.0).to(dev)
+    raw = scenes.random_scene_camera_frame(args.num_gaussians, seed=5).to(dev)
+    tgt = scenes.random_scene_camera_frame(args.num_gaussians, seed=5).to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    tgt.xyz += (0.01 * torch.randn(tgt.xyz.shape, generator=gen)).to(dev)
+    tgt.features_dc += (0.1 * torch.randn(tgt.features_dc.shape, generator=gen)).to(dev)
+    bg = torch.zeros(3, device=dev)
+    rs = GaussianRasterizationSettings(S, S, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 3, cam.camera_center, False, False, False)
+    rast = GaussianRasterizer(rs)
+
+    def render(r, grad):
+        params = [r.xyz, r.features_dc, r.features_rest, r.opacity, r.scaling, r.rotation]
+        if grad:
+            for p in params:
+                p.requires_grad_(True)
+                p.grad = None
+        shs = torch.cat((r.features_dc, r.features_rest), dim=1)
+        means2D = torch.zeros_like(r.xyz, requires_grad=grad)
+        color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=shs, opacities=torch.sigmoid(r.opacity),
+                                  scales=torch.exp(r.scaling), rotations=torch.nn.functional.normalize(r.rotation))
+        return color.clamp(0, 1), radii
+
+    with torch.no_grad():
+        gt, _ = render(tgt, False)
+    gt = gt.detach()
+
+    def step():
+        img, radii = render(raw, True)
+        l1 = (img - gt).abs().mean()
+        loss = 0.8 * l1 + 0.2 * (1.0 - fused_ssim(img[None], gt[None]))
+        loss.backward()
+        return loss, radii
+
+    for _ in range(args.warmup):
+        loss, radii = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, radii = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    finite = all(torch.isfinite(p.grad).all().item() for p in (raw.xyz, raw.features_dc, raw.features_rest,
+                                                               raw.opacity, raw.scaling, raw.rotation))
+    print(json.dumps({
+        "metric": "training iterations/sec (forward + backward, fused-ssim loss)", "value": 1.0 / dt,
+        "unit": "it/s", "ms_per_step": dt * 1e3, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
+                               "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step "
+                               "(BASELINE.json configs[4])",
+                   "num_visible": int((radii > 0).sum().item()), "loss": float(loss.item()),
+                   "grads_finite": bool(finite)}}))
+
+
+if __name__ == "__main__":
+    main()
