@@ -52,18 +52,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
-    f32 = dict(dtype=torch.float32, device=dev)
-    # allocated uninitialised: gsr_backward zeroes every gradient buffer on the stream
-    dL_dmeans3D = torch.empty((P, 3), **f32)
-    dL_dmeans2D = torch.empty((P, 3), **f32)
-    dL_dcolors = torch.empty((P, 3), **f32)
-    dL_dconic = torch.empty((P, 2, 2), **f32)
-    dL_dopacity = torch.empty((P, 1), **f32)
-    dL_dcov3D = torch.empty((P, 6), **f32)
-    dL_dsh = torch.empty((P, M, 3), **f32)
-    dL_dscales = torch.empty((P, 3), **f32)
-    dL_drotations = torch.empty((P, 4), **f32)
-    dL_dinvdepths = torch.empty((P, 1), **f32)
+    # One uninitialised arena sliced into the ten gradient buffers: gsr_backward zeroes adjacent buffers with a
+    # single memset on the stream.  (P,4)-shaped pieces first so that every slice stays 16-byte aligned.
+    shapes = [("dL_drotations", (P, 4)), ("dL_dconic", (P, 2, 2)), ("dL_dsh", (P, M, 3)), ("dL_dcov3D", (P, 6)),
+              ("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, 3)), ("dL_dscales", (P, 3)),
+              ("dL_dopacity", (P, 1)), ("dL_dinvdepths", (P, 1))]
+    sizes = [max(1, int(torch.tensor(s).prod())) if 0 not in s else 0 for _, s in shapes]
+    arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    views, off = {}, 0
+    for (name, shape), sz in zip(shapes, sizes):
+        views[name] = arena[off:off + sz].view(shape)
+        off += sz
+    dL_drotations, dL_dconic, dL_dsh, dL_dcov3D = (views[k] for k in ("dL_drotations", "dL_dconic", "dL_dsh",
+                                                                       "dL_dcov3D"))
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dscales = (views[k] for k in ("dL_dmeans3D", "dL_dmeans2D",
+                                                                           "dL_dcolors", "dL_dscales"))
+    dL_dopacity, dL_dinvdepths = views["dL_dopacity"], views["dL_dinvdepths"]
     if P != 0:
         tensors = [_f32(t, dev) for t in (background, means3D, colors, opacities, scales, rotations, cov3D_precomp,
                                           viewmatrix, projmatrix, sh, campos, dL_dout_color)]

@@ -376,16 +376,40 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
         const float *sh = a.shs + (size_t)i * a.M * 3;
         float *dsh = a.dL_dsh + (size_t)i * a.M * 3;
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        if (D == 3 && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.dL_dsh)) & 15u) == 0) {
+            // 48 contiguous floats in, 48 out: 12 + 12 dwordx4 accesses instead of 96 dword ones
+            float4 v[12], o[12];
+            const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (k < nb) {
+            for (int q = 0; q < 12; q++) v[q] = sh4[q];
+            const float *f = reinterpret_cast<const float *>(v);
+            float *of = reinterpret_cast<float *>(o);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    dsh[3 * k + ch] = bas[k] * dRGB[ch];
-                    const float sv = sh[3 * k + ch] * dRGB[ch];
+                    of[3 * k + ch] = bas[k] * dRGB[ch];
+                    const float sv = f[3 * k + ch] * dRGB[ch];
                     ddx += bx[k] * sv;
                     ddy += by[k] * sv;
                     ddz += bz[k] * sv;
+                }
+            }
+            float4 *dsh4 = reinterpret_cast<float4 *>(dsh);
+#pragma unroll
+            for (int q = 0; q < 12; q++) dsh4[q] = o[q];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < nb) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dsh[3 * k + ch] = bas[k] * dRGB[ch];
+                        const float sv = sh[3 * k + ch] * dRGB[ch];
+                        ddx += bx[k] * sv;
+                        ddy += by[k] * sv;
+                        ddz += bz[k] * sv;
+                    }
                 }
             }
         }
@@ -480,16 +504,33 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: dL_dsh / dL_dscales / dL_drots required for this input combination");
         return GSR_E_INVALID;
     }
-#define ZERO(ptr, count)                                                                                  \
-    if ((ptr) && hipMemsetAsync((ptr), 0, (size_t)(count) * sizeof(float), stream) != hipSuccess) {     \
-        gsr_set_error("gsr_backward: hipMemsetAsync failed");                                            \
-        return GSR_E_HIP;                                                                                 \
+    // zero every gradient buffer; buffers that are adjacent in memory (one arena sliced by the caller, as
+    // gsworld_amd/_backward.py does) are cleared by ONE memset instead of ten launches
+    {
+        const size_t n = (size_t)(P > 0 ? P : 0);
+        struct Range { char *p; size_t bytes; } r[10] = {
+            {(char *)gr->dL_dmeans2D, 3 * n * 4}, {(char *)gr->dL_dcolors, 3 * n * 4}, {(char *)gr->dL_dopacity, n * 4},
+            {(char *)gr->dL_dmeans3D, 3 * n * 4}, {(char *)gr->dL_dcov3D, 6 * n * 4},
+            {(char *)gr->dL_dsh, 3 * n * (size_t)M * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
+            {(char *)gr->dL_drots, 4 * n * 4}, {(char *)gr->dL_dconic, 4 * n * 4}, {(char *)gr->dL_dinvdepths, n * 4}};
+        for (int i = 1; i < 10; i++)  // insertion sort by address
+            for (int j = i; j > 0 && r[j].p < r[j - 1].p; j--) {
+                const Range t = r[j];
+                r[j] = r[j - 1];
+                r[j - 1] = t;
+            }
+        for (int i = 0; i < 10;) {
+            char *p = r[i].p;
+            size_t bytes = r[i].bytes;
+            int j = i + 1;
+            while (j < 10 && p && r[j].p == p + bytes) bytes += r[j++].bytes;
+            if (p && bytes && hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) {
+                gsr_set_error("gsr_backward: hipMemsetAsync failed");
+                return GSR_E_HIP;
+            }
+            i = j;
+        }
     }
-    const size_t n = (size_t)(P > 0 ? P : 0);
-    ZERO(gr->dL_dmeans2D, 3 * n) ZERO(gr->dL_dcolors, 3 * n) ZERO(gr->dL_dopacity, n) ZERO(gr->dL_dmeans3D, 3 * n)
-    ZERO(gr->dL_dcov3D, 6 * n) ZERO(gr->dL_dsh, 3 * n * (size_t)M) ZERO(gr->dL_dscales, 3 * n)
-    ZERO(gr->dL_drots, 4 * n) ZERO(gr->dL_dconic, 4 * n) ZERO(gr->dL_dinvdepths, n)
-#undef ZERO
     if (P == 0 || bw->num_rendered == 0) return GSR_OK;
     if (!bw->geom || !bw->binning || !bw->image || !bw->dL_dout_color || !bw->radii) {
         gsr_set_error("gsr_backward: forward state / dL_dout_color / radii missing");

@@ -162,12 +162,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_count_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ table, int nb_stride) {
     extern __shared__ uint32_t s_cnt[];  // [4][T]
     const uint32_t V = hdr->V;
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
+    const uint32_t k = gsr_place_batches(V);  // 64-Gaussian batches per wave: the workgroup owns 256 k ranks
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK * k;
     if (base >= V) return;
     for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
     __syncthreads();
-    walk_wave<false>(order, tiles_touched, rects, V, base + (uint32_t)gsr_wave() * 64u, gx, s_cnt + gsr_wave() * T,
-                     nullptr);
+    for (uint32_t bt = 0; bt < k; bt++)
+        walk_wave<false>(order, tiles_touched, rects, V, base + ((uint32_t)gsr_wave() * k + bt) * 64u, gx,
+                         s_cnt + gsr_wave() * T, nullptr);
     __syncthreads();
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK)
         table[(size_t)t * nb_stride + blockIdx.x] = s_cnt[t] + s_cnt[T + t] + s_cnt[2 * T + t] + s_cnt[3 * T + t];
@@ -216,12 +218,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ point_list) {
     extern __shared__ uint32_t s_cnt[];  // [4][T]: counts, then running cursors
     const uint32_t V = hdr->V;
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
+    const uint32_t k = gsr_place_batches(V);
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK * k;
     if (base >= V || hdr->overflow) return;
     for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
     __syncthreads();
     const int wave = gsr_wave();
-    walk_wave<false>(order, tiles_touched, rects, V, base + (uint32_t)wave * 64u, gx, s_cnt + wave * T, nullptr);
+    for (uint32_t bt = 0; bt < k; bt++)
+        walk_wave<false>(order, tiles_touched, rects, V, base + ((uint32_t)wave * k + bt) * 64u, gx, s_cnt + wave * T,
+                         nullptr);
     __syncthreads();
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) {
         const uint32_t c0 = s_cnt[t], c1 = s_cnt[T + t], c2 = s_cnt[2 * T + t];
@@ -235,7 +240,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *_
         }
     }
     __syncthreads();
-    walk_wave<true>(order, tiles_touched, rects, V, base + (uint32_t)wave * 64u, gx, s_cnt + wave * T, point_list);
+    for (uint32_t bt = 0; bt < k; bt++)  // a wave's batches are consecutive depth ranks: cursors carry over
+        walk_wave<true>(order, tiles_touched, rects, V, base + ((uint32_t)wave * k + bt) * 64u, gx, s_cnt + wave * T,
+                        point_list);
 }
 
 }  // namespace
@@ -250,7 +257,8 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     hipLaunchKernelGGL(tile_count_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
                        g.hdr, gx, T, g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
-    if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
+    // chunk < 0: the row length follows the adaptive workgroup size, ceil(V / (256 * gsr_place_batches(V)))
+    if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, -1, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
                        img.ranges, img.tile_order);
     return gsr_check_launch("tile_starts", debug, stream);

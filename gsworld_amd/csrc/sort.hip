@@ -110,6 +110,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__re
                                                                   uint32_t *__restrict__ totals, int chunk) {
     __shared__ uint32_t s_w[4];
     const uint32_t n = *n_ptr;
+    if (chunk < 0) chunk = GSR_BLOCK * (int)gsr_place_batches(n);  // adaptive workgroup size of the tile counting
     const int nb = (int)((n + (uint32_t)chunk - 1u) / (uint32_t)chunk);
     uint32_t *row = table + (size_t)blockIdx.x * nb_stride;
     uint32_t carry = 0;
