@@ -112,8 +112,8 @@ def lib() -> C.CDLL:
     L.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.gsr_pack_rgb8.restype = C.c_int
     L.gsr_pack_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-    L.gsr_debug_force_radix_binning.restype = C.c_int
-    L.gsr_debug_force_radix_binning.argtypes = [C.c_int]
+    L.gsr_debug_set_binning_mode.restype = C.c_int
+    L.gsr_debug_set_binning_mode.argtypes = [C.c_int]
     L.gsr_profile_enable.restype = C.c_int
     L.gsr_profile_enable.argtypes = [C.c_int]
     L.gsr_profile_collect.restype = C.c_int

@@ -10,7 +10,7 @@
 
 namespace {
 thread_local char g_err[512] = "";
-bool g_force_radix_binning = false;  // tests: exercise the large-grid fallback on small images
+int g_binning_mode = 2;  // 2 bin-then-sort (default), 1 depth sort + counting, 0 depth sort + radix (fallback)
 
 // ---- optional stage timing with HIP events on the caller's stream (bench / profiling only) ----------------
 constexpr int kStages = GSR_PROFILE_STAGES;
@@ -143,19 +143,33 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const GeomState g = GeomState::carve(geom_mem, in->P, tiles);
     const ImageState img = ImageState::carve(img_mem, W, H);
 
-    // the frame header is reset by the first kernel that writes it (scan of the block counts)
-    prof_mark(0, stream);
-    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, stream)) return e;
-    if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
-    prof_mark(1, stream);
-    if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
-    prof_mark(2, stream);
-
+    // binning path: 2 = bin-then-sort (default), 1 = depth sort + counting placement, 0 = depth sort + radix
+    // (tile grids above GSR_MAX_COUNT_TILES always take 0)
+    const int mode = GeomState::counting(tiles) ? g_binning_mode : 0;
     const bool exact = r_capacity <= 0;
-    const bool counting = GeomState::counting(tiles) && !g_force_radix_binning;
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
-    if (counting) {
+
+    if (mode == 2) {
+        // header + per-tile totals are adjacent: one memset; both are accumulated by preprocess
+        const size_t clear = (size_t)((char *)g.tile_cursor - (char *)g.hdr);
+        if (hipMemsetAsync(g.hdr, 0, clear, stream) != hipSuccess) {
+            gsr_set_error("gsr_forward: hipMemsetAsync(header) failed");
+            return GSR_E_HIP;
+        }
+    }
+    prof_mark(0, stream);
+    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, stream)) return e;
+    if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
+    prof_mark(1, stream);
+    if (mode != 2) {
+        // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
+        if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+    }
+    prof_mark(2, stream);
+    if (mode == 2) {
+        if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
+    } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
     } else {
         if (int e = gsr_launch_tile_offsets(in->P, g, cap32, debug, stream)) return e;
@@ -182,22 +196,29 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         return GSR_E_ALLOC;
     }
     const BinningState b = BinningState::carve(bin_mem, cap);
-    if (counting) {
+    if (mode == 2) {
+        if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
+    } else if (mode == 1) {
         if (int e = gsr_launch_tile_place(*st, in->P, g, b, img, debug, stream)) return e;
     } else {
         if (int e = gsr_launch_emit_and_tile_sort(*st, in->P, g, b, img, cap, debug, stream)) return e;
     }
     prof_mark(4, stream);
-    // both binning paths leave the point list in gidx[0]
-    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, counting, stream))
+    // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
+    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, mode != 0,
+                                  stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();
     return gsr_check_launch("render", debug, stream);
 }
 
-int gsr_debug_force_radix_binning(int enable) {
-    g_force_radix_binning = enable != 0;
+int gsr_debug_set_binning_mode(int mode) {
+    if (mode < 0 || mode > 2) {
+        gsr_set_error("gsr_debug_set_binning_mode: mode must be 0, 1 or 2");
+        return GSR_E_INVALID;
+    }
+    g_binning_mode = mode;
     return GSR_OK;
 }
 
@@ -276,7 +297,7 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity,
         v->clamped = reinterpret_cast<const uint8_t *>(g.clamped);
         v->tiles_touched = g.tiles_touched;
         v->rects = reinterpret_cast<const uint16_t *>(g.rects);
-        v->depth_order = g.idx[0];
+        v->depth_order = g_binning_mode == 2 && GeomState::counting(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) ? nullptr : g.idx[0];  // no global depth order on the default path
     }
     if (binning) {
         const BinningState b = BinningState::carve((char *)binning, r_capacity);

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_count_kernel(const uint32_t *_
 __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *__restrict__ totals, int T,
                                                                 GsrHeader *hdr, uint32_t r_capacity,
                                                                 uint2 *__restrict__ ranges,
-                                                                uint32_t *__restrict__ tile_order) {
+                                                                uint32_t *__restrict__ tile_order,
+                                                                uint32_t *__restrict__ cursor_to_zero) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
     uint32_t sum = 0;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
         if (t < T) {
             const uint32_t start = carry + incl - v;
             ranges[t] = (v == 0u || overflow) ? make_uint2(0u, 0u) : make_uint2(start, start + v);
+            if (cursor_to_zero) cursor_to_zero[t] = 0u;
         }
         carry += total;
     }
@@ -245,6 +247,129 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *_
                         point_list);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Bin-then-sort placement (default path).
+//
+// No global depth sort at all: preprocess accumulates per-tile instance totals (LDS histogram per workgroup +
+// one global add per touched tile), tile_starts turns them into ranges, bin_scatter drops every instance into
+// its tile's segment in ARBITRARY order as the 64-bit key (depth bits << 32 | Gaussian index) -- a workgroup
+// reserves a contiguous piece of each touched segment with one returning global atomic and ranks inside it with
+// LDS atomics -- and tile_sort orders each segment by that key in LDS.  Sorting the key is exactly the
+// reference's order inside a tile (ascending depth bits, ascending index on ties), so the point list is still
+// bit-identical, while the 9-launch radix chain and the index-ordered compaction disappear and the work per
+// workgroup no longer grows with tiles x Gaussians.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_BLOCK) void bin_scatter_kernel(int P, const uint32_t *__restrict__ tiles_touched,
+                                                                const uint2 *__restrict__ rects,
+                                                                const float4 *__restrict__ splat,
+                                                                const uint2 *__restrict__ ranges,
+                                                                uint32_t *__restrict__ tile_cursor,
+                                                                const GsrHeader *__restrict__ hdr, int gx, int T,
+                                                                uint64_t *__restrict__ keys) {
+    extern __shared__ uint32_t s_mem[];  // [T] counts -> ranks, [T] segment bases
+    uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
+    if (hdr->overflow) return;
+    const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
+    const uint32_t t = i < P ? tiles_touched[i] : 0u;
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t dbits = 0u;
+    if (t != 0u) {
+        rc = rects[i];
+        dbits = __float_as_uint(splat[3 * (size_t)i].z);
+    }
+    if (__syncthreads_count(t != 0u) == 0) return;
+    for (int k = (int)threadIdx.x; k < T; k += GSR_BLOCK) s_cnt[k] = 0u;
+    __syncthreads();
+    gsr_for_each_tile(t, rc, gx, 0u, 0u, [s_cnt](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
+    __syncthreads();
+    // reserve this workgroup's piece of every touched segment: 4 returning atomics in flight per thread
+    for (int k0 = (int)threadIdx.x; k0 < T; k0 += 4 * GSR_BLOCK) {
+        uint32_t c[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + u * GSR_BLOCK;
+            c[u] = k < T ? s_cnt[k] : 0u;
+            b[u] = 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u] != 0u) b[u] = atomicAdd(&tile_cursor[k0 + u * GSR_BLOCK], c[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + u * GSR_BLOCK;
+            if (c[u] != 0u) {
+                s_base[k] = ranges[k].x + b[u];
+                s_cnt[k] = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    gsr_for_each_tile(t, rc, gx, (uint32_t)i, dbits, [=](uint32_t tile, uint32_t lo, uint32_t hi) {
+        const uint32_t pos = s_base[tile] + atomicAdd(&s_cnt[tile], 1u);
+        keys[pos] = ((uint64_t)hi << 32) | lo;
+    });
+}
+
+// Ascending-only bitonic network over `n` keys padded (virtually) to N = 2^k with +inf: every comparator puts the
+// minimum at the lower index, so padding slots never move and need not exist.  256 threads, barrier per stage.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
+    for (int k = 2; k <= N; k <<= 1) {
+        const int hk = k >> 1;
+        // flip step: i <-> mirror position inside each block of k
+        for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
+            const int blk = p / hk, off = p - blk * hk;
+            const int i = blk * k + off, j = blk * k + k - 1 - off;
+            if (j < n) {
+                const uint64_t x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (int d = hk >> 1; d > 0; d >>= 1) {
+            for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
+                const int i = 2 * d * (p / d) + (p % d), j = i + d;
+                if (j < n) {
+                    const uint64_t x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int kSortLds = 8192;  // keys held in LDS (64 KiB); longer tile lists are sorted in place in global memory
+
+__global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2 *__restrict__ ranges,
+                                                              const uint32_t *__restrict__ tile_order,
+                                                              uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ point_list) {
+    extern __shared__ uint64_t s_keys[];
+    const int tile = (int)tile_order[blockIdx.x];  // longest lists first
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n == 0) return;
+    int N = 2;
+    while (N < n) N <<= 1;
+    uint64_t *seg = keys + range.x;
+    if (n == 1) {
+        if (threadIdx.x == 0) point_list[range.x] = (uint32_t)seg[0];
+        return;
+    }
+    if (N <= kSortLds) {
+        for (int i = (int)threadIdx.x; i < n; i += GSR_BLOCK) s_keys[i] = seg[i];
+        __syncthreads();
+        bitonic_sort_block(s_keys, n, N);
+        for (int i = (int)threadIdx.x; i < n; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
+    } else {
+        __syncthreads();
+        bitonic_sort_block(seg, n, N);  // same network on global memory (one workgroup: barriers order the passes)
+        for (int i = (int)threadIdx.x; i < n; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)seg[i];
+    }
+}
+
 }  // namespace
 
 // default path, part 1: per-tile instance counts -> ranges and R (no instance buffer needed yet)
@@ -260,7 +385,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     // chunk < 0: the row length follows the adaptive workgroup size, ceil(V / (256 * gsr_place_batches(V)))
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, -1, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
-                       img.ranges, img.tile_order);
+                       img.ranges, img.tile_order, (uint32_t *)nullptr);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 
@@ -274,6 +399,29 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
     hipLaunchKernelGGL(tile_place_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
                        g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
+}
+
+// bin-then-sort path, part 1: tile totals (accumulated by preprocess) -> ranges, R, tile order; cursors zeroed
+int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
+                          bool debug, hipStream_t stream) {
+    const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_accum, T, g.hdr, r_capacity,
+                       img.ranges, img.tile_order, g.tile_cursor);
+    return gsr_check_launch("bin_starts", debug, stream);
+}
+
+// bin-then-sort path, part 2: unordered scatter of the 64-bit keys, then the per-tile sort -> point list
+int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                                    const ImageState &img, bool debug, hipStream_t stream) {
+    const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
+    const int T = gx * gy;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(GeomState::prep_blocks(P)), dim3(GSR_BLOCK),
+                       (size_t)2 * T * sizeof(uint32_t), stream, P, g.tiles_touched, g.rects, g.splat, img.ranges,
+                       g.tile_cursor, g.hdr, gx, T, b.keys64);
+    if (int e = gsr_check_launch("bin_scatter", debug, stream)) return e;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(GSR_BLOCK), (size_t)kSortLds * sizeof(uint64_t), stream,
+                       img.ranges, img.tile_order, b.keys64, b.gidx[0]);
+    return gsr_check_launch("tile_sort", debug, stream);
 }
 
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

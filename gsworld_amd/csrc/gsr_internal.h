@@ -37,6 +37,9 @@ static inline int gsr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 // ---- geometry state (per Gaussian) -------------------------------------------------------------------
 struct GeomState {
     GsrHeader *hdr;
+    uint32_t *tile_accum;     // [tiles] per-tile instance totals accumulated by preprocess (bin-then-sort path);
+                              //         sits right behind the header so that one memset clears both
+    uint32_t *tile_cursor;    // [tiles] segment cursors of the unordered binning
     float4 *splat;            // [3P]  rec0 = (px, py, depth, 1/depth) rec1 = (conic.x, conic.y, conic.z, opacity)
                               //       rec2 = (r, g, b, radius as float)
     float *cov3D;             // [6P]
@@ -67,6 +70,8 @@ struct GeomState {
         char *p = base;
         const size_t n = (size_t)(P > 0 ? P : 1);
         g.hdr = take<GsrHeader>(p, 1);
+        g.tile_accum = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles : 0) + 1);
+        g.tile_cursor = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles : 0) + 1);
         g.splat = take<float4>(p, 3 * n);
         g.cov3D = take<float>(p, 6 * n);
         g.clamped = take<uint32_t>(p, n);
@@ -99,12 +104,14 @@ struct BinningState {
     uint32_t *gidx[2];     // [Rcap] Gaussian index per instance, ping-pong
     uint32_t *sort_table;  // [256 * nb]
     uint32_t *sort_totals; // [256]
+    uint64_t *keys64;      // [Rcap] (depth bits << 32 | Gaussian index) per instance, grouped by tile, unsorted
 
     static int sort_blocks(int64_t rcap) { return gsr_div_up(rcap > 0 ? rcap : 1, GSR_SORT_CHUNK); }
     static BinningState carve(char *base, int64_t rcap, size_t *bytes = nullptr) {
         BinningState b;
         char *p = base;
         const size_t n = (size_t)(rcap > 0 ? rcap : 1);
+        b.keys64 = GeomState::take<uint64_t>(p, n);
         b.tile[0] = GeomState::take<uint32_t>(p, n);
         b.tile[1] = GeomState::take<uint32_t>(p, n);
         b.gidx[0] = GeomState::take<uint32_t>(p, n);
@@ -160,7 +167,12 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
 
 // ---- launchers implemented in the kernel files -----------------------------------------------------------
 int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          hipStream_t stream);
+                          bool count_tiles, hipStream_t stream);
+// bin-then-sort path (default): unordered binning into tile segments, then a per-tile (depth, index) sort
+int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
+                          bool debug, hipStream_t stream);
+int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                                    const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
@@ -221,6 +233,41 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t *s_
     __syncthreads();
     return incl + add;
 }
+// Visits every tile of this lane's rect (t = tiles touched, rc = packed rect; t == 0 for lanes without a
+// Gaussian).  Lists of up to 32 tiles are walked by the owning lane; longer ones are spread over the whole wave,
+// 64 tiles per step, so that one large splat does not serialise its wave.  f(tile, lo, hi) runs once per
+// (Gaussian, tile) with the OWNER's 64-bit payload.  All 64 lanes must call this together.
+template <typename F>
+__device__ __forceinline__ void gsr_for_each_tile(uint32_t t, uint2 rc, int gx, uint32_t lo, uint32_t hi, F f) {
+    const int lane = gsr_lane();
+    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16, maxx = rc.y & 0xffffu, width = maxx - minx;
+    if (t > 0u && t <= 32u) {
+        uint32_t x = minx, row = miny * (uint32_t)gx;
+        for (uint32_t j = 0; j < t; j++) {
+            f(row + x, lo, hi);
+            if (++x == maxx) { x = minx; row += (uint32_t)gx; }
+        }
+    }
+    uint64_t todo = __builtin_amdgcn_ballot_w64(t > 32u);
+    // j / width without an integer division: (j + 0.5) * (1 / width) truncates to the exact quotient (j < 2^21)
+    const float inv_w = 1.0f / (float)(width > 0u ? width : 1u);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)t, src);
+        const uint32_t bminx = (uint32_t)__builtin_amdgcn_readlane((int)minx, src);
+        const uint32_t bminy = (uint32_t)__builtin_amdgcn_readlane((int)miny, src);
+        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)width, src);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
+        const float binv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), src));
+        for (uint32_t j = (uint32_t)lane; j < bt; j += 64u) {
+            const uint32_t yy = (uint32_t)(((float)j + 0.5f) * binv), xx = j - yy * bw;
+            f((bminy + yy) * (uint32_t)gx + (bminx + xx), blo, bhi);
+        }
+    }
+}
+
 // Longest-first tile order for the compositing queue: a 64-bucket counting sort of the tile list lengths, run by
 // ONE workgroup (callers: tile_starts_kernel on the counting path, tile_order_kernel on the radix fallback).
 // s_bins: 64 uint32 in LDS, s_red: 4 uint32 in LDS.  The ranges must be visible to the whole workgroup.

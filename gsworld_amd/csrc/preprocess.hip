@@ -25,6 +25,10 @@ struct PreprocessArgs {
     uint32_t *tiles_touched;
     uint2 *rects;
     uint32_t *block_counts;
+    // bin-then-sort path: per-tile instance totals and the visible count are accumulated here
+    int num_tiles;
+    uint32_t *tile_accum;
+    GsrHeader *hdr;
 };
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -64,11 +68,17 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-template <bool FAST_SH16>
+template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
+    extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
     const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
     bool visible = false;
     float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);  // xyz + radius, handed to the colour phase
+    uint32_t my_tiles = 0;
+    uint2 my_rect = make_uint2(0u, 0u);
+    if (COUNT_TILES) {
+        for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
+    }
     if (i < a.P) {
         const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1],
                     pz = a.means3D[3 * (size_t)i + 2];
@@ -180,10 +190,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                     cv[0] = make_float2(c0, c1);
                     cv[1] = make_float2(c2, c3);
                     cv[2] = make_float2(c4, c5);
-                    a.rects[i] = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
-                                            (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+                    my_rect = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
+                                         (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+                    a.rects[i] = my_rect;
                     radius = ir;
                     touched = (uint32_t)area;
+                    my_tiles = touched;
                     visible = true;
                     mypos = make_float4(px, py, pz, fr);
                 }
@@ -204,8 +216,22 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         s_pos[incl - 1u] = mypos;
         s_idx[incl - 1u] = i;
     }
-    if (threadIdx.x == 0) a.block_counts[blockIdx.x] = cnt;  // consumed by the index-ordered compaction
+    if (threadIdx.x == 0) {
+        a.block_counts[blockIdx.x] = cnt;  // consumed by the index-ordered compaction (depth-sorted paths)
+        if (COUNT_TILES && cnt != 0u) atomicAdd(&a.hdr->V, cnt);
+    }
     __syncthreads();
+    if (COUNT_TILES) {
+        // per-workgroup tile histogram in LDS, then one global add per touched tile
+        uint32_t *cnt_lds = s_tcnt;
+        gsr_for_each_tile(my_tiles, my_rect, a.gx, 0u, 0u,
+                          [cnt_lds](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&cnt_lds[tile], 1u); });
+        __syncthreads();
+        for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) {
+            const uint32_t c = s_tcnt[t];
+            if (c != 0u) atomicAdd(&a.tile_accum[t], c);
+        }
+    }
     if (threadIdx.x < cnt) {
         const int g = s_idx[threadIdx.x];
         const float4 pp = s_pos[threadIdx.x];
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 }  // namespace
 
 int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          hipStream_t stream) {
+                          bool count_tiles, hipStream_t stream) {
     PreprocessArgs a;
     a.P = in.P;
     a.D = st.sh_degree;
@@ -299,13 +325,24 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.tiles_touched = g.tiles_touched;
     a.rects = g.rects;
     a.block_counts = g.block_counts;
+    a.num_tiles = a.gx * a.gy;
+    a.tile_accum = g.tile_accum;
+    a.hdr = g.hdr;
     const int blocks = GeomState::prep_blocks(in.P);
     const bool fast = (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
                       ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
-    if (fast)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
-    else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+    const size_t lds = count_tiles ? (size_t)a.num_tiles * sizeof(uint32_t) : 0;
+    if (count_tiles) {
+        if (fast)
+            hipLaunchKernelGGL((preprocess_kernel<true, true>), dim3(blocks), dim3(GSR_BLOCK), lds, stream, a);
+        else
+            hipLaunchKernelGGL((preprocess_kernel<false, true>), dim3(blocks), dim3(GSR_BLOCK), lds, stream, a);
+    } else {
+        if (fast)
+            hipLaunchKernelGGL((preprocess_kernel<true, false>), dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+        else
+            hipLaunchKernelGGL((preprocess_kernel<false, false>), dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+    }
     return GSR_OK;
 }
 

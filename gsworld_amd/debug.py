@@ -39,7 +39,8 @@ def state_view(P: int, width: int, height: int, num_rendered: int, num_visible: 
     out["clamped"] = _view(geomBuffer, v.clamped, 4 * P, torch.uint8).view(P, 4)[:, :3]
     out["tiles_touched"] = _view(geomBuffer, v.tiles_touched, P, torch.int32)
     out["rects"] = _view(geomBuffer, v.rects, 4 * P, torch.int16).view(P, 4)
-    out["depth_order"] = _view(geomBuffer, v.depth_order, max(num_visible, 0), torch.int32)
+    if v.depth_order:  # only the depth-sorted binning paths (modes 0 / 1) materialise a global depth order
+        out["depth_order"] = _view(geomBuffer, v.depth_order, max(num_visible, 0), torch.int32)
     if binningBuffer is not None and num_rendered > 0:
         out["point_list"] = _view(binningBuffer, v.point_list, num_rendered, torch.int32)
     if imgBuffer is not None and "point_list" in out:

@@ -148,8 +148,10 @@ int gsr_profile_enable(int mode);
  * 2 = batched + persistent workgroups on a longest-first tile queue (default).  blocks_per_cu (1..8, 0 = keep)
  * sizes variant 2's grid. */
 int gsr_debug_set_render_variant(int variant, int blocks_per_cu);
-/* Tests only: route binning through the radix-sort fallback used for tile grids above 3840 tiles. */
-int gsr_debug_force_radix_binning(int enable);
+/* Tests / A-B: binning path.  2 = unordered binning + per-tile (depth, index) sort in LDS (default),
+ * 1 = global depth sort + counting placement, 0 = global depth sort + emit + tile-id radix sort (always used for
+ * tile grids above 3840 tiles).  All three produce the same point list. */
+int gsr_debug_set_binning_mode(int mode);
 int gsr_profile_collect(GsrProfile *out);
 
 /*

@@ -102,20 +102,30 @@ def test_tabletop_config2_full(cuda_device):
     assert rep["P"] == scenes.XARM6_ALIGN_NUM_GAUSSIANS
 
 
-def test_radix_fallback_binning_matches_too(cuda_device):
-    """Tile grids above 3840 tiles use emit + radix sort instead of the counting placement: same point list."""
+@pytest.mark.parametrize("mode", [0, 1])
+def test_alternative_binning_paths_match_too(cuda_device, mode):
+    """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 3840 tiles use) and mode 1 (depth
+    sort + counting placement) must give the same point list as the default bin-then-sort path."""
     from gsworld_amd._lib import lib
 
     raw = scenes.random_scene_camera_frame(30_000, seed=14)
-    lib().gsr_debug_force_radix_binning(1)
+    lib().gsr_debug_set_binning_mode(mode)
     try:
         _run(raw, scenes.identity_camera(200, 120, 60.0))   # 104 tiles: 1 radix pass (result side 1 -> copied)
         _run(raw, scenes.identity_camera(640, 480, 60.0))   # 1200 tiles: 2 passes
     finally:
-        lib().gsr_debug_force_radix_binning(0)
-    # a grid that is natively above the counting limit (120 x 68 = 8160 tiles)
+        lib().gsr_debug_set_binning_mode(2)
+
+
+def test_large_tile_grid_and_long_tile_lists(cuda_device):
+    # a grid that is natively above the counting limit (120 x 68 = 8160 tiles) -> radix fallback
     rep = _run(scenes.random_scene_camera_frame(30_000, seed=15), scenes.identity_camera(1920, 1080, 60.0))
     assert rep["R"] > 0
+    # tile lists longer than the 8192-key LDS sort: 30k big splats on a 64x64 image (16 tiles)
+    raw = scenes.random_scene_camera_frame(30_000, seed=16)
+    raw.scaling += 1.5
+    rep = _run(raw, scenes.identity_camera(64, 64, 60.0))
+    assert rep["R"] / 16 > 8192
 
 
 def test_mark_visible(cuda_device):
