@@ -292,14 +292,15 @@ __global__ __launch_bounds__(GSR_BLOCK) void bin_scatter_kernel(int P, const uin
             c[u] = k < T ? s_cnt[k] : 0u;
             b[u] = 0u;
         }
+        uint32_t *cur = tile_cursor + (size_t)(blockIdx.x % GSR_BIN_SLOTS) * T;  // this workgroup's counter copy
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (c[u] != 0u) b[u] = atomicAdd(&tile_cursor[k0 + u * GSR_BLOCK], c[u]);
+            if (c[u] != 0u) b[u] = atomicAdd(&cur[k0 + u * GSR_BLOCK], c[u]);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int k = k0 + u * GSR_BLOCK;
             if (c[u] != 0u) {
-                s_base[k] = ranges[k].x + b[u];
+                s_base[k] = b[u];  // cursors hold absolute positions in the instance list
                 s_cnt[k] = 0u;
             }
         }
@@ -311,25 +312,77 @@ __global__ __launch_bounds__(GSR_BLOCK) void bin_scatter_kernel(int P, const uin
     });
 }
 
+// one workgroup: slot-replicated tile totals -> ranges, R, overflow, tile order; cursor[s][t] = first slot of
+// the piece of tile t's segment that the workgroups of slot s fill
+__global__ __launch_bounds__(GSR_BLOCK) void bin_starts_kernel(const uint32_t *__restrict__ accum, int T,
+                                                               GsrHeader *hdr, uint32_t r_capacity,
+                                                               uint2 *__restrict__ ranges,
+                                                               uint32_t *__restrict__ tile_order,
+                                                               uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_bins[64];
+    uint32_t sum = 0;
+    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK)
+#pragma unroll
+        for (int s = 0; s < GSR_BIN_SLOTS; s++) sum += accum[(size_t)s * T + t];
+    uint32_t grand;
+    gsr_block_incl_scan(sum, s_w, grand);
+    const bool overflow = grand > r_capacity;
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += GSR_BLOCK) {
+        const int t = base + (int)threadIdx.x;
+        uint32_t part[GSR_BIN_SLOTS], v = 0;
+#pragma unroll
+        for (int s = 0; s < GSR_BIN_SLOTS; s++) {
+            part[s] = t < T ? accum[(size_t)s * T + t] : 0u;
+            v += part[s];
+        }
+        uint32_t total;
+        const uint32_t incl = gsr_block_incl_scan(v, s_w, total);
+        if (t < T) {
+            const uint32_t start = carry + incl - v;
+            ranges[t] = (v == 0u || overflow) ? make_uint2(0u, 0u) : make_uint2(start, start + v);
+            uint32_t run = start;
+#pragma unroll
+            for (int s = 0; s < GSR_BIN_SLOTS; s++) {
+                cursor[(size_t)s * T + t] = run;
+                run += part[s];
+            }
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        hdr->R_raw = grand;
+        hdr->r_capacity = r_capacity;
+        hdr->overflow = overflow ? 1u : 0u;
+        hdr->R = overflow ? 0u : grand;
+    }
+    __syncthreads();
+    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
+}
+
 // Ascending-only bitonic network over `n` keys padded (virtually) to N = 2^k with +inf: every comparator puts the
 // minimum at the lower index, so padding slots never move and need not exist.  256 threads, barrier per stage.
 template <typename Ptr>
 __device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
-    for (int k = 2; k <= N; k <<= 1) {
-        const int hk = k >> 1;
+    // all sizes are powers of two: index arithmetic with shifts and masks only
+    for (int lk = 1; (1 << lk) <= N; lk++) {
+        const int k = 1 << lk, hk = k >> 1;
         // flip step: i <-> mirror position inside each block of k
         for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
-            const int blk = p / hk, off = p - blk * hk;
-            const int i = blk * k + off, j = blk * k + k - 1 - off;
+            const int off = p & (hk - 1);
+            const int blk0 = (p >> (lk - 1)) << lk;
+            const int i = blk0 + off, j = blk0 + k - 1 - off;
             if (j < n) {
                 const uint64_t x = a[i], y = a[j];
                 if (x > y) { a[i] = y; a[j] = x; }
             }
         }
         __syncthreads();
-        for (int d = hk >> 1; d > 0; d >>= 1) {
+        for (int ld = lk - 2; ld >= 0; ld--) {
+            const int d = 1 << ld;
             for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
-                const int i = 2 * d * (p / d) + (p % d), j = i + d;
+                const int i = ((p >> ld) << (ld + 1)) | (p & (d - 1)), j = i + d;
                 if (j < n) {
                     const uint64_t x = a[i], y = a[j];
                     if (x > y) { a[i] = y; a[j] = x; }
@@ -405,7 +458,7 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
 int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                           bool debug, hipStream_t stream) {
     const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_accum, T, g.hdr, r_capacity,
+    hipLaunchKernelGGL(bin_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_accum, T, g.hdr, r_capacity,
                        img.ranges, img.tile_order, g.tile_cursor);
     return gsr_check_launch("bin_starts", debug, stream);
 }

@@ -16,6 +16,7 @@
 #define GSR_RADIX_BINS 256
 #define GSR_DEPTH_RADIX_BITS 11       // digit width of the 32-bit depth sort and the 30-bit Morton sort: 3 passes
 #define GSR_DEPTH_RADIX_BINS 2048
+#define GSR_BIN_SLOTS 16              // replicated per-tile counters of the bin-then-sort path
 #define GSR_MAX_COUNT_TILES 3840         // counting placement keeps 4 x tiles LDS counters per workgroup (<= 60 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
@@ -70,8 +71,10 @@ struct GeomState {
         char *p = base;
         const size_t n = (size_t)(P > 0 ? P : 1);
         g.hdr = take<GsrHeader>(p, 1);
-        g.tile_accum = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles : 0) + 1);
-        g.tile_cursor = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles : 0) + 1);
+        // GSR_BIN_SLOTS copies of each per-tile counter: workgroup b uses copy b % GSR_BIN_SLOTS, which divides the
+        // same-address contention of the device-scope atomics (they resolve memory-side, ~100 ns apiece) by 16
+        g.tile_accum = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles * GSR_BIN_SLOTS : 0) + 1);
+        g.tile_cursor = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles * GSR_BIN_SLOTS : 0) + 1);
         g.splat = take<float4>(p, 3 * n);
         g.cov3D = take<float>(p, 6 * n);
         g.clamped = take<uint32_t>(p, n);

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         __syncthreads();
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) {
             const uint32_t c = s_tcnt[t];
-            if (c != 0u) atomicAdd(&a.tile_accum[t], c);
+            if (c != 0u) atomicAdd(&a.tile_accum[(size_t)(blockIdx.x % GSR_BIN_SLOTS) * a.num_tiles + t], c);
         }
     }
     if (threadIdx.x < cnt) {
