@@ -10,7 +10,9 @@
 
 namespace {
 thread_local char g_err[512] = "";
-int g_binning_mode = 2;  // 2 bin-then-sort (default), 1 depth sort + counting, 0 depth sort + radix (fallback)
+// 1 = depth sort + counting placement (default: fastest at config 2), 2 = bin-then-sort (scales better with V and
+// tiles, its per-tile LDS sort is not tuned yet -- profiles/round1/binning_modes.md), 0 = depth sort + radix (fallback)
+int g_binning_mode = 1;
 
 // ---- optional stage timing with HIP events on the caller's stream (bench / profiling only) ----------------
 constexpr int kStages = GSR_PROFILE_STAGES;

@@ -102,10 +102,10 @@ def test_tabletop_config2_full(cuda_device):
     assert rep["P"] == scenes.XARM6_ALIGN_NUM_GAUSSIANS
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 2])
 def test_alternative_binning_paths_match_too(cuda_device, mode):
-    """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 3840 tiles use) and mode 1 (depth
-    sort + counting placement) must give the same point list as the default bin-then-sort path."""
+    """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 3840 tiles use) and mode 2 (unordered
+    binning + per-tile LDS sort) must give the same point list as the default mode 1 (depth sort + counting)."""
     from gsworld_amd._lib import lib
 
     raw = scenes.random_scene_camera_frame(30_000, seed=14)
@@ -114,7 +114,7 @@ def test_alternative_binning_paths_match_too(cuda_device, mode):
         _run(raw, scenes.identity_camera(200, 120, 60.0))   # 104 tiles: 1 radix pass (result side 1 -> copied)
         _run(raw, scenes.identity_camera(640, 480, 60.0))   # 1200 tiles: 2 passes
     finally:
-        lib().gsr_debug_set_binning_mode(2)
+        lib().gsr_debug_set_binning_mode(1)
 
 
 def test_large_tile_grid_and_long_tile_lists(cuda_device):
@@ -122,9 +122,15 @@ def test_large_tile_grid_and_long_tile_lists(cuda_device):
     rep = _run(scenes.random_scene_camera_frame(30_000, seed=15), scenes.identity_camera(1920, 1080, 60.0))
     assert rep["R"] > 0
     # tile lists longer than the 8192-key LDS sort: 30k big splats on a 64x64 image (16 tiles)
+    from gsworld_amd._lib import lib
+
     raw = scenes.random_scene_camera_frame(30_000, seed=16)
     raw.scaling += 3.0
-    rep = _run(raw, scenes.identity_camera(64, 64, 60.0))
+    lib().gsr_debug_set_binning_mode(2)
+    try:
+        rep = _run(raw, scenes.identity_camera(64, 64, 60.0))
+    finally:
+        lib().gsr_debug_set_binning_mode(1)
     assert rep["R"] / 16 > 8192, rep["R"]
 
 
