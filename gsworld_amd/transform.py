@@ -72,6 +72,74 @@ def _compose_rotation(quat_r: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
     return quaternion_multiply(quat_r, r / norm) * norm
 
 
+class FusedPartTransform:
+    """One-pass replacement of ``GSWorldWrapper.transform_gs_perlink`` + the write-back loop of
+    ``_render_gsworld`` (gs_world_wrapper.py:110-162, 244-265) for ``num_envs = 1``.
+
+    ``part_labels`` maps a part name (robot link or tracked actor) to its semantic label(s), as
+    ``xarm_gs_semantics`` / ``obj_gs_semantics`` do (/root/reference/gsworld/constants.py:402-505).  Per step the
+    caller passes one 4x4 per part -- for a link ``sim2gs @ link_now @ inv(link_scan) @ inv(sim2gs)``
+    (gs_world_wrapper.py:120), for an actor the rigid part of ``sim2gs @ pose @ inv(sim2gs_obj)`` plus its uniform
+    scale (``:146-156``) -- and gets the transformed ``xyz`` / ``rotation`` buffers the rasterizer should read.
+    What the wrapper writes back at ``num_envs = 1`` is exactly xyz and rotation (scaling and opacity keep their
+    shapes and fail its ``shape[0] == num_envs`` test), which is what this op produces.
+    """
+
+    def __init__(self, part_labels: dict, semantics: torch.Tensor, lut_size: int = 2048):
+        self.names = list(part_labels.keys())
+        lut = torch.full((lut_size,), -1, dtype=torch.int32)
+        for k, name in enumerate(self.names):
+            labels = part_labels[name]
+            for lab in (labels if isinstance(labels, (list, tuple)) else [labels]):
+                if not 0 <= int(lab) < lut_size:
+                    raise ValueError(f"label {lab} of part {name!r} outside the LUT (size {lut_size})")
+                lut[int(lab)] = k
+        self.device = semantics.device
+        self.lut = lut.to(self.device)
+        self.semantics = semantics.reshape(-1).to(torch.float32).contiguous()
+        self._xyz_out = None
+        self._rot_out = None
+
+    def pack(self, matrices: torch.Tensor, scales: torch.Tensor | None = None) -> torch.Tensor:
+        """(K,4,4) rigid matrices (+ optional (K,) uniform scales) -> (K,17) transform table (host math, K ~ 18)."""
+        M = matrices.detach().to("cpu", torch.float32)
+        K = M.shape[0]
+        if K != len(self.names):
+            raise ValueError(f"expected {len(self.names)} matrices, got {K}")
+        q = matrix_to_quaternion(M[:, :3, :3])
+        s = torch.ones(K) if scales is None else scales.detach().to("cpu", torch.float32).reshape(K)
+        return torch.cat((M[:, :3, :3].reshape(K, 9), M[:, :3, 3], s[:, None], q), dim=1).contiguous()
+
+    def apply(self, xyz: torch.Tensor, rotation: torch.Tensor, matrices: torch.Tensor, scales=None):
+        """-> (xyz', rotation') in persistent output buffers (overwritten by the next call)."""
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        if not xyz.is_cuda:
+            raise RuntimeError("FusedPartTransform.apply: tensors must live on a HIP device (no CPU path)")
+        L = lib()
+        if not getattr(L, "_xf_bound", False):
+            L.gsr_transform_gaussians.restype = C.c_int
+            L.gsr_transform_gaussians.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L._xf_bound = True
+        xyz = xyz.detach().to(torch.float32).contiguous()
+        rotation = rotation.detach().to(torch.float32).contiguous()
+        P = xyz.shape[0]
+        if self._xyz_out is None or self._xyz_out.shape[0] != P:
+            self._xyz_out = torch.empty_like(xyz)
+            self._rot_out = torch.empty_like(rotation)
+        table = self.pack(matrices, scales).to(self.device, non_blocking=True)
+        with torch.cuda.device(self.device):
+            check(L.gsr_transform_gaussians(
+                P, C.c_void_p(xyz.data_ptr()), C.c_void_p(rotation.data_ptr()), C.c_void_p(self.semantics.data_ptr()),
+                C.c_void_p(self.lut.data_ptr()), self.lut.numel(), C.c_void_p(table.data_ptr()), table.shape[0],
+                C.c_void_p(self._xyz_out.data_ptr()), C.c_void_p(self._rot_out.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return self._xyz_out, self._rot_out
+
+
 def transform_gaussians(gaussians, selected_indices, scale=None, rot_mat=None, translation=None, new_opacity=None):
     """Same contract as the reference function (gs_utils.py:283-385), including its output shapes:
     one rotation ``(1,3,3)`` keeps xyz ``(N,3)`` but yields rotations ``(1,N,4)``; a ``(B,3)`` translation

@@ -203,6 +203,17 @@ int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, flo
                       const float *img2, const float *dL_dmap, const float *dm_dmu1, const float *dm_dsigma1_sq,
                       const float *dm_dsigma12, float *dL_dimg1, void *stream);
 
+/*
+ * Fused per-step rigid transform of labelled Gaussians -- replaces GSWorld's per-link isin() mask / gather /
+ * transform_gaussians / masked scatter passes (gs_world_wrapper.py:110-162,244-265; gs_utils.py:283-385) and the
+ * full-model deepcopy with one pass.  label = (int)semantics[i]; k = lut[label] (or -1 / out of range: copy through);
+ * transforms[k] = 17 floats: R row-major (9), t (3), uniform scale (1), quaternion of R as (w,x,y,z) (4).
+ *   xyz' = R (scale * xyz) + t;   rot' = standardize(q_R (x) rot/|rot|) * |rot|.
+ */
+int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const float *semantics,
+                            const int32_t *lut, int32_t lut_size, const float *transforms, int32_t K,
+                            float *xyz_out, float *rot_out, void *stream);
+
 /* Self-test of the DPP wave reduction used by the backward: out4[w] = sum(in256[64w .. 64w+63]). */
 int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream);
 
