@@ -1,0 +1,103 @@
+"""End-to-end through the drop-in import surfaces exactly as GSWorld reaches them: ``dropin`` and
+``gs_compat`` on sys.path, then ``from gaussian_renderer import render`` / ``from scene.cameras import Camera`` /
+``from scene.gaussian_model import GaussianModel`` / ``from simple_knn._C import distCUDA2`` / ``fused_ssim``."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gs_paths():
+    added = [os.path.join(ROOT, "gsworld_amd", "dropin"), os.path.join(ROOT, "gsworld_amd", "gs_compat")]
+    for p in added:
+        sys.path.insert(0, p)
+    yield
+    for p in added:
+        sys.path.remove(p)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("scene", "gaussian_renderer", "arguments", "utils",
+                                                            "diff_gaussian_rasterization", "simple_knn", "fused_ssim")]:
+        del sys.modules[m]
+
+
+def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
+    from arguments import PipelineParams
+    from gaussian_renderer import render
+    from scene.cameras import Camera
+    from scene.gaussian_model import GaussianModel
+
+    from gsworld_amd import scenes
+    from tests import helpers as hp
+
+    try:
+        import diff_gaussian_rasterization
+        assert not hasattr(diff_gaussian_rasterization, "SparseGaussianAdam")  # GSWorld's probe must fail
+    except ImportError:
+        pytest.fail("drop-in diff_gaussian_rasterization not importable")
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=3)
+    pc = GaussianModel(3)
+    pc._xyz, pc._features_dc, pc._features_rest = raw.xyz.to(dev), raw.features_dc.to(dev), raw.features_rest.to(dev)
+    pc._opacity = raw.opacity.to(dev)[..., None]  # (N,1,1) as Semantic3DGSWrapper.load_ply leaves it
+    pc._scaling, pc._rotation = raw.scaling.to(dev), raw.rotation.to(dev)
+    pc.active_sh_degree = 3
+    ref_cam = scenes.sensor_camera("xarm6_align")
+    # the wrapper builds the Camera from (R = world2cam[:3,:3].T, T = world2cam[:3,3]) (gs_world_wrapper.py:300-322)
+    W2C = ref_cam.world_view_transform.T
+    cam = Camera(resolution=(640, 480), colmap_id=0, R=W2C[:3, :3].T.numpy(), T=W2C[:3, 3].numpy(), FoVx=ref_cam.FoVx,
+                 FoVy=ref_cam.FoVy, depth_params=None, image=None, invdepthmap=None, image_name="right_cam", uid=0,
+                 data_device=dev)
+    np.testing.assert_allclose(cam.full_proj_transform.cpu().numpy(), ref_cam.full_proj_transform.numpy(), atol=1e-6)
+    pipe = PipelineParams().extract(types.SimpleNamespace())
+    bg = torch.zeros(3, device=dev)
+    out = render(cam, pc, pipe, bg, use_trained_exp=False, separate_sh=False)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+    img = out["render"]
+    assert img.shape == (3, 480, 640) and float(img.min()) >= 0 and float(img.max()) <= 1
+    # same frame through the oracle
+    inp = hp.np_inputs(raw, ref_cam)
+    inp["viewmatrix"] = cam.world_view_transform.cpu().numpy().reshape(-1)
+    inp["projmatrix"] = cam.full_proj_transform.cpu().numpy().reshape(-1)
+    inp["campos"] = cam.camera_center.cpu().numpy()
+    o = hp.oracle_forward(inp, hp.oracle_settings(ref_cam), np.zeros(3, np.float32))
+    ok = o["borderline"] == 0
+    assert np.abs(img.cpu().numpy() - np.clip(o["color"], 0, 1))[:, ok].max() <= 1e-4
+    assert int((out["radii"] > 0).sum()) == int((o["geom"]["radii"] > 0).sum())
+    # GSWorld's uint8 conversion (gs_world_wrapper.py:268-270) vs FrameRenderer.pack_rgb8
+    from gsworld_amd.renderer import FrameRenderer
+
+    want = (img.permute(1, 2, 0).unsqueeze(0) * 255).clamp(0, 255).to(torch.uint8)[0]
+    got = FrameRenderer(dev).pack_rgb8(img.contiguous())
+    assert torch.equal(got, want)
+    # convert_SHs_python / compute_cov3D_python pipeline flags route through colors_precomp / cov3D_precomp
+    pipe2 = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=False, antialiasing=False)
+    img2 = render(cam, pc, pipe2, bg)["render"]
+    assert float((img2 - img).abs().max()) < 2e-3
+
+
+def test_create_from_pcd_uses_distcuda2_and_ssim_imports(cuda_device, gs_paths):
+    from fused_ssim import fused_ssim
+    from scene.gaussian_model import GaussianModel
+    from simple_knn._C import distCUDA2
+
+    from oracle import gs_oracle as go
+
+    rng = np.random.default_rng(0)
+    pts = rng.random((3000, 3)).astype(np.float32)
+    pcd = types.SimpleNamespace(points=pts, colors=rng.random((3000, 3)).astype(np.float32))
+    m = GaussianModel(3)
+    m.create_from_pcd(pcd, [], 1.0)
+    want = np.log(np.sqrt(np.maximum(go.knn_dist2(pts), 1e-7)))
+    np.testing.assert_allclose(m._scaling[:, 0].detach().cpu().numpy(), want, rtol=1e-6)
+    assert m._features_dc.shape == (3000, 1, 3) and m._features_rest.shape == (3000, 15, 3)
+    assert torch.allclose(m.get_opacity, torch.full_like(m.get_opacity, 0.1), atol=1e-6)
+    assert distCUDA2(torch.from_numpy(pts).to(cuda_device)).shape == (3000,)
+    a = torch.rand(1, 3, 32, 32, device=cuda_device)
+    assert abs(float(fused_ssim(a, a)) - 1.0) < 1e-6
