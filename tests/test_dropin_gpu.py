@@ -59,7 +59,8 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     bg = torch.zeros(3, device=dev)
     out = render(cam, pc, pipe, bg, use_trained_exp=False, separate_sh=False)
     assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
-    img = out["render"]
+    assert out["render"].requires_grad  # the means2D gradient carrier keeps the autograd graph alive, as upstream
+    img = out["render"].detach()
     assert img.shape == (3, 480, 640) and float(img.min()) >= 0 and float(img.max()) <= 1
     # same frame through the oracle
     inp = hp.np_inputs(raw, ref_cam)
@@ -78,7 +79,7 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     assert torch.equal(got, want)
     # convert_SHs_python / compute_cov3D_python pipeline flags route through colors_precomp / cov3D_precomp
     pipe2 = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=False, antialiasing=False)
-    img2 = render(cam, pc, pipe2, bg)["render"]
+    img2 = render(cam, pc, pipe2, bg)["render"].detach()
     assert float((img2 - img).abs().max()) < 2e-3
 
 
