@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage event timing table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the frame in a hipGraph")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent frames in flight, each on its own HIP stream with its own renderer state "
+                         "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time)")
     return ap.parse_args()
 
 
@@ -68,34 +71,39 @@ def main():
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
 
-    r = FrameRenderer(dev)
+    S = max(1, args.in_flight)
     K_g = max(1, args.gather_every)
+    K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
     fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world)
+    rs_ = [FrameRenderer(dev) for _ in range(S)]
+    lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    r = rs_[0]
 
-    def frame(slot):
-        color, _radii, _invd = r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg)
-        r.pack_rgb8(color, fg.frames[slot])
+    def frame(slot, lane=None):
+        rr = rs_[slot % S if lane is None else lane]
+        color, _radii, _invd = rr.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg)
+        rr.pack_rgb8(color, fg.frames[slot])
 
     # exact-mode frame sizes the binning capacity from the real R; then check the no-sync path is valid
-    frame(0)
-    st0 = r.ensure_valid(lambda: frame(0))
-    frame(0)
-    st0 = r.ensure_valid(lambda: frame(0))
+    for l in range(S):
+        for _ in range(2):
+            frame(l, l)
+            rs_[l].ensure_valid(lambda l=l: frame(l, l))
     torch.cuda.synchronize()
 
-    # ---- hipGraph capture of one frame (launch-bound inner loop) -------------------------------------------------
+    # ---- hipGraph capture of one frame per slot (launch-bound inner loop) ----------------------------------------
     graph = None
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                frame(0)
-            torch.cuda.current_stream().wait_stream(side)
             graphs = []
             for slot in range(K_g):
+                st = lanes[slot % S] if S > 1 else torch.cuda.Stream(dev)
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    frame(slot)  # warm the capture stream
+                torch.cuda.current_stream().wait_stream(st)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=st):
                     frame(slot)
                 graphs.append(g)
             graph = graphs
@@ -106,11 +114,25 @@ def main():
 
     def step(i):
         slot = i % K_g
-        if graph is not None:
-            graph[slot].replay()
+        if S > 1:
+            with torch.cuda.stream(lanes[slot % S]):
+                if graph is not None:
+                    graph[slot].replay()
+                else:
+                    frame(slot)
+            if world > 1 and slot == K_g - 1:
+                cur = torch.cuda.current_stream()
+                for st in lanes:
+                    cur.wait_stream(st)  # every lane has written its slots of this batch
+                fg.step_done(i)          # RCCL all_gather on a side stream; `cur` then waits for it
+                for st in lanes:
+                    st.wait_stream(cur)  # the next batch may overwrite the slots only after the gather read them
         else:
-            frame(slot)
-        fg.step_done(i)  # RCCL all_gather of the batch of finished frames on a side stream (N > 1)
+            if graph is not None:
+                graph[slot].replay()
+            else:
+                frame(slot)
+            fg.step_done(i)  # RCCL all_gather of the batch of finished frames on a side stream (N > 1)
 
     def barrier():
         if world > 1:
@@ -148,6 +170,9 @@ def main():
         stage_ms[-1] = prof.stage_ms[len(PROFILE_STAGES) - 1] / prof.frames  # measured inside the timed region
 
     stats = r.ensure_valid(lambda: frame(0))
+    for l in range(1, S):
+        if rs_[l].stats().overflow:
+            raise SystemExit("binning capacity overflowed on a lane during the timed region: result invalid")
     if stats.overflow:
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
 
@@ -179,6 +204,7 @@ def main():
                             "(BASELINE.json configs[1]; one scene per GPU for N>1 = configs[3])",
                 "num_gaussians": n, "num_visible": stats.num_visible, "num_rendered": stats.num_rendered,
                 "sh_degree": 3, "launch": "hipGraph replay" if graph is not None else "eager",
+                "frames_in_flight": S,
                 "frame_gather": f"RCCL all_gather of uint8 frames every {K_g} frames" if world > 1 else "none",
             },
             "roofline": {
