@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage event timing table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the frame in a hipGraph")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--render-bpc", type=int, default=0, help="persistent compositing workgroups per CU (0 = library default)")
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="independent frames in flight, each on its own HIP stream with its own renderer state "
                          "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time)")
     return ap.parse_args()
@@ -71,6 +72,10 @@ def main():
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
 
+    if args.render_bpc:
+        import ctypes
+        lib().gsr_debug_set_render_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+        check(lib().gsr_debug_set_render_variant(2, args.render_bpc))
     S = max(1, args.in_flight)
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
