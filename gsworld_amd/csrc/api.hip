@@ -167,9 +167,6 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     if (mode != 2) {
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
         if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
-        // colour (SH -> RGB) of the visible Gaussians: dense over the sorted list, needed only by the compositor
-        if (int e = gsr_launch_colour(*st, *in, out->radii, g, g.idx[0], stream)) return e;
-        if (int e = gsr_check_launch("colour", debug, stream)) return e;
     }
     prof_mark(2, stream);
     if (mode == 2) {

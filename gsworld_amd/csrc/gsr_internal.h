@@ -171,9 +171,7 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
 // ---- launchers implemented in the kernel files -----------------------------------------------------------
 int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
                           bool count_tiles, hipStream_t stream);
-int gsr_launch_colour(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                      const uint32_t *list, hipStream_t stream);
-// bin-then-sort path: unordered binning into tile segments, then a per-tile (depth, index) sort
+// bin-then-sort path (default): unordered binning into tile segments, then a per-tile (depth, index) sort
 int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                           bool debug, hipStream_t stream);
 int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

@@ -68,53 +68,6 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-// rec2 = (r, g, b, radius) and the SH clamp flags of one visible Gaussian (forward.cu computeColorFromSH)
-template <bool FAST_SH16>
-__device__ __forceinline__ void splat_colour(const PreprocessArgs &a, int g, float px, float py, float pz, float fr) {
-    float cr, cg, cb;
-    uint32_t clamp_bits = 0;
-    if (a.colors_precomp) {
-        cr = a.colors_precomp[3 * (size_t)g];
-        cg = a.colors_precomp[3 * (size_t)g + 1];
-        cb = a.colors_precomp[3 * (size_t)g + 2];
-    } else {
-        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
-        const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
-        dx = dx / len; dy = dy / len; dz = dz / len;
-        float b[16];
-        sh_basis(a.D, dx, dy, dz, b);
-        if (FAST_SH16) {
-            // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
-            const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
-            float4 v[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) v[k] = sh4[k];
-            const float *f = reinterpret_cast<const float *>(v);
-            cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
-#pragma unroll
-            for (int k = 1; k < 16; k++) {
-                cr = fma_(b[k], f[3 * k], cr);
-                cg = fma_(b[k], f[3 * k + 1], cg);
-                cb = fma_(b[k], f[3 * k + 2], cb);
-            }
-        } else {
-            const float *sh = a.shs + (size_t)g * a.M * 3;
-            const int nb = (a.D + 1) * (a.D + 1);
-            cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
-            for (int k = 1; k < nb; k++) {
-                cr = fma_(b[k], sh[3 * k], cr);
-                cg = fma_(b[k], sh[3 * k + 1], cg);
-                cb = fma_(b[k], sh[3 * k + 2], cb);
-            }
-        }
-        cr += 0.5f; cg += 0.5f; cb += 0.5f;
-        clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
-        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
-    }
-    a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, fr);
-    a.clamped[g] = clamp_bits;
-}
-
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
@@ -259,7 +212,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
     __shared__ int s_idx[GSR_BLOCK];
     uint32_t cnt;
     const uint32_t incl = gsr_block_incl_scan(visible ? 1u : 0u, s_w, cnt);
-    if (COUNT_TILES && visible) {
+    if (visible) {
         s_pos[incl - 1u] = mypos;
         s_idx[incl - 1u] = i;
     }
@@ -279,26 +232,52 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
             if (c != 0u) atomicAdd(&a.tile_accum[(size_t)(blockIdx.x % GSR_BIN_SLOTS) * a.num_tiles + t], c);
         }
     }
-    if (COUNT_TILES) {
-        // bin-then-sort path: no compacted list will exist later, evaluate the colour here on dense lanes
-        if (threadIdx.x < cnt) {
-            const float4 pp = s_pos[threadIdx.x];
-            splat_colour<FAST_SH16>(a, s_idx[threadIdx.x], pp.x, pp.y, pp.z, pp.w);
+    if (threadIdx.x < cnt) {
+        const int g = s_idx[threadIdx.x];
+        const float4 pp = s_pos[threadIdx.x];
+        float cr, cg, cb;
+        uint32_t clamp_bits = 0;
+        if (a.colors_precomp) {
+            cr = a.colors_precomp[3 * (size_t)g];
+            cg = a.colors_precomp[3 * (size_t)g + 1];
+            cb = a.colors_precomp[3 * (size_t)g + 2];
+        } else {
+            float dx = pp.x - a.campos[0], dy = pp.y - a.campos[1], dz = pp.z - a.campos[2];
+            const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            float b[16];
+            sh_basis(a.D, dx, dy, dz, b);
+            if (FAST_SH16) {
+                // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
+                const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
+                float4 v[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) v[k] = sh4[k];
+                const float *f = reinterpret_cast<const float *>(v);
+                cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    cr = fma_(b[k], f[3 * k], cr);
+                    cg = fma_(b[k], f[3 * k + 1], cg);
+                    cb = fma_(b[k], f[3 * k + 2], cb);
+                }
+            } else {
+                const float *sh = a.shs + (size_t)g * a.M * 3;
+                const int nb = (a.D + 1) * (a.D + 1);
+                cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
+                for (int k = 1; k < nb; k++) {
+                    cr = fma_(b[k], sh[3 * k], cr);
+                    cg = fma_(b[k], sh[3 * k + 1], cg);
+                    cb = fma_(b[k], sh[3 * k + 2], cb);
+                }
+            }
+            cr += 0.5f; cg += 0.5f; cb += 0.5f;
+            clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
+            cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
         }
+        a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, pp.w);
+        a.clamped[g] = clamp_bits;
     }
-}
-
-// Colour of the visible Gaussians on the depth-sorted paths: one dense thread per entry of the compacted list
-// (any order).  Keeping the 48-float SH fetch out of preprocess_kernel halves its VGPR budget, which is what the
-// latency-bound streaming cull over all N Gaussians needs.
-template <bool FAST_SH16>
-__global__ __launch_bounds__(GSR_BLOCK) void colour_kernel(const PreprocessArgs a, const uint32_t *__restrict__ list,
-                                                           const GsrHeader *__restrict__ hdr) {
-    const uint32_t t = blockIdx.x * (uint32_t)GSR_BLOCK + threadIdx.x;
-    if (t >= hdr->V) return;
-    const int g = (int)list[t];
-    splat_colour<FAST_SH16>(a, g, a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2],
-                            (float)a.radii[g]);
 }
 
 __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const float *means3D, const float *m,
@@ -312,7 +291,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 
 }  // namespace
 
-static PreprocessArgs pack_args(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g) {
+int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
+                          bool count_tiles, hipStream_t stream) {
     PreprocessArgs a;
     a.P = in.P;
     a.D = st.sh_degree;
@@ -348,31 +328,9 @@ static PreprocessArgs pack_args(const GsrSettings &st, const GsrInputs &in, int3
     a.num_tiles = a.gx * a.gy;
     a.tile_accum = g.tile_accum;
     a.hdr = g.hdr;
-    return a;
-}
-
-static bool fast_sh(const GsrSettings &st, const GsrInputs &in) {
-    return (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
-           ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
-}
-
-// colour of the visible Gaussians listed in `list[0 .. hdr->V)` (depth-sorted paths; see colour_kernel)
-int gsr_launch_colour(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                      const uint32_t *list, hipStream_t stream) {
-    const PreprocessArgs a = pack_args(st, in, radii, g);
     const int blocks = GeomState::prep_blocks(in.P);
-    if (fast_sh(st, in))
-        hipLaunchKernelGGL(colour_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a, list, g.hdr);
-    else
-        hipLaunchKernelGGL(colour_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, a, list, g.hdr);
-    return GSR_OK;
-}
-
-int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          bool count_tiles, hipStream_t stream) {
-    const PreprocessArgs a = pack_args(st, in, radii, g);
-    const int blocks = GeomState::prep_blocks(in.P);
-    const bool fast = fast_sh(st, in);
+    const bool fast = (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
+                      ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
     const size_t lds = count_tiles ? (size_t)a.num_tiles * sizeof(uint32_t) : 0;
     if (count_tiles) {
         if (fast)
