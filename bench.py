@@ -75,7 +75,7 @@ def main():
     if args.render_bpc:
         import ctypes
         lib().gsr_debug_set_render_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-        check(lib().gsr_debug_set_render_variant(2, args.render_bpc))
+        check(lib().gsr_debug_set_render_variant(4, args.render_bpc))
     S = max(1, args.in_flight)
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S

@@ -12,8 +12,8 @@
 
 namespace {
 
-int g_render_variant = 2;
-int g_render_blocks_per_cu = 5;
+int g_render_variant = 4;
+int g_render_blocks_per_cu = 6;
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -230,11 +230,43 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_wave_kernel(const uint2 *__r
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBatch = 4;
 
+// Can instance (centre, conic|opacity) reach alpha >= 1/255 on ANY pixel of the 8x8 quadrant whose first pixel is
+// (x0, y0)?  alpha >= 1/255 <=> power >= tau = -ln(255 * opacity), and power(d) = -(A dx^2 + C dy^2)/2 - B dx dy is
+// concave in d = centre - pixel, so its maximum over the quadrant's (continuous) rectangle of offsets is at
+// d = 0 when the centre is inside, otherwise on an edge facing the centre; on an edge it is a 1-D concave
+// parabola whose maximiser is the clamped stationary point.  Evaluating both the dx = clamp(0) line and the
+// dy = clamp(0) line covers every case (extra candidates are points of the rectangle, they cannot exceed the
+// true maximum).  The answer must never be a false "no": the slack covers the float rounding of this bound and
+// of the per-pixel evaluation (a few ulps of the largest term), and a conic that is not positive definite in
+// float is never culled.  A culled instance is one every pixel of the quadrant would have skipped (alpha < 1/255),
+// so the image, final_T and n_contrib are bit-identical with and without the test.
+__device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float4 q, float x0, float y0) {
+    const float A = q.x, B = q.y, C = q.z;
+    // the same subtractions the corner pixels perform: every pixel's rounded offset lies in [dxl, dxh] x [dyl, dyh]
+    const float dxh = cx - x0, dxl = cx - (x0 + 7.0f);
+    const float dyh = cy - y0, dyl = cy - (y0 + 7.0f);
+    const float tau = -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * q.w);  // opacity 0 -> +inf
+    const float ex = fminf(fmaxf(0.0f, dxl), dxh);
+    const float ey = fminf(fmaxf(0.0f, dyl), dyh);
+    const float sy = fminf(fmaxf(-(B * ex) * __builtin_amdgcn_rcpf(C), dyl), dyh);
+    const float sx = fminf(fmaxf(-(B * ey) * __builtin_amdgcn_rcpf(A), dxl), dxh);
+    const float f1 = fma_(-B * ex, sy, -0.5f * fma_(C * sy, sy, (A * ex) * ex));
+    const float f2 = fma_(-B * sx, ey, -0.5f * fma_(C * ey, ey, (A * sx) * sx));
+    const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
+    const float mag = fma_(A * mx, mx, fma_(C * my, my, 2.0f * fabsf(B) * mx * my));
+    const float slack = fma_(4e-6f, mag, 1e-4f);
+    const bool concave = A > 0.0f && C > 0.0f && A * C > B * B * 1.00001f;
+    const bool miss = fmaxf(f1, f2) < tau - slack;  // false on NaN
+    // opacity < 1/255: alpha = opacity * exp(power <= 0) <= opacity can never pass (a NaN opacity is not culled:
+    // fminf(0.99, NaN) = 0.99 composites, as it does upstream)
+    return !(q.w < 1.0f / 255.0f || (concave && miss));
+}
+
+template <bool CULL>
 __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ point_list,
                                                                  const float4 *__restrict__ splat, int W, int H, int gx,
                                                                  int num_tiles, const uint32_t *__restrict__ tile_order,
-                                                                 uint32_t *__restrict__ queue_head,
                                                                  const float *__restrict__ bg,
                                                                  float *__restrict__ out_color,
                                                                  float *__restrict__ out_invdepth,
@@ -243,7 +275,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
     __shared__ float4 s_rec0[GSR_BLOCK + kBatch];
     __shared__ float4 s_rec1[GSR_BLOCK + kBatch];
     __shared__ float4 s_rec2[GSR_BLOCK + kBatch];
-    __shared__ uint32_t s_ticket;
     const int lane = gsr_lane(), wave = gsr_wave();
     const int lx = ((wave & 1) << 3) | (lane & 7);
     const int ly = ((wave >> 1) << 3) | (lane >> 3);
@@ -253,12 +284,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
         s_rec1[GSR_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_rec2[GSR_BLOCK + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (;;) {
-        __syncthreads();  // previous tile fully consumed (LDS records and the ticket)
-        if (threadIdx.x == 0) s_ticket = atomicAdd(queue_head, 1u);
-        __syncthreads();
-        const uint32_t ticket = s_ticket;
-        if (ticket >= (uint32_t)num_tiles) break;
+    // static longest-first deal (see render_stream_kernel: a global ticket counter costs more than it balances)
+    for (uint32_t ticket = blockIdx.x; ticket < (uint32_t)num_tiles; ticket += gridDim.x) {
+        __syncthreads();  // previous tile fully consumed (LDS records)
         const int tile = tile_order ? (int)tile_order[ticket] : (int)ticket;
         const int tile_x = tile % gx, tile_y = tile / gx;
         const int px = tile_x * GSR_TILE + lx, py = tile_y * GSR_TILE + ly;
@@ -301,13 +329,49 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
             }
             const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
             const uint32_t pos0 = (uint32_t)(rd * GSR_BLOCK);
-            for (int j = 0; j < cnt; j += kBatch) {
+            // instances this wave has to look at: all of the round, or (CULL) those that can reach its quadrant.
+            // The masks come out of ballots, i.e. they live in SGPRs and the walk below is scalar code.
+            uint64_t m0 = ~0ull, m1 = ~0ull, m2 = ~0ull, m3 = ~0ull;
+            if (CULL) {
+                const float qx = (float)(tile_x * GSR_TILE + ((wave & 1) << 3));
+                const float qy = (float)(tile_y * GSR_TILE + ((wave >> 1) << 3));
+                uint64_t mm[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const float4 a = s_rec0[s * GSR_WAVE + lane], b = s_rec1[s * GSR_WAVE + lane];
+                    mm[s] = __builtin_amdgcn_ballot_w64(quadrant_may_hit(a.x, a.y, b, qx, qy));
+                }
+                m0 = mm[0]; m1 = mm[1]; m2 = mm[2]; m3 = mm[3];
+            }
+            int base = 0;
+            for (int j = 0; CULL || j < cnt; j += kBatch) {  // (CULL: the masks, not j, end the walk)
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                int jj[kBatch];
+                if (CULL) {
+                    // next kBatch surviving positions in list order; short batches are padded with the zero records
+#pragma unroll
+                    for (int k = 0; k < kBatch; k++) {
+                        while (m0 == 0ull && base < 3 * GSR_WAVE) {
+                            m0 = m1; m1 = m2; m2 = m3; m3 = 0ull;
+                            base += GSR_WAVE;
+                        }
+                        if (m0 != 0ull) {
+                            jj[k] = base + (int)__builtin_ctzll(m0);
+                            m0 &= m0 - 1ull;
+                        } else {
+                            jj[k] = GSR_BLOCK + k;
+                        }
+                    }
+                    if (jj[0] >= GSR_BLOCK) break;  // nothing left in this round
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kBatch; k++) jj[k] = j + k;
+                }
                 float4 c0[kBatch], c1[kBatch];
 #pragma unroll
                 for (int k = 0; k < kBatch; k++) {  // one batch of ds_reads, one lgkmcnt wait
-                    c0[k] = s_rec0[j + k];
-                    c1[k] = s_rec1[j + k];
+                    c0[k] = s_rec0[jj[k]];
+                    c1[k] = s_rec1[jj[k]];
                 }
                 float alpha[kBatch];
                 bool valid[kBatch];
@@ -326,7 +390,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
                     for (int k = 0; k < kBatch; k++) {
                         const bool hit = valid[k] && !done;
                         if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
-                        const float4 r2 = s_rec2[j + k];
+                        const float4 r2 = s_rec2[jj[k]];
                         // non-hit lanes run with alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0
                         const float a_eff = hit ? alpha[k] : 0.0f;
                         const float test_T = T * (1.0f - a_eff);
@@ -337,11 +401,174 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
                         C2 = fma_(r2.z, w, C2);
                         Dacc = fma_(c0[k].w, w, Dacc);
                         T = stop ? T : test_T;
-                        last_contributor = (hit && !stop) ? pos0 + (uint32_t)(j + k) + 1u : last_contributor;
+                        last_contributor = (hit && !stop) ? pos0 + (uint32_t)jj[k] + 1u : last_contributor;
                         done = done || stop;
                     }
                 }
             }
+        }
+        if (inside) {
+            const size_t pid = (size_t)py * W + px;
+            const size_t plane = (size_t)H * W;
+            final_T[pid] = T;
+            n_contrib[pid] = last_contributor;
+            out_color[pid] = fma_(T, bg0, C0);
+            out_color[plane + pid] = fma_(T, bg1, C1);
+            out_color[2 * plane + pid] = fma_(T, bg2, C2);
+            out_invdepth[pid] = Dacc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 4 (default): wave-decoupled compositing.
+//
+// Counters of variant 3 on the config-2 frame (profiles/round1/pmc): the 4 waves of a tile spend half their life
+// parked (workgroup barriers around every 256-instance round, lgkmcnt waits inside 4 serial blend steps, a scalar
+// walk over the survivor masks that issues as many SALU as VALU instructions), and the kernel ends with the few
+// longest tiles running alone.  Here the unit of work is one 8x8 QUADRANT = one wave, pulled from a queue of
+// 4 x tiles tickets; a wave shares nothing with the other waves of its workgroup:
+//  * per round it gathers 128 instances (2 per lane: index, then the 3 x 16 B record), one round ahead;
+//  * each lane runs quadrant_may_hit on its two candidates; survivors are compacted (ballot + mbcnt rank) into
+//    the wave's private LDS list, in list order, with their list position in the record's spare slot;
+//  * the replay reads the list back 4 consecutive survivors at a time -- 12 ds_read_b128 off one base register
+//    with immediate offsets, one lgkmcnt wait per batch -- and composites exactly as variants 2/3 do.
+// No workgroup barrier, no scalar bit-walk, a quadrant retires the moment its 64 pixels saturate, and the queue
+// balances 4x finer units.  LDS traffic (3 b128 per survivor per wave) stays below the VALU time.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kStreamLanesItems = 2;                              // candidates per lane per round
+constexpr int kStreamRound = kStreamLanesItems * GSR_WAVE;        // 128 candidates per round
+constexpr int kStreamList = kStreamRound + kBatch;                // survivors + zero padding of the last batch
+
+__global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *__restrict__ ranges,
+                                                                  const uint32_t *__restrict__ point_list,
+                                                                  const float4 *__restrict__ splat, int W, int H, int gx,
+                                                                  int num_tiles, const uint32_t *__restrict__ tile_order,
+                                                                  const float *__restrict__ bg,
+                                                                  float *__restrict__ out_color,
+                                                                  float *__restrict__ out_invdepth,
+                                                                  float *__restrict__ final_T,
+                                                                  uint32_t *__restrict__ n_contrib) {
+    __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList][3];
+    const int lane = gsr_lane(), wave = gsr_wave();
+    float4(*list)[3] = s_list[wave];
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t num_tickets = 4u * (uint32_t)num_tiles;
+    // static LPT schedule: units sorted longest-first are dealt round-robin over the resident waves (no global
+    // ticket counter: same-address device-scope atomics resolve memory-side, ~10 ns apiece back to back, which
+    // cost more than the compositing itself)
+    const uint32_t ticket_stride = gridDim.x * (uint32_t)(GSR_BLOCK / GSR_WAVE);
+    for (uint32_t ticket = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave; ticket < num_tickets;
+         ticket += ticket_stride) {
+        const int tile = tile_order ? (int)tile_order[ticket >> 2] : (int)(ticket >> 2);
+        const int quad = (int)(ticket & 3u);
+        const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3), qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3);
+        const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const float pfx = (float)px, pfy = (float)py;
+        const float qxf = (float)qx0, qyf = (float)qy0;
+        const uint2 range = ranges[tile];
+        const int n_inst = (int)(range.y - range.x);
+        const uint32_t *src = point_list + range.x;
+
+        bool done = !inside;
+        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
+        uint32_t last_contributor = 0;
+
+        // global -> register pipeline: records of round rd in (f0,f1,f2), Gaussian indices of round rd+1 in g_next
+        float4 f0[kStreamLanesItems], f1[kStreamLanesItems], f2[kStreamLanesItems];
+        uint32_t g_next[kStreamLanesItems];
+#pragma unroll
+        for (int s = 0; s < kStreamLanesItems; s++) {
+            const int p = s * GSR_WAVE + lane;
+            f0[s] = zero4; f1[s] = zero4; f2[s] = zero4;
+            g_next[s] = 0;
+            if (p < n_inst) {
+                const float4 *rec = splat + 3 * (size_t)src[p];
+                f0[s] = rec[0]; f1[s] = rec[1]; f2[s] = rec[2];
+            }
+            if (p + kStreamRound < n_inst) g_next[s] = src[p + kStreamRound];
+        }
+        const int rounds = (n_inst + kStreamRound - 1) / kStreamRound;
+        for (int rd = 0; rd < rounds; rd++) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            // ---- cull + compact this round's candidates into the private list
+            int n_surv = 0;
+#pragma unroll
+            for (int s = 0; s < kStreamLanesItems; s++) {
+                const int p = rd * kStreamRound + s * GSR_WAVE + lane;
+                const bool keep = p < n_inst && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf);
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+                const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (keep) {
+                    list[rank][0] = f0[s];
+                    list[rank][1] = f1[s];
+                    list[rank][2] = make_float4(f2[s].x, f2[s].y, f2[s].z, __uint_as_float((uint32_t)p + 1u));
+                }
+                n_surv += (int)__builtin_popcountll(mask);
+            }
+            if (lane < kBatch) {  // alpha = 0 padding behind the last survivor
+                list[n_surv + lane][0] = zero4;
+                list[n_surv + lane][1] = zero4;
+                list[n_surv + lane][2] = zero4;
+            }
+            // ---- next round's gathers go out before the replay so that they fly under it
+#pragma unroll
+            for (int s = 0; s < kStreamLanesItems; s++) {
+                const int p = (rd + 1) * kStreamRound + s * GSR_WAVE + lane;
+                f0[s] = zero4; f1[s] = zero4; f2[s] = zero4;
+                if (p < n_inst) {
+                    const float4 *rec = splat + 3 * (size_t)g_next[s];
+                    f0[s] = rec[0]; f1[s] = rec[1]; f2[s] = rec[2];
+                }
+                if (p + kStreamRound < n_inst) g_next[s] = src[p + kStreamRound];
+            }
+            __builtin_amdgcn_wave_barrier();  // (scheduling fence: list writes above, list reads below; same wave)
+            // ---- replay the survivors, 4 at a time
+            for (int i = 0; i < n_surv; i += kBatch) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                float4 c0[kBatch], c1[kBatch], c2[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    c0[k] = list[i + k][0];
+                    c1[k] = list[i + k][1];
+                    c2[k] = list[i + k][2];
+                }
+                float alpha[kBatch];
+                bool valid[kBatch];
+                uint64_t any = 0ull;
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const float dx = c0[k].x - pfx, dy = c0[k].y - pfy;
+                    const float q = fma_(c1[k].z * dy, dy, (c1[k].x * dx) * dx);
+                    const float power = fma_(-(c1[k].y * dx), dy, -0.5f * q);
+                    alpha[k] = fminf(0.99f, c1[k].w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+                    valid[k] = power <= 0.0f && alpha[k] >= 1.0f / 255.0f;
+                    any |= __builtin_amdgcn_ballot_w64(valid[k]);
+                }
+                if ((any & __builtin_amdgcn_ballot_w64(!done)) != 0ull) {
+#pragma unroll
+                    for (int k = 0; k < kBatch; k++) {
+                        const bool hit = valid[k] && !done;
+                        if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
+                        // non-hit lanes run with alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0
+                        const float a_eff = hit ? alpha[k] : 0.0f;
+                        const float test_T = T * (1.0f - a_eff);
+                        const bool stop = test_T < 0.0001f;
+                        const float w = stop ? 0.0f : a_eff * T;
+                        C0 = fma_(c2[k].x, w, C0);
+                        C1 = fma_(c2[k].y, w, C1);
+                        C2 = fma_(c2[k].z, w, C2);
+                        Dacc = fma_(c0[k].w, w, Dacc);
+                        T = stop ? T : test_T;
+                        last_contributor = (hit && !stop) ? __float_as_uint(c2[k].w) : last_contributor;
+                        done = done || stop;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
         if (inside) {
             const size_t pid = (size_t)py * W + px;
@@ -410,7 +637,7 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
                       hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
-    if (g_render_variant == 2) {
+    if (g_render_variant >= 2) {
         static int num_cus = 0;
         if (num_cus == 0) {
             int dev = 0;
@@ -425,9 +652,18 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
         if (!order_ready)
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
         const int blocks = min(T, num_cus * g_render_blocks_per_cu);
-        hipLaunchKernelGGL(render_queue_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
-                           g.splat, W, H, gx, T, img.tile_order, &g.hdr->tile_queue, background, out_color,
-                           out_invdepth, img.final_T, img.n_contrib);
+        if (g_render_variant == 4)
+            hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
+                               g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth, img.final_T,
+                               img.n_contrib);
+        else if (g_render_variant == 3)
+            hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
+                               point_list, g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth,
+                               img.final_T, img.n_contrib);
+        else
+            hipLaunchKernelGGL(render_queue_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
+                               point_list, g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth,
+                               img.final_T, img.n_contrib);
     } else if (g_render_variant == 0)
         hipLaunchKernelGGL(render_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list, g.splat,
                            W, H, gx, background, out_color, out_invdepth, img.final_T, img.n_contrib);
@@ -438,11 +674,12 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     return GSR_OK;
 }
 
-// 0 = LDS-staged tile kernel, 1 = wave-independent readlane kernel, 2 = batched / queued kernel (default);
-// variants 0 and 1 are kept for within-process A/B measurements.  blocks_per_cu sizes variant 2's persistent grid.
+// 0 = LDS-staged tile kernel, 1 = wave-independent readlane kernel, 2 = batched / queued kernel, 3 = the same with
+// per-quadrant instance culling, 4 = wave-decoupled culling kernel (default); the others are kept for within-process
+// A/B measurements and the bit-identity test.  blocks_per_cu sizes the persistent grid of variants 2-4.
 extern "C" int gsr_debug_set_render_variant(int variant, int blocks_per_cu) {
-    if (variant < 0 || variant > 2 || blocks_per_cu < 0 || blocks_per_cu > 8) {
-        gsr_set_error("gsr_debug_set_render_variant: variant must be 0..2, blocks_per_cu 0..8");
+    if (variant < 0 || variant > 4 || blocks_per_cu < 0 || blocks_per_cu > 8) {
+        gsr_set_error("gsr_debug_set_render_variant: variant must be 0..4, blocks_per_cu 0..8");
         return GSR_E_INVALID;
     }
     g_render_variant = variant;

@@ -117,6 +117,42 @@ def test_alternative_binning_paths_match_too(cuda_device, mode):
         lib().gsr_debug_set_binning_mode(1)
 
 
+@pytest.mark.parametrize("scene", ["random", "tabletop", "thin"])
+def test_compositing_variants_are_bit_identical(cuda_device, scene):
+    """The default compositing kernel culls, per 8x8 quadrant, instances that cannot reach alpha >= 1/255 there.
+    That must not change a single bit of the image state: compare with the plain tile kernel (variant 0) and the
+    unculled queue kernel (variant 2)."""
+    import ctypes as C
+
+    from gsworld_amd._lib import check, lib
+
+    if scene == "random":
+        raw, cam = scenes.random_scene_camera_frame(60_000, seed=21), scenes.identity_camera(333, 201, 60.0)
+    elif scene == "tabletop":
+        raw, cam = scenes.tabletop_scene("xarm6_align", n=300_000, seed=5), scenes.sensor_camera("xarm6_align")
+    else:  # needle-like splats with low opacity: the cull bound is tight and the conic nearly singular
+        raw, cam = scenes.random_scene_camera_frame(40_000, seed=22), scenes.identity_camera(256, 256, 60.0)
+        raw.scaling[:, 0] += 2.5
+        raw.scaling[:, 1:] -= 3.0
+        raw.opacity -= 2.0
+    inp, st = hp.np_inputs(raw, cam), hp.oracle_settings(cam)
+    bg = np.asarray((0.1, 0.2, 0.3), np.float32)
+    L = lib()
+    L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
+    outs = {}
+    try:
+        for variant in (0, 2, 3, 4):
+            check(L.gsr_debug_set_render_variant(variant, 0))
+            g = hp.gpu_forward(inp, st, bg)
+            outs[variant] = (g["color"], g["invdepth"], g["views"]["final_T"], g["views"]["n_contrib"])
+    finally:
+        check(L.gsr_debug_set_render_variant(4, 0))
+    assert outs[0][3].max() > 0
+    for variant in (2, 3, 4):
+        for name, a, b in zip(("color", "invdepth", "final_T", "n_contrib"), outs[0], outs[variant]):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=f"variant {variant}: {name}")
+
+
 def test_large_tile_grid_and_long_tile_lists(cuda_device):
     # a grid that is natively above the counting limit (120 x 68 = 8160 tiles) -> radix fallback
     rep = _run(scenes.random_scene_camera_frame(30_000, seed=15), scenes.identity_camera(1920, 1080, 60.0))
