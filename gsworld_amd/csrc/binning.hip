@@ -102,18 +102,41 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t *
 //   tile_starts : exclusive scan of totals -> ranges[t] = [start, start+total), R, overflow check
 //   tile_place  : recount per wave, turn the counters into running cursors, write the point list
 // This replaces emit + a 2-pass radix sort of R (tile, index) pairs + identifyTileRanges.
+//
+// A workgroup always owns 256 consecutive depth ranks (one table column), split over NW waves: 8 waves x 32 ranks
+// when the NW x tiles LDS counters fit the 64 KiB a kernel gets by default (tiles <= 2048), else 4 x 64.  The
+// placement walk is a serial chain per wave (one returning LDS atomic + one scattered store per Gaussian), so
+// halving the ranks per wave halves the critical path; the lanes that hold no Gaussian still help spread tiles.
 // ---------------------------------------------------------------------------------------------------------
-template <bool PLACE>
-__device__ __forceinline__ void walk_wave(const uint32_t *__restrict__ order, const uint32_t *__restrict__ tiles_touched,
-                                          const uint2 *__restrict__ rects, uint32_t V, uint32_t rank0, int gx,
-                                          uint32_t *cnt, uint32_t *__restrict__ out) {
+inline int place_waves(int T) { return (size_t)8 * T * sizeof(uint32_t) <= 65536 ? 8 : 4; }
+
+struct WaveSplats {  // this lane's Gaussian (t == 0: none)
+    uint32_t g, t;
+    uint2 rc;
+};
+
+template <int NW>
+__device__ __forceinline__ WaveSplats load_wave_splats(const uint32_t *__restrict__ order,
+                                                       const uint32_t *__restrict__ tiles_touched,
+                                                       const uint2 *__restrict__ rects, uint32_t V, uint32_t block_base) {
+    constexpr int PER_WAVE = GSR_BLOCK / NW;
     const int lane = gsr_lane();
-    const uint32_t rank = rank0 + (uint32_t)lane;
-    const bool valid = rank < V;
-    const uint32_t g = valid ? order[rank] : 0u;
-    const uint32_t t = valid ? tiles_touched[g] : 0u;
-    uint2 rc = make_uint2(0u, 0u);
-    if (valid) rc = rects[g];
+    const uint32_t rank = block_base + (uint32_t)(gsr_wave() * PER_WAVE + lane);
+    WaveSplats s;
+    s.g = 0u; s.t = 0u; s.rc = make_uint2(0u, 0u);
+    if (lane < PER_WAVE && rank < V) {
+        s.g = order[rank];
+        s.t = tiles_touched[s.g];
+        s.rc = rects[s.g];
+    }
+    return s;
+}
+
+template <bool PLACE>
+__device__ __forceinline__ void walk_wave(const WaveSplats s, int gx, uint32_t *cnt, uint32_t *__restrict__ out) {
+    const int lane = gsr_lane();
+    const uint32_t g = s.g, t = s.t;
+    const uint2 rc = s.rc;
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16, maxx = rc.y & 0xffffu, width = maxx - minx;
     uint64_t todo;
     if (!PLACE) {
@@ -155,24 +178,28 @@ __device__ __forceinline__ void walk_wave(const uint32_t *__restrict__ order, co
     }
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void tile_count_kernel(const uint32_t *__restrict__ order,
-                                                               const uint32_t *__restrict__ tiles_touched,
-                                                               const uint2 *__restrict__ rects,
-                                                               const GsrHeader *__restrict__ hdr, int gx, int T,
-                                                               uint32_t *__restrict__ table, int nb_stride) {
-    extern __shared__ uint32_t s_cnt[];  // [4][T]
+template <int NW>
+__global__ __launch_bounds__(NW * GSR_WAVE) void tile_count_kernel(const uint32_t *__restrict__ order,
+                                                                   const uint32_t *__restrict__ tiles_touched,
+                                                                   const uint2 *__restrict__ rects,
+                                                                   const GsrHeader *__restrict__ hdr, int gx, int T,
+                                                                   uint32_t *__restrict__ table, int nb_stride) {
+    extern __shared__ uint32_t s_cnt[];  // [NW][T]
+    constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
-    const uint32_t k = gsr_place_batches(V);  // 64-Gaussian batches per wave: the workgroup owns 256 k ranks
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK * k;
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
     if (base >= V) return;
-    for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
+    const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);  // gathers fly under the zeroing
+    for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
     __syncthreads();
-    for (uint32_t bt = 0; bt < k; bt++)
-        walk_wave<false>(order, tiles_touched, rects, V, base + ((uint32_t)gsr_wave() * k + bt) * 64u, gx,
-                         s_cnt + gsr_wave() * T, nullptr);
+    walk_wave<false>(mine, gx, s_cnt + gsr_wave() * T, nullptr);
     __syncthreads();
-    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK)
-        table[(size_t)t * nb_stride + blockIdx.x] = s_cnt[t] + s_cnt[T + t] + s_cnt[2 * T + t] + s_cnt[3 * T + t];
+    for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) sum += s_cnt[w * T + t];
+        table[(size_t)t * nb_stride + blockIdx.x] = sum;
+    }
 }
 
 // one workgroup: totals[T] -> ranges, R; untouched tiles keep (0,0) like the reference's memset
@@ -211,40 +238,43 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
 }
 
-__global__ __launch_bounds__(GSR_BLOCK) void tile_place_kernel(const uint32_t *__restrict__ order,
-                                                               const uint32_t *__restrict__ tiles_touched,
-                                                               const uint2 *__restrict__ rects,
-                                                               const GsrHeader *__restrict__ hdr, int gx, int T,
-                                                               const uint32_t *__restrict__ table, int nb_stride,
-                                                               const uint2 *__restrict__ ranges,
-                                                               uint32_t *__restrict__ point_list) {
-    extern __shared__ uint32_t s_cnt[];  // [4][T]: counts, then running cursors
+template <int NW>
+__global__ __launch_bounds__(NW * GSR_WAVE) void tile_place_kernel(const uint32_t *__restrict__ order,
+                                                                   const uint32_t *__restrict__ tiles_touched,
+                                                                   const uint2 *__restrict__ rects,
+                                                                   const GsrHeader *__restrict__ hdr, int gx, int T,
+                                                                   const uint32_t *__restrict__ table, int nb_stride,
+                                                                   const uint2 *__restrict__ ranges,
+                                                                   uint32_t *__restrict__ point_list) {
+    extern __shared__ uint32_t s_cnt[];  // [NW][T]: counts, then running cursors
+    constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
-    const uint32_t k = gsr_place_batches(V);
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK * k;
+    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
     if (base >= V || hdr->overflow) return;
-    for (int i = (int)threadIdx.x; i < 4 * T; i += GSR_BLOCK) s_cnt[i] = 0u;
+    const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);
+    for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
     __syncthreads();
     const int wave = gsr_wave();
-    for (uint32_t bt = 0; bt < k; bt++)
-        walk_wave<false>(order, tiles_touched, rects, V, base + ((uint32_t)wave * k + bt) * 64u, gx, s_cnt + wave * T,
-                         nullptr);
+    walk_wave<false>(mine, gx, s_cnt + wave * T, nullptr);
     __syncthreads();
-    for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) {
-        const uint32_t c0 = s_cnt[t], c1 = s_cnt[T + t], c2 = s_cnt[2 * T + t];
-        const uint32_t c3 = s_cnt[3 * T + t];
-        if ((c0 | c1 | c2 | c3) != 0u) {
-            const uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + blockIdx.x];
-            s_cnt[t] = s;
-            s_cnt[T + t] = s + c0;
-            s_cnt[2 * T + t] = s + c0 + c1;
-            s_cnt[3 * T + t] = s + c0 + c1 + c2;
+    for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+        uint32_t c[NW], any = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            c[w] = s_cnt[w * T + t];
+            any |= c[w];
+        }
+        if (any != 0u) {
+            uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + blockIdx.x];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                s_cnt[w * T + t] = s;
+                s += c[w];
+            }
         }
     }
     __syncthreads();
-    for (uint32_t bt = 0; bt < k; bt++)  // a wave's batches are consecutive depth ranks: cursors carry over
-        walk_wave<true>(order, tiles_touched, rects, V, base + ((uint32_t)wave * k + bt) * 64u, gx, s_cnt + wave * T,
-                        point_list);
+    walk_wave<true>(mine, gx, s_cnt + wave * T, point_list);
 }
 
 
@@ -431,12 +461,15 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    const size_t lds = (size_t)4 * T * sizeof(uint32_t);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
-                       g.hdr, gx, T, g.tile_table, nb);
+    if (place_waves(T) == 8)
+        hipLaunchKernelGGL(tile_count_kernel<8>, dim3(nb), dim3(8 * GSR_WAVE), (size_t)8 * T * sizeof(uint32_t), stream,
+                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
+    else
+        hipLaunchKernelGGL(tile_count_kernel<4>, dim3(nb), dim3(4 * GSR_WAVE), (size_t)4 * T * sizeof(uint32_t), stream,
+                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
-    // chunk < 0: the row length follows the adaptive workgroup size, ceil(V / (256 * gsr_place_batches(V)))
-    if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, -1, T, g.tile_totals, debug, stream)) return e;
+    // one table column per 256 depth ranks: the live row length is ceil(V / 256)
+    if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
                        img.ranges, img.tile_order, (uint32_t *)nullptr);
     return gsr_check_launch("tile_starts", debug, stream);
@@ -448,9 +481,12 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    const size_t lds = (size_t)4 * T * sizeof(uint32_t);
-    hipLaunchKernelGGL(tile_place_kernel, dim3(nb), dim3(GSR_BLOCK), lds, stream, g.idx[0], g.tiles_touched, g.rects,
-                       g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
+    if (place_waves(T) == 8)
+        hipLaunchKernelGGL(tile_place_kernel<8>, dim3(nb), dim3(8 * GSR_WAVE), (size_t)8 * T * sizeof(uint32_t), stream,
+                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
+    else
+        hipLaunchKernelGGL(tile_place_kernel<4>, dim3(nb), dim3(4 * GSR_WAVE), (size_t)4 * T * sizeof(uint32_t), stream,
+                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
 }
 

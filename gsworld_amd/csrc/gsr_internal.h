@@ -195,17 +195,6 @@ int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr
                        hipStream_t stream);
 
 #ifdef __HIPCC__
-// Batches of 64 depth-consecutive Gaussians per wave in the counting placement: the workgroup owns 256 k ranks.
-// The per-workgroup fixed cost is O(tiles) (LDS counters, one table column), so k grows with V to hold the
-// workgroup count near 512 (1..2 per CU) instead of letting tiles x V / 256 table entries pile up.
-// MEASURED (profiles/round1/train_*): k > 1 loses -- the per-Gaussian walk of a wave is a serial latency chain, so
-// 4x fewer, 4x longer walks cost more than the table traffic they save (tile_place 367 -> 1320 us at V = 499k).
-// Kept at 1 until the placement is restructured (DESIGN.md "next").
-__device__ __forceinline__ uint32_t gsr_place_batches(uint32_t V) {
-    (void)V;
-    return 1u;
-}
-
 // ---- wave64 / block primitives ---------------------------------------------------------------------------
 __device__ __forceinline__ int gsr_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int gsr_wave() { return (int)(threadIdx.x >> 6); }

@@ -10,8 +10,7 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // Exclusive scan (in place) of a small array by ONE workgroup; writes the grand total to data[n].
-// mode 0: the total is V (and the frame header is reset).  mode 1: the total is num_rendered -- record R_raw,
-// clamp against the binning capacity.
+// mode 0: plain scan.  mode 1: the total is num_rendered -- record R_raw, clamp against the binning capacity.
 // `n_items_ptr`/`chunk` (optional): the live length is ceil(*n_items_ptr / chunk) instead of n_static.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, int n_static,
@@ -35,15 +34,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, i
     }
     if (threadIdx.x == 0) {
         data[n] = carry;  // arrays carry one spare slot: exclusive offsets have n+1 entries
-        if (mode == 0) {
-            // first kernel of the frame that touches the header: reset it here (saves a memset launch)
-            hdr->V = carry;
-            hdr->R = 0u;
-            hdr->overflow = 0u;
-            hdr->r_capacity = 0u;
-            hdr->R_raw = 0u;
-            hdr->tile_queue = 0u;
-        } else {
+        if (mode == 1) {
             hdr->R_raw = carry;
             hdr->r_capacity = r_capacity;
             if (carry > r_capacity) {
@@ -61,20 +52,38 @@ __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, i
 // Compaction in INDEX order: visible Gaussian i of preprocess block b lands at block_offsets[b] + rank.
 // Index order matters: the stable depth sort that follows breaks depth ties by ascending Gaussian index,
 // which is what the reference's stable (tile|depth) key sort over index-ordered emission produces.
+//
+// The block's offset is the sum of the visible counts preprocess left for the blocks before it.  Every block adds
+// those up itself (<= nb/256 coalesced loads per thread, L2-resident) instead of waiting for a single-workgroup
+// scan kernel in between (14 us of pure latency at 5738 blocks).  The last block knows the grand total: it writes
+// V and resets the rest of the frame header (first kernel of the frame that touches it).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_t *__restrict__ tiles_touched,
                                                             const float4 *__restrict__ splat,
-                                                            const uint32_t *__restrict__ block_offsets,
-                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+                                                            const uint32_t *__restrict__ block_counts,
+                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                            GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_w[4];
+    uint32_t part = 0;
+    for (int j = (int)threadIdx.x; j < (int)blockIdx.x; j += GSR_BLOCK) part += block_counts[j];
+    uint32_t offset;
+    (void)gsr_block_incl_scan(part, s_w, offset);
     const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
     const bool vis = i < P && tiles_touched[i] != 0u;
     uint32_t total;
     const uint32_t incl = gsr_block_incl_scan(vis ? 1u : 0u, s_w, total);
     if (vis) {
-        const uint32_t pos = block_offsets[blockIdx.x] + incl - 1u;
+        const uint32_t pos = offset + incl - 1u;
         keys[pos] = __float_as_uint(splat[3 * (size_t)i].z);  // depth > 0: float bits are order-preserving
         idx[pos] = (uint32_t)i;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        hdr->V = offset + total;
+        hdr->R = 0u;
+        hdr->overflow = 0u;
+        hdr->r_capacity = 0u;
+        hdr->R_raw = 0u;
+        hdr->tile_queue = 0u;
     }
 }
 
@@ -110,7 +119,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__re
                                                                   uint32_t *__restrict__ totals, int chunk) {
     __shared__ uint32_t s_w[4];
     const uint32_t n = *n_ptr;
-    if (chunk < 0) chunk = GSR_BLOCK * (int)gsr_place_batches(n);  // adaptive workgroup size of the tile counting
     const int nb = (int)((n + (uint32_t)chunk - 1u) / (uint32_t)chunk);
     uint32_t *row = table + (size_t)blockIdx.x * nb_stride;
     uint32_t carry = 0;
@@ -148,10 +156,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     for (int i = tid; i < 4 * BINS; i += GSR_BLOCK) (&s_cur[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t wbase = base + (uint32_t)wave * WAVE_ITEMS;
+    // the wave's keys and values stay in registers for the whole kernel: every load is issued up front and the
+    // ranking rounds below never wait for memory
+    constexpr int ROUNDS = WAVE_ITEMS / 64;
+    uint32_t rkey[ROUNDS], rval[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < WAVE_ITEMS / 64; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-        if (i < n) atomicAdd(&s_cur[wave][(keys_in[i] >> shift) & mask], 1u);
+        rkey[r] = i < n ? keys_in[i] : 0u;
+        rval[r] = i < n ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
+        if (i < n) atomicAdd(&s_cur[wave][(rkey[r] >> shift) & mask], 1u);
     }
     __syncthreads();
     {
@@ -179,11 +197,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     }
     __syncthreads();
     uint32_t *cur = s_cur[wave];
-    for (int r = 0; r < WAVE_ITEMS / 64; r++) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
         const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
         const bool valid = i < n;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t key = rkey[r], val = rval[r];
         const uint32_t d = (key >> shift) & mask;
         uint64_t same = __builtin_amdgcn_ballot_w64(valid);
         for (int b = 0; b < nbits; b++) {
@@ -281,12 +299,9 @@ int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr
 // 11 bits).  The compaction writes into side 1 so that the sorted depth order ends in g.idx[0].
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.block_counts, nb1,
-                       (const uint32_t *)nullptr, 1, g.hdr, 0, 0u);
-    if (int e = gsr_check_launch("scan_block_counts", debug, stream)) return e;
     const int start = gsr_radix_passes(32, GSR_DEPTH_RADIX_BITS) & 1;
     hipLaunchKernelGGL(compact_kernel, dim3(nb1), dim3(GSR_BLOCK), 0, stream, P, g.tiles_touched, g.splat,
-                       g.block_counts, g.key[start], g.idx[start]);
+                       g.block_counts, g.key[start], g.idx[start], g.hdr);
     if (int e = gsr_check_launch("compact", debug, stream)) return e;
     uint32_t *key[2] = {g.key[0], g.key[1]};
     uint32_t *val[2] = {g.idx[0], g.idx[1]};
