@@ -72,11 +72,14 @@ def main():
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
 
-    if args.render_bpc:
+    S = max(1, args.in_flight)
+    # compositing workgroups per CU: the library default (6: every tile quadrant resident at once) is the optimum
+    # both for one frame and for 3 frames in flight (tools/sweep_bench.sh); the flag is for sweeps
+    bpc = args.render_bpc
+    if bpc:
         import ctypes
         lib().gsr_debug_set_render_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-        check(lib().gsr_debug_set_render_variant(4, args.render_bpc))
-    S = max(1, args.in_flight)
+        check(lib().gsr_debug_set_render_variant(4, bpc))
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
     fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world)
@@ -213,16 +216,20 @@ def main():
                 "frame_gather": f"RCCL all_gather of uint8 frames every {K_g} frames" if world > 1 else "none",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "render_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "hbm", "kernel": "render_stream_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
-                "note": "compositing is VALU/exp-bound, not HBM-bound (DESIGN.md); whole-frame figures below",
+                "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
+                        "recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not HBM-bound: "
+                        "saturated pixels stop reading their tile list early, so real traffic is far below the "
+                        "algorithmic 40 B x num_rendered (DESIGN.md); whole-frame figures below",
             },
             "frame_roofline": {
                 "algorithmic_bytes_per_frame": b_alg, "achieved_GBs": b_alg * fps / world / 1e9,
                 "frac_of_8TBs": b_alg * fps / world / 1e9 / HBM_PEAK_GBS,
                 "frac_of_6.3TBs": b_alg * fps / world / 1e9 / 6290.0,
                 "stage_ms": dict(zip(PROFILE_STAGES, stage_ms)),
+                "single_frame_latency_ms": sum(stage_ms),
             },
         }
         if args.breakdown:

@@ -103,12 +103,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t *
 //   tile_place  : recount per wave, turn the counters into running cursors, write the point list
 // This replaces emit + a 2-pass radix sort of R (tile, index) pairs + identifyTileRanges.
 //
-// A workgroup always owns 256 consecutive depth ranks (one table column), split over NW waves: 8 waves x 32 ranks
-// when the NW x tiles LDS counters fit the 64 KiB a kernel gets by default (tiles <= 2048), else 4 x 64.  The
-// placement walk is a serial chain per wave (one returning LDS atomic + one scattered store per Gaussian), so
-// halving the ranks per wave halves the critical path; the lanes that hold no Gaussian still help spread tiles.
+// A workgroup always owns 256 consecutive depth ranks (one table column), split over NW waves.  The placement walk
+// is a serial chain per wave (one returning LDS atomic + one scattered store per Gaussian), so the fewer ranks a
+// wave owns the shorter the critical path; lanes that hold no Gaussian still help spread tiles.  Measured on
+// MI355X: 8 waves x 32 ranks beats 4 x 64 at every grid size (53 -> 37 us at 1200 tiles, 364 -> 300 us at 2500) and
+// 16 x 16 buys nothing more.  8 x tiles LDS counters: up to 120 KiB at the 3840-tile limit of this path.
 // ---------------------------------------------------------------------------------------------------------
-inline int place_waves(int T) { return (size_t)8 * T * sizeof(uint32_t) <= 65536 ? 8 : 4; }
+constexpr int kPlaceWaves = 8;
+
+// kernels that may need more than the default 64 KiB of dynamic LDS opt in once per process
+template <typename K>
+int allow_dynamic_lds(K kernel, size_t bytes, size_t &allowed) {
+    if (bytes <= 65536 || bytes <= allowed) return GSR_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) {
+        gsr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", bytes);
+        return GSR_E_HIP;
+    }
+    allowed = bytes;
+    return GSR_OK;
+}
 
 struct WaveSplats {  // this lane's Gaussian (t == 0: none)
     uint32_t g, t;
@@ -461,12 +475,11 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    if (place_waves(T) == 8)
-        hipLaunchKernelGGL(tile_count_kernel<8>, dim3(nb), dim3(8 * GSR_WAVE), (size_t)8 * T * sizeof(uint32_t), stream,
-                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
-    else
-        hipLaunchKernelGGL(tile_count_kernel<4>, dim3(nb), dim3(4 * GSR_WAVE), (size_t)4 * T * sizeof(uint32_t), stream,
-                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
+    static size_t lds_allowed = 0;
+    const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
+    if (int e = allow_dynamic_lds(tile_count_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
+    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.idx[0],
+                       g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
@@ -481,12 +494,11 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    if (place_waves(T) == 8)
-        hipLaunchKernelGGL(tile_place_kernel<8>, dim3(nb), dim3(8 * GSR_WAVE), (size_t)8 * T * sizeof(uint32_t), stream,
-                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
-    else
-        hipLaunchKernelGGL(tile_place_kernel<4>, dim3(nb), dim3(4 * GSR_WAVE), (size_t)4 * T * sizeof(uint32_t), stream,
-                           g.idx[0], g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
+    static size_t lds_allowed = 0;
+    const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
+    if (int e = allow_dynamic_lds(tile_place_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
+    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.idx[0],
+                       g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
 }
 

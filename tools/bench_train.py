@@ -27,7 +27,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--num-gaussians", type=int, default=500_000)
     ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--binning-mode", type=int, default=-1, help="A/B: 0 radix, 1 counting placement, 2 bin-then-sort")
     args = ap.parse_args()
+    if args.binning_mode >= 0:
+        from gsworld_amd._lib import check, lib
+        check(lib().gsr_debug_set_binning_mode(args.binning_mode))
     dev = torch.device("cuda:0")
     S = args.size
     cam = scenes.training_camera(S, S, 60.0).to(dev)
