@@ -51,7 +51,58 @@ __global__ __launch_bounds__(GSR_BLOCK) void transform_kernel(int P, const float
     *reinterpret_cast<float4 *>(rot_out + 4 * (size_t)i) = q;
 }
 
+// (K,4,4) rigid matrices (+ uniform scales) -> the 17-float transform table, on the device, so that a closed loop
+// whose link poses already live on the GPU (ManiSkill hands them over as device tensors) never touches the host.
+// The quaternion is ManiSkill's / PyTorch3D's matrix_to_quaternion in its exact float32 order (mirror:
+// gsworld_amd/transform.py): 4 candidate rows scaled by 1 / (2 max(q_abs, 0.1)), the row of the largest q_abs (first
+// on ties), sign standardised to a non-negative real part.
+__global__ void pack_transforms_kernel(int K, const float *__restrict__ matrices, const float *__restrict__ scales,
+                                       float *__restrict__ table) {
+    const int k = blockIdx.x * blockDim.x + (int)threadIdx.x;
+    if (k >= K) return;
+    const float *M = matrices + 16 * (size_t)k;
+    const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[4], m11 = M[5], m12 = M[6], m20 = M[8], m21 = M[9],
+                m22 = M[10];
+    const float d[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+    float qa[4];
+    int best = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        qa[r] = d[r] > 0.0f ? sqrtf(d[r]) : 0.0f;
+        if (qa[r] > qa[best]) best = r;
+    }
+    const float c[4][4] = {{qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01},
+                           {m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20},
+                           {m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21},
+                           {m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]}};
+    const float denom = 2.0f * fmaxf(qa[best], 0.1f);
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = c[best][j] / denom;
+    if (q[0] < 0.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = -q[j];
+    }
+    float *T = table + (size_t)k * kXf;
+    T[0] = m00; T[1] = m01; T[2] = m02; T[3] = m10; T[4] = m11; T[5] = m12; T[6] = m20; T[7] = m21; T[8] = m22;
+    T[9] = M[3]; T[10] = M[7]; T[11] = M[11];
+    T[12] = scales ? scales[k] : 1.0f;
+    T[13] = q[0]; T[14] = q[1]; T[15] = q[2]; T[16] = q[3];
+}
+
 }  // namespace
+
+extern "C" int gsr_pack_part_transforms(int32_t K, const float *matrices, const float *scales, float *table,
+                                        void *stream) {
+    if (K < 0 || (K > 0 && (!matrices || !table))) {
+        gsr_set_error("gsr_pack_part_transforms: negative K or null pointer");
+        return GSR_E_INVALID;
+    }
+    if (K == 0) return GSR_OK;
+    hipLaunchKernelGGL(pack_transforms_kernel, dim3(gsr_div_up(K, 64)), dim3(64), 0, (hipStream_t)stream, K, matrices,
+                       scales, table);
+    return gsr_check_launch("pack_part_transforms", false, (hipStream_t)stream);
+}
 
 extern "C" int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const float *semantics,
                                        const int32_t *lut, int32_t lut_size, const float *transforms, int32_t K,

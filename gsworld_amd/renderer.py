@@ -107,3 +107,54 @@ class FrameRenderer:
             rerender()
             s = self.stats()
         return s
+
+
+class MultiCameraRenderer:
+    """All cameras of one simulation step rendered concurrently.
+
+    GSWorld renders its sensor cameras one after the other inside ``_render_gsworld``
+    (gs_world_wrapper.py:239-267: ``for cam_name, cam_param in self.camera_params.items()``).  At 640x480 most kernels
+    of a frame are launch/latency-bound (the 10-kernel binning chain keeps ~1/4 of the chip busy), so two cameras of
+    the same Gaussians overlap almost perfectly when each gets its own HIP stream and its own renderer state: the
+    step's render latency is ~one frame, not ``num_cameras`` frames.  Results are bit-identical to sequential
+    :class:`FrameRenderer` calls (same kernels, disjoint state).
+
+    The Gaussian tensors are only READ on the side streams; they must stay alive until the caller's stream has
+    passed the join at the end of :meth:`render` (true for the per-step buffers of a closed loop).
+    """
+
+    def __init__(self, num_cameras: int, device="cuda", **renderer_kw):
+        self.device = torch.device(device)
+        self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)]
+
+    def render(self, views, means3D, opacities, rgb8_out=None, **render_kw):
+        """``views``: one :class:`gsworld_amd.camera.ViewParams` per camera.  Returns ``[(color, radii, invdepth)]``
+        per camera (renderer-owned tensors, overwritten by the next call).  ``rgb8_out``: optional list of (H,W,3)
+        uint8 tensors that receive GSWorld's uint8 frame conversion on the same stream as the frame."""
+        if len(views) != len(self.lanes):
+            raise ValueError(f"expected {len(self.lanes)} cameras, got {len(views)}")
+        cur = torch.cuda.current_stream(self.device)
+        outs = []
+        for k, (lane, stream, view) in enumerate(zip(self.lanes, self.streams, views)):
+            stream.wait_stream(cur)  # the step's transformed Gaussians are ready
+            with torch.cuda.stream(stream):
+                color, radii, invd = lane.render(view, means3D, opacities, **render_kw)
+                if rgb8_out is not None:
+                    lane.pack_rgb8(color, rgb8_out[k])
+            outs.append((color, radii, invd))
+        for stream in self.streams:
+            cur.wait_stream(stream)  # join: the caller's stream sees every frame
+        return outs
+
+    def ensure_valid(self, rerender) -> list:
+        """Overflow check of every lane's last frame (synchronises); ``rerender()`` must repeat the step's
+        :meth:`render` call.  Returns the per-camera :class:`FrameStats`."""
+        stats = [lane.stats() for lane in self.lanes]
+        if any(s.overflow for s in stats):
+            for lane, s in zip(self.lanes, stats):
+                if s.overflow:
+                    lane.r_capacity = int(s.num_rendered * lane.growth)
+            rerender()
+            stats = [lane.stats() for lane in self.lanes]
+        return stats

@@ -99,6 +99,7 @@ class FusedPartTransform:
         self.semantics = semantics.reshape(-1).to(torch.float32).contiguous()
         self._xyz_out = None
         self._rot_out = None
+        self._table = None
 
     def pack(self, matrices: torch.Tensor, scales: torch.Tensor | None = None) -> torch.Tensor:
         """(K,4,4) rigid matrices (+ optional (K,) uniform scales) -> (K,17) transform table (host math, K ~ 18)."""
@@ -110,8 +111,35 @@ class FusedPartTransform:
         s = torch.ones(K) if scales is None else scales.detach().to("cpu", torch.float32).reshape(K)
         return torch.cat((M[:, :3, :3].reshape(K, 9), M[:, :3, 3], s[:, None], q), dim=1).contiguous()
 
+    def pack_on_device(self, matrices: torch.Tensor, scales: torch.Tensor | None = None) -> torch.Tensor:
+        """Same table as :meth:`pack`, built by ``gsr_pack_part_transforms`` from DEVICE matrices: no host
+        round trip, hipGraph-capturable (the table buffer is persistent)."""
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        L = lib()
+        if not getattr(L, "_xfp_bound", False):
+            L.gsr_pack_part_transforms.restype = C.c_int
+            L.gsr_pack_part_transforms.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L._xfp_bound = True
+        K = len(self.names)
+        if tuple(matrices.shape) != (K, 4, 4) or matrices.dtype != torch.float32 or not matrices.is_contiguous():
+            raise ValueError(f"expected contiguous float32 ({K},4,4) matrices, got {tuple(matrices.shape)}")
+        if scales is not None and (tuple(scales.shape) != (K,) or scales.dtype != torch.float32):
+            raise ValueError(f"expected float32 ({K},) scales")
+        if self._table is None:
+            self._table = torch.empty((K, 17), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.gsr_pack_part_transforms(
+                K, C.c_void_p(matrices.data_ptr()), C.c_void_p(scales.data_ptr() if scales is not None else 0),
+                C.c_void_p(self._table.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return self._table
+
     def apply(self, xyz: torch.Tensor, rotation: torch.Tensor, matrices: torch.Tensor, scales=None):
-        """-> (xyz', rotation') in persistent output buffers (overwritten by the next call)."""
+        """-> (xyz', rotation') in persistent output buffers (overwritten by the next call).  ``matrices`` (K,4,4)
+        (+ ``scales`` (K,)) may live on the host (packed with torch, one small H2D copy) or on the device (packed by a
+        kernel: no synchronisation, capturable)."""
         import ctypes as C
 
         from ._lib import check, lib
@@ -130,7 +158,10 @@ class FusedPartTransform:
         if self._xyz_out is None or self._xyz_out.shape[0] != P:
             self._xyz_out = torch.empty_like(xyz)
             self._rot_out = torch.empty_like(rotation)
-        table = self.pack(matrices, scales).to(self.device, non_blocking=True)
+        if matrices.is_cuda:
+            table = self.pack_on_device(matrices, scales)
+        else:
+            table = self.pack(matrices, scales).to(self.device, non_blocking=True)
         with torch.cuda.device(self.device):
             check(L.gsr_transform_gaussians(
                 P, C.c_void_p(xyz.data_ptr()), C.c_void_p(rotation.data_ptr()), C.c_void_p(self.semantics.data_ptr()),

@@ -214,6 +214,14 @@ int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const
                             const int32_t *lut, int32_t lut_size, const float *transforms, int32_t K,
                             float *xyz_out, float *rot_out, void *stream);
 
+/*
+ * Builds the 17-float transform table on the DEVICE from K row-major 4x4 rigid matrices (and optional uniform
+ * scales, NULL = 1): the link / actor poses a GPU simulator already holds as device tensors
+ * (gs_world_wrapper.py:118-120,146-156 compute them with torch on the simulation device).  The quaternion is
+ * ManiSkill's matrix_to_quaternion (real part first, non-negative) in its float32 operation order.
+ */
+int gsr_pack_part_transforms(int32_t K, const float *matrices, const float *scales, float *table, void *stream);
+
 /* Self-test of the DPP wave reduction used by the backward: out4[w] = sum(in256[64w .. 64w+63]). */
 int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream);
 

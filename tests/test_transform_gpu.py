@@ -70,3 +70,69 @@ def test_fused_transform_errors(cuda_device):
         op.pack(torch.eye(4)[None])
     with pytest.raises(RuntimeError, match="no CPU path"):
         op.apply(torch.zeros(4, 3), torch.zeros(4, 4), torch.eye(4).repeat(2, 1, 1))
+
+
+def _pack_ieee(M, scales):
+    """matrix_to_quaternion + table layout in strict IEEE float32 scalar arithmetic (numpy), the order of
+    gsworld_amd/transform.py.  torch's vectorised CPU kernels are NOT a bit-level reference: the same call differs in
+    the last ulp between an AVX2 and an AVX-512 host (seen between the build container and the MI355X box)."""
+    f = np.float32
+    out = np.zeros((M.shape[0], 17), np.float32)
+    for k, m in enumerate(M.numpy().astype(np.float32)):
+        m00, m01, m02, m10, m11, m12, m20, m21, m22 = [f(x) for x in m[:3, :3].reshape(-1)]
+        d = [f(1) + m00 + m11 + m22, f(1) + m00 - m11 - m22, f(1) - m00 + m11 - m22, f(1) - m00 - m11 + m22]
+        qa = [np.sqrt(x) if x > 0 else f(0) for x in d]
+        best = int(np.argmax(qa))
+        c = [[qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01], [m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20],
+             [m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21], [m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]]]
+        den = f(2) * max(qa[best], f(0.1))
+        q = np.array([x / den for x in c[best]], np.float32)
+        if q[0] < 0:
+            q = -q
+        out[k, :9] = m[:3, :3].reshape(-1)
+        out[k, 9:12] = m[:3, 3]
+        out[k, 12] = scales[k]
+        out[k, 13:] = q
+    return out
+
+
+def test_device_side_table_matches_the_host_pack(cuda_device):
+    """gsr_pack_part_transforms (matrix -> quaternion on the device, for poses that already live on the GPU): every
+    float equal to the IEEE restatement of FusedPartTransform.pack, including the branch points of the quaternion
+    extraction (identity, half turns about each axis, tiny angles); within an ulp of torch's own CPU result."""
+    gen = torch.Generator().manual_seed(3)
+    special = []
+    for diag in ((1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1)):  # identity and the three half turns
+        M = torch.eye(4)
+        M[0, 0], M[1, 1], M[2, 2] = diag
+        special.append(M)
+    tiny = torch.eye(4)
+    tiny[0, 1], tiny[1, 0] = -1e-7, 1e-7
+    special.append(tiny)
+    M = torch.cat((torch.stack(special), _rand_rigid(gen, 59)))
+    K = M.shape[0]
+    scales = torch.rand(K, generator=gen) + 0.5
+    op = tf.FusedPartTransform({f"p{k}": k for k in range(K)}, torch.zeros(8, device=cuda_device))
+    got = op.pack_on_device(M.to(cuda_device).contiguous(), scales.to(cuda_device)).cpu()
+    want = torch.from_numpy(_pack_ieee(M, scales.numpy()))
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert float((got - op.pack(M, scales)).abs().max()) <= 2.5e-7
+    got1 = op.pack_on_device(M.to(cuda_device).contiguous()).cpu()  # scales default to 1
+    assert torch.equal(got1[:, 12], torch.ones(K)) and torch.equal(got1[:, 13:], want[:, 13:])
+
+
+def test_apply_with_device_matrices_needs_no_host_copy(cuda_device):
+    gen = torch.Generator().manual_seed(4)
+    N, K = 20_000, 18
+    labels = torch.randint(0, 30, (N,), generator=gen).float().to(cuda_device)
+    xyz = torch.randn(N, 3, generator=gen).to(cuda_device)
+    rot = (torch.randn(N, 4, generator=gen) * 1.3).to(cuda_device)
+    M, scales = _rand_rigid(gen, K), torch.rand(K, generator=gen) + 0.5
+    op_h = tf.FusedPartTransform({f"p{k}": k + 1 for k in range(K)}, labels)
+    op_d = tf.FusedPartTransform({f"p{k}": k + 1 for k in range(K)}, labels)
+    xh, rh = op_h.apply(xyz, rot, M, scales)
+    xd, rd = op_d.apply(xyz, rot, M.to(cuda_device), scales.to(cuda_device))
+    # (host torch pack vs device pack may differ in the last ulp of the quaternion, see _pack_ieee)
+    assert float((xh - xd).abs().max()) == 0.0 and float((rh - rd).abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        op_d.pack_on_device(M[:3].to(cuda_device))

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gsworld_amd import scenes, transform as tf  # noqa: E402
 from gsworld_amd.camera import extract_rigid_transform, look_at_view  # noqa: E402
-from gsworld_amd.renderer import FrameRenderer  # noqa: E402
+from gsworld_amd.renderer import MultiCameraRenderer  # noqa: E402
 
 
 def small_rigid(gen, k, angle=0.05, shift=0.01):
@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--glue", choices=["fused", "reference"], default="fused")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--num-gaussians", type=int, default=scenes.XARM6_ALIGN_NUM_GAUSSIANS)
+    ap.add_argument("--graph", action="store_true", help="fused glue: replay one hipGraph per simulation step")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     raw = scenes.tabletop_scene("xarm6_align", n=args.num_gaussians, seed=1).to(dev)
@@ -66,7 +67,7 @@ def main():
     gen = torch.Generator().manual_seed(0)
     link_now = torch.eye(4).repeat(K, 1, 1)
     bg = torch.zeros(3, device=dev)
-    renderers = {n: FrameRenderer(dev) for n in cams}
+    multi = MultiCameraRenderer(len(cams), dev)
     obs = {n: torch.empty((1, 480, 640, 3), dtype=torch.uint8, device=dev) for n in cams}
 
     # static activations (fused path): only xyz / rotation change per step
@@ -87,17 +88,42 @@ def main():
         scales[-2:] = scale[-2:] * torch.tensor([1.0, 1.0])
         return rigid, scales
 
+    # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
+    M_dev = torch.eye(4, device=dev).repeat(K, 1, 1).contiguous()
+    S_dev = torch.ones(K, device=dev)
+    RING = 8  # pinned staging slots: the host may run several steps ahead of the GPU
+    M_pin = [torch.empty((K, 4, 4), pin_memory=True) for _ in range(RING)]
+    S_pin = [torch.empty((K,), pin_memory=True) for _ in range(RING)]
+    slot_free = [None] * RING
+    step_no = 0
+    step_graph = None
+
+    def gpu_step():
+        """Everything the GPU does per step: pose table, fused transform, quaternion normalisation, both cameras."""
+        xyz, rot = op.apply(raw.xyz, raw.rotation, M_dev, S_dev)
+        rot_n = torch.nn.functional.normalize(rot)
+        multi.render(list(cams.values()), xyz, opac, rgb8_out=[obs[n][0] for n in cams], shs=shs, scales=scl,
+                     rotations=rot_n, bg=bg)
+
     def step_fused():
-        nonlocal t_glue, t_render
+        nonlocal t_glue, t_render, step_no
         t0 = time.perf_counter()
         M, scales = part_matrices()
-        xyz, rot = op.apply(raw.xyz, raw.rotation, M, scales)
-        rot_n = torch.nn.functional.normalize(rot)
+        s = step_no % RING
+        step_no += 1
+        if slot_free[s] is not None:
+            slot_free[s].synchronize()  # the copy that last used this staging slot has been consumed
+        M_pin[s].copy_(M)
+        S_pin[s].copy_(scales)
+        M_dev.copy_(M_pin[s], non_blocking=True)
+        S_dev.copy_(S_pin[s], non_blocking=True)
+        slot_free[s] = torch.cuda.Event()
+        slot_free[s].record()
         t1 = time.perf_counter()
-        for name, cam in cams.items():
-            r = renderers[name]
-            color, _, _ = r.render(cam, xyz, opac, shs=shs, scales=scl, rotations=rot_n, bg=bg)
-            r.pack_rgb8(color, obs[name][0])
+        if step_graph is not None:
+            step_graph.replay()  # one launch per simulation step
+        else:
+            gpu_step()
         t2 = time.perf_counter()
         t_glue += t1 - t0
         t_render += t2 - t1
@@ -141,6 +167,20 @@ def main():
     step = step_fused if args.glue == "fused" else step_reference
     step()  # reset() renders once
     torch.cuda.synchronize()
+    if args.glue == "fused" and args.graph:
+        # the exact-mode frames above sized every lane's binning capacity; capture the whole GPU side of a step
+        step()
+        multi.ensure_valid(gpu_step)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gpu_step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            gpu_step()
+        step_graph = g
+        torch.cuda.synchronize()
     t_glue = t_render = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -152,6 +192,7 @@ def main():
     print(json.dumps({
         "metric": "closed-loop rendered frames/sec (surrogate of AlignXArmEnv-v1 rand-action rollout)",
         "value": frames / dt, "unit": "frames/s", "steps_per_s": args.steps / dt, "glue": args.glue,
+        "launch": "hipGraph replay per step" if step_graph is not None else "eager",
         "config": {"workload": f"{args.num_gaussians} Gaussians, 2 cameras 640x480, {args.steps} steps, 18 moving parts",
                    "host_ms_per_step": {"transform_glue": 1e3 * t_glue / args.steps,
                                         "render_enqueue": 1e3 * t_render / args.steps},
