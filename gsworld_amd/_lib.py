@@ -37,6 +37,7 @@ class GsrInputs(C.Structure):
         ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
         ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("shs_rest", C.c_void_p),  # optional features_rest (P,M-1,3): `shs` is then features_dc (forward only)
     ]
 
 

@@ -104,6 +104,10 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
                 return GSR_E_INVALID;
             }
         }
+        if (in->shs_rest && (!in->shs || st->sh_coeffs < 2)) {
+            gsr_set_error("gsr_forward: shs_rest needs shs (= features_dc) and sh_coeffs >= 2");
+            return GSR_E_INVALID;
+        }
     }
     if (!buf->geom_resize || !buf->binning_resize || !buf->image_resize) {
         gsr_set_error("gsr_forward: resize callbacks are required");

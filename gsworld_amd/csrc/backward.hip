@@ -485,6 +485,10 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: null argument struct");
         return GSR_E_INVALID;
     }
+    if (in->shs_rest) {
+        gsr_set_error("gsr_backward: split SH storage (shs_rest) is a forward-only layout");
+        return GSR_E_INVALID;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const bool debug = st->debug != 0;
     const int P = in->P, W = st->image_width, H = st->image_height;

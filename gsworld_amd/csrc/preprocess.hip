@@ -16,7 +16,7 @@ struct PreprocessArgs {
     int W, H, gx, gy;
     float tanfovx, tanfovy, fx, fy, scale_modifier, near_plane;
     int antialiasing;
-    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;
     int32_t *radii;
     float4 *splat;
@@ -247,7 +247,30 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
             dx = dx / len; dy = dy / len; dz = dz / len;
             float b[16];
             sh_basis(a.D, dx, dy, dz, b);
-            if (FAST_SH16) {
+            if (a.shs_rest) {
+                // split storage (features_dc | features_rest): coefficient 0 from one array, 1.. from the other
+                const float *dc = a.shs + 3 * (size_t)g;
+                const float *rest = a.shs_rest + (size_t)g * (a.M - 1) * 3;
+                const int nb = (a.D + 1) * (a.D + 1);
+                cr = b[0] * dc[0]; cg = b[0] * dc[1]; cb = b[0] * dc[2];
+                if (a.D == 3) {
+                    float f[45];
+#pragma unroll
+                    for (int k = 0; k < 45; k++) f[k] = rest[k];  // 15 x dwordx3, all in flight together
+#pragma unroll
+                    for (int k = 1; k < 16; k++) {
+                        cr = fma_(b[k], f[3 * k - 3], cr);
+                        cg = fma_(b[k], f[3 * k - 2], cg);
+                        cb = fma_(b[k], f[3 * k - 1], cb);
+                    }
+                } else {
+                    for (int k = 1; k < nb; k++) {
+                        cr = fma_(b[k], rest[3 * k - 3], cr);
+                        cg = fma_(b[k], rest[3 * k - 2], cg);
+                        cb = fma_(b[k], rest[3 * k - 1], cb);
+                    }
+                }
+            } else if (FAST_SH16) {
                 // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
                 const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
                 float4 v[12];
@@ -310,6 +333,7 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.antialiasing = st.antialiasing;
     a.means3D = in.means3D;
     a.shs = in.shs;
+    a.shs_rest = in.shs_rest;
     a.colors_precomp = in.colors_precomp;
     a.opacities = in.opacities;
     a.scales = in.scales;

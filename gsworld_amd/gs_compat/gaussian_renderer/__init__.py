@@ -50,6 +50,29 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         scales = pc.get_scaling
         rotations = pc.get_rotation
 
+    # Inference fast path: when no gradient can flow -- GSWorld renders a detached deepcopy of the
+    # model -- the two SH parameters are handed to the rasterizer as they are stored instead of being concatenated
+    # into a fresh (N,16,3) tensor for every frame (upstream `shs = pc.get_features`: 564 MB of traffic at 1.47 M
+    # Gaussians, as much as the whole frame).  Same colours bit for bit (tests/test_dropin_gpu.py).
+    params = (means3D, opacity, scales, rotations, cov3D_precomp, getattr(pc, "_features_dc", None),
+              getattr(pc, "_features_rest", None))
+    no_grad = not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in params)
+    if (no_grad and override_color is None and not getattr(pipe, "convert_SHs_python", False)
+            and getattr(pc, "_features_rest", None) is not None and pc._features_rest.shape[1] > 0
+            and pc._features_dc.is_contiguous() and pc._features_rest.is_contiguous()):
+        from gsworld_amd import _C
+
+        empty = torch.empty(0, device=means3D.device)
+        rs = raster_settings
+        with torch.no_grad():
+            _, rendered_image, radii, _, _, _, depth_image = _C.rasterize_gaussians(
+                rs.bg, means3D, empty, opacity, scales if scales is not None else empty,
+                rotations if rotations is not None else empty, rs.scale_modifier,
+                cov3D_precomp if cov3D_precomp is not None else empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                rs.tanfovy, rs.image_height, rs.image_width, pc._features_dc, rs.sh_degree, rs.campos, rs.prefiltered,
+                rs.antialiasing, rs.debug, sh_rest=pc._features_rest)
+        return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
+
     shs = colors_precomp = None
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
@@ -68,7 +91,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii, depth_image = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
         rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
 
+
+def _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp):
     if use_trained_exp:
         exposure = pc.get_exposure_from_name(viewpoint_camera.image_name)
         rendered_image = torch.matmul(rendered_image.permute(1, 2, 0), exposure[:3, :3]).permute(2, 0, 1) + \

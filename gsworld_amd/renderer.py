@@ -52,9 +52,11 @@ class FrameRenderer:
 
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
-               antialiasing: bool = False, debug: bool = False, exact: bool = False):
+               antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
-        renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device."""
+        renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
+        ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
+        ``shs_rest=features_rest`` (P,M-1,3), instead of concatenating them for every frame."""
         dev = self.device
         P = means3D.shape[0]
         H, W = view.image_height, view.image_width
@@ -64,6 +66,10 @@ class FrameRenderer:
             bg = torch.zeros(3, device=dev)
         empty = torch.empty(0, device=dev)
         M = shs.shape[1] if shs is not None else 0
+        if shs_rest is not None:
+            if shs is None or shs.shape[1] != 1 or not shs.is_contiguous() or not shs_rest.is_contiguous():
+                raise ValueError("shs_rest needs shs = features_dc of shape (P,1,3); both contiguous")
+            M = 1 + shs_rest.shape[1]
         st = GsrSettings(H, W, view.tanfovx, view.tanfovy, float(scale_modifier), int(sh_degree), int(M), 0,
                          int(antialiasing), int(debug), float(self.near_plane))
         cap = 0 if (exact or self.r_capacity == 0) else self.r_capacity
@@ -72,7 +78,7 @@ class FrameRenderer:
             scales if scales is not None else empty, rotations if rotations is not None else empty,
             cov3D_precomp if cov3D_precomp is not None else empty, view.world_view_transform,
             view.full_proj_transform, shs if shs is not None else empty, view.camera_center, color, invd, radii,
-            self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0))
+            self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest)
         if cap == 0:
             self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
         return color, radii, invd

@@ -68,6 +68,12 @@ typedef struct GsrInputs {
     const float *viewmatrix;     /* (16) world->view, element [r][c] at m[c*4+r] */
     const float *projmatrix;     /* (16) full projection, same layout */
     const float *campos;         /* (3) */
+    /* Optional split SH storage (forward only).  3DGS keeps the SH coefficients as two parameters, features_dc
+     * (P,1,3) and features_rest (P,M-1,3), and upstream's render() concatenates them for every frame
+     * (gaussian_renderer/__init__.py `shs = pc.get_features`: a 2 x 192 B/Gaussian copy, 564 MB of traffic at
+     * 1.47 M Gaussians).  When shs_rest is not NULL, `shs` is features_dc and `shs_rest` is features_rest; the
+     * colours are bit-identical to the concatenated call.  NULL = upstream layout. */
+    const float *shs_rest;       /* (P,M-1,3) or NULL */
 } GsrInputs;
 
 typedef struct GsrOutputs {

@@ -59,7 +59,16 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     bg = torch.zeros(3, device=dev)
     out = render(cam, pc, pipe, bg, use_trained_exp=False, separate_sh=False)
     assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
-    assert out["render"].requires_grad  # the means2D gradient carrier keeps the autograd graph alive, as upstream
+    # frozen parameters (what Semantic3DGSWrapper.load_ply produces): inference fast path, SH read as stored
+    # (features_dc | features_rest) with no per-frame cat.  A parameter that requires grad takes upstream's autograd
+    # path (cat + Function); both must give the same image bit for bit.
+    assert not out["render"].requires_grad
+    pc._xyz.requires_grad_(True)
+    out_ag = render(cam, pc, pipe, bg, use_trained_exp=False, separate_sh=False)
+    pc._xyz.requires_grad_(False)
+    assert out_ag["render"].requires_grad
+    assert torch.equal(out_ag["render"].detach(), out["render"]) and torch.equal(out_ag["radii"], out["radii"])
+    assert torch.equal(out_ag["depth"].detach(), out["depth"])
     img = out["render"].detach()
     assert img.shape == (3, 480, 640) and float(img.min()) >= 0 and float(img.max()) <= 1
     # same frame through the oracle

@@ -61,3 +61,21 @@ def test_multi_camera_recovers_from_capacity_overflow(cuda_device):
     assert not any(s.overflow for s in stats)
     ref = FrameRenderer(dev).render(cams[1], means, op, **kw)[0]
     assert torch.equal(outs[1][0], ref)  # renderer-owned output tensor now holds the re-rendered frame
+
+
+def test_split_sh_storage_is_bit_identical_to_the_concatenated_call(cuda_device):
+    """features_dc / features_rest read in place (GsrInputs.shs_rest) vs upstream's per-frame cat."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=7)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    dc, rest = raw.features_dc.to(dev).contiguous(), raw.features_rest.to(dev).contiguous()
+    assert torch.equal(torch.cat((dc, rest), dim=1), shs)
+    for deg in (3, 2, 0):
+        a = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, sh_degree=deg)
+        b = FrameRenderer(dev).render(cam, means, op, shs=dc, shs_rest=rest, scales=sc, rotations=rot, sh_degree=deg)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"degree {deg}"
+    with pytest.raises(ValueError):
+        FrameRenderer(dev).render(cam, means, op, shs=shs, shs_rest=rest, scales=sc, rotations=rot)
