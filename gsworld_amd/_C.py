@@ -55,15 +55,17 @@ def _require_gpu(t: torch.Tensor, what: str):
 
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
-                imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None):
+                imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
-    ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation."""
+    ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
+    ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
+    inside preprocess instead of by three torch passes."""
     dev = means3D.device
     inp = GsrInputs(
         P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
         colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix), projmatrix=_ptr(projmatrix),
-        campos=_ptr(campos), shs_rest=_ptr(sh_rest) if sh_rest is not None else None)
+        campos=_ptr(campos), shs_rest=_ptr(sh_rest) if sh_rest is not None else None, param_space=int(param_space))
     out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii))
     cbs = (_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer))
     buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
@@ -76,11 +78,13 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, antialiasing, debug, sh_rest=None):
+                        prefiltered, antialiasing, debug, sh_rest=None, param_space: int = 0):
     """-> (num_rendered, out_color (3,H,W), radii (P,), geomBuffer, binningBuffer, imgBuffer, out_invdepth (1,H,W)).
 
-    Upstream's positional signature; the one extension is the keyword ``sh_rest`` (forward only): ``sh`` = features_dc
-    (P,1,3), ``sh_rest`` = features_rest (P,M-1,3), read in place instead of a per-frame ``cat``."""
+    Upstream's positional signature; the extensions are keywords (forward only): ``sh_rest`` -- ``sh`` = features_dc
+    (P,1,3), ``sh_rest`` = features_rest (P,M-1,3), read in place instead of a per-frame ``cat``; ``param_space`` --
+    OR of ``_lib.RAW_*``: ``opacity`` / ``scales`` / ``rotations`` are the raw parameters and are activated inside
+    preprocess."""
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if sh_rest is not None and (sh.ndim != 3 or sh.size(1) != 1 or sh_rest.ndim != 3 or sh_rest.size(0) != sh.size(0)):
@@ -109,7 +113,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             _f32(cov3D_precomp, dev, "cov3D_precomp"), _f32(viewmatrix, dev, "viewmatrix"),
             _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"), _f32(campos, dev, "campos"),
             out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer, r_capacity=0,
-            sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None)
+            sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space)
         rendered = int(stats.num_rendered)
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
 

@@ -38,7 +38,11 @@ class GsrInputs(C.Structure):
         ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("shs_rest", C.c_void_p),  # optional features_rest (P,M-1,3): `shs` is then features_dc (forward only)
+        ("param_space", C.c_int32),  # RAW_* flags: activations evaluated inside preprocess (forward only)
     ]
+
+
+RAW_OPACITY, RAW_SCALES, RAW_ROTATIONS = 1, 2, 4  # include/gsr.h GSR_RAW_*
 
 
 class GsrOutputs(C.Structure):

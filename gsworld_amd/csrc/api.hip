@@ -104,6 +104,10 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
                 return GSR_E_INVALID;
             }
         }
+        if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
+            gsr_set_error("gsr_forward: unknown bits in param_space");
+            return GSR_E_INVALID;
+        }
         if (in->shs_rest && (!in->shs || st->sh_coeffs < 2)) {
             gsr_set_error("gsr_forward: shs_rest needs shs (= features_dc) and sh_coeffs >= 2");
             return GSR_E_INVALID;

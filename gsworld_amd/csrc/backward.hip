@@ -485,8 +485,8 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: null argument struct");
         return GSR_E_INVALID;
     }
-    if (in->shs_rest) {
-        gsr_set_error("gsr_backward: split SH storage (shs_rest) is a forward-only layout");
+    if (in->shs_rest || in->param_space != 0) {
+        gsr_set_error("gsr_backward: split SH storage (shs_rest) and raw parameters (param_space) are forward-only");
         return GSR_E_INVALID;
     }
     hipStream_t stream = (hipStream_t)stream_;

@@ -16,6 +16,7 @@ struct PreprocessArgs {
     int W, H, gx, gy;
     float tanfovx, tanfovy, fx, fy, scale_modifier, near_plane;
     int antialiasing;
+    int param_space;  // GSR_RAW_* flags: activations evaluated here instead of three torch passes per frame
     const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;
     int32_t *radii;
@@ -68,6 +69,25 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// exp in the canonical float32 order of oracle/gs_oracle.c gso_expf (raw-parameter path):
+// 2^n * p(r) with n = rint(x log2e), r = x - n ln2 (Cody-Waite), p = the Cephes expf polynomial.  Bit-identical
+// on host and device because every operation is a correctly rounded IEEE one (fma, rint, ldexp).
+__device__ __forceinline__ float exp_canonical(float x) {
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.972084045410f) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma_(n, -0.693359375f, x);
+    r = fma_(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    const float y = fma_(p, r * r, r) + 1.0f;
+    return __builtin_ldexpf(y, (int)n);
+}
+
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
@@ -103,11 +123,22 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                 const float *c = a.cov3D_precomp + 6 * (size_t)i;
                 c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
             } else {
-                const float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+                float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+                float sc0 = a.scales[3 * (size_t)i], sc1 = a.scales[3 * (size_t)i + 1], sc2 = a.scales[3 * (size_t)i + 2];
+                if (a.param_space & GSR_RAW_ROTATIONS) {  // F.normalize: q / max(|q|, 1e-12)
+                    const float n2 = fma_(rq.w, rq.w, fma_(rq.z, rq.z, fma_(rq.y, rq.y, rq.x * rq.x)));
+                    const float d = fmaxf(sqrtf(n2), 1e-12f);
+                    rq = make_float4(rq.x / d, rq.y / d, rq.z / d, rq.w / d);
+                }
+                if (a.param_space & GSR_RAW_SCALES) {
+                    sc0 = exp_canonical(sc0);
+                    sc1 = exp_canonical(sc1);
+                    sc2 = exp_canonical(sc2);
+                }
                 const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
-                const float s0 = a.scale_modifier * a.scales[3 * (size_t)i];
-                const float s1 = a.scale_modifier * a.scales[3 * (size_t)i + 1];
-                const float s2 = a.scale_modifier * a.scales[3 * (size_t)i + 2];
+                const float s0 = a.scale_modifier * sc0;
+                const float s1 = a.scale_modifier * sc1;
+                const float s2 = a.scale_modifier * sc2;
                 const float R00 = fma_(-2.f, fma_(z, z, y * y), 1.f);
                 const float R01 = 2.f * fma_(-r, z, x * y);
                 const float R02 = 2.f * fma_(r, y, x * z);
@@ -182,7 +213,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                 rmaxy = min(a.gy, max(0, rmaxy));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
-                    const float opacity = a.opacities[i] * h_scale;
+                    float opacity_in = a.opacities[i];
+                    if (a.param_space & GSR_RAW_OPACITY) opacity_in = 1.0f / (1.0f + exp_canonical(-opacity_in));
+                    const float opacity = opacity_in * h_scale;
                     float4 *rec = a.splat + 3 * (size_t)i;
                     rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
                     rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
@@ -334,6 +367,7 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.means3D = in.means3D;
     a.shs = in.shs;
     a.shs_rest = in.shs_rest;
+    a.param_space = in.param_space;
     a.colors_precomp = in.colors_precomp;
     a.opacities = in.opacities;
     a.scales = in.scales;

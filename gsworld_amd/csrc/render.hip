@@ -428,16 +428,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
 // walk over the survivor masks that issues as many SALU as VALU instructions), and the kernel ends with the few
 // longest tiles running alone.  Here the unit of work is one 8x8 QUADRANT = one wave, pulled from a queue of
 // 4 x tiles tickets; a wave shares nothing with the other waves of its workgroup:
-//  * per round it gathers 128 instances (2 per lane: index, then the 3 x 16 B record), one round ahead;
-//  * each lane runs quadrant_may_hit on its two candidates; survivors are compacted (ballot + mbcnt rank) into
+//  * per round it gathers 64 instances (one per lane: index, then the 3 x 16 B record), one round ahead;
+//  * each lane runs quadrant_may_hit on its candidate; survivors are compacted (ballot + mbcnt rank) into
 //    the wave's private LDS list, in list order, with their list position in the record's spare slot;
 //  * the replay reads the list back 4 consecutive survivors at a time -- 12 ds_read_b128 off one base register
 //    with immediate offsets, one lgkmcnt wait per batch -- and composites exactly as variants 2/3 do.
 // No workgroup barrier, no scalar bit-walk, a quadrant retires the moment its 64 pixels saturate, and the queue
 // balances 4x finer units.  LDS traffic (3 b128 per survivor per wave) stays below the VALU time.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kStreamLanesItems = 2;                              // candidates per lane per round
-constexpr int kStreamRound = kStreamLanesItems * GSR_WAVE;        // 128 candidates per round
+constexpr int kStreamLanesItems = 1;                              // candidates per lane per round (A/B: 1 ~ 2 > 3;
+                                                                  // 1 halves the LDS list: 13 KiB per workgroup)
+constexpr int kStreamRound = kStreamLanesItems * GSR_WAVE;        // 64 candidates per round
 constexpr int kStreamList = kStreamRound + kBatch;                // survivors + zero padding of the last batch
 
 __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *__restrict__ ranges,

@@ -41,26 +41,38 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
+
+    # Inference fast path: when no gradient can flow -- GSWorld renders a detached deepcopy of a
+    # frozen model -- the two SH parameters are handed to the rasterizer as they are stored instead of being
+    # concatenated into a fresh (N,16,3) tensor for every frame (upstream `shs = pc.get_features`: 564 MB of
+    # traffic at 1.47 M Gaussians, as much as the whole frame).  Same image bit for bit (tests/test_dropin_gpu.py).
+    raw = tuple(getattr(pc, n, None) for n in ("_xyz", "_opacity", "_scaling", "_rotation", "_features_dc",
+                                              "_features_rest"))
+    no_grad = not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in raw)
+    fast = (no_grad and override_color is None and not getattr(pipe, "convert_SHs_python", False)
+            and raw[5] is not None and raw[5].shape[1] > 0 and raw[4].is_contiguous() and raw[5].is_contiguous())
+    # opt-in on top of it (pipe.fused_activations): hand over the RAW parameters and let preprocess apply sigmoid /
+    # exp / normalize in its canonical float32 order -- three fewer passes over the model per frame, but exp is then
+    # this library's, not torch's (last-ulp differences in the image), so it is not the default
+    fused = (fast and getattr(pipe, "fused_activations", False) and not getattr(pipe, "compute_cov3D_python", False)
+             and getattr(pc, "opacity_activation", None) is torch.sigmoid
+             and getattr(pc, "scaling_activation", None) is torch.exp
+             and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
 
     scales = rotations = cov3D_precomp = None
-    if getattr(pipe, "compute_cov3D_python", False):
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    if fused:
+        opacity, scales, rotations = pc._opacity, pc._scaling, pc._rotation
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
+        opacity = pc.get_opacity
+        if getattr(pipe, "compute_cov3D_python", False):
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales = pc.get_scaling
+            rotations = pc.get_rotation
 
-    # Inference fast path: when no gradient can flow -- GSWorld renders a detached deepcopy of the
-    # model -- the two SH parameters are handed to the rasterizer as they are stored instead of being concatenated
-    # into a fresh (N,16,3) tensor for every frame (upstream `shs = pc.get_features`: 564 MB of traffic at 1.47 M
-    # Gaussians, as much as the whole frame).  Same colours bit for bit (tests/test_dropin_gpu.py).
-    params = (means3D, opacity, scales, rotations, cov3D_precomp, getattr(pc, "_features_dc", None),
-              getattr(pc, "_features_rest", None))
-    no_grad = not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in params)
-    if (no_grad and override_color is None and not getattr(pipe, "convert_SHs_python", False)
-            and getattr(pc, "_features_rest", None) is not None and pc._features_rest.shape[1] > 0
-            and pc._features_dc.is_contiguous() and pc._features_rest.is_contiguous()):
+    if fast:
         from gsworld_amd import _C
+        from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
 
         empty = torch.empty(0, device=means3D.device)
         rs = raster_settings
@@ -70,7 +82,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                 rotations if rotations is not None else empty, rs.scale_modifier,
                 cov3D_precomp if cov3D_precomp is not None else empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
                 rs.tanfovy, rs.image_height, rs.image_width, pc._features_dc, rs.sh_degree, rs.campos, rs.prefiltered,
-                rs.antialiasing, rs.debug, sh_rest=pc._features_rest)
+                rs.antialiasing, rs.debug, sh_rest=pc._features_rest,
+                param_space=(RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS) if fused else 0)
         return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
 
     shs = colors_precomp = None

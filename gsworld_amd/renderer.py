@@ -52,11 +52,15 @@ class FrameRenderer:
 
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
-               antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None):
+               antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
+               param_space: int = 0):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
         renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
         ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
-        ``shs_rest=features_rest`` (P,M-1,3), instead of concatenating them for every frame."""
+        ``shs_rest=features_rest`` (P,M-1,3), instead of concatenating them for every frame.
+        ``param_space``: OR of ``gsworld_amd._lib.RAW_OPACITY / RAW_SCALES / RAW_ROTATIONS`` -- the corresponding
+        arguments are the model's RAW parameters (logits, log scales, un-normalised quaternions) and are activated
+        inside preprocess (no sigmoid / exp / normalize passes per frame)."""
         dev = self.device
         P = means3D.shape[0]
         H, W = view.image_height, view.image_width
@@ -78,7 +82,8 @@ class FrameRenderer:
             scales if scales is not None else empty, rotations if rotations is not None else empty,
             cov3D_precomp if cov3D_precomp is not None else empty, view.world_view_transform,
             view.full_proj_transform, shs if shs is not None else empty, view.camera_center, color, invd, radii,
-            self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest)
+            self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
+            param_space=param_space)
         if cap == 0:
             self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
         return color, radii, invd

@@ -74,7 +74,16 @@ typedef struct GsrInputs {
      * 1.47 M Gaussians).  When shs_rest is not NULL, `shs` is features_dc and `shs_rest` is features_rest; the
      * colours are bit-identical to the concatenated call.  NULL = upstream layout. */
     const float *shs_rest;       /* (P,M-1,3) or NULL */
+    /* Optional raw parameter space (forward only): OR of GSR_RAW_* -- the activations upstream's GaussianModel
+     * getters apply per frame (scene/gaussian_model.py: torch.sigmoid / torch.exp / F.normalize, three passes over
+     * the model) are then evaluated inside preprocess, in the float32 order fixed by oracle/gs_oracle.c
+     * (gso_activate_params; exp = 2^n * Cephes polynomial, ~1 ulp).  0 = upstream contract (activated inputs). */
+    int32_t param_space;
 } GsrInputs;
+
+#define GSR_RAW_OPACITY 1   /* opacities are logits:        opacity  = 1 / (1 + exp(-x)) */
+#define GSR_RAW_SCALES 2    /* scales are log-scales:        scale    = exp(x) */
+#define GSR_RAW_ROTATIONS 4 /* rotations are un-normalised:  rotation = q / max(|q|, 1e-12) */
 
 typedef struct GsrOutputs {
     float *out_color;    /* (3,H,W) */

@@ -791,3 +791,50 @@ void gso_preprocess_backward(const GsoSettings *st, int P, const float *means3D,
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Parameter activations at the boundary: what upstream's GaussianModel getters apply per frame
+ * before the rasterizer -- opacity = sigmoid(logit), scale = exp(log scale), rotation = q / max(|q|, 1e-12)
+ * (scene/gaussian_model.py get_opacity / get_scaling / get_rotation = torch.sigmoid / torch.exp /
+ * torch.nn.functional.normalize).  torch's exp is a platform library call, so the canonical float32 order is
+ * fixed HERE and the HIP preprocess evaluates exactly these operations when it is handed raw parameters:
+ * exp(x) = 2^n * p(r), n = rint(x * log2e), r = x - n * ln2 (Cody-Waite split), p = the Cephes expf polynomial,
+ * every multiply-add an explicit fmaf.  ~1 ulp from the true exponential, i.e. as close as two exp libraries are
+ * to each other.  flags: 1 = opacity logits, 2 = log scales, 4 = un-normalised rotations; untouched inputs copy.
+ * --------------------------------------------------------------------------------------------------------- */
+float gso_expf(float x) {
+    if (x > 88.72283905206835f) return INFINITY;
+    if (x < -103.972084045410f) return 0.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, r * r, r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+void gso_activate_params(int P, int flags, const float *opacities, const float *scales, const float *rotations,
+                         float *opacities_out, float *scales_out, float *rotations_out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        if (opacities && opacities_out)
+            opacities_out[i] = (flags & 1) ? 1.0f / (1.0f + gso_expf(-opacities[i])) : opacities[i];
+        if (scales && scales_out)
+            for (int k = 0; k < 3; k++)
+                scales_out[3 * (size_t)i + k] = (flags & 2) ? gso_expf(scales[3 * (size_t)i + k]) : scales[3 * (size_t)i + k];
+        if (rotations && rotations_out) {
+            const float *q = rotations + 4 * (size_t)i;
+            float d = 1.0f;
+            if (flags & 4) {
+                const float n2 = fmaf(q[3], q[3], fmaf(q[2], q[2], fmaf(q[1], q[1], q[0] * q[0])));
+                d = fmaxf(sqrtf(n2), 1e-12f);
+            }
+            for (int k = 0; k < 4; k++) rotations_out[4 * (size_t)i + k] = (flags & 4) ? q[k] / d : q[k];
+        }
+    }
+}

@@ -244,3 +244,28 @@ def knn_dist2(points):
     out = np.zeros(P, np.float32)
     lib().gso_knn_dist2(C.c_int(P), _p(points), _p(out))
     return out
+
+
+def activate_params(opacities=None, scales=None, rotations=None, flags=7):
+    """Canonical float32 activations of raw 3DGS parameters (gso_activate_params): flags 1 = sigmoid(opacity
+    logits), 2 = exp(log scales), 4 = rotation / max(|rotation|, 1e-12).  Returns (opacities, scales, rotations)."""
+    L = lib()
+    L.gso_activate_params.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.gso_activate_params.restype = None
+    P = next(a.shape[0] for a in (opacities, scales, rotations) if a is not None)
+    op = _f32(opacities).reshape(-1) if opacities is not None else None
+    sc = _f32(scales) if scales is not None else None
+    ro = _f32(rotations) if rotations is not None else None
+    op_o = np.zeros_like(op) if op is not None else None
+    sc_o = np.zeros_like(sc) if sc is not None else None
+    ro_o = np.zeros_like(ro) if ro is not None else None
+    L.gso_activate_params(C.c_int(P), C.c_int(flags), _p(op), _p(sc), _p(ro), _p(op_o), _p(sc_o), _p(ro_o))
+    return op_o, sc_o, ro_o
+
+
+def expf(x):
+    """gso_expf elementwise (the canonical exp of the raw-parameter path)."""
+    L = lib()
+    L.gso_expf.argtypes = [C.c_float]
+    L.gso_expf.restype = C.c_float
+    return np.array([L.gso_expf(float(v)) for v in np.asarray(x, np.float32).reshape(-1)], np.float32)

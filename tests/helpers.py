@@ -41,7 +41,7 @@ def oracle_forward(inp, st, bg, border_eps=BORDER_EPS, colors_precomp=None, cov3
                       inp["projmatrix"], inp["campos"], border_eps=border_eps, border_eps_T=border_eps_T)
 
 
-def gpu_forward(inp, st, bg, device="cuda", colors_precomp=None, cov3D_precomp=None, debug=False):
+def gpu_forward(inp, st, bg, device="cuda", colors_precomp=None, cov3D_precomp=None, debug=False, param_space=0):
     """Runs gsworld_amd._C.rasterize_gaussians on ``device`` and returns outputs + typed state views (CPU numpy)."""
     from gsworld_amd import _C, debug as dbg
 
@@ -60,7 +60,7 @@ def gpu_forward(inp, st, bg, device="cuda", colors_precomp=None, cov3D_precomp=N
             t(np.asarray(bg, np.float32)), t(inp["means3D"]), colors, t(inp["opacities"]).reshape(-1, 1), scales, rots,
             st.scale_modifier, cov, t(inp["viewmatrix"]).reshape(4, 4), t(inp["projmatrix"]).reshape(4, 4),
             st.tanfovx, st.tanfovy, st.image_height, st.image_width, sh, st.sh_degree, t(inp["campos"]),
-            st.prefiltered, st.antialiasing, debug)
+            st.prefiltered, st.antialiasing, debug, param_space=param_space)
     finally:
         _C.NEAR_PLANE = old_near
     torch.cuda.synchronize()

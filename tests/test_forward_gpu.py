@@ -202,3 +202,32 @@ def test_api_errors(cuda_device):
     with pytest.raises(RuntimeError, match="no CPU path"):
         r(means3D=m.cpu(), means2D=m.cpu(), opacities=torch.ones(4, 1), colors_precomp=torch.ones(4, 3),
           scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+
+
+def test_raw_parameter_space_matches_the_canonical_activations(cuda_device):
+    """logits / log scales / un-normalised quaternions handed over as stored (GSR_RAW_*); preprocess
+    applies sigmoid / exp / normalize in the float32 order fixed by oracle/gs_oracle.c (gso_activate_params), so
+    every downstream float and index is still bit-exact against the oracle run on the activated values."""
+    from oracle import gs_oracle as go
+
+    raw = scenes.random_scene_camera_frame(40_000, seed=31)
+    cam = scenes.identity_camera(320, 200, 60.0)
+    inp = hp.np_inputs(raw, cam)  # activated by torch (sigmoid / exp / normalize)
+    op, sc, ro = go.activate_params(raw.opacity.numpy().reshape(-1), raw.scaling.numpy(), raw.rotation.numpy(), flags=7)
+    # the canonical activations agree with torch's to the last ulp or two ...
+    assert np.abs(op - inp["opacities"].reshape(-1)).max() <= 2e-7
+    assert (np.abs(sc - inp["scales"]) / inp["scales"]).max() <= 3e-7
+    assert np.abs(ro - inp["rotations"]).max() <= 2e-7
+    # ... and the HIP raw path reproduces the oracle on them bit for bit
+    st = hp.oracle_settings(cam)
+    bg = np.asarray((0.0, 0.1, 0.0), np.float32)
+    act = dict(inp, opacities=op, scales=sc, rotations=ro)
+    o = hp.oracle_forward(act, st, bg)
+    rawin = dict(inp, opacities=raw.opacity.numpy().reshape(-1), scales=raw.scaling.numpy(),
+                 rotations=raw.rotation.numpy())
+    g = hp.gpu_forward(rawin, st, bg, param_space=7)
+    rep = hp.compare_forward(o, g, st)
+    assert rep["V"] > 10_000
+    # one flag at a time composes the same way (opacity only: scales / rotations arrive activated)
+    g1 = hp.gpu_forward(dict(act, opacities=rawin["opacities"]), st, bg, param_space=1)
+    hp.compare_forward(o, g1, st)

@@ -236,3 +236,32 @@ def test_c_oracle_agrees_with_torch_cpu_restatement(n, w, h, seed):
     frac_bad = (diff.max(0) > 1e-5)[ok].mean()
     assert frac_bad < 2e-3, frac_bad
     assert np.median(diff) < 1e-6
+
+
+def test_canonical_activations_of_the_raw_parameter_path():
+    """gso_expf / gso_activate_params (the float32 order the HIP raw-parameter path reproduces):
+    within ~1 ulp of the true exponential, and what upstream's getters compute (sigmoid / exp / F.normalize)."""
+    import torch
+
+    from oracle import gs_oracle as go
+
+    x = np.concatenate((np.linspace(-30, 20, 4001), [-104.5, -103.0, -87.5, 0.0, 1e-8, 88.7, 88.73, 100.0]))
+    x = x.astype(np.float32)
+    e = go.expf(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    finite = (ref < 3.4e38) & (ref > 1.2e-38)
+    assert (np.abs(e - ref)[finite] / ref[finite]).max() <= 1.3e-7
+    assert np.isinf(e[x > 88.73]).all() and (e[x < -104] == 0).all() and go.expf([0.0])[0] == 1.0
+    rng = np.random.default_rng(0)
+    logit = rng.uniform(-8, 8, 5000).astype(np.float32)
+    logs = rng.uniform(-9, 2, (5000, 3)).astype(np.float32)
+    quat = (rng.standard_normal((5000, 4)) * 1.7).astype(np.float32)
+    quat[0] = 0.0  # F.normalize clamps the norm at 1e-12: the zero quaternion stays zero
+    op, sc, ro = go.activate_params(logit, logs, quat, flags=7)
+    assert np.abs(op - torch.sigmoid(torch.from_numpy(logit)).numpy()).max() <= 2e-7
+    t_sc = torch.exp(torch.from_numpy(logs)).numpy()
+    assert (np.abs(sc - t_sc) / t_sc).max() <= 3e-7
+    assert np.abs(ro - torch.nn.functional.normalize(torch.from_numpy(quat)).numpy()).max() <= 2e-7
+    assert (ro[0] == 0).all()
+    op2, sc2, ro2 = go.activate_params(logit, logs, quat, flags=0)  # no flag: copied through
+    assert (op2 == logit).all() and (sc2 == logs).all() and (ro2 == quat).all()
