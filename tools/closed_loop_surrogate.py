@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gsworld_amd import scenes, transform as tf  # noqa: E402
 from gsworld_amd.camera import extract_rigid_transform, look_at_view  # noqa: E402
+from gsworld_amd._lib import RAW_ROTATIONS  # noqa: E402
 from gsworld_amd.renderer import MultiCameraRenderer  # noqa: E402
 
 
@@ -71,7 +72,7 @@ def main():
     obs = {n: torch.empty((1, 480, 640, 3), dtype=torch.uint8, device=dev) for n in cams}
 
     # static activations (fused path): only xyz / rotation change per step
-    shs = torch.cat((raw.features_dc, raw.features_rest), dim=1).contiguous()
+    raw.features_dc, raw.features_rest = raw.features_dc.contiguous(), raw.features_rest.contiguous()
     opac = torch.sigmoid(raw.opacity)
     scl = torch.exp(raw.scaling)
     op = tf.FusedPartTransform(parts, raw.semantics)
@@ -101,9 +102,9 @@ def main():
     def gpu_step():
         """Everything the GPU does per step: pose table, fused transform, quaternion normalisation, both cameras."""
         xyz, rot = op.apply(raw.xyz, raw.rotation, M_dev, S_dev)
-        rot_n = torch.nn.functional.normalize(rot)
-        multi.render(list(cams.values()), xyz, opac, rgb8_out=[obs[n][0] for n in cams], shs=shs, scales=scl,
-                     rotations=rot_n, bg=bg)
+        # the transformed quaternions keep their norm (reference semantics); preprocess normalises them on load
+        multi.render(list(cams.values()), xyz, opac, rgb8_out=[obs[n][0] for n in cams], shs=raw.features_dc,
+                     shs_rest=raw.features_rest, scales=scl, rotations=rot, param_space=RAW_ROTATIONS, bg=bg)
 
     def step_fused():
         nonlocal t_glue, t_render, step_no
