@@ -177,6 +177,20 @@ def main():
     if prof.frames > 0:
         stage_ms[-1] = prof.stage_ms[len(PROFILE_STAGES) - 1] / prof.frames  # measured inside the timed region
 
+    # per-frame latency distribution (hipEvent per frame, median and p95), strictly one frame at a time
+    n_lat = min(args.steps, 200)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
+    for i, (e0, e1) in enumerate(ev):
+        e0.record()
+        if graph is not None and S == 1:
+            graph[i % K_g].replay()
+        else:
+            frame(i % K_g)
+        e1.record()
+    torch.cuda.synchronize()
+    lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    frame_ms_p50, frame_ms_p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
+
     stats = r.ensure_valid(lambda: frame(0))
     for l in range(1, S):
         if rs_[l].stats().overflow:
@@ -230,6 +244,7 @@ def main():
                 "frac_of_6.3TBs": b_alg * fps / world / 1e9 / 6290.0,
                 "stage_ms": dict(zip(PROFILE_STAGES, stage_ms)),
                 "single_frame_latency_ms": sum(stage_ms),
+                "frame_ms_p50": frame_ms_p50, "frame_ms_p95": frame_ms_p95,  # one frame at a time, HIP events
             },
         }
         if args.breakdown:
