@@ -459,9 +459,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
     // static LPT schedule: units sorted longest-first are dealt round-robin over the resident waves (no global
     // ticket counter: same-address device-scope atomics resolve memory-side, ~10 ns apiece back to back, which
     // cost more than the compositing itself)
+    // (snake order: pass 0 deals the longest units to waves 0..S-1, pass 1 deals the next ones to waves S-1..0, so a
+    // wave that started with a long unit continues with a short one)
     const uint32_t ticket_stride = gridDim.x * (uint32_t)(GSR_BLOCK / GSR_WAVE);
-    for (uint32_t ticket = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave; ticket < num_tickets;
-         ticket += ticket_stride) {
+    const uint32_t wave_global = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
+    for (uint32_t pass = 0, ticket = wave_global; ticket < num_tickets;
+         pass++, ticket = pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
         const int tile = tile_order ? (int)tile_order[ticket >> 2] : (int)(ticket >> 2);
         const int quad = (int)(ticket & 3u);
         const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3), qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3);
