@@ -1,10 +1,10 @@
-// render.hip -- front-to-back alpha compositing, one 16x16-pixel tile per 256-thread workgroup
-// (upstream forward.cu renderCUDA).
+// render.hip -- front-to-back alpha compositing (upstream forward.cu renderCUDA).
 //
-// CDNA4 mapping: the 4 waves of a workgroup own the four 8x8 quadrants of the tile (lane -> (x&7, y>>3)), so
-// that a wave's 64 pixels are spatially compact and its alpha-test / early-exit decisions are coherent.
-// Each round stages 256 instances (3 x 16 B each: xy|depth|1/depth, conic|opacity, rgb|radius) into LDS with one
-// gather per thread; the inner loop reads them back as wave-uniform ds_read_b128 broadcasts.
+// CDNA4 mapping: a wave owns one 8x8 quadrant of a 16x16 tile (lane -> (x&7, y>>3)), so that its 64 pixels are
+// spatially compact and its alpha-test / early-exit decisions are coherent.  Four kernels, all bit-identical
+// (tests/test_forward_gpu.py): render_kernel = upstream's structure, one tile per workgroup, the reference point of
+// the bit-identity test; render_queue_kernel<CULL> = batched tile kernels; render_stream_kernel = the default, one
+// quadrant per wave with per-quadrant instance culling (see the block comments below for what was measured).
 //
 // Arithmetic contract (matches oracle/gs_oracle.c gso_render): -ffp-contract=off, explicit fmaf; the only
 // non-bit-reproducible operation is exp(): exp2(power * log2e) on the hardware transcendental unit.
@@ -100,121 +100,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_kernel(const uint2 *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Variant 1 (default): wave-independent compositing, no LDS, no barriers.
-//
-// Each of the 4 waves of a tile walks the tile's instance list on its own.  A chunk of 64 instances is fetched
-// with ONE instance per lane (index -> 3 x dwordx4 record gather, software-pipelined one chunk ahead) and then
-// replayed j = 0..63 by pulling instance j out of lane j with v_readlane: the instance becomes wave-uniform SGPR
-// operands of the per-pixel VALU work.  The inner loop is pure VALU/SALU -- no ds_read latency, no LDS bandwidth
-// shared between the CU's 4 SIMDs, no workgroup barrier -- and a wave retires as soon as ITS 64 pixels are
-// saturated.  The 4x redundant record gathers are L1/L2 hits; the tile -> workgroup map keeps each XCD on a
-// contiguous band of tiles so that its private L2 holds that band's splat records.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rl(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__global__ __launch_bounds__(GSR_BLOCK) void render_wave_kernel(const uint2 *__restrict__ ranges,
-                                                                const uint32_t *__restrict__ point_list,
-                                                                const float4 *__restrict__ splat, int W, int H, int gx,
-                                                                int num_tiles, const float *__restrict__ bg,
-                                                                float *__restrict__ out_color,
-                                                                float *__restrict__ out_invdepth,
-                                                                float *__restrict__ final_T,
-                                                                uint32_t *__restrict__ n_contrib) {
-    // XCD-aware, bijective remap: workgroup b runs on XCD b % 8 (observed dispatch order, speed only);
-    // give XCD x the contiguous tile band [start(x), start(x) + len(x)).
-    int tile;
-    {
-        const int b = (int)blockIdx.x, xcd = b & 7, q = num_tiles >> 3, r = num_tiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
-    const int tile_x = tile % gx, tile_y = tile / gx;
-    const int lane = gsr_lane(), wave = gsr_wave();
-    const int lx = ((wave & 1) << 3) | (lane & 7);
-    const int ly = ((wave >> 1) << 3) | (lane >> 3);
-    const int px = tile_x * GSR_TILE + lx, py = tile_y * GSR_TILE + ly;
-    const bool inside = px < W && py < H;
-    const float pfx = (float)px, pfy = (float)py;
-
-    const uint2 range = ranges[tile];
-    const int n_inst = (int)(range.y - range.x);
-    const uint32_t *list = point_list + range.x;
-
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
-
-    // software pipeline: records of chunk c are in (a0,a1,a2); the index of chunk c+1's instance is in g_next
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    uint32_t g_next = 0;
-    if (lane < n_inst) {
-        const uint32_t g = list[lane];
-        const float4 *rec = splat + 3 * (size_t)g;
-        a0 = rec[0]; a1 = rec[1]; a2 = rec[2];
-    }
-    if (64 + lane < n_inst) g_next = list[64 + lane];
-
-    for (int base = 0; base < n_inst; base += 64) {
-        if (__ballot(!done) == 0ull) break;  // this wave's 64 pixels are saturated
-        // issue the next chunk's gathers before touching the current chunk
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, b2 = b0;
-        uint32_t g_next2 = 0;
-        if (base + 64 + lane < n_inst) {
-            const float4 *rec = splat + 3 * (size_t)g_next;
-            b0 = rec[0]; b1 = rec[1]; b2 = rec[2];
-        }
-        if (base + 128 + lane < n_inst) g_next2 = list[base + 128 + lane];
-
-        const int cnt = min(64, n_inst - base);
-#pragma unroll 2
-        for (int j = 0; j < cnt; j++) {
-            const float sx = rl(a0.x, j), sy = rl(a0.y, j);
-            const float cxx = rl(a1.x, j), cxy = rl(a1.y, j), cyy = rl(a1.z, j), op = rl(a1.w, j);
-            const float dx = sx - pfx, dy = sy - pfy;
-            const float q = fma_(cyy * dy, dy, (cxx * dx) * dx);
-            const float power = fma_(-(cxy * dx), dy, -0.5f * q);
-            const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
-            const bool live = !done;
-            const bool hit = live && power <= 0.0f && alpha >= 1.0f / 255.0f;
-            contributor += live ? 1u : 0u;
-            if (__ballot(hit) == 0ull) {
-                if (__ballot(live) == 0ull) break;
-                continue;
-            }
-            // wave-uniform here: broadcast colour and 1/depth before the lanes diverge
-            const float cr = rl(a2.x, j), cg = rl(a2.y, j), cb = rl(a2.z, j), invd = rl(a0.w, j);
-            if (hit) {
-                const float test_T = T * (1.0f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                } else {
-                    const float w = alpha * T;
-                    C0 = fma_(cr, w, C0);
-                    C1 = fma_(cg, w, C1);
-                    C2 = fma_(cb, w, C2);
-                    Dacc = fma_(invd, w, Dacc);
-                    T = test_T;
-                    last_contributor = contributor;
-                }
-            }
-        }
-        a0 = b0; a1 = b1; a2 = b2;
-        g_next = g_next2;
-    }
-    if (inside) {
-        const size_t pid = (size_t)py * W + px;
-        const size_t plane = (size_t)H * W;
-        final_T[pid] = T;
-        n_contrib[pid] = last_contributor;
-        out_color[pid] = fma_(T, bg[0], C0);
-        out_color[plane + pid] = fma_(T, bg[1], C1);
-        out_color[2 * plane + pid] = fma_(T, bg[2], C2);
-        out_invdepth[pid] = Dacc;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Variant 2: LDS-staged, 4 instances per step, predicated, persistent workgroups on a longest-first tile queue.
 //
 // What the counters of variant 0 showed (profiles/round1): half of the wave time parked on lgkmcnt / barriers,
@@ -225,8 +110,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_wave_kernel(const uint2 *__r
 //    wave that is alone on its SIMD at the tail;
 //  * no divergent control flow: lane state is updated with selects, branches are wave-uniform (ballot);
 //    n_contrib needs no per-lane counter because a live lane has examined exactly (position + 1) instances;
-//  * workgroups are persistent and pull tiles from a queue ordered by descending list length, so the chip
-//    drains evenly instead of waiting for the CU that happened to receive the long tiles.
+//  * workgroups are persistent and take tiles dealt in descending list length, so the chip drains evenly
+//    instead of waiting for the CU that happened to receive the long tiles.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBatch = 4;
 
@@ -668,22 +553,19 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
             hipLaunchKernelGGL(render_queue_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
                                point_list, g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth,
                                img.final_T, img.n_contrib);
-    } else if (g_render_variant == 0)
+    } else {
         hipLaunchKernelGGL(render_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list, g.splat,
                            W, H, gx, background, out_color, out_invdepth, img.final_T, img.n_contrib);
-    else
-        hipLaunchKernelGGL(render_wave_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
-                           g.splat, W, H, gx, gx * gy, background, out_color, out_invdepth, img.final_T,
-                           img.n_contrib);
+    }
     return GSR_OK;
 }
 
-// 0 = LDS-staged tile kernel, 1 = wave-independent readlane kernel, 2 = batched / queued kernel, 3 = the same with
-// per-quadrant instance culling, 4 = wave-decoupled culling kernel (default); the others are kept for within-process
-// A/B measurements and the bit-identity test.  blocks_per_cu sizes the persistent grid of variants 2-4.
+// 0 = LDS-staged tile kernel (upstream's structure), 2 = batched tile kernel, 3 = the same with per-quadrant instance
+// culling, 4 = wave-decoupled culling kernel (default); the others are kept for within-process A/B measurements and
+// the bit-identity test.  (1 was a v_readlane broadcast kernel: measured slower than 0, removed.)  blocks_per_cu sizes the persistent grid of variants 2-4.
 extern "C" int gsr_debug_set_render_variant(int variant, int blocks_per_cu) {
-    if (variant < 0 || variant > 4 || blocks_per_cu < 0 || blocks_per_cu > 8) {
-        gsr_set_error("gsr_debug_set_render_variant: variant must be 0..4, blocks_per_cu 0..8");
+    if (variant < 0 || variant > 4 || variant == 1 || blocks_per_cu < 0 || blocks_per_cu > 8) {
+        gsr_set_error("gsr_debug_set_render_variant: variant must be 0, 2, 3 or 4; blocks_per_cu 0..8");
         return GSR_E_INVALID;
     }
     g_render_variant = variant;

@@ -1,5 +1,5 @@
 """Within-process interleaved A/B of compositing-kernel variants on the config-2 frame (stage times from HIP
-events recorded inside libgsr_hip.so).  Usage: ab_render.py "0,0 2,5 2,8"  (variant,blocks_per_cu pairs)"""
+events recorded inside libgsr_hip.so).  Usage: ab_render.py "0,0 3,6 4,6"  (variant,blocks_per_cu pairs)"""
 import ctypes as C
 import json
 import os
@@ -13,7 +13,7 @@ from gsworld_amd import scenes  # noqa: E402
 from gsworld_amd._lib import GsrProfile, PROFILE_STAGES, check, lib  # noqa: E402
 from gsworld_amd.renderer import FrameRenderer  # noqa: E402
 
-configs = [tuple(int(x) for x in c.split(",")) for c in (sys.argv[1] if len(sys.argv) > 1 else "0,0 1,0 2,5").split()]
+configs = [tuple(int(x) for x in c.split(",")) for c in (sys.argv[1] if len(sys.argv) > 1 else "0,0 3,6 4,6").split()]
 dev = torch.device("cuda:0")
 raw = scenes.tabletop_scene("xarm6_align")
 cam = scenes.sensor_camera("xarm6_align").to(dev)

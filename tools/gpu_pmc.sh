@@ -2,7 +2,7 @@
 # PMC counter passes (one rocprofv3 run per counter group; kernel-trace only, as the pool requires).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${1:-pmc}; VARIANT=${2:-1}
+TAG=${1:-pmc}; VARIANT=${2:-4}
 export TMPDIR=/tmp
 REPO=$PWD
 mkdir -p gpurun_out/$TAG

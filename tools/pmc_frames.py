@@ -11,7 +11,7 @@ from gsworld_amd import scenes  # noqa: E402
 from gsworld_amd._lib import check, lib  # noqa: E402
 from gsworld_amd.renderer import FrameRenderer  # noqa: E402
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda:0")
