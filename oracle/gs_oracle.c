@@ -182,6 +182,16 @@ static void sh_basis(int deg, float x, float y, float z, float *b) {
 /* forward.cu preprocessCUDA (forward).  All per-Gaussian outputs are written for every index; culled
  * Gaussians get radii = 0 and tiles_touched = 0 (other fields are left as passed in / zero).
  * rects: (min.x, min.y, max.x, max.y) per Gaussian, the getRect result (int32). */
+/* float -> int32 as a GPU converts it (CUDA cvt.rzi.s32.f32, AMD v_cvt_i32_f32): truncation, SATURATING at the
+ * int32 range, NaN -> 0.  A C cast is undefined out of range (x86 gives INT_MIN); absurdly large splats -- radius
+ * beyond 2^31 pixels -- must still take the same rect on both sides. */
+static inline int32_t f2i_sat(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+
 void gso_preprocess(const GsoSettings *st, int P, const float *means3D, const float *shs,
                     const float *colors_precomp, const float *opacities, const float *scales,
                     const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
@@ -233,11 +243,11 @@ void gso_preprocess(const GsoSettings *st, int P, const float *means3D, const fl
         const float lambda1 = mid + root, lambda2 = mid - root;
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
         const float pix_x = ndc2pix(pprx, W), pix_y = ndc2pix(ppry, H);
-        const int ir = (int)my_radius; /* getRect takes the radius as int */
-        int rminx = (int)((pix_x - (float)ir) / (float)GSO_BLOCK_X);
-        int rminy = (int)((pix_y - (float)ir) / (float)GSO_BLOCK_Y);
-        int rmaxx = (int)((pix_x + (float)ir + (float)(GSO_BLOCK_X - 1)) / (float)GSO_BLOCK_X);
-        int rmaxy = (int)((pix_y + (float)ir + (float)(GSO_BLOCK_Y - 1)) / (float)GSO_BLOCK_Y);
+        const int ir = f2i_sat(my_radius); /* getRect takes the radius as int */
+        int rminx = f2i_sat((pix_x - (float)ir) / (float)GSO_BLOCK_X);
+        int rminy = f2i_sat((pix_y - (float)ir) / (float)GSO_BLOCK_Y);
+        int rmaxx = f2i_sat((pix_x + (float)ir + (float)(GSO_BLOCK_X - 1)) / (float)GSO_BLOCK_X);
+        int rmaxy = f2i_sat((pix_y + (float)ir + (float)(GSO_BLOCK_Y - 1)) / (float)GSO_BLOCK_Y);
         rminx = rminx < 0 ? 0 : (rminx > gx ? gx : rminx);
         rminy = rminy < 0 ? 0 : (rminy > gy ? gy : rminy);
         rmaxx = rmaxx < 0 ? 0 : (rmaxx > gx ? gx : rmaxx);
