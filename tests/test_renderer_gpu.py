@@ -79,3 +79,48 @@ def test_split_sh_storage_is_bit_identical_to_the_concatenated_call(cuda_device)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), f"degree {deg}"
     with pytest.raises(ValueError):
         FrameRenderer(dev).render(cam, means, op, shs=shs, shs_rest=rest, scales=sc, rotations=rot)
+
+
+def test_frame_and_step_replay_from_a_hipgraph(cuda_device):
+    """No-sync frames are hipGraph-capturable (bench.py and the closed-loop tool rely on it): a captured
+    MultiCameraRenderer step -- fork onto the per-camera streams, two frames, join -- replays bit-identically, and
+    follows new Gaussian positions written into the captured input buffer."""
+    from gsworld_amd.renderer import MultiCameraRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=150_000, seed=9)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cams = _two_cameras(dev)
+    mc = MultiCameraRenderer(2, dev)
+    frames = [torch.empty((480, 640, 3), dtype=torch.uint8, device=dev) for _ in cams]
+    xyz = means.clone()  # captured input buffer
+
+    def step():
+        return mc.render(cams, xyz, op, rgb8_out=frames, shs=shs, scales=sc, rotations=rot)
+
+    step()
+    step()
+    assert not any(s.overflow for s in mc.ensure_valid(step))
+    eager = [f.clone() for f in frames]
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        step()
+    for f in frames:
+        f.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(frames, eager))
+    xyz += torch.tensor([0.02, -0.01, 0.0], device=dev)  # the scene moves; same graph
+    g.replay()
+    torch.cuda.synchronize()
+    moved = [f.clone() for f in frames]
+    assert not torch.equal(moved[0], eager[0])
+    step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(frames, moved)) and not any(s.overflow for s in
+                                                                              mc.ensure_valid(step))
