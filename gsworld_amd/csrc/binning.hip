@@ -248,6 +248,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
         hdr->overflow = overflow ? 1u : 0u;
         hdr->R = overflow ? 0u : grand;
     }
+    if (tile_order == nullptr) return;  // every tile resident at once in the compositor: no order needed
     __syncthreads();  // this workgroup's range stores are visible to all of its threads
     gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
 }
@@ -484,7 +485,8 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
-                       img.ranges, img.tile_order, (uint32_t *)nullptr);
+                       img.ranges, gsr_render_wants_tile_order(T) ? img.tile_order : (uint32_t *)nullptr,
+                       (uint32_t *)nullptr);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

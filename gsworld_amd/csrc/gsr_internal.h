@@ -17,7 +17,7 @@
 #define GSR_DEPTH_RADIX_BITS 11       // digit width of the 32-bit depth sort and the 30-bit Morton sort: 3 passes
 #define GSR_DEPTH_RADIX_BINS 2048
 #define GSR_BIN_SLOTS 16              // replicated per-tile counters of the bin-then-sort path
-#define GSR_MAX_COUNT_TILES 3840         // counting placement keeps 4 x tiles LDS counters per workgroup (<= 60 KiB)
+#define GSR_MAX_COUNT_TILES 3840      // counting placement keeps 8 x tiles LDS counters per workgroup (<= 120 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
 // depends on a value the host would have to read back.
@@ -180,6 +180,7 @@ int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug,
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
+bool gsr_render_wants_tile_order(int num_tiles);
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
                       bool order_ready, hipStream_t stream);

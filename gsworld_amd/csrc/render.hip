@@ -521,37 +521,49 @@ extern "C" int gsr_pack_rgb8(const float *color, int32_t width, int32_t height, 
     return gsr_check_launch("pack_rgb8", false, (hipStream_t)stream);
 }
 
+static int render_num_cus() {
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            num_cus = prop.multiProcessorCount;
+        else
+            num_cus = 256;
+    }
+    return num_cus;
+}
+
+// The longest-first tile order only matters when workgroups take more than one tile: with every tile resident at
+// once (1200 tiles on 256 CUs x 6) the deal is the identity and the binning stage need not build the order.
+bool gsr_render_wants_tile_order(int num_tiles) {
+    return g_render_variant >= 2 && num_tiles > render_num_cus() * g_render_blocks_per_cu;
+}
+
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
                       const float *background, float *out_color, float *out_invdepth, bool order_ready,
                       hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     if (g_render_variant >= 2) {
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-                gsr_set_error("render: hipGetDeviceProperties failed");
-                return GSR_E_HIP;
-            }
-            num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
         const int T = gx * gy;
-        if (!order_ready)
+        const bool ordered = gsr_render_wants_tile_order(T);
+        const uint32_t *order = ordered ? img.tile_order : nullptr;
+        if (ordered && !order_ready)
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
-        const int blocks = min(T, num_cus * g_render_blocks_per_cu);
+        const int blocks = min(T, render_num_cus() * g_render_blocks_per_cu);
         if (g_render_variant == 4)
             hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
-                               g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth, img.final_T,
+                               g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
                                img.n_contrib);
         else if (g_render_variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
-                               point_list, g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth,
+                               point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,
                                img.final_T, img.n_contrib);
         else
             hipLaunchKernelGGL(render_queue_kernel<false>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
-                               point_list, g.splat, W, H, gx, T, img.tile_order, background, out_color, out_invdepth,
+                               point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,
                                img.final_T, img.n_contrib);
     } else {
         hipLaunchKernelGGL(render_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list, g.splat,
