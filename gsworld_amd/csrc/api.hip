@@ -307,7 +307,7 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity,
         v->clamped = reinterpret_cast<const uint8_t *>(g.clamped);
         v->tiles_touched = g.tiles_touched;
         v->rects = reinterpret_cast<const uint16_t *>(g.rects);
-        v->depth_order = g_binning_mode == 2 && GeomState::counting(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) ? nullptr : g.idx[0];  // no global depth order on the default path
+        v->depth_order = g_binning_mode == 2 && GeomState::counting(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) ? nullptr : g.order;  // no global depth order on the default path
     }
     if (binning) {
         const BinningState b = BinningState::carve((char *)binning, r_capacity);

@@ -479,7 +479,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     static size_t lds_allowed = 0;
     const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
     if (int e = allow_dynamic_lds(tile_count_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.idx[0],
+    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order,
                        g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
@@ -499,7 +499,7 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
     static size_t lds_allowed = 0;
     const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
     if (int e = allow_dynamic_lds(tile_place_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.idx[0],
+    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order,
                        g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
 }
@@ -534,7 +534,7 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
     hipLaunchKernelGGL(zero_ranges_kernel, dim3(gsr_div_up(tiles, GSR_BLOCK)), dim3(GSR_BLOCK), 0, stream,
                        img.ranges, tiles);
     if (int e = gsr_check_launch("zero_ranges", debug, stream)) return e;
-    hipLaunchKernelGGL(emit_kernel, dim3(GeomState::sort_blocks(P)), dim3(GSR_BLOCK), 0, stream, g.idx[0],
+    hipLaunchKernelGGL(emit_kernel, dim3(GeomState::sort_blocks(P)), dim3(GSR_BLOCK), 0, stream, g.order,
                        g.tiles_touched, g.rects, g.tile_bsum, g.hdr, gx, b.tile[0], b.gidx[0]);
     if (int e = gsr_check_launch("emit", debug, stream)) return e;
     uint32_t *key[2] = {b.tile[0], b.tile[1]};

@@ -48,8 +48,8 @@ struct GeomState {
     uint32_t *tiles_touched;  // [P]
     uint2 *rects;             // [P]   x = min.x | min.y<<16, y = max.x | max.y<<16
     uint32_t *block_counts;   // [ceil(P/256)+1]  visible per preprocess block -> exclusive offsets
-    uint32_t *key[2];         // [P]   depth-sort ping-pong keys (float bits of depth)
-    uint32_t *idx[2];         // [P]   depth-sort ping-pong values (Gaussian index)
+    uint2 *pair[2];           // [P]   depth-sort ping-pong records (float bits of depth, Gaussian index)
+    uint32_t *order;          // [P]   Gaussian indices in depth order (depth bits, index on ties)
     uint32_t *sort_table;     // [256 * nb]  per-block digit histograms (digit-major)
     uint32_t *sort_totals;    // [256]
     uint32_t *tile_bsum;      // [nb+1] tiles touched per 2048 depth-ordered Gaussians -> exclusive offsets
@@ -81,10 +81,9 @@ struct GeomState {
         g.tiles_touched = take<uint32_t>(p, n);
         g.rects = take<uint2>(p, n);
         g.block_counts = take<uint32_t>(p, (size_t)prep_blocks(P) + 1);
-        g.key[0] = take<uint32_t>(p, n);
-        g.key[1] = take<uint32_t>(p, n);
-        g.idx[0] = take<uint32_t>(p, n);
-        g.idx[1] = take<uint32_t>(p, n);
+        g.pair[0] = take<uint2>(p, n);
+        g.pair[1] = take<uint2>(p, n);
+        g.order = take<uint32_t>(p, n);
         g.sort_table = take<uint32_t>(p, (size_t)GSR_DEPTH_RADIX_BINS * sort_blocks(P));
         g.sort_totals = take<uint32_t>(p, GSR_DEPTH_RADIX_BINS);
         g.tile_bsum = take<uint32_t>(p, (size_t)sort_blocks(P) + 1);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, i
 __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_t *__restrict__ tiles_touched,
                                                             const float4 *__restrict__ splat,
                                                             const uint32_t *__restrict__ block_counts,
-                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                            uint2 *__restrict__ pairs,
                                                             GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_w[4];
     uint32_t part = 0;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_
     const uint32_t incl = gsr_block_incl_scan(vis ? 1u : 0u, s_w, total);
     if (vis) {
         const uint32_t pos = offset + incl - 1u;
-        keys[pos] = __float_as_uint(splat[3 * (size_t)i].z);  // depth > 0: float bits are order-preserving
-        idx[pos] = (uint32_t)i;
+        // depth > 0: float bits are order-preserving
+        pairs[pos] = make_uint2(__float_as_uint(splat[3 * (size_t)i].z), (uint32_t)i);
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         hdr->V = offset + total;
@@ -92,7 +92,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_
 // A workgroup owns GSR_SORT_CHUNK consecutive keys; wave w owns the contiguous quarter [w*512, w*512+512).
 // table[d * nb_stride + b] = number of keys with digit d in workgroup b.
 // ---------------------------------------------------------------------------------------------------------
-template <int BITS>
+// PAIRED: `keys` is an array of (key, value) uint2 records (depth sort: one 8-byte scattered store per element and pass
+// instead of two 4-byte ones -- scattered stores are what a scatter workgroup spends its time on).
+template <int BITS, bool PAIRED>
 __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t *__restrict__ keys,
                                                                const uint32_t *__restrict__ n_ptr,
                                                                uint32_t *__restrict__ table, int nb_stride, int shift,
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_hist_kernel(const uint32_t *_
 #pragma unroll
     for (int r = 0; r < GSR_SORT_ITEMS; r++) {
         const uint32_t i = base + (uint32_t)r * GSR_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & mask], 1u);
+        if (i < n) atomicAdd(&s_h[(keys[PAIRED ? 2u * i : i] >> shift) & mask], 1u);
     }
     __syncthreads();
     for (int d = (int)threadIdx.x; d < BINS; d += GSR_BLOCK) table[(size_t)d * nb_stride + blockIdx.x] = s_h[d];
@@ -138,7 +140,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_rowscan_kernel(uint32_t *__re
 // without any workgroup barrier: lanes holding the same digit find each other with BITS ballots, the rank inside
 // the group is a popcount of the lanes below, the group's first lane advances the cursor.  LDS operations of one
 // wave retire in order, so round r+1 sees the cursors round r left behind.
-template <int BITS>
+// PAIRED: keys_in / keys_out are uint2 (key, value) records (vals_in unused); LAST (paired only): the final pass
+// writes only the values, to vals_out.
+template <int BITS, bool PAIRED, bool LAST>
 __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ table,
@@ -163,8 +167,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
         const uint32_t i = wbase + (uint32_t)r * 64u + (uint32_t)lane;
-        rkey[r] = i < n ? keys_in[i] : 0u;
-        rval[r] = i < n ? vals_in[i] : 0u;
+        if (PAIRED) {
+            const uint2 kv = i < n ? reinterpret_cast<const uint2 *>(keys_in)[i] : make_uint2(0u, 0u);
+            rkey[r] = kv.x;
+            rval[r] = kv.y;
+        } else {
+            rkey[r] = i < n ? keys_in[i] : 0u;
+            rval[r] = i < n ? vals_in[i] : 0u;
+        }
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
@@ -212,8 +222,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void radix_scatter_kernel(
         const uint32_t rank = (uint32_t)__popcll(same & lt);
         if (valid) {
             const uint32_t pos = cur[d] + rank;
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+            if (PAIRED && !LAST) {
+                reinterpret_cast<uint2 *>(keys_out)[pos] = make_uint2(key, val);
+            } else if (PAIRED) {
+                vals_out[pos] = val;
+            } else {
+                keys_out[pos] = key;
+                vals_out[pos] = val;
+            }
         }
         __builtin_amdgcn_wave_barrier();  // every lane has read its cursor before the group leader moves it
         if (valid && rank == 0u) cur[d] += (uint32_t)__popcll(same);
@@ -245,14 +261,36 @@ template <int BITS>
 int radix_pass(uint32_t *kin, uint32_t *vin, uint32_t *kout, uint32_t *vout, const uint32_t *n_ptr, int nb, int shift,
                int nbits, uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream) {
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel<BITS>, dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, n_ptr, table, nb, shift,
+    hipLaunchKernelGGL((radix_hist_kernel<BITS, false>), dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, n_ptr, table, nb, shift,
                        mask);
     if (int e = gsr_check_launch("radix_hist", debug, stream)) return e;
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb, totals,
                        GSR_SORT_CHUNK);
     if (int e = gsr_check_launch("radix_rowscan", debug, stream)) return e;
-    hipLaunchKernelGGL(radix_scatter_kernel<BITS>, dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, vin, kout, vout, n_ptr,
+    hipLaunchKernelGGL((radix_scatter_kernel<BITS, false, false>), dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, vin, kout, vout, n_ptr,
                        table, totals, nb, shift, mask, nbits);
+    return gsr_check_launch("radix_scatter", debug, stream);
+}
+
+// one pass over (key, value) records; `last`: write only the values to `order`
+template <int BITS>
+int radix_pass_paired(const uint2 *in, uint2 *out, uint32_t *order, bool last, const uint32_t *n_ptr, int nb, int shift,
+                      int nbits, uint32_t *table, uint32_t *totals, bool debug, hipStream_t stream) {
+    const uint32_t mask = (1u << nbits) - 1u;
+    const uint32_t *kin = reinterpret_cast<const uint32_t *>(in);
+    uint32_t *kout = reinterpret_cast<uint32_t *>(out);
+    hipLaunchKernelGGL((radix_hist_kernel<BITS, true>), dim3(nb), dim3(GSR_BLOCK), 0, stream, kin, n_ptr, table, nb,
+                       shift, mask);
+    if (int e = gsr_check_launch("radix_hist", debug, stream)) return e;
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1 << BITS), dim3(GSR_BLOCK), 0, stream, table, n_ptr, nb, totals,
+                       GSR_SORT_CHUNK);
+    if (int e = gsr_check_launch("radix_rowscan", debug, stream)) return e;
+    if (last)
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, true>), dim3(nb), dim3(GSR_BLOCK), 0, stream, kin,
+                           (const uint32_t *)nullptr, kout, order, n_ptr, table, totals, nb, shift, mask, nbits);
+    else
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, false>), dim3(nb), dim3(GSR_BLOCK), 0, stream, kin,
+                           (const uint32_t *)nullptr, kout, order, n_ptr, table, totals, nb, shift, mask, nbits);
     return gsr_check_launch("radix_scatter", debug, stream);
 }
 
@@ -296,23 +334,30 @@ int gsr_radix_sort_u32(uint32_t *key[2], uint32_t *val[2], const uint32_t *n_ptr
 }
 
 // block_counts -> exclusive offsets + V; index-ordered compaction; depth sort (32-bit float keys, 3 passes of
-// 11 bits).  The compaction writes into side 1 so that the sorted depth order ends in g.idx[0].
+// 11 bits) on (key, index) records.  The sorted depth order ends in g.order.
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
-    const int start = gsr_radix_passes(32, GSR_DEPTH_RADIX_BITS) & 1;
     hipLaunchKernelGGL(compact_kernel, dim3(nb1), dim3(GSR_BLOCK), 0, stream, P, g.tiles_touched, g.splat,
-                       g.block_counts, g.key[start], g.idx[start], g.hdr);
+                       g.block_counts, g.pair[0], g.hdr);
     if (int e = gsr_check_launch("compact", debug, stream)) return e;
-    uint32_t *key[2] = {g.key[0], g.key[1]};
-    uint32_t *val[2] = {g.idx[0], g.idx[1]};
-    return gsr_radix_sort_u32(key, val, &g.hdr->V, P, 32, GSR_DEPTH_RADIX_BITS, start, g.sort_table, g.sort_totals,
-                              debug, stream);
+    // (key, index) records ping-pong between pair[0] and pair[1]; the last pass leaves the bare indices in g.order
+    const int nb = GeomState::sort_blocks(P);
+    const int passes = gsr_radix_passes(32, GSR_DEPTH_RADIX_BITS);
+    for (int k = 0; k < passes; k++) {
+        const int shift = k * GSR_DEPTH_RADIX_BITS;
+        const int nbits = (32 - shift) < GSR_DEPTH_RADIX_BITS ? (32 - shift) : GSR_DEPTH_RADIX_BITS;
+        if (int e = radix_pass_paired<GSR_DEPTH_RADIX_BITS>(g.pair[k & 1], g.pair[(k & 1) ^ 1], g.order, k == passes - 1,
+                                                            &g.hdr->V, nb, shift, nbits, g.sort_table, g.sort_totals,
+                                                            debug, stream))
+            return e;
+    }
+    return GSR_OK;
 }
 
 // per-chunk tile counts in depth order -> exclusive chunk offsets, R (clamped against the capacity)
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream) {
     const int nb = GeomState::sort_blocks(P);
-    hipLaunchKernelGGL(tile_blocksum_kernel, dim3(nb), dim3(GSR_BLOCK), 0, stream, g.idx[0], g.tiles_touched, g.hdr,
+    hipLaunchKernelGGL(tile_blocksum_kernel, dim3(nb), dim3(GSR_BLOCK), 0, stream, g.order, g.tiles_touched, g.hdr,
                        g.tile_bsum);
     if (int e = gsr_check_launch("tile_blocksum", debug, stream)) return e;
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_bsum, 0, &g.hdr->V,
