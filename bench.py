@@ -89,8 +89,8 @@ def main():
 
     def frame(slot, lane=None):
         rr = rs_[slot % S if lane is None else lane]
-        color, _radii, _invd = rr.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg)
-        rr.pack_rgb8(color, fg.frames[slot])
+        # the uint8 HWC frame GSWorld consumes is written by the compositor itself (GsrOutputs.out_rgb8)
+        rr.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=fg.frames[slot])
 
     # exact-mode frame sizes the binning capacity from the real R; then check the no-sync path is valid
     for l in range(S):

@@ -55,7 +55,8 @@ def _require_gpu(t: torch.Tensor, what: str):
 
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
-                imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0):
+                imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
+                rgb8_out=None):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
@@ -66,7 +67,8 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix), projmatrix=_ptr(projmatrix),
         campos=_ptr(campos), shs_rest=_ptr(sh_rest) if sh_rest is not None else None, param_space=int(param_space))
-    out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii))
+    out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii),
+                     _ptr(rgb8_out) if rgb8_out is not None else None)
     cbs = (_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer))
     buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
     stats = GsrFrameStats()

@@ -133,7 +133,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
         const size_t n = (size_t)W * H;
         if (hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess ||
-            hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess) {
+            hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess ||
+            (out->out_rgb8 && hipMemsetAsync(out->out_rgb8, 0, 3 * n, stream) != hipSuccess)) {
             gsr_set_error("gsr_forward: hipMemsetAsync(outputs) failed");
             return GSR_E_HIP;
         }
@@ -215,8 +216,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     }
     prof_mark(4, stream);
     // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
-    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth, mode != 0,
-                                  stream))
+    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth,
+                                  out->out_rgb8, mode != 0, stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();

@@ -182,7 +182,7 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
 bool gsr_render_wants_tile_order(int num_tiles);
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
-                      bool order_ready, hipStream_t stream);
+                      uint8_t *out_rgb8, bool order_ready, hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

@@ -334,7 +334,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                                                   float *__restrict__ out_color,
                                                                   float *__restrict__ out_invdepth,
                                                                   float *__restrict__ final_T,
-                                                                  uint32_t *__restrict__ n_contrib) {
+                                                                  uint32_t *__restrict__ n_contrib,
+                                                                  uint8_t *__restrict__ rgb8 /* optional */) {
     __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList][3];
     const int lane = gsr_lane(), wave = gsr_wave();
     float4(*list)[3] = s_list[wave];
@@ -464,10 +465,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             const size_t plane = (size_t)H * W;
             final_T[pid] = T;
             n_contrib[pid] = last_contributor;
-            out_color[pid] = fma_(T, bg0, C0);
-            out_color[plane + pid] = fma_(T, bg1, C1);
-            out_color[2 * plane + pid] = fma_(T, bg2, C2);
+            const float r = fma_(T, bg0, C0), g = fma_(T, bg1, C1), b = fma_(T, bg2, C2);
+            out_color[pid] = r;
+            out_color[plane + pid] = g;
+            out_color[2 * plane + pid] = b;
             out_invdepth[pid] = Dacc;
+            if (rgb8) {  // GSWorld's frame conversion, same arithmetic as pack_rgb8_kernel
+                uint8_t *o = rgb8 + 3 * pid;
+                o[0] = (uint8_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
+                o[1] = (uint8_t)fminf(fmaxf(g * 255.0f, 0.0f), 255.0f);
+                o[2] = (uint8_t)fminf(fmaxf(b * 255.0f, 0.0f), 255.0f);
+            }
         }
     }
 }
@@ -542,10 +550,12 @@ bool gsr_render_wants_tile_order(int num_tiles) {
 }
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
-                      const float *background, float *out_color, float *out_invdepth, bool order_ready,
-                      hipStream_t stream) {
+                      const float *background, float *out_color, float *out_invdepth, uint8_t *out_rgb8,
+                      bool order_ready, hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
+    // the default kernel writes the uint8 frame itself; the A/B variants get a separate conversion pass
+    const bool pack_after = out_rgb8 != nullptr && g_render_variant != 4;
     if (g_render_variant >= 2) {
         const int T = gx * gy;
         const bool ordered = gsr_render_wants_tile_order(T);
@@ -556,7 +566,7 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
         if (g_render_variant == 4)
             hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
                                g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
-                               img.n_contrib);
+                               img.n_contrib, out_rgb8);
         else if (g_render_variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
                                point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,
@@ -568,6 +578,11 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     } else {
         hipLaunchKernelGGL(render_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list, g.splat,
                            W, H, gx, background, out_color, out_invdepth, img.final_T, img.n_contrib);
+    }
+    if (pack_after) {
+        const int n_pix = W * H;
+        hipLaunchKernelGGL(pack_rgb8_kernel, dim3(gsr_div_up(gsr_div_up(n_pix, 4), GSR_BLOCK)), dim3(GSR_BLOCK), 0,
+                           stream, out_color, n_pix, out_rgb8);
     }
     return GSR_OK;
 }

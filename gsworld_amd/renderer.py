@@ -53,14 +53,16 @@ class FrameRenderer:
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
                antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
-               param_space: int = 0):
+               param_space: int = 0, rgb8_out=None):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
         renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
         ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
         ``shs_rest=features_rest`` (P,M-1,3), instead of concatenating them for every frame.
         ``param_space``: OR of ``gsworld_amd._lib.RAW_OPACITY / RAW_SCALES / RAW_ROTATIONS`` -- the corresponding
         arguments are the model's RAW parameters (logits, log scales, un-normalised quaternions) and are activated
-        inside preprocess (no sigmoid / exp / normalize passes per frame)."""
+        inside preprocess (no sigmoid / exp / normalize passes per frame).
+        ``rgb8_out``: optional (H,W,3) uint8 tensor that receives GSWorld's uint8 frame conversion directly from the
+        compositing kernel (same bytes as :meth:`pack_rgb8` of the returned colour image)."""
         dev = self.device
         P = means3D.shape[0]
         H, W = view.image_height, view.image_width
@@ -83,7 +85,7 @@ class FrameRenderer:
             cov3D_precomp if cov3D_precomp is not None else empty, view.world_view_transform,
             view.full_proj_transform, shs if shs is not None else empty, view.camera_center, color, invd, radii,
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
-            param_space=param_space)
+            param_space=param_space, rgb8_out=rgb8_out)
         if cap == 0:
             self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
         return color, radii, invd
@@ -150,9 +152,8 @@ class MultiCameraRenderer:
         for k, (lane, stream, view) in enumerate(zip(self.lanes, self.streams, views)):
             stream.wait_stream(cur)  # the step's transformed Gaussians are ready
             with torch.cuda.stream(stream):
-                color, radii, invd = lane.render(view, means3D, opacities, **render_kw)
-                if rgb8_out is not None:
-                    lane.pack_rgb8(color, rgb8_out[k])
+                color, radii, invd = lane.render(view, means3D, opacities,
+                                                 rgb8_out=rgb8_out[k] if rgb8_out is not None else None, **render_kw)
             outs.append((color, radii, invd))
         for stream in self.streams:
             cur.wait_stream(stream)  # join: the caller's stream sees every frame

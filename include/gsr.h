@@ -89,6 +89,10 @@ typedef struct GsrOutputs {
     float *out_color;    /* (3,H,W) */
     float *out_invdepth; /* (1,H,W) */
     int32_t *radii;      /* (P) */
+    /* Optional: the frame as GSWorld consumes it (gs_world_wrapper.py:268-270), (H,W,3) uint8 =
+     * (uint8)clamp(255 * out_color, 0, 255), written by the compositor itself instead of a second pass over the
+     * image (gsr_pack_rgb8 remains for callers that convert later).  NULL = not wanted. */
+    uint8_t *out_rgb8;
 } GsrOutputs;
 
 /* resize callback: must return a device pointer to at least `bytes` bytes (256-byte aligned), or NULL. */
