@@ -110,6 +110,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t *
 // 16 x 16 buys nothing more.  8 x tiles LDS counters: up to 120 KiB at the 3840-tile limit of this path.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kPlaceWaves = 8;
+constexpr int kPlaceGrid = 1536;  // workgroups launched at most (256 CUs x 6); they stride over the 256-rank chunks
 
 // kernels that may need more than the default 64 KiB of dynamic LDS opt in once per process
 template <typename K>
@@ -201,18 +202,22 @@ __global__ __launch_bounds__(NW * GSR_WAVE) void tile_count_kernel(const uint32_
     extern __shared__ uint32_t s_cnt[];  // [NW][T]
     constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
-    if (base >= V) return;
-    const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);  // gathers fly under the zeroing
-    for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
-    __syncthreads();
-    walk_wave<false>(mine, gx, s_cnt + gsr_wave() * T, nullptr);
-    __syncthreads();
-    for (int t = (int)threadIdx.x; t < T; t += THREADS) {
-        uint32_t sum = 0;
+    // the grid is capped (the launch covers the capacity P, the live count V is usually a fraction of it and dead
+    // workgroups are not free to dispatch): a workgroup strides over the 256-rank chunks
+    for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)GSR_BLOCK < V; chunk += gridDim.x) {
+        const uint32_t base = chunk * (uint32_t)GSR_BLOCK;
+        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);  // gathers fly under the zeroing
+        for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
+        __syncthreads();
+        walk_wave<false>(mine, gx, s_cnt + gsr_wave() * T, nullptr);
+        __syncthreads();
+        for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) sum += s_cnt[w * T + t];
-        table[(size_t)t * nb_stride + blockIdx.x] = sum;
+            for (int w = 0; w < NW; w++) sum += s_cnt[w * T + t];
+            table[(size_t)t * nb_stride + chunk] = sum;
+        }
+        __syncthreads();  // the counters are zeroed again by the next chunk
     }
 }
 
@@ -264,32 +269,35 @@ __global__ __launch_bounds__(NW * GSR_WAVE) void tile_place_kernel(const uint32_
     extern __shared__ uint32_t s_cnt[];  // [NW][T]: counts, then running cursors
     constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
-    const uint32_t base = blockIdx.x * (uint32_t)GSR_BLOCK;
-    if (base >= V || hdr->overflow) return;
-    const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);
-    for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
-    __syncthreads();
+    if (hdr->overflow) return;
     const int wave = gsr_wave();
-    walk_wave<false>(mine, gx, s_cnt + wave * T, nullptr);
-    __syncthreads();
-    for (int t = (int)threadIdx.x; t < T; t += THREADS) {
-        uint32_t c[NW], any = 0u;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            c[w] = s_cnt[w * T + t];
-            any |= c[w];
-        }
-        if (any != 0u) {
-            uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + blockIdx.x];
+    for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)GSR_BLOCK < V; chunk += gridDim.x) {  // (capped grid)
+        const uint32_t base = chunk * (uint32_t)GSR_BLOCK;
+        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);
+        for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
+        __syncthreads();
+        walk_wave<false>(mine, gx, s_cnt + wave * T, nullptr);
+        __syncthreads();
+        for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+            uint32_t c[NW], any = 0u;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
-                s_cnt[w * T + t] = s;
-                s += c[w];
+                c[w] = s_cnt[w * T + t];
+                any |= c[w];
+            }
+            if (any != 0u) {
+                uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + chunk];
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    s_cnt[w * T + t] = s;
+                    s += c[w];
+                }
             }
         }
+        __syncthreads();
+        walk_wave<true>(mine, gx, s_cnt + wave * T, point_list);
+        __syncthreads();  // the cursors are zeroed again by the next chunk
     }
-    __syncthreads();
-    walk_wave<true>(mine, gx, s_cnt + wave * T, point_list);
 }
 
 
@@ -479,8 +487,9 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     static size_t lds_allowed = 0;
     const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
     if (int e = allow_dynamic_lds(tile_count_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order,
-                       g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb);
+    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid),
+                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, T,
+                       g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
@@ -499,8 +508,9 @@ int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, 
     static size_t lds_allowed = 0;
     const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
     if (int e = allow_dynamic_lds(tile_place_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb), dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order,
-                       g.tiles_touched, g.rects, g.hdr, gx, T, g.tile_table, nb, img.ranges, b.gidx[0]);
+    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid),
+                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, T,
+                       g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
 }
 
