@@ -124,3 +124,34 @@ def test_frame_and_step_replay_from_a_hipgraph(cuda_device):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(frames, moved)) and not any(s.overflow for s in
                                                                               mc.ensure_valid(step))
+
+
+def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
+    """GsrOutputs.out_rgb8: written inside the default compositing kernel, by a conversion pass behind the A/B
+    variants -- and always equal to GSWorld's own conversion of the float image (gs_world_wrapper.py:268-270)."""
+    import ctypes as C
+
+    from gsworld_amd._lib import check, lib
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=11)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    bg = torch.tensor([0.9, 1.0, 0.4], device=dev)  # bright background: exercises the clamp at 255
+    L = lib()
+    L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
+    frames = {}
+    try:
+        for variant in (4, 0, 3):
+            check(L.gsr_debug_set_render_variant(variant, 0))
+            out = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+            color, _, _ = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg,
+                                                    rgb8_out=out)
+            want = (color.permute(1, 2, 0) * 255).clamp(0, 255).to(torch.uint8)
+            assert torch.equal(out, want), f"variant {variant}"
+            frames[variant] = out
+    finally:
+        check(L.gsr_debug_set_render_variant(4, 0))
+    assert torch.equal(frames[4], frames[0]) and torch.equal(frames[4], frames[3])
+    assert int(frames[4].max()) == 255
