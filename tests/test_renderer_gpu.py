@@ -138,7 +138,9 @@ def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
     cam = scenes.sensor_camera("xarm6_align").to(dev)
     raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=11)
     means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
-    bg = torch.tensor([0.9, 1.0, 0.4], device=dev)  # bright background: exercises the clamp at 255
+    shs = shs.clone()
+    shs[::3, 0] += 3.0  # a third of the splats far brighter than 1: exercises the clamp at 255
+    bg = torch.tensor([0.9, 1.0, 0.4], device=dev)
     L = lib()
     L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
     frames = {}
