@@ -1,0 +1,17 @@
+"""A short slice of tools/fuzz_parity.py (random sizes / image shapes / scales / options / parameter spaces, HIP vs
+oracle and variant-0 bit-identity) in the GPU suite; the tool itself runs hundreds of cases (400 clean at round 1)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_parity_slice(cuda_device):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "16", "123"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "fuzz ok: 16 cases" in out.stdout
