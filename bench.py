@@ -209,13 +209,19 @@ def main():
         render_ms = stage_ms[-1]
         render_bytes = 40 * stats.num_rendered + 16 * W * H  # 40 B per composited instance + outputs
         ach = render_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
-        traffic = None
+        traffic = valu_frac = None
         pmc = os.path.join(ROOT, "profiles", "pmc_render.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_launch")
+                # what actually bounds the compositor: VALU issue.  SQ_INSTS_VALU wave-instructions (committed PMC
+                # run of the same frame) x 4 cycles on 256 CUs x 4 SIMDs at 2.4 GHz, over the kernel time measured now
+                insts = rec.get("counters", {}).get("SQ_INSTS_VALU")
+                if insts and render_ms > 0:
+                    valu_frac = insts * 4.0 / (256 * 4 * 2.4e9 * render_ms * 1e-3)
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic = valu_frac = None
         out = {
             "metric": "rendered frames/sec @640x480, 1.5M Gaussians",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,6 +239,7 @@ def main():
                 "bound": "hbm", "kernel": "render_stream_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
+                "valu_issue_frac": valu_frac,
                 "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
                         "recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not HBM-bound: "
                         "saturated pixels stop reading their tile list early, so real traffic is far below the "
