@@ -154,9 +154,10 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const GeomState g = GeomState::carve(geom_mem, in->P, tiles);
     const ImageState img = ImageState::carve(img_mem, W, H);
 
-    // binning path: 2 = bin-then-sort (default), 1 = depth sort + counting placement, 0 = depth sort + radix
-    // (tile grids above GSR_MAX_COUNT_TILES always take 0)
-    const int mode = GeomState::counting(tiles) ? g_binning_mode : 0;
+    // binning path: 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
+    // (tile grids above GSR_MAX_COUNT_TILES, or wider than 2048 tiles -- one band row of counters must fit 64 KiB of
+    // LDS -- always take 0)
+    const int mode = GeomState::counting(tiles) && gsr_div_up(W, GSR_TILE) <= 2048 ? g_binning_mode : 0;
     const bool exact = r_capacity <= 0;
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;

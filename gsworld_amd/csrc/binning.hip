@@ -107,22 +107,20 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_ranges_kernel(const uint32_t *
 // is a serial chain per wave (one returning LDS atomic + one scattered store per Gaussian), so the fewer ranks a
 // wave owns the shorter the critical path; lanes that hold no Gaussian still help spread tiles.  Measured on
 // MI355X: 8 waves x 32 ranks beats 4 x 64 at every grid size (53 -> 37 us at 1200 tiles, 364 -> 300 us at 2500) and
-// 16 x 16 buys nothing more.  8 x tiles LDS counters: up to 120 KiB at the 3840-tile limit of this path.
+// 16 x 16 buys nothing more.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kPlaceWaves = 8;
 constexpr int kPlaceGrid = 1536;  // workgroups launched at most (256 CUs x 6); they stride over the 256-rank chunks
 
-// kernels that may need more than the default 64 KiB of dynamic LDS opt in once per process
-template <typename K>
-int allow_dynamic_lds(K kernel, size_t bytes, size_t &allowed) {
-    if (bytes <= 65536 || bytes <= allowed) return GSR_OK;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) {
-        gsr_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", bytes);
-        return GSR_E_HIP;
-    }
-    allowed = bytes;
-    return GSR_OK;
+// rows of tiles per band: the NW x (band tiles) counters stay within 40 KiB so that four workgroups share a CU
+// (one band at 1200 tiles, two at 2500, seven at 1920x1080)
+inline int place_band_rows(int gx, int gy) {
+    // (measured at 800x800 / 500 k Gaussians: 10 / 20 / 30 / 40 / 64 KiB -> 1.37 / 1.37 / 1.31 / 1.31 / 1.35 ms per
+    // training step, one 80 KiB band 1.42 ms; at 640x480 splitting the 38 KiB grid only costs)
+    const int max_tiles = 40 * 1024 / (kPlaceWaves * (int)sizeof(uint32_t));
+    int rows = max_tiles / gx;
+    if (rows < 1) rows = 1;
+    return rows < gy ? rows : gy;
 }
 
 struct WaveSplats {  // this lane's Gaussian (t == 0: none)
@@ -130,10 +128,14 @@ struct WaveSplats {  // this lane's Gaussian (t == 0: none)
     uint2 rc;
 };
 
+// Tile rows [row0, row1) are this workgroup's band: grids whose NW x tiles counters would not leave room for several
+// workgroups per CU are cut into bands of rows (blockIdx.y), and a Gaussian's rect is clipped to the band here, so
+// the walks below only ever see tiles of the band.
 template <int NW>
 __device__ __forceinline__ WaveSplats load_wave_splats(const uint32_t *__restrict__ order,
                                                        const uint32_t *__restrict__ tiles_touched,
-                                                       const uint2 *__restrict__ rects, uint32_t V, uint32_t block_base) {
+                                                       const uint2 *__restrict__ rects, uint32_t V, uint32_t block_base,
+                                                       uint32_t row0, uint32_t row1) {
     constexpr int PER_WAVE = GSR_BLOCK / NW;
     const int lane = gsr_lane();
     const uint32_t rank = block_base + (uint32_t)(gsr_wave() * PER_WAVE + lane);
@@ -141,14 +143,20 @@ __device__ __forceinline__ WaveSplats load_wave_splats(const uint32_t *__restric
     s.g = 0u; s.t = 0u; s.rc = make_uint2(0u, 0u);
     if (lane < PER_WAVE && rank < V) {
         s.g = order[rank];
-        s.t = tiles_touched[s.g];
-        s.rc = rects[s.g];
+        const uint2 rc = rects[s.g];
+        const uint32_t minx = rc.x & 0xffffu, maxx = rc.y & 0xffffu;
+        const uint32_t miny = max(rc.x >> 16, row0), maxy = min(rc.y >> 16, row1);
+        if (tiles_touched[s.g] != 0u && maxy > miny) {
+            s.t = (maxx - minx) * (maxy - miny);
+            s.rc = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
+        }
     }
     return s;
 }
 
 template <bool PLACE>
-__device__ __forceinline__ void walk_wave(const WaveSplats s, int gx, uint32_t *cnt, uint32_t *__restrict__ out) {
+__device__ __forceinline__ void walk_wave(const WaveSplats s, int gx, uint32_t tile0, uint32_t *cnt,
+                                          uint32_t *__restrict__ out) {
     const int lane = gsr_lane();
     const uint32_t g = s.g, t = s.t;
     const uint2 rc = s.rc;
@@ -158,7 +166,7 @@ __device__ __forceinline__ void walk_wave(const WaveSplats s, int gx, uint32_t *
         // counting does not care about order: a lane walks a short tile list itself (LDS atomics resolve any
         // collisions between lanes), only long lists are spread over the wave
         if (t > 0u && t <= 32u) {
-            uint32_t x = minx, tile_row = miny * (uint32_t)gx;
+            uint32_t x = minx, tile_row = miny * (uint32_t)gx - tile0;
             for (uint32_t j = 0; j < t; j++) {
                 atomicAdd(&cnt[tile_row + x], 1u);
                 if (++x == maxx) { x = minx; tile_row += (uint32_t)gx; }
@@ -182,7 +190,7 @@ __device__ __forceinline__ void walk_wave(const WaveSplats s, int gx, uint32_t *
         const float binv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), src));
         for (uint32_t j = (uint32_t)lane; j < bt; j += 64u) {
             const uint32_t yy = (uint32_t)(((float)j + 0.5f) * binv), xx = j - yy * bw;
-            const uint32_t tile = (bminy + yy) * (uint32_t)gx + (bminx + xx);
+            const uint32_t tile = (bminy + yy) * (uint32_t)gx + (bminx + xx) - tile0;  // index inside the band
             if (PLACE) {
                 const uint32_t pos = atomicAdd(&cnt[tile], 1u);
                 out[pos] = bg;
@@ -197,25 +205,30 @@ template <int NW>
 __global__ __launch_bounds__(NW * GSR_WAVE) void tile_count_kernel(const uint32_t *__restrict__ order,
                                                                    const uint32_t *__restrict__ tiles_touched,
                                                                    const uint2 *__restrict__ rects,
-                                                                   const GsrHeader *__restrict__ hdr, int gx, int T,
-                                                                   uint32_t *__restrict__ table, int nb_stride) {
-    extern __shared__ uint32_t s_cnt[];  // [NW][T]
+                                                                   const GsrHeader *__restrict__ hdr, int gx, int gy,
+                                                                   int band_rows, uint32_t *__restrict__ table,
+                                                                   int nb_stride) {
+    extern __shared__ uint32_t s_cnt[];  // [NW][Tb]
     constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
+    const uint32_t row0 = blockIdx.y * (uint32_t)band_rows, row1 = min((uint32_t)gy, row0 + (uint32_t)band_rows);
+    const uint32_t tile0 = row0 * (uint32_t)gx;
+    const int Tb = (int)((row1 - row0) * (uint32_t)gx);
     // the grid is capped (the launch covers the capacity P, the live count V is usually a fraction of it and dead
     // workgroups are not free to dispatch): a workgroup strides over the 256-rank chunks
     for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)GSR_BLOCK < V; chunk += gridDim.x) {
         const uint32_t base = chunk * (uint32_t)GSR_BLOCK;
-        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);  // gathers fly under the zeroing
-        for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
+        // (gathers fly under the zeroing)
+        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base, row0, row1);
+        for (int i = (int)threadIdx.x; i < NW * Tb; i += THREADS) s_cnt[i] = 0u;
         __syncthreads();
-        walk_wave<false>(mine, gx, s_cnt + gsr_wave() * T, nullptr);
+        walk_wave<false>(mine, gx, tile0, s_cnt + gsr_wave() * Tb, nullptr);
         __syncthreads();
-        for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+        for (int t = (int)threadIdx.x; t < Tb; t += THREADS) {
             uint32_t sum = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) sum += s_cnt[w * T + t];
-            table[(size_t)t * nb_stride + chunk] = sum;
+            for (int w = 0; w < NW; w++) sum += s_cnt[w * Tb + t];
+            table[(size_t)(tile0 + (uint32_t)t) * nb_stride + chunk] = sum;
         }
         __syncthreads();  // the counters are zeroed again by the next chunk
     }
@@ -262,40 +275,44 @@ template <int NW>
 __global__ __launch_bounds__(NW * GSR_WAVE) void tile_place_kernel(const uint32_t *__restrict__ order,
                                                                    const uint32_t *__restrict__ tiles_touched,
                                                                    const uint2 *__restrict__ rects,
-                                                                   const GsrHeader *__restrict__ hdr, int gx, int T,
-                                                                   const uint32_t *__restrict__ table, int nb_stride,
-                                                                   const uint2 *__restrict__ ranges,
+                                                                   const GsrHeader *__restrict__ hdr, int gx, int gy,
+                                                                   int band_rows, const uint32_t *__restrict__ table,
+                                                                   int nb_stride, const uint2 *__restrict__ ranges,
                                                                    uint32_t *__restrict__ point_list) {
-    extern __shared__ uint32_t s_cnt[];  // [NW][T]: counts, then running cursors
+    extern __shared__ uint32_t s_cnt[];  // [NW][Tb]: counts, then running cursors
     constexpr int THREADS = NW * GSR_WAVE;
     const uint32_t V = hdr->V;
     if (hdr->overflow) return;
+    const uint32_t row0 = blockIdx.y * (uint32_t)band_rows, row1 = min((uint32_t)gy, row0 + (uint32_t)band_rows);
+    const uint32_t tile0 = row0 * (uint32_t)gx;
+    const int Tb = (int)((row1 - row0) * (uint32_t)gx);
     const int wave = gsr_wave();
     for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)GSR_BLOCK < V; chunk += gridDim.x) {  // (capped grid)
         const uint32_t base = chunk * (uint32_t)GSR_BLOCK;
-        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base);
-        for (int i = (int)threadIdx.x; i < NW * T; i += THREADS) s_cnt[i] = 0u;
+        const WaveSplats mine = load_wave_splats<NW>(order, tiles_touched, rects, V, base, row0, row1);
+        for (int i = (int)threadIdx.x; i < NW * Tb; i += THREADS) s_cnt[i] = 0u;
         __syncthreads();
-        walk_wave<false>(mine, gx, s_cnt + wave * T, nullptr);
+        walk_wave<false>(mine, gx, tile0, s_cnt + wave * Tb, nullptr);
         __syncthreads();
-        for (int t = (int)threadIdx.x; t < T; t += THREADS) {
+        for (int t = (int)threadIdx.x; t < Tb; t += THREADS) {
             uint32_t c[NW], any = 0u;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
-                c[w] = s_cnt[w * T + t];
+                c[w] = s_cnt[w * Tb + t];
                 any |= c[w];
             }
             if (any != 0u) {
-                uint32_t s = ranges[t].x + table[(size_t)t * nb_stride + chunk];
+                const uint32_t tile = tile0 + (uint32_t)t;
+                uint32_t s = ranges[tile].x + table[(size_t)tile * nb_stride + chunk];
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
-                    s_cnt[w * T + t] = s;
+                    s_cnt[w * Tb + t] = s;
                     s += c[w];
                 }
             }
         }
         __syncthreads();
-        walk_wave<true>(mine, gx, s_cnt + wave * T, point_list);
+        walk_wave<true>(mine, gx, tile0, s_cnt + wave * Tb, point_list);
         __syncthreads();  // the cursors are zeroed again by the next chunk
     }
 }
@@ -484,12 +501,12 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    static size_t lds_allowed = 0;
-    const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
-    if (int e = allow_dynamic_lds(tile_count_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid),
-                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, T,
-                       g.tile_table, nb);
+    const int band_rows = place_band_rows(gx, gy);
+    const int bands = gsr_div_up(gy, band_rows);
+    const size_t lds = (size_t)kPlaceWaves * band_rows * gx * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_count_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid, bands),
+                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, gy,
+                       band_rows, g.tile_table, nb);
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
@@ -503,14 +520,13 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                           const ImageState &img, bool debug, hipStream_t stream) {
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    const int T = gx * gy;
     const int nb = GeomState::prep_blocks(P);
-    static size_t lds_allowed = 0;
-    const size_t lds = (size_t)kPlaceWaves * T * sizeof(uint32_t);
-    if (int e = allow_dynamic_lds(tile_place_kernel<kPlaceWaves>, lds, lds_allowed)) return e;
-    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid),
-                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, T,
-                       g.tile_table, nb, img.ranges, b.gidx[0]);
+    const int band_rows = place_band_rows(gx, gy);
+    const int bands = gsr_div_up(gy, band_rows);
+    const size_t lds = (size_t)kPlaceWaves * band_rows * gx * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_place_kernel<kPlaceWaves>, dim3(nb < kPlaceGrid ? nb : kPlaceGrid, bands),
+                       dim3(kPlaceWaves * GSR_WAVE), lds, stream, g.order, g.tiles_touched, g.rects, g.hdr, gx, gy,
+                       band_rows, g.tile_table, nb, img.ranges, b.gidx[0]);
     return gsr_check_launch("tile_place", debug, stream);
 }
 

@@ -17,7 +17,7 @@
 #define GSR_DEPTH_RADIX_BITS 11       // digit width of the 32-bit depth sort and the 30-bit Morton sort: 3 passes
 #define GSR_DEPTH_RADIX_BINS 2048
 #define GSR_BIN_SLOTS 16              // replicated per-tile counters of the bin-then-sort path
-#define GSR_MAX_COUNT_TILES 3840      // counting placement keeps 8 x tiles LDS counters per workgroup (<= 120 KiB)
+#define GSR_MAX_COUNT_TILES 16384     // counting placement: tile_table is tiles x ceil(P/256) words (bands keep LDS <= 40 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
 // depends on a value the host would have to read back.
@@ -135,8 +135,6 @@ struct BinningState {
         return bits;
     }
     static int tile_passes(int num_tiles) { return (tile_bits(num_tiles) + GSR_RADIX_BITS - 1) / GSR_RADIX_BITS; }
-    // which ping-pong side holds the final point list
-    static int result_side(int num_tiles) { return num_tiles <= GSR_MAX_COUNT_TILES ? 0 : (tile_passes(num_tiles) & 1); }
 };
 
 // ---- image state (per pixel / per tile) ----------------------------------------------------------------

@@ -104,7 +104,7 @@ def test_tabletop_config2_full(cuda_device):
 
 @pytest.mark.parametrize("mode", [0, 2])
 def test_alternative_binning_paths_match_too(cuda_device, mode):
-    """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 3840 tiles use) and mode 2 (unordered
+    """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 16384 tiles use) and mode 2 (unordered
     binning + per-tile LDS sort) must give the same point list as the default mode 1 (depth sort + counting)."""
     from gsworld_amd._lib import lib
 
@@ -154,8 +154,14 @@ def test_compositing_variants_are_bit_identical(cuda_device, scene):
 
 
 def test_large_tile_grid_and_long_tile_lists(cuda_device):
-    # a grid that is natively above the counting limit (120 x 68 = 8160 tiles) -> radix fallback
+    # 120 x 68 = 8160 tiles: counting placement in seven bands of tile rows
     rep = _run(scenes.random_scene_camera_frame(30_000, seed=15), scenes.identity_camera(1920, 1080, 60.0))
+    assert rep["R"] > 0
+    # a grid above the counting limit (132 x 132 = 17424 tiles) -> radix fallback
+    rep = _run(scenes.random_scene_camera_frame(20_000, seed=17), scenes.identity_camera(2100, 2100, 60.0))
+    assert rep["R"] > 0
+    # a strip wider than 2048 tiles (one row of counters would not fit the LDS) -> radix fallback as well
+    rep = _run(scenes.random_scene_camera_frame(20_000, seed=18), scenes.identity_camera(33_000, 16, 60.0))
     assert rep["R"] > 0
     # tile lists longer than the 8192-key LDS sort: 30k big splats on a 64x64 image (16 tiles)
     from gsworld_amd._lib import lib
