@@ -326,6 +326,23 @@ constexpr int kStreamLanesItems = 1;                              // candidates 
 constexpr int kStreamRound = kStreamLanesItems * GSR_WAVE;        // 64 candidates per round
 constexpr int kStreamList = kStreamRound + kBatch;                // survivors + zero padding of the last batch
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// survivor number `rank` of the round -> its half of pair rank / 2 (layout: see s_list in render_stream_kernel)
+__device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, float4 geo, float4 conic_op, float4 rgbd,
+                                                float pos) {
+    float4 *pr = list[rank >> 1];
+    float *f = reinterpret_cast<float *>(pr) + (rank & 1);
+    f[0] = geo.x;
+    f[2] = geo.y;
+    f[4] = conic_op.x;
+    f[6] = conic_op.z;
+    f[8] = conic_op.y;
+    f[10] = conic_op.w;
+    pr[3 + (rank & 1)] = rgbd;
+    f[20] = pos;
+}
+
 __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ point_list,
                                                                   const float4 *__restrict__ splat, int W, int H, int gx,
@@ -336,15 +353,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                                                   float *__restrict__ final_T,
                                                                   uint32_t *__restrict__ n_contrib,
                                                                   uint8_t *__restrict__ rgb8 /* optional */) {
-    __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList][3];
+    // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
+    // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
+    // accumulators per instruction for the blend).  One pair = 6 x 16 B:
+    //   [0] x0 x1 y0 y1   [1] A0 A1 C0 C1   [2] B0 B1 o0 o1   [3] r0 g0 b0 d0   [4] r1 g1 b1 d1   [5] pos0 pos1 - -
+    __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList / 2][6];
     const int lane = gsr_lane(), wave = gsr_wave();
-    float4(*list)[3] = s_list[wave];
+    float4(*list)[6] = s_list[wave];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t num_tickets = 4u * (uint32_t)num_tiles;
-    // static LPT schedule: units sorted longest-first are dealt round-robin over the resident waves (no global
-    // ticket counter: same-address device-scope atomics resolve memory-side, ~10 ns apiece back to back, which
-    // cost more than the compositing itself)
+    // static LPT schedule: units sorted longest-first are dealt round-robin over the resident waves.  Measured
+    // alternatives: one device-wide ticket counter (same-address device-scope atomics resolve memory-side, ~10 ns
+    // apiece back to back: cost more than the compositing itself) and 8 per-XCD counters pulled one unit ahead with
+    // 2-4 workgroups per CU resident (98-111 us against 77 us for everything resident: a wave is a latency chain, so
+    // the more of them are in flight the better, and with 4 x tiles <= resident waves nothing is left to balance).
+    // Giving each XCD a contiguous part of the image (row chunks, or a 4 x 2 split) instead of every 8th tile did not
+    // pay either (80-82 us): what the L2s gain in locality the XCDs lose in balance.
     // (snake order: pass 0 deals the longest units to waves 0..S-1, pass 1 deals the next ones to waves S-1..0, so a
     // wave that started with a long unit continues with a short one)
     const uint32_t ticket_stride = gridDim.x * (uint32_t)(GSR_BLOCK / GSR_WAVE);
@@ -362,8 +387,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         const int n_inst = (int)(range.y - range.x);
         const uint32_t *src = point_list + range.x;
 
+        const v2f pf2x = {pfx, pfx}, pf2y = {pfy, pfy};
         bool done = !inside;
-        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
+        float T = 1.0f;
+        v2f acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};  // (red, green), (blue, inverse depth)
         uint32_t last_contributor = 0;
 
         // global -> register pipeline: records of round rd in (f0,f1,f2), Gaussian indices of round rd+1 in g_next
@@ -392,18 +419,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
                 const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (keep) {
-                    list[rank][0] = f0[s];
-                    list[rank][1] = f1[s];
-                    list[rank][2] = make_float4(f2[s].x, f2[s].y, f2[s].z, __uint_as_float((uint32_t)p + 1u));
-                }
+                if (keep)
+                    stream_list_put(list, rank, f0[s], f1[s], make_float4(f2[s].x, f2[s].y, f2[s].z, f0[s].w),
+                                    __uint_as_float((uint32_t)p + 1u));
                 n_surv += (int)__builtin_popcountll(mask);
             }
-            if (lane < kBatch) {  // alpha = 0 padding behind the last survivor
-                list[n_surv + lane][0] = zero4;
-                list[n_surv + lane][1] = zero4;
-                list[n_surv + lane][2] = zero4;
-            }
+            if (lane < kBatch)  // alpha = 0 padding behind the last survivor
+                stream_list_put(list, n_surv + lane, zero4, zero4, zero4, 0.0f);
             // ---- next round's gathers go out before the replay so that they fly under it
 #pragma unroll
             for (int s = 0; s < kStreamLanesItems; s++) {
@@ -424,22 +446,35 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             // predicates as 0/1 floats instead of wave masks: +6 us, costs an occupancy step; batches of 2 / 8.)
             for (int i = 0; i < n_surv; i += kBatch) {
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-                float4 c0[kBatch], c1[kBatch], c2[kBatch];
+                float4 qxy[kBatch / 2], qac[kBatch / 2], qbo[kBatch / 2], col[kBatch];
+                float2 qpos[kBatch / 2];
 #pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    c0[k] = list[i + k][0];
-                    c1[k] = list[i + k][1];
-                    c2[k] = list[i + k][2];
+                for (int h = 0; h < kBatch / 2; h++) {
+                    const float4 *pr = list[(i >> 1) + h];
+                    qxy[h] = pr[0];
+                    qac[h] = pr[1];
+                    qbo[h] = pr[2];
+                    col[2 * h] = pr[3];
+                    col[2 * h + 1] = pr[4];
+                    qpos[h] = *reinterpret_cast<const float2 *>(pr + 5);
                 }
-                float alpha[kBatch];
+                float alpha[kBatch], pos[kBatch];
                 bool valid[kBatch];
 #pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    const float dx = c0[k].x - pfx, dy = c0[k].y - pfy;
-                    const float q = fma_(c1[k].z * dy, dy, (c1[k].x * dx) * dx);
-                    const float power = fma_(-(c1[k].y * dx), dy, -0.5f * q);
-                    alpha[k] = fminf(0.99f, c1[k].w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
-                    valid[k] = power <= 0.0f && alpha[k] >= 1.0f / 255.0f;
+                for (int h = 0; h < kBatch / 2; h++) {  // same operations in the same order as the scalar kernels
+                    const v2f dx = v2f{qxy[h].x, qxy[h].y} - pf2x, dy = v2f{qxy[h].z, qxy[h].w} - pf2y;
+                    const v2f cA = {qac[h].x, qac[h].y}, cC = {qac[h].z, qac[h].w};
+                    const v2f cB = {qbo[h].x, qbo[h].y}, op = {qbo[h].z, qbo[h].w};
+                    const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
+                    const v2f power = __builtin_elementwise_fma(-(cB * dx), dy, v2f{-0.5f, -0.5f} * q);
+                    const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
+                    const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
+                    alpha[2 * h] = fminf(0.99f, a.x);
+                    alpha[2 * h + 1] = fminf(0.99f, a.y);
+                    valid[2 * h] = power.x <= 0.0f && alpha[2 * h] >= 1.0f / 255.0f;
+                    valid[2 * h + 1] = power.y <= 0.0f && alpha[2 * h + 1] >= 1.0f / 255.0f;
+                    pos[2 * h] = qpos[h].x;
+                    pos[2 * h + 1] = qpos[h].y;
                 }
 #pragma unroll
                 for (int k = 0; k < kBatch; k++) {
@@ -449,12 +484,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                     const float test_T = T * (1.0f - a_eff);
                     const bool stop = test_T < 0.0001f;
                     const float w = stop ? 0.0f : a_eff * T;
-                    C0 = fma_(c2[k].x, w, C0);
-                    C1 = fma_(c2[k].y, w, C1);
-                    C2 = fma_(c2[k].z, w, C2);
-                    Dacc = fma_(c0[k].w, w, Dacc);
+                    acc_rg = __builtin_elementwise_fma(v2f{col[k].x, col[k].y}, v2f{w, w}, acc_rg);
+                    acc_bd = __builtin_elementwise_fma(v2f{col[k].z, col[k].w}, v2f{w, w}, acc_bd);
                     T = stop ? T : test_T;
-                    last_contributor = (hit && !stop) ? __float_as_uint(c2[k].w) : last_contributor;
+                    last_contributor = (hit && !stop) ? __float_as_uint(pos[k]) : last_contributor;
                     done = done || stop;
                 }
             }
@@ -465,11 +498,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             const size_t plane = (size_t)H * W;
             final_T[pid] = T;
             n_contrib[pid] = last_contributor;
-            const float r = fma_(T, bg0, C0), g = fma_(T, bg1, C1), b = fma_(T, bg2, C2);
+            const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
             out_color[pid] = r;
             out_color[plane + pid] = g;
             out_color[2 * plane + pid] = b;
-            out_invdepth[pid] = Dacc;
+            out_invdepth[pid] = acc_bd.y;
             if (rgb8) {  // GSWorld's frame conversion, same arithmetic as pack_rgb8_kernel
                 uint8_t *o = rgb8 + 3 * pid;
                 o[0] = (uint8_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
