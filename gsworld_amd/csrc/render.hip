@@ -328,6 +328,55 @@ constexpr int kStreamList = kStreamRound + kBatch;                // survivors +
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// one batch of survivors, evaluated for this lane's pixel (alpha: 0 for an instance that does not touch it)
+struct StreamBatch {
+    float alpha[kBatch], pos[kBatch];
+    bool valid[kBatch];
+    float4 col[kBatch];
+};
+
+// same operations in the same order as the scalar kernels, two survivors per packed instruction
+__device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int i, v2f pf2x, v2f pf2y) {
+    StreamBatch b;
+#pragma unroll
+    for (int h = 0; h < kBatch / 2; h++) {
+        const float4 *pr = list[(i >> 1) + h];
+        const float4 qxy = pr[0], qac = pr[1], qbo = pr[2];
+        b.col[2 * h] = pr[3];
+        b.col[2 * h + 1] = pr[4];
+        const float2 qpos = *reinterpret_cast<const float2 *>(pr + 5);
+        const v2f dx = v2f{qxy.x, qxy.y} - pf2x, dy = v2f{qxy.z, qxy.w} - pf2y;
+        const v2f cA = {qac.x, qac.y}, cC = {qac.z, qac.w};
+        const v2f cB = {qbo.x, qbo.y}, op = {qbo.z, qbo.w};
+        const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
+        const v2f power = __builtin_elementwise_fma(-(cB * dx), dy, v2f{-0.5f, -0.5f} * q);
+        const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
+        const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
+        const float a0 = fminf(0.99f, a.x), a1 = fminf(0.99f, a.y);
+        b.valid[2 * h] = power.x <= 0.0f && a0 >= 1.0f / 255.0f;
+        b.valid[2 * h + 1] = power.y <= 0.0f && a1 >= 1.0f / 255.0f;
+        b.alpha[2 * h] = b.valid[2 * h] ? a0 : 0.0f;
+        b.alpha[2 * h + 1] = b.valid[2 * h + 1] ? a1 : 0.0f;
+        b.pos[2 * h] = qpos.x;
+        b.pos[2 * h + 1] = qpos.y;
+    }
+    return b;
+}
+
+__device__ __forceinline__ void stream_blend(const StreamBatch &b, float &T, v2f &acc_rg, v2f &acc_bd, uint32_t &last) {
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+        // alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0; T < 0 (finished): stop again
+        const float test_T = T * (1.0f - b.alpha[k]);
+        const bool stop = test_T < 0.0001f;
+        const float w = stop ? 0.0f : b.alpha[k] * T;
+        acc_rg = __builtin_elementwise_fma(v2f{b.col[k].x, b.col[k].y}, v2f{w, w}, acc_rg);
+        acc_bd = __builtin_elementwise_fma(v2f{b.col[k].z, b.col[k].w}, v2f{w, w}, acc_bd);
+        last = (b.valid[k] && !stop) ? __float_as_uint(b.pos[k]) : last;
+        T = stop ? -fabsf(T) : test_T;
+    }
+}
+
 // survivor number `rank` of the round -> its half of pair rank / 2 (layout: see s_list in render_stream_kernel)
 __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, float4 geo, float4 conic_op, float4 rgbd,
                                                 float pos) {
@@ -388,8 +437,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         const uint32_t *src = point_list + range.x;
 
         const v2f pf2x = {pfx, pfx}, pf2y = {pfy, pfy};
-        bool done = !inside;
-        float T = 1.0f;
+        // A pixel that is finished (saturated, or outside the image) carries its transmittance NEGATED: T * (1 - a) is
+        // then negative, so the saturation test below fires for it again by itself and no separate done flag has to
+        // sit on the dependent chain (per survivor: multiply -> compare -> select).
+        float T = inside ? 1.0f : -1.0f;
         v2f acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};  // (red, green), (blue, inverse depth)
         uint32_t last_contributor = 0;
 
@@ -409,7 +460,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         }
         const int rounds = (n_inst + kStreamRound - 1) / kStreamRound;
         for (int rd = 0; rd < rounds; rd++) {
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
             // ---- cull + compact this round's candidates into the private list
             int n_surv = 0;
 #pragma unroll
@@ -439,63 +490,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             }
             __builtin_amdgcn_wave_barrier();  // (scheduling fence: list writes above, list reads below; same wave)
             // ---- replay the survivors, 4 at a time
-            // A wave's life is one dependent chain through this loop (a lone wave is as slow as a crowded one:
-            // ~600 clk per survivor), so it is written for latency: no branch inside a batch (the per-instance
-            // "does any lane hit" skips cost more in compare -> SGPR -> branch round trips than the 11 VALU they
-            // saved -- after the cull, 77 % of the evaluated pixel-instances hit anyway).  (Measured alternatives:
-            // predicates as 0/1 floats instead of wave masks: +6 us, costs an occupancy step; batches of 2 / 8.)
+            // Cycle counters per wave (config-2 frame, 5 waves per SIMD): waiting for the gathers 1 %, cull + compaction
+            // 13 %, this loop 80 % at ~270 clk per survivor -- and a wave alone on its SIMD is hardly faster, so the loop
+            // is written for the fewest instructions on the shortest chain: no branch inside a batch (per-instance
+            // "does any lane hit" skips cost more in compare -> SGPR -> branch round trips than the VALU they saved:
+            // after the cull 77 % of the evaluated pixel-instances hit anyway), survivor pairs through the packed
+            // pipe, the finished state carried in T's sign.  (Measured alternatives: predicates as 0/1 floats instead
+            // of wave masks: +6 us, costs an occupancy step; batches of 2 / 8.)
+            // (Evaluating batch i + 1 ahead of the blend of batch i -- one basic block, ping-pong registers -- was
+            // measured: +17 % replay time; the loop is bound by instruction count, not by exposed latency.)
             for (int i = 0; i < n_surv; i += kBatch) {
-                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-                float4 qxy[kBatch / 2], qac[kBatch / 2], qbo[kBatch / 2], col[kBatch];
-                float2 qpos[kBatch / 2];
-#pragma unroll
-                for (int h = 0; h < kBatch / 2; h++) {
-                    const float4 *pr = list[(i >> 1) + h];
-                    qxy[h] = pr[0];
-                    qac[h] = pr[1];
-                    qbo[h] = pr[2];
-                    col[2 * h] = pr[3];
-                    col[2 * h + 1] = pr[4];
-                    qpos[h] = *reinterpret_cast<const float2 *>(pr + 5);
-                }
-                float alpha[kBatch], pos[kBatch];
-                bool valid[kBatch];
-#pragma unroll
-                for (int h = 0; h < kBatch / 2; h++) {  // same operations in the same order as the scalar kernels
-                    const v2f dx = v2f{qxy[h].x, qxy[h].y} - pf2x, dy = v2f{qxy[h].z, qxy[h].w} - pf2y;
-                    const v2f cA = {qac[h].x, qac[h].y}, cC = {qac[h].z, qac[h].w};
-                    const v2f cB = {qbo[h].x, qbo[h].y}, op = {qbo[h].z, qbo[h].w};
-                    const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
-                    const v2f power = __builtin_elementwise_fma(-(cB * dx), dy, v2f{-0.5f, -0.5f} * q);
-                    const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
-                    const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
-                    alpha[2 * h] = fminf(0.99f, a.x);
-                    alpha[2 * h + 1] = fminf(0.99f, a.y);
-                    valid[2 * h] = power.x <= 0.0f && alpha[2 * h] >= 1.0f / 255.0f;
-                    valid[2 * h + 1] = power.y <= 0.0f && alpha[2 * h + 1] >= 1.0f / 255.0f;
-                    pos[2 * h] = qpos[h].x;
-                    pos[2 * h + 1] = qpos[h].y;
-                }
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    const bool hit = valid[k] && !done;
-                    // non-hit lanes run with alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0
-                    const float a_eff = hit ? alpha[k] : 0.0f;
-                    const float test_T = T * (1.0f - a_eff);
-                    const bool stop = test_T < 0.0001f;
-                    const float w = stop ? 0.0f : a_eff * T;
-                    acc_rg = __builtin_elementwise_fma(v2f{col[k].x, col[k].y}, v2f{w, w}, acc_rg);
-                    acc_bd = __builtin_elementwise_fma(v2f{col[k].z, col[k].w}, v2f{w, w}, acc_bd);
-                    T = stop ? T : test_T;
-                    last_contributor = (hit && !stop) ? __float_as_uint(pos[k]) : last_contributor;
-                    done = done || stop;
-                }
+                if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+                const StreamBatch b = stream_eval(list, i, pf2x, pf2y);
+                stream_blend(b, T, acc_rg, acc_bd, last_contributor);
             }
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
         if (inside) {
             const size_t pid = (size_t)py * W + px;
             const size_t plane = (size_t)H * W;
+            T = fabsf(T);
             final_T[pid] = T;
             n_contrib[pid] = last_contributor;
             const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
