@@ -94,7 +94,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
 
 def selftest_wave_sum(x256: torch.Tensor) -> torch.Tensor:
     L = _bind()
-    out = torch.zeros(4, dtype=torch.float32, device=x256.device)
+    out = torch.zeros(44, dtype=torch.float32, device=x256.device)  # 4 wave sums + 4 x 10 transpose-reduce totals
     with torch.cuda.device(x256.device):
         check(L.gsr_selftest_wave_sum(_ptr(x256), _ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out

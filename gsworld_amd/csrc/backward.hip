@@ -39,6 +39,45 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kGrad = 10;  // mean2D.x, mean2D.y, conic.xx, conic.xy(half), conic.yy, opacity, r, g, b, invdepth
 
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+// Wave totals of 10 per-lane values at once, as a transpose-reduce: v_permlane32_swap exchanges the upper half of
+// one register with the lower half of another, so ONE swap + ONE add folds lane l with lane l + 32 for TWO values
+// (lanes 0-31 then carry the first, 32-63 the second); v_permlane16_swap does the same across rows of 16 for two
+// such registers (four values, one per row); the last four levels are DPP adds inside the rows.  28 instructions
+// instead of the 10 x 13 of ten separate wave_sum calls.  Lanes (row r = lane / 16, column s = lane % 16) end up with
+//   s == 0: components 0, 2, 1, 3 in rows 0..3     s == 1: components 4, 6, 5, 7     s == 2: 8, 8, 9, 9
+// wave_reduce10_component gives that map; the value in any other lane is not meaningful.
+__device__ __forceinline__ float fold32(float a, float b) {
+    const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+    const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum(float v) {  // every lane of a row of 16 gets the row total
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_reduce10(const float (&v)[kGrad]) {
+    const float z0 = fold32(v[0], v[1]), z1 = fold32(v[2], v[3]), z2 = fold32(v[4], v[5]), z3 = fold32(v[6], v[7]),
+                z4 = fold32(v[8], v[9]);
+    const float w0 = row_sum(fold16(z0, z1)), w1 = row_sum(fold16(z2, z3)), w2 = row_sum(fold16(z4, z4));
+    const int s = gsr_lane() & 15;
+    return s == 0 ? w0 : s == 1 ? w1 : w2;
+}
+// component held by this lane after wave_reduce10, or -1
+__device__ __forceinline__ int wave_reduce10_component() {
+    const int lane = gsr_lane(), r = lane >> 4, s = lane & 15;
+    if (s < 2) return 4 * s + (((r & 1) << 1) | (r >> 1));
+    if (s == 2 && !(r & 1)) return 8 + (r >> 1);
+    return -1;
+}
+
 __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, const float4 *__restrict__ splat,
     int W, int H, int gx, const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -89,6 +128,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     const int n_inst = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     const int rounds = (n_inst + GSR_BLOCK - 1) / GSR_BLOCK;
 
+    const int my_comp = wave_reduce10_component();
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
     float lastc0 = 0.f, lastc1 = 0.f, lastc2 = 0.f, lastd = 0.f, last_alpha = 0.f;
 
@@ -162,14 +202,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
                 }
             }
             if (__ballot(hit) == 0ull) continue;  // nothing in this wave touches the instance
-            const float t0 = wave_sum(g_mx), t1 = wave_sum(g_my), t2 = wave_sum(g_cxx), t3 = wave_sum(g_cxy),
-                        t4 = wave_sum(g_cyy), t5 = wave_sum(g_op), t6 = wave_sum(g_r), t7 = wave_sum(g_g),
-                        t8 = wave_sum(g_b), t9 = wave_sum(g_d);
-            if (lane < kGrad) {
-                const float v = lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : lane == 3 ? t3 : lane == 4 ? t4
-                              : lane == 5 ? t5 : lane == 6 ? t6 : lane == 7 ? t7 : lane == 8 ? t8 : t9;
-                atomicAdd(&s_grad[lane * GSR_BLOCK + j], v);  // LDS: at most 4 waves meet on one address
-            }
+            const float gv[kGrad] = {g_mx, g_my, g_cxx, g_cxy, g_cyy, g_op, g_r, g_g, g_b, g_d};
+            const float total = wave_reduce10(gv);
+            if (my_comp >= 0) atomicAdd(&s_grad[my_comp * GSR_BLOCK + j], total);  // LDS: at most 4 waves per address
         }
         __syncthreads();
         // flush: thread j owns staged instance j
@@ -470,12 +505,20 @@ __global__ void wave_sum_selftest_kernel(const float *in, float *out) {
     const float v = in[threadIdx.x];
     const float s = wave_sum(v);
     if (gsr_lane() == 17) out[gsr_wave()] = s;
+    // out[4 + w*10 + c] = sum over the wave's lanes of (c + 1) * in[..] * (lane % (c + 2) == 0): ten different
+    // per-lane values through wave_reduce10
+    float g[kGrad];
+#pragma unroll
+    for (int c = 0; c < kGrad; c++) g[c] = (gsr_lane() % (c + 2) == 0) ? (float)(c + 1) * v : 0.f;
+    const float t = wave_reduce10(g);
+    const int comp = wave_reduce10_component();
+    if (comp >= 0) out[4 + gsr_wave() * kGrad + comp] = t;
 }
 
 }  // namespace
 
-extern "C" int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream) {
-    hipLaunchKernelGGL(wave_sum_selftest_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in256, out4);
+extern "C" int gsr_selftest_wave_sum(const float *in256, float *out44, void *stream) {
+    hipLaunchKernelGGL(wave_sum_selftest_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in256, out44);
     return gsr_check_launch("wave_sum_selftest", true, (hipStream_t)stream);
 }
 

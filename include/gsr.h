@@ -241,8 +241,10 @@ int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const
  */
 int gsr_pack_part_transforms(int32_t K, const float *matrices, const float *scales, float *table, void *stream);
 
-/* Self-test of the DPP wave reduction used by the backward: out4[w] = sum(in256[64w .. 64w+63]). */
-int gsr_selftest_wave_sum(const float *in256, float *out4, void *stream);
+/* Self-test of the wave reductions used by the backward: out44[w] = sum(in256[64w .. 64w+63]) for the 4 waves, then
+ * out44[4 + 10w + c] = sum over the wave's lanes l with l % (c + 2) == 0 of (c + 1) * in256[64w + l]  (ten different
+ * per-lane values through the 10-component transpose-reduce). */
+int gsr_selftest_wave_sum(const float *in256, float *out44, void *stream);
 
 /* GSWorld's frame conversion (gs_world_wrapper.py:268-270): (3,H,W) float -> (H,W,3) uint8 with
  * (x*255).clamp(0,255) and a truncating cast.  `out` must be 4-byte aligned. */

@@ -19,10 +19,18 @@ def test_wave_sum_dpp_selftest(cuda_device):
     x = torch.randn(256, device=cuda_device)
     out = _backward.selftest_wave_sum(x).cpu()
     want = x.cpu().double().view(4, 64).sum(1)
-    assert torch.allclose(out.double(), want, atol=1e-4), (out, want)
+    assert torch.allclose(out[:4].double(), want, atol=1e-4), (out, want)
+    # the 10-component transpose-reduce (permlane32/16 swaps + row DPP): component c sums (c+1)*x over lanes l % (c+2) == 0
+    lanes = torch.arange(64)
+    xw = x.cpu().double().view(4, 64)
+    want10 = torch.stack([((c + 1) * xw * (lanes % (c + 2) == 0)).sum(1) for c in range(10)], 1)  # (4, 10)
+    assert torch.allclose(out[4:].double().view(4, 10), want10, atol=1e-4), (out[4:].view(4, 10), want10)
     ones = torch.arange(256, device=cuda_device, dtype=torch.float32)
     out = _backward.selftest_wave_sum(ones).cpu()
-    assert out.tolist() == [2016.0, 6112.0, 10208.0, 14304.0]
+    assert out[:4].tolist() == [2016.0, 6112.0, 10208.0, 14304.0]
+    iw = ones.cpu().double().view(4, 64)
+    want10 = torch.stack([((c + 1) * iw * (lanes % (c + 2) == 0)).sum(1) for c in range(10)], 1)
+    assert torch.equal(out[4:].double().view(4, 10), want10)  # integers: exact in any summation order
 
 
 @pytest.mark.parametrize("n,w,h,aa,deg", [(2000, 64, 48, False, 3), (5000, 96, 64, True, 3), (3000, 70, 50, False, 1),
