@@ -71,19 +71,34 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             rotations = pc.get_rotation
 
     if fast:
-        from gsworld_amd import _C
         from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
 
-        empty = torch.empty(0, device=means3D.device)
+        # ... and the frame goes through a renderer that is kept per device: its state buffers and the instance
+        # capacity of the previous frame are reused, so nothing is allocated and the host is not consulted in the
+        # middle of the frame (upstream's contract -- fresh byte tensors sized from a D2H read of num_rendered --
+        # is only needed when a backward will follow).  The capacity flag is checked once the frame is enqueued;
+        # an overflow (the scene grew by more than the head-room) re-renders exactly.
         rs = raster_settings
-        with torch.no_grad():
-            _, rendered_image, radii, _, _, _, depth_image = _C.rasterize_gaussians(
-                rs.bg, means3D, empty, opacity, scales if scales is not None else empty,
-                rotations if rotations is not None else empty, rs.scale_modifier,
-                cov3D_precomp if cov3D_precomp is not None else empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
-                rs.tanfovy, rs.image_height, rs.image_width, pc._features_dc, rs.sh_degree, rs.campos, rs.prefiltered,
-                rs.antialiasing, rs.debug, sh_rest=pc._features_rest,
+        renderer = _frame_renderer(means3D.device)
+        view = _View(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.viewmatrix, rs.projmatrix, rs.campos)
+
+        def enqueue():
+            return renderer.render(
+                view, means3D, opacity, shs=pc._features_dc, shs_rest=pc._features_rest, scales=scales,
+                rotations=rotations, cov3D_precomp=cov3D_precomp, bg=rs.bg, sh_degree=rs.sh_degree,
+                scale_modifier=rs.scale_modifier, antialiasing=rs.antialiasing, debug=rs.debug,
                 param_space=(RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS) if fused else 0)
+
+        with torch.no_grad():
+            if means3D.shape[0] == 0:  # upstream: no launch, zero image
+                rendered_image = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
+                radii = torch.zeros((0,), dtype=torch.int32, device=means3D.device)
+                depth_image = torch.zeros((1, rs.image_height, rs.image_width), device=means3D.device)
+            else:
+                color, radii, depth_image = enqueue()
+                renderer.ensure_valid(enqueue)
+                # the renderer owns its outputs and overwrites them on the next call; callers keep frames
+                rendered_image, radii, depth_image = color.clone(), radii.clone(), depth_image.clone()
         return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
 
     shs = colors_precomp = None
@@ -105,6 +120,29 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
         rotations=rotations, cov3D_precomp=cov3D_precomp)
     return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
+
+
+class _View:
+    """What FrameRenderer reads from a camera (gsworld_amd.camera.ViewParams duck type)."""
+    __slots__ = ("image_height", "image_width", "tanfovx", "tanfovy", "world_view_transform", "full_proj_transform",
+                 "camera_center")
+
+    def __init__(self, h, w, tanfovx, tanfovy, view, proj, campos):
+        self.image_height, self.image_width, self.tanfovx, self.tanfovy = h, w, tanfovx, tanfovy
+        self.world_view_transform, self.full_proj_transform, self.camera_center = view, proj, campos
+
+
+_RENDERERS = {}
+
+
+def _frame_renderer(device):
+    from gsworld_amd.renderer import FrameRenderer
+
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    r = _RENDERERS.get(key)
+    if r is None:
+        r = _RENDERERS[key] = FrameRenderer(torch.device(key[0], key[1]))
+    return r
 
 
 def _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp):

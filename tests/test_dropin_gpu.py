@@ -69,6 +69,23 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     assert out_ag["render"].requires_grad
     assert torch.equal(out_ag["render"].detach(), out["render"]) and torch.equal(out_ag["radii"], out["radii"])
     assert torch.equal(out_ag["depth"].detach(), out["depth"])
+    # the fast path renders through a cached renderer: returned frames must not alias its buffers, and a scene that
+    # outgrows the instance capacity remembered from the previous frame must be re-rendered, not truncated
+    keep = {k: out[k].clone() for k in ("render", "radii", "depth")}
+    small = GaussianModel(3)
+    sel = slice(0, 2_000)
+    small._xyz, small._features_dc, small._features_rest = pc._xyz[sel], pc._features_dc[sel].contiguous(), \
+        pc._features_rest[sel].contiguous()
+    small._opacity, small._scaling, small._rotation = pc._opacity[sel], pc._scaling[sel], pc._rotation[sel]
+    small.active_sh_degree = 3
+    import gaussian_renderer as gr_mod
+
+    out_small = render(cam, small, pipe, bg)
+    assert out_small["radii"].shape == (2_000,)
+    assert all(torch.equal(out[k], keep[k]) for k in keep)
+    gr_mod._frame_renderer(pc._xyz.device).r_capacity = 1 << 16  # as if the previous scene had been tiny
+    out_again = render(cam, pc, pipe, bg)
+    assert all(torch.equal(out_again[k], keep[k]) for k in keep)
     # opt-in pipe.fused_activations: raw parameters, activations inside preprocess (canonical exp, not torch's):
     # the image moves in the last bits only and (almost) every radius is unchanged
     pipe_f = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False,
