@@ -58,6 +58,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GSWORLD_DIST_BACKEND", "") == "gloo":
+        local_rank = 0  # test hook: all ranks on the one GPU of a test box (see gsworld_amd/distributed.py)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rank, world, _ = gd.init_from_env(dev)  # RCCL ("nccl" backend on ROCm) when WORLD_SIZE > 1
@@ -82,7 +84,8 @@ def main():
         check(lib().gsr_debug_set_render_variant(4, bpc))
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
-    fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world)
+    fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1)
+    n_slots = fg.num_slots
     rs_ = [FrameRenderer(dev) for _ in range(S)]
     lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     r = rs_[0]
@@ -104,7 +107,7 @@ def main():
     if not args.no_graph:
         try:
             graphs = []
-            for slot in range(K_g):
+            for slot in range(n_slots):
                 st = lanes[slot % S] if S > 1 else torch.cuda.Stream(dev)
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
@@ -121,21 +124,24 @@ def main():
             torch.cuda.synchronize()
 
     def step(i):
-        slot = i % K_g
+        slot = i % n_slots
         if S > 1:
-            with torch.cuda.stream(lanes[slot % S]):
+            lane = lanes[slot % S]
+            if world > 1 and (i % K_g) < S:
+                fg.wait_reusable(i, lane)  # first frame of a batch on this lane: its half was gathered a batch ago
+            with torch.cuda.stream(lane):
                 if graph is not None:
                     graph[slot].replay()
                 else:
                     frame(slot)
-            if world > 1 and slot == K_g - 1:
+            if world > 1 and (i % K_g) == K_g - 1:
                 cur = torch.cuda.current_stream()
                 for st in lanes:
                     cur.wait_stream(st)  # every lane has written its slots of this batch
-                fg.step_done(i)          # RCCL all_gather on a side stream; `cur` then waits for it
-                for st in lanes:
-                    st.wait_stream(cur)  # the next batch may overwrite the slots only after the gather read them
+                fg.step_done(i)          # RCCL all_gather on a side stream; the lanes go on with the other half
         else:
+            if world > 1 and (i % K_g) == 0:
+                fg.wait_reusable(i)
             if graph is not None:
                 graph[slot].replay()
             else:
@@ -168,7 +174,7 @@ def main():
     # per-kernel time of the dominant kernel: eager re-run of K frames with events (same stream, same inputs)
     check(lib().gsr_profile_enable(2))
     for i in range(min(args.steps, 200)):
-        frame(i % K_g)
+        frame(i % n_slots)
     torch.cuda.synchronize()
     prof2 = GsrProfile()
     check(lib().gsr_profile_collect(prof2))
@@ -183,9 +189,9 @@ def main():
     for i, (e0, e1) in enumerate(ev):
         e0.record()
         if graph is not None and S == 1:
-            graph[i % K_g].replay()
+            graph[i % n_slots].replay()
         else:
-            frame(i % K_g)
+            frame(i % n_slots)
         e1.record()
     torch.cuda.synchronize()
     lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)

@@ -17,14 +17,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, buffers):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     r, w, _ = gd.init_from_env(torch.device("cpu"))
     assert (r, w) == (rank, world)
     name, seed = gd.scene_for_rank(rank, scenes.SCENE_NAMES)
     H, W, K = 6, 8, 4
-    fg = gd.FrameGather(H, W, batch=K, device="cpu")
+    fg = gd.FrameGather(H, W, batch=K, device="cpu", buffers=buffers)
+    assert fg.num_slots == buffers * K
     got = []
     for i in range(2 * K + 1):  # the last frame starts a batch that is never gathered
         fg.slot(i).fill_((10 * rank + i) % 256)
@@ -35,11 +36,16 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_frame_gather_and_scene_sharding():
+import pytest
+
+
+@pytest.mark.parametrize("buffers", [1, 2])
+def test_two_rank_frame_gather_and_scene_sharding(buffers):
+    # buffers = 2: the double-buffered slots bench.py uses for N > 1 (gather of batch b overlaps rendering of b + 1)
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, buffers)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=120) for _ in range(world))
