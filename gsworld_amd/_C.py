@@ -123,14 +123,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_invdepth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 antialiasing, debug):
-    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+                                 antialiasing, debug, sh_rest=None, param_space=0):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    [+ dL_dsh_rest with ``sh_rest``; opacity / scale / rotation gradients w.r.t. the raw parameters with ``param_space``]."""
     from . import _backward
 
     return _backward.rasterize_gaussians_backward(
         background, means3D, radii, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
         projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth, sh, degree, campos, geomBuffer, R,
-        binningBuffer, imageBuffer, antialiasing, debug, NEAR_PLANE)
+        binningBuffer, imageBuffer, antialiasing, debug, NEAR_PLANE, sh_rest=sh_rest, param_space=param_space)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

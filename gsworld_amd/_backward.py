@@ -16,7 +16,8 @@ class GsrBackwardInputs(C.Structure):
 
 class GsrGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
-                                          "dL_dsh", "dL_dscales", "dL_drots", "dL_dconic", "dL_dinvdepths")]
+                                          "dL_dsh", "dL_dscales", "dL_drots", "dL_dconic", "dL_dinvdepths",
+                                          "dL_dsh_rest")]
 
 
 def _bind():
@@ -46,15 +47,24 @@ def _f32(t, dev):
 def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_invdepth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 antialiasing, debug, near_plane):
+                                 antialiasing, debug, near_plane, sh_rest=None, param_space=0):
+    """``sh_rest`` / ``param_space`` as in :func:`gsworld_amd._C.rasterize_gaussians`: with ``sh_rest`` the SH gradient
+    comes back in two parts (dL_dsh is then (P,1,3), and a ninth result dL_dsh_rest (P,M-1,3) is appended); with
+    ``param_space`` bits the opacity / scale / rotation gradients are w.r.t. the RAW parameters."""
     L = _bind()
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
+    split = sh_rest is not None
+    if split:
+        if M != 1:
+            raise RuntimeError("sh_rest needs sh = features_dc of shape (P,1,3)")
+        M = 1 + sh_rest.size(1)
     # One uninitialised arena sliced into the ten gradient buffers: gsr_backward zeroes adjacent buffers with a
     # single memset on the stream.  (P,4)-shaped pieces first so that every slice stays 16-byte aligned.
-    shapes = [("dL_drotations", (P, 4)), ("dL_dconic", (P, 2, 2)), ("dL_dsh", (P, M, 3)), ("dL_dcov3D", (P, 6)),
+    shapes = [("dL_drotations", (P, 4)), ("dL_dconic", (P, 2, 2)), ("dL_dsh", (P, 1 if split else M, 3)),
+              ("dL_dsh_rest", (P, M - 1 if split else 0, 3)), ("dL_dcov3D", (P, 6)),
               ("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, 3)), ("dL_dscales", (P, 3)),
               ("dL_dopacity", (P, 1)), ("dL_dinvdepths", (P, 1))]
     sizes = [max(1, int(torch.tensor(s).prod())) if 0 not in s else 0 for _, s in shapes]
@@ -68,11 +78,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dscales = (views[k] for k in ("dL_dmeans3D", "dL_dmeans2D",
                                                                            "dL_dcolors", "dL_dscales"))
     dL_dopacity, dL_dinvdepths = views["dL_dopacity"], views["dL_dinvdepths"]
+    dL_dsh_rest = views["dL_dsh_rest"]
     if P != 0:
         tensors = [_f32(t, dev) for t in (background, means3D, colors, opacities, scales, rotations, cov3D_precomp,
                                           viewmatrix, projmatrix, sh, campos, dL_dout_color)]
         (background, means3D, colors, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, campos,
          dL_dout_color) = tensors
+        if split:
+            sh_rest = _f32(sh_rest, dev)
         dLd = None
         if dL_dout_invdepth is not None and dL_dout_invdepth.numel() != 0:
             dLd = _f32(dL_dout_invdepth, dev)
@@ -81,15 +94,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
         inp = GsrInputs(P=P, background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
                         colors_precomp=_ptr(colors), opacities=_ptr(opacities), scales=_ptr(scales),
                         rotations=_ptr(rotations), cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix),
-                        projmatrix=_ptr(projmatrix), campos=_ptr(campos))
+                        projmatrix=_ptr(projmatrix), campos=_ptr(campos), shs_rest=_ptr(sh_rest) if split else None,
+                        param_space=int(param_space))
         bw = GsrBackwardInputs(_ptr(dL_dout_color), _ptr(dLd), _ptr(radii), int(R), _ptr(geomBuffer),
                                _ptr(binningBuffer), _ptr(imageBuffer))
         gr = GsrGrads(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                      _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dconic), _ptr(dL_dinvdepths))
+                      _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dconic), _ptr(dL_dinvdepths),
+                      _ptr(dL_dsh_rest) if split else None)
         with torch.cuda.device(dev):
             check(L.gsr_backward(C.byref(st), C.byref(inp), C.byref(bw), C.byref(gr),
                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dsh_rest,) if split else out
 
 
 def selftest_wave_sum(x256: torch.Tensor) -> torch.Tensor:

@@ -242,12 +242,15 @@ struct BwdArgs {
     int P, D, M, W, H;
     float tanfovx, tanfovy, fx, fy, scale_modifier;
     int antialiasing, cov_precomp, colors_precomp, have_invdepth;
+    int param_space;           // GSR_RAW_*: the inputs are raw parameters, the gradients are returned w.r.t. them
     const float *means3D, *shs, *opacities, *scales, *rotations, *view, *proj, *campos;
+    const float *shs_rest;     // split SH storage: shs = (P,1,3) dc, shs_rest = (P,M-1,3)
     const int32_t *radii;
     const float *cov3D;        // precomputed input or the forward's stored copy
     const uint32_t *clamped;
     const float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dinvdepths;
     float *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+    float *dL_dsh_rest;        // with shs_rest: dL_dsh is the dc part
 };
 
 // per-Gaussian chain rule; one thread per Gaussian
@@ -289,6 +292,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     float cc = fma_(B[1][2], A[1][2], fma_(B[1][1], A[1][1], B[1][0] * A[1][0]));
     const float h_var = 0.3f;
     float dL_da_aa = 0.f, dL_db_aa = 0.f, dL_dc_aa = 0.f;
+    // raw parameter space (GsrInputs.param_space): the same canonical activations as the forward, then their chain rule
+    const bool raw_opacity = (a.param_space & GSR_RAW_OPACITY) != 0;
+    float opacity_act = 0.f;
+    if (a.antialiasing || raw_opacity) opacity_act = raw_opacity ? sigmoid_canonical(a.opacities[i]) : a.opacities[i];
+    if (raw_opacity && !a.antialiasing) a.dL_dopacity[i] *= opacity_act * (1.0f - opacity_act);
     if (a.antialiasing) {
         const float det_cov = fma_(-cb, cb, ca * cc);
         ca += h_var;
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
         const float ratio = det_cov / det_plus;
         const float h_scale = sqrtf(fmaxf(0.000025f, ratio));
         const float dL_dop = a.dL_dopacity[i];
-        const float d_h = dL_dop * a.opacities[i];
-        a.dL_dopacity[i] = dL_dop * h_scale;
+        const float d_h = dL_dop * opacity_act;
+        a.dL_dopacity[i] = raw_opacity ? (dL_dop * h_scale) * (opacity_act * (1.0f - opacity_act)) : dL_dop * h_scale;
         const float d_root = ratio <= 0.000025f ? 0.f : d_h / (2.f * h_scale);
         const float inv2 = 1.f / (det_plus * det_plus);
         dL_da_aa = d_root * ((cc - h_var) * det_plus - det_cov * cc) * inv2;
@@ -413,7 +421,53 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
         const float *sh = a.shs + (size_t)i * a.M * 3;
         float *dsh = a.dL_dsh + (size_t)i * a.M * 3;
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-        if (D == 3 && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.dL_dsh)) & 15u) == 0) {
+        if (a.shs_rest) {
+            // split storage (features_dc | features_rest): coefficient 0 in one pair of arrays, 1.. in the other
+            const float *dc = a.shs + 3 * (size_t)i;
+            float *ddc = a.dL_dsh + 3 * (size_t)i;
+            const float *rest = a.shs_rest + (size_t)i * (a.M - 1) * 3;
+            float *drest = a.dL_dsh_rest + (size_t)i * (a.M - 1) * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                ddc[ch] = bas[0] * dRGB[ch];
+                const float sv = dc[ch] * dRGB[ch];
+                ddx += bx[0] * sv;
+                ddy += by[0] * sv;
+                ddz += bz[0] * sv;
+            }
+            if (D == 3 && a.M == 16) {
+                // 45 floats in, 45 out, every load ahead of every store: 15 + 15 dwordx3 accesses
+                const float3 *rest3 = reinterpret_cast<const float3 *>(rest);
+                float3 *drest3 = reinterpret_cast<float3 *>(drest);
+                float3 f[15], o[15];
+#pragma unroll
+                for (int k = 0; k < 15; k++) f[k] = rest3[k];
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    o[k - 1] = make_float3(bas[k] * dRGB[0], bas[k] * dRGB[1], bas[k] * dRGB[2]);
+                    const float s0 = f[k - 1].x * dRGB[0], s1 = f[k - 1].y * dRGB[1], s2 = f[k - 1].z * dRGB[2];
+                    ddx += bx[k] * s0; ddy += by[k] * s0; ddz += bz[k] * s0;
+                    ddx += bx[k] * s1; ddy += by[k] * s1; ddz += bz[k] * s1;
+                    ddx += bx[k] * s2; ddy += by[k] * s2; ddz += bz[k] * s2;
+                }
+#pragma unroll
+                for (int k = 0; k < 15; k++) drest3[k] = o[k];
+            } else {
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    if (k < nb) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            drest[3 * (k - 1) + ch] = bas[k] * dRGB[ch];
+                            const float sv = rest[3 * (k - 1) + ch] * dRGB[ch];
+                            ddx += bx[k] * sv;
+                            ddy += by[k] * sv;
+                            ddz += bz[k] * sv;
+                        }
+                    }
+                }
+            }
+        } else if (D == 3 && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.dL_dsh)) & 15u) == 0) {
             // 48 contiguous floats in, 48 out: 12 + 12 dwordx4 accesses instead of 96 dword ones
             float4 v[12], o[12];
             const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
@@ -461,15 +515,25 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     // 3D covariance -> scale, quaternion
     if (!a.cov_precomp) {
-        const float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+        float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+        float q_norm = 1.0f;
+        if (a.param_space & GSR_RAW_ROTATIONS) {  // F.normalize, as in the forward
+            const float n2 = fma_(rq.w, rq.w, fma_(rq.z, rq.z, fma_(rq.y, rq.y, rq.x * rq.x)));
+            q_norm = fmaxf(sqrtf(n2), 1e-12f);
+            rq = make_float4(rq.x / q_norm, rq.y / q_norm, rq.z / q_norm, rq.w / q_norm);
+        }
         const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
         float R[3][3];
         R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
         R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
         R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
-        float s[3];
+        float s[3], sc[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) s[k] = a.scale_modifier * a.scales[3 * (size_t)i + k];
+        for (int k = 0; k < 3; k++) {
+            sc[k] = a.scales[3 * (size_t)i + k];
+            if (a.param_space & GSR_RAW_SCALES) sc[k] = exp_canonical(sc[k]);
+            s[k] = a.scale_modifier * sc[k];
+        }
         float Mm[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++)
@@ -486,7 +550,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
                 dM[k][j] = 2.f * (Mm[k][0] * Gs[0][j] + Mm[k][1] * Gs[1][j] + Mm[k][2] * Gs[2][j]);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            a.dL_dscales[3 * (size_t)i + k] = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
+            const float dsk = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
+            a.dL_dscales[3 * (size_t)i + k] = (a.param_space & GSR_RAW_SCALES) ? dsk * sc[k] : dsk;  // d exp(x) = exp(x)
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][k] = s[k] * dM[k][j];
         }
@@ -498,6 +563,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
                       z * dR[2][1] - 2.f * y * dR[2][2]);
         dq.w = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] +
                       y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        if (a.param_space & GSR_RAW_ROTATIONS) {  // q_hat = q / n: dL/dq = (dL/dq_hat - q_hat (q_hat . dL/dq_hat)) / n
+            const float dot = fma_(rq.w, dq.w, fma_(rq.z, dq.z, fma_(rq.y, dq.y, rq.x * dq.x)));
+            dq = make_float4((dq.x - rq.x * dot) / q_norm, (dq.y - rq.y * dot) / q_norm, (dq.z - rq.z * dot) / q_norm,
+                             (dq.w - rq.w * dot) / q_norm);
+        }
         *reinterpret_cast<float4 *>(a.dL_drots + 4 * (size_t)i) = dq;
     }
 }
@@ -530,8 +600,16 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: null argument struct");
         return GSR_E_INVALID;
     }
-    if (in->shs_rest || in->param_space != 0) {
-        gsr_set_error("gsr_backward: split SH storage (shs_rest) and raw parameters (param_space) are forward-only");
+    if (in->shs_rest && (!in->shs || !gr->dL_dsh_rest || st->sh_coeffs < 2)) {
+        gsr_set_error("gsr_backward: shs_rest needs shs (the dc part), sh_coeffs >= 2 and GsrGrads.dL_dsh_rest");
+        return GSR_E_INVALID;
+    }
+    if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
+        gsr_set_error("gsr_backward: unknown param_space bits");
+        return GSR_E_INVALID;
+    }
+    if ((in->param_space & (GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) && in->cov3D_precomp) {
+        gsr_set_error("gsr_backward: raw scales / rotations cannot be combined with cov3D_precomp");
         return GSR_E_INVALID;
     }
     hipStream_t stream = (hipStream_t)stream_;
@@ -557,22 +635,25 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
     // gsworld_amd/_backward.py does) are cleared by ONE memset instead of ten launches
     {
         const size_t n = (size_t)(P > 0 ? P : 0);
-        struct Range { char *p; size_t bytes; } r[10] = {
+        const size_t m_dc = in->shs_rest ? 1u : (size_t)M, m_rest = in->shs_rest ? (size_t)M - 1u : 0u;
+        constexpr int NR = 11;
+        struct Range { char *p; size_t bytes; } r[NR] = {
             {(char *)gr->dL_dmeans2D, 3 * n * 4}, {(char *)gr->dL_dcolors, 3 * n * 4}, {(char *)gr->dL_dopacity, n * 4},
             {(char *)gr->dL_dmeans3D, 3 * n * 4}, {(char *)gr->dL_dcov3D, 6 * n * 4},
-            {(char *)gr->dL_dsh, 3 * n * (size_t)M * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
-            {(char *)gr->dL_drots, 4 * n * 4}, {(char *)gr->dL_dconic, 4 * n * 4}, {(char *)gr->dL_dinvdepths, n * 4}};
-        for (int i = 1; i < 10; i++)  // insertion sort by address
+            {(char *)gr->dL_dsh, 3 * n * m_dc * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
+            {(char *)gr->dL_drots, 4 * n * 4}, {(char *)gr->dL_dconic, 4 * n * 4}, {(char *)gr->dL_dinvdepths, n * 4},
+            {(char *)(in->shs_rest ? gr->dL_dsh_rest : nullptr), 3 * n * m_rest * 4}};
+        for (int i = 1; i < NR; i++)  // insertion sort by address
             for (int j = i; j > 0 && r[j].p < r[j - 1].p; j--) {
                 const Range t = r[j];
                 r[j] = r[j - 1];
                 r[j - 1] = t;
             }
-        for (int i = 0; i < 10;) {
+        for (int i = 0; i < NR;) {
             char *p = r[i].p;
             size_t bytes = r[i].bytes;
             int j = i + 1;
-            while (j < 10 && p && r[j].p == p + bytes) bytes += r[j++].bytes;
+            while (j < NR && p && r[j].p == p + bytes) bytes += r[j++].bytes;
             if (p && bytes && hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) {
                 gsr_set_error("gsr_backward: hipMemsetAsync failed");
                 return GSR_E_HIP;
@@ -601,6 +682,7 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
     a.scale_modifier = st->scale_modifier;
     a.antialiasing = st->antialiasing; a.cov_precomp = cov_precomp; a.colors_precomp = colors_precomp;
     a.have_invdepth = bw->dL_dout_invdepth != nullptr;
+    a.param_space = in->param_space; a.shs_rest = in->shs_rest; a.dL_dsh_rest = gr->dL_dsh_rest;
     a.means3D = in->means3D; a.shs = in->shs; a.opacities = in->opacities; a.scales = in->scales;
     a.rotations = in->rotations; a.view = in->viewmatrix; a.proj = in->projmatrix; a.campos = in->campos;
     a.radii = bw->radii;

@@ -161,6 +161,30 @@ struct ImageState {
     }
 };
 
+#if defined(__HIPCC__)
+// exp in the canonical float32 order of oracle/gs_oracle.c gso_expf (raw-parameter path):
+// 2^n * p(r) with n = rint(x log2e), r = x - n ln2 (Cody-Waite), p = the Cephes expf polynomial.  Bit-identical
+// on host and device because every operation is a correctly rounded IEEE one (fma, rint, ldexp).
+__device__ __forceinline__ float exp_canonical(float x) {
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.972084045410f) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    return __builtin_ldexpf(y, (int)n);
+}
+
+// sigmoid of the raw-parameter path (forward and backward use the same value)
+__device__ __forceinline__ float sigmoid_canonical(float x) { return 1.0f / (1.0f + exp_canonical(-x)); }
+#endif
+
 // ---- error plumbing ------------------------------------------------------------------------------------
 void gsr_set_error(const char *fmt, ...);
 int gsr_check_launch(const char *what, bool debug, hipStream_t stream);

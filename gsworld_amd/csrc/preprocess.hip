@@ -69,25 +69,6 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-// exp in the canonical float32 order of oracle/gs_oracle.c gso_expf (raw-parameter path):
-// 2^n * p(r) with n = rint(x log2e), r = x - n ln2 (Cody-Waite), p = the Cephes expf polynomial.  Bit-identical
-// on host and device because every operation is a correctly rounded IEEE one (fma, rint, ldexp).
-__device__ __forceinline__ float exp_canonical(float x) {
-    if (x > 88.72283905206835f) return __builtin_inff();
-    if (x < -103.972084045410f) return 0.0f;
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = fma_(n, -0.693359375f, x);
-    r = fma_(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fma_(p, r, 1.3981999507e-3f);
-    p = fma_(p, r, 8.3334519073e-3f);
-    p = fma_(p, r, 4.1665795894e-2f);
-    p = fma_(p, r, 1.6666665459e-1f);
-    p = fma_(p, r, 5.0000001201e-1f);
-    const float y = fma_(p, r * r, r) + 1.0f;
-    return __builtin_ldexpf(y, (int)n);
-}
-
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
@@ -214,7 +195,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
                     float opacity_in = a.opacities[i];
-                    if (a.param_space & GSR_RAW_OPACITY) opacity_in = 1.0f / (1.0f + exp_canonical(-opacity_in));
+                    if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
                     const float opacity = opacity_in * h_scale;
                     float4 *rec = a.splat + 3 * (size_t)i;
                     rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);

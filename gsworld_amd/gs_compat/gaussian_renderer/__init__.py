@@ -54,10 +54,23 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # opt-in on top of it (pipe.fused_activations): hand over the RAW parameters and let preprocess apply sigmoid /
     # exp / normalize in its canonical float32 order -- three fewer passes over the model per frame, but exp is then
     # this library's, not torch's (last-ulp differences in the image), so it is not the default
-    fused = (fast and getattr(pipe, "fused_activations", False) and not getattr(pipe, "compute_cov3D_python", False)
-             and getattr(pc, "opacity_activation", None) is torch.sigmoid
-             and getattr(pc, "scaling_activation", None) is torch.exp
-             and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
+    fused_ok = (getattr(pipe, "fused_activations", False) and not getattr(pipe, "compute_cov3D_python", False)
+                and getattr(pc, "opacity_activation", None) is torch.sigmoid
+                and getattr(pc, "scaling_activation", None) is torch.exp
+                and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
+    fused = fast and fused_ok
+    # the same opt-in while TRAINING: raw parameters and the two SH tensors go through the autograd Function as they
+    # are stored; activations and their chain rule run inside the preprocess kernels (no sigmoid / exp / normalize /
+    # cat passes and none of their backward passes per step)
+    if (fused_ok and not no_grad and override_color is None and not getattr(pipe, "convert_SHs_python", False)
+            and raw[5] is not None and raw[5].shape[1] > 0):
+        from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+
+        rendered_image, radii, depth_image = rasterizer(
+            means3D=means3D, means2D=means2D, opacities=pc._opacity, shs=pc._features_dc.contiguous(),
+            shs_rest=pc._features_rest.contiguous(), scales=pc._scaling, rotations=pc._rotation,
+            param_space=RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS)
+        return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
 
     scales = rotations = cov3D_precomp = None
     if fused:

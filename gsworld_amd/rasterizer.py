@@ -97,6 +97,41 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_rotations, grad_cov3Ds_precomp, None)
 
 
+class _RasterizeGaussiansFused(torch.autograd.Function):
+    """Extension of the upstream Function: the model's parameters go in AS STORED -- features_dc and
+    features_rest separately (no per-step ``cat``), and, per ``param_space`` bit, opacity logits / log scales /
+    un-normalised quaternions, whose sigmoid / exp / normalize run inside preprocess and whose chain rule runs
+    inside the backward kernel.  Gradients come back in the same parameter space."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, raster_settings, param_space):
+        rs = raster_settings
+        empty = torch.empty(0, device=means3D.device)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians(
+            rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos, rs.prefiltered,
+            rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
+        ctx.raster_settings, ctx.num_rendered, ctx.param_space = rs, num_rendered, param_space
+        ctx.save_for_backward(means3D, scales, rotations, radii, sh_dc, sh_rest, opacities, geomBuffer, binningBuffer,
+                              imgBuffer)
+        return color, radii, invdepths
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, grad_out_depth):
+        rs = ctx.raster_settings
+        (means3D, scales, rotations, radii, sh_dc, sh_rest, opacities, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        empty = torch.empty(0, device=means3D.device)
+        (grad_means2D, _gc, grad_opacities, grad_means3D, _gcov, grad_dc, grad_scales, grad_rotations,
+         grad_rest) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, sh_dc, rs.sh_degree, rs.campos,
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.debug, sh_rest=sh_rest,
+            param_space=ctx.param_space)
+        return (grad_means3D, grad_means2D, grad_dc, grad_rest, grad_opacities.view_as(opacities), grad_scales,
+                grad_rotations, None, None)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -108,8 +143,16 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, shs_rest=None, param_space=0):
+        """Upstream's signature; ``shs_rest`` / ``param_space`` are this library's extension (see
+        :class:`_RasterizeGaussiansFused`): ``shs`` is then features_dc (P,1,3)."""
         rs = self.raster_settings
+        if shs_rest is not None or param_space:
+            if shs is None or shs_rest is None or colors_precomp is not None or cov3D_precomp is not None or \
+                    scales is None or rotations is None:
+                raise Exception("shs_rest / param_space need shs (dc) + shs_rest, scales and rotations")
+            return _RasterizeGaussiansFused.apply(means3D, means2D, shs, shs_rest, opacities, scales, rotations, rs,
+                                                  int(param_space))
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \

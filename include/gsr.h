@@ -197,6 +197,7 @@ typedef struct GsrGrads {
     float *dL_drots;      /* (P,4) or NULL with cov3D_precomp */
     float *dL_dconic;     /* (P,4) scratch: xx, xy (half, upstream convention), -, yy */
     float *dL_dinvdepths; /* (P)   scratch */
+    float *dL_dsh_rest;   /* (P,M-1,3) with GsrInputs.shs_rest (dL_dsh is then the (P,1,3) dc part), else NULL */
 } GsrGrads;
 
 int gsr_backward(const GsrSettings *settings, const GsrInputs *in, const GsrBackwardInputs *bw,

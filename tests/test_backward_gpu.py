@@ -96,3 +96,52 @@ def test_autograd_through_gaussian_rasterizer(cuda_device):
                dL_dscales=sc.grad, dL_drotations=rot.grad)
     hb.compare_grads(ref, {k: v.cpu().numpy() for k, v in got.items()}, names=tuple(got))
     assert radii.dtype == torch.int32 and int((radii > 0).sum()) == int((fwd["geom"]["radii"] > 0).sum())
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_fused_parameter_space_gradients_match_the_torch_packing(cuda_device, aa):
+    """SURVEY.md 8f-2 for training: raw opacity / scale / rotation parameters and the two SH tensors through the
+    autograd Function (activations and their chain rule inside the kernels) against upstream's packing (torch sigmoid /
+    exp / normalize / cat feeding the same rasterizer, autograd doing their backward)."""
+    from gsworld_amd import scenes
+    from gsworld_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = cuda_device
+    S = 96
+    cam = scenes.training_camera(S, S, 60.0).to(dev)
+    raw = scenes.random_scene_camera_frame(6_000, seed=41).to(dev)
+    raw.scaling += 1.0
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    rs = GaussianRasterizationSettings(S, S, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 3, cam.camera_center, False, False, aa)
+    rast = GaussianRasterizer(rs)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    w_img = torch.randn((3, S, S), generator=gen).to(dev)
+    w_dep = torch.randn((1, S, S), generator=gen).to(dev)
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+
+    def run(fused):
+        ps = [getattr(raw, n).detach().clone().requires_grad_(True) for n in names]
+        xyz, dc, rest, op, sc, rot = ps
+        m2d = torch.zeros_like(xyz, requires_grad=True)
+        if fused:
+            color, radii, invd = rast(means3D=xyz, means2D=m2d, shs=dc, shs_rest=rest, opacities=op, scales=sc,
+                                      rotations=rot, param_space=7)
+        else:
+            color, radii, invd = rast(means3D=xyz, means2D=m2d, shs=torch.cat((dc, rest), dim=1),
+                                      opacities=torch.sigmoid(op), scales=torch.exp(sc),
+                                      rotations=torch.nn.functional.normalize(rot))
+        ((color * w_img).sum() + (invd * w_dep).sum()).backward()
+        return color.detach(), radii, [p.grad for p in ps] + [m2d.grad]
+
+    c0, r0, g0 = run(False)
+    c1, r1, g1 = run(True)
+    # forward: canonical exp vs torch's (last-ulp alpha changes can flip a threshold decision on a few pixels)
+    assert float(((c1 - c0).abs() > 1e-5).float().mean()) <= 2e-3
+    assert int((r0 != r1).sum()) <= 3
+    for n, a, b in zip(names + ("means2D",), g0, g1):
+        assert a is not None and b is not None and a.shape == b.shape, n
+        scale = float(a.abs().max()) + 1e-12
+        err = float((a - b).abs().max()) / scale
+        assert err <= 2e-3, (n, err)
+        assert float(b.abs().max()) > 0, n

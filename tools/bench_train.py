@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--num-gaussians", type=int, default=500_000)
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--binning-mode", type=int, default=-1, help="A/B: 0 radix, 1 counting placement, 2 bin-then-sort")
+    ap.add_argument("--fused", action="store_true",
+                    help="raw parameters + split SH through the autograd Function (activations and their chain rule "
+                         "inside the kernels) instead of upstream's torch packing")
     args = ap.parse_args()
     if args.binning_mode >= 0:
         from gsworld_amd._lib import check, lib
@@ -51,8 +54,12 @@ def main():
             for p in params:
                 p.requires_grad_(True)
                 p.grad = None
-        shs = torch.cat((r.features_dc, r.features_rest), dim=1)
         means2D = torch.zeros_like(r.xyz, requires_grad=grad)
+        if args.fused:
+            color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=r.features_dc, shs_rest=r.features_rest,
+                                      opacities=r.opacity, scales=r.scaling, rotations=r.rotation, param_space=7)
+            return color.clamp(0, 1), radii
+        shs = torch.cat((r.features_dc, r.features_rest), dim=1)
         color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=shs, opacities=torch.sigmoid(r.opacity),
                                   scales=torch.exp(r.scaling), rotations=torch.nn.functional.normalize(r.rotation))
         return color.clamp(0, 1), radii
@@ -85,6 +92,7 @@ def main():
         "config": {"workload": f"{args.num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
                                "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step "
                                "(BASELINE.json configs[4])",
+                   "parameter_packing": "fused (raw parameters, split SH)" if args.fused else "upstream (torch)",
                    "num_visible": int((radii > 0).sum().item()), "loss": float(loss.item()),
                    "grads_finite": bool(finite)}}))
 
