@@ -96,6 +96,18 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     diff = (out_f["render"] - out["render"]).abs()
     assert float(diff.max()) <= 0.02 and float((diff > 1e-5).float().mean()) <= 2e-3
     assert int((out_f["radii"] != out["radii"]).sum()) <= 20
+    # the same opt-in with trainable parameters: one autograd Function over the raw parameters and the two SH tensors
+    leaves = [pc._xyz, pc._opacity, pc._scaling, pc._rotation, pc._features_dc, pc._features_rest]
+    for t in leaves:
+        t.requires_grad_(True)
+    out_t = render(cam, pc, pipe_f, bg)
+    assert out_t["render"].requires_grad and torch.equal(out_t["render"].detach(), out_f["render"])
+    out_t["render"].sum().backward()
+    for t in leaves:
+        assert t.grad is not None and t.grad.shape == t.shape and bool(torch.isfinite(t.grad).all())
+        assert float(t.grad.abs().max()) > 0
+        t.requires_grad_(False)
+        t.grad = None
     img = out["render"].detach()
     assert img.shape == (3, 480, 640) and float(img.min()) >= 0 and float(img.max()) <= 1
     # same frame through the oracle
