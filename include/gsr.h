@@ -163,13 +163,13 @@ typedef struct GsrProfile {
     double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
 } GsrProfile;
 int gsr_profile_enable(int mode);
-/* A/B measurements: compositing kernel 0 = LDS-staged per tile, 1 = wave-independent (readlane broadcast),
- * 2 = batched + persistent workgroups on a longest-first tile queue (default).  blocks_per_cu (1..8, 0 = keep)
- * sizes variant 2's grid. */
+/* A/B measurements: compositing kernel 0 = LDS-staged per tile (upstream's structure), 2 = batched tile kernel,
+ * 3 = the same with per-quadrant instance culling, 4 = wave-decoupled culling kernel (default).  blocks_per_cu
+ * (1..8, 0 = keep) sizes the grid of variants 2-4.  All variants produce bit-identical image state. */
 int gsr_debug_set_render_variant(int variant, int blocks_per_cu);
-/* Tests / A-B: binning path.  2 = unordered binning + per-tile (depth, index) sort in LDS (default),
- * 1 = global depth sort + counting placement, 0 = global depth sort + emit + tile-id radix sort (always used for
- * tile grids above 3840 tiles).  All three produce the same point list. */
+/* Tests / A-B: binning path.  1 = global depth sort + counting placement (default), 2 = unordered binning + per-tile
+ * (depth, index) sort in LDS, 0 = global depth sort + emit + tile-id radix sort (always used for tile grids above
+ * 16384 tiles or wider than 2048 tiles).  All three produce the same point list. */
 int gsr_debug_set_binning_mode(int mode);
 int gsr_profile_collect(GsrProfile *out);
 
