@@ -239,7 +239,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 GsrHeader *hdr, uint32_t r_capacity,
                                                                 uint2 *__restrict__ ranges,
                                                                 uint32_t *__restrict__ tile_order,
-                                                                uint32_t *__restrict__ cursor_to_zero) {
+                                                                uint32_t *__restrict__ cursor_to_zero,
+                                                                const uint32_t *__restrict__ quad_work) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
     uint32_t sum = 0;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     }
     if (tile_order == nullptr) return;  // every tile resident at once in the compositor: no order needed
     __syncthreads();  // this workgroup's range stores are visible to all of its threads
-    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
+    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
 }
 
 template <int NW>
@@ -512,7 +513,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
                        img.ranges, gsr_render_wants_tile_order(T) ? img.tile_order : (uint32_t *)nullptr,
-                       (uint32_t *)nullptr);
+                       (uint32_t *)nullptr, (const uint32_t *)img.quad_work);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

@@ -143,12 +143,15 @@ struct ImageState {
     float *final_T;      // [W*H]
     uint32_t *n_contrib; // [W*H]
     uint32_t *tile_order; // [tiles] tile ids, longest instance list first (compositing queue order)
+    uint32_t *quad_work;  // [4*tiles] cost of each 8x8 quadrant in the compositor's LAST frame on this state (order key of
+                          // the next frame; garbage on a fresh state -- any key gives a valid permutation)
     static ImageState carve(char *base, int32_t W, int32_t H, size_t *bytes = nullptr) {
         ImageState s;
         char *p = base;
         const size_t tiles = (size_t)gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE);
         s.ranges = GeomState::take<uint2>(p, tiles);
         s.tile_order = GeomState::take<uint32_t>(p, tiles);
+        s.quad_work = GeomState::take<uint32_t>(p, 4 * tiles);
         s.final_T = GeomState::take<float>(p, (size_t)W * H);
         s.n_contrib = GeomState::take<uint32_t>(p, (size_t)W * H);
         if (bytes) *bytes = (size_t)(p - base);
@@ -285,10 +288,19 @@ __device__ __forceinline__ void gsr_for_each_tile(uint32_t t, uint2 rc, int gx, 
 // Longest-first tile order for the compositing queue: a 64-bucket counting sort of the tile list lengths, run by
 // ONE workgroup (callers: tile_starts_kernel on the counting path, tile_order_kernel on the radix fallback).
 // s_bins: 64 uint32 in LDS, s_red: 4 uint32 in LDS.  The ranges must be visible to the whole workgroup.
+// With `work` (4 words per tile: the cost of its quadrants in the previous frame) the key is that cost instead of the
+// list length.
+__device__ __forceinline__ uint32_t gsr_tile_order_key(const uint2 *ranges, const uint32_t *work, int t) {
+    if (work != nullptr) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(work + 4 * t);
+        return (w.x >> 2) + (w.y >> 2) + (w.z >> 2) + (w.w >> 2);  // (no wrap-around on a fresh state's garbage)
+    }
+    return ranges[t].y - ranges[t].x;
+}
 __device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int num_tiles, uint32_t *order,
-                                                     uint32_t *s_bins, uint32_t *s_red) {
+                                                     uint32_t *s_bins, uint32_t *s_red, const uint32_t *work = nullptr) {
     uint32_t mx = 0;
-    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) mx = max(mx, ranges[t].y - ranges[t].x);
+    for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) mx = max(mx, gsr_tile_order_key(ranges, work, t));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     if (gsr_lane() == 0) s_red[gsr_wave()] = mx;
@@ -297,7 +309,7 @@ __device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int nu
     mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
     for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK)  // bucket 0 = longest lists
-        atomicAdd(&s_bins[63 - (int)((float)(ranges[t].y - ranges[t].x) * scale)], 1u);
+        atomicAdd(&s_bins[63 - (int)((float)gsr_tile_order_key(ranges, work, t) * scale)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
@@ -309,7 +321,7 @@ __device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int nu
     }
     __syncthreads();
     for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
-        const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)(ranges[t].y - ranges[t].x) * scale)], 1u);
+        const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)gsr_tile_order_key(ranges, work, t) * scale)], 1u);
         order[pos] = (uint32_t)t;
     }
 }

@@ -401,7 +401,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                                                   float *__restrict__ out_invdepth,
                                                                   float *__restrict__ final_T,
                                                                   uint32_t *__restrict__ n_contrib,
-                                                                  uint8_t *__restrict__ rgb8 /* optional */) {
+                                                                  uint8_t *__restrict__ rgb8 /* optional */,
+                                                                  uint32_t *__restrict__ quad_work /* optional */,
+                                                                  int num_cus) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
@@ -425,7 +427,17 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
     const uint32_t wave_global = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
     for (uint32_t pass = 0, ticket = wave_global; ticket < num_tickets;
          pass++, ticket = pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
-        const int tile = tile_order ? (int)tile_order[ticket >> 2] : (int)(ticket >> 2);
+        uint32_t unit = ticket >> 2;
+        if (tile_order != nullptr && gridDim.x >= (uint32_t)num_tiles) {
+            // Every tile resident at once: workgroups b, b + #CUs, b + 2 #CUs ... share a CU (observed placement on
+            // MI355X: s_getreg HW_ID of every workgroup), so position p of the cost-sorted order goes to workgroup
+            // p in even groups of #CUs and to the mirrored workgroup in odd ones: every CU gets one tile of each cost
+            // class, and the CU that got the costliest of one class gets the cheapest of the next.
+            const uint32_t group = unit / (uint32_t)num_cus, idx = unit - group * (uint32_t)num_cus;
+            const uint32_t size = min((uint32_t)num_cus, (uint32_t)num_tiles - group * (uint32_t)num_cus);
+            unit = group * (uint32_t)num_cus + ((group & 1u) ? size - 1u - idx : idx);
+        }
+        const int tile = tile_order ? (int)tile_order[unit] : (int)unit;
         const int quad = (int)(ticket & 3u);
         const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3), qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3);
         const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -459,6 +471,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             if (p + kStreamRound < n_inst) g_next[s] = src[p + kStreamRound];
         }
         const int rounds = (n_inst + kStreamRound - 1) / kStreamRound;
+        uint32_t work = 0;  // what this unit cost, in survivor evaluations (+ 5 per candidate round): next frame's order key
         for (int rd = 0; rd < rounds; rd++) {
             if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
             // ---- cull + compact this round's candidates into the private list
@@ -475,6 +488,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                     __uint_as_float((uint32_t)p + 1u));
                 n_surv += (int)__builtin_popcountll(mask);
             }
+            work += (uint32_t)n_surv + 5u;
             if (lane < kBatch)  // alpha = 0 padding behind the last survivor
                 stream_list_put(list, n_surv + lane, zero4, zero4, zero4, 0.0f);
             // ---- next round's gathers go out before the replay so that they fly under it
@@ -506,6 +520,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             }
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
+        if (quad_work != nullptr && lane == 0) quad_work[4 * tile + quad] = work;
         if (inside) {
             const size_t pid = (size_t)py * W + px;
             const size_t plane = (size_t)H * W;
@@ -592,8 +607,10 @@ static int render_num_cus() {
 
 // The longest-first tile order only matters when workgroups take more than one tile: with every tile resident at
 // once (1200 tiles on 256 CUs x 6) the deal is the identity and the binning stage need not build the order.
+// The default compositor always takes an order: with every unit resident at once (tiles <= CUs x workgroups per CU) it
+// decides which tiles share a CU; beyond that it is the longest-first queue order.
 bool gsr_render_wants_tile_order(int num_tiles) {
-    return g_render_variant >= 2 && num_tiles > render_num_cus() * g_render_blocks_per_cu;
+    return g_render_variant == 4 || (g_render_variant >= 2 && num_tiles > render_num_cus() * g_render_blocks_per_cu);
 }
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
@@ -613,7 +630,7 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
         if (g_render_variant == 4)
             hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
                                g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
-                               img.n_contrib, out_rgb8);
+                               img.n_contrib, out_rgb8, img.quad_work, render_num_cus());
         else if (g_render_variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
                                point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,
