@@ -243,6 +243,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ quad_work) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
+    // order keys (last frame's cost of each tile) asked for first: they are needed last
+    const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 8 * GSR_BLOCK;
+    uint32_t key[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int t = (int)threadIdx.x + i * GSR_BLOCK;
+        key[i] = (keyed && t < T) ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+    }
     uint32_t sum = 0;
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) sum += totals[t];
     uint32_t grand;
@@ -269,7 +277,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     }
     if (tile_order == nullptr) return;  // every tile resident at once in the compositor: no order needed
     __syncthreads();  // this workgroup's range stores are visible to all of its threads
-    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
+    if (keyed)
+        gsr_tile_order_block_keys(key, T, tile_order, s_bins, s_w);
+    else
+        gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
 }
 
 template <int NW>

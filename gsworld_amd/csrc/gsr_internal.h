@@ -311,18 +311,56 @@ __device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int nu
     for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK)  // bucket 0 = longest lists
         atomicAdd(&s_bins[63 - (int)((float)gsr_tile_order_key(ranges, work, t) * scale)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int b = 0; b < 64; b++) {
-            const uint32_t c = s_bins[b];
-            s_bins[b] = acc;
-            acc += c;
+    if (threadIdx.x < 64) {  // exclusive scan of the 64 buckets by the first wave
+        const uint32_t c = s_bins[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += v;
         }
+        s_bins[threadIdx.x] = incl - c;
     }
     __syncthreads();
     for (int t = (int)threadIdx.x; t < num_tiles; t += GSR_BLOCK) {
         const uint32_t pos = atomicAdd(&s_bins[63 - (int)((float)gsr_tile_order_key(ranges, work, t) * scale)], 1u);
         order[pos] = (uint32_t)t;
+    }
+}
+// The same for up to 8 x GSR_BLOCK tiles with the keys already in registers (key[i] belongs to tile
+// threadIdx.x + i * GSR_BLOCK): the caller loads them at the top of its kernel, so no global read sits between the passes.
+__device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[8], int num_tiles, uint32_t *order,
+                                                          uint32_t *s_bins, uint32_t *s_red) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((int)threadIdx.x + i * GSR_BLOCK < num_tiles) mx = max(mx, key[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (gsr_lane() == 0) s_red[gsr_wave()] = mx;
+    if (threadIdx.x < 64) s_bins[threadIdx.x] = 0u;
+    __syncthreads();
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((int)threadIdx.x + i * GSR_BLOCK < num_tiles) atomicAdd(&s_bins[63 - (int)((float)key[i] * scale)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t c = s_bins[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += v;
+        }
+        s_bins[threadIdx.x] = incl - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int t = (int)threadIdx.x + i * GSR_BLOCK;
+        if (t < num_tiles) order[atomicAdd(&s_bins[63 - (int)((float)key[i] * scale)], 1u)] = (uint32_t)t;
     }
 }
 #endif  // __HIPCC__
