@@ -336,6 +336,17 @@ struct StreamBatch {
 };
 
 // same operations in the same order as the scalar kernels, two survivors per packed instruction
+// B^2 <= (1 - 1e-3) A C with A, C > 0 (and A C out of the subnormal range): the exact power is then at most
+// -2.5e-4 (A dx^2 + C dy^2), while the rounding errors of the five float operations that compute it stay below
+// 2e-7 of that sum, so the float result is <= 0 for every pixel offset (an exact 0 offset gives -0).
+__device__ __forceinline__ bool stream_conic_is_safe(const float4 conic_op) {
+    const float ac = conic_op.x * conic_op.z;
+    return conic_op.x > 0.0f && conic_op.z > 0.0f && ac > 1e-20f && conic_op.y * conic_op.y <= 0.999f * ac;
+}
+
+// CHECK_POWER = false: every survivor of the round has a comfortably positive definite conic (stream_conic_is_safe), for
+// which the computed power cannot come out positive -- the `power <= 0` half of the validity test is then dropped.
+template <bool CHECK_POWER>
 __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int i, v2f pf2x, v2f pf2y) {
     StreamBatch b;
 #pragma unroll
@@ -353,8 +364,8 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
         const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
         const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
         const float a0 = fminf(0.99f, a.x), a1 = fminf(0.99f, a.y);
-        b.valid[2 * h] = power.x <= 0.0f && a0 >= 1.0f / 255.0f;
-        b.valid[2 * h + 1] = power.y <= 0.0f && a1 >= 1.0f / 255.0f;
+        b.valid[2 * h] = (!CHECK_POWER || power.x <= 0.0f) && a0 >= 1.0f / 255.0f;
+        b.valid[2 * h + 1] = (!CHECK_POWER || power.y <= 0.0f) && a1 >= 1.0f / 255.0f;
         b.alpha[2 * h] = b.valid[2 * h] ? a0 : 0.0f;
         b.alpha[2 * h + 1] = b.valid[2 * h + 1] ? a1 : 0.0f;
         b.pos[2 * h] = qpos.x;
@@ -476,11 +487,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
             // ---- cull + compact this round's candidates into the private list
             int n_surv = 0;
+            uint64_t unsafe = 0ull;  // survivors whose conic is not comfortably positive definite
 #pragma unroll
             for (int s = 0; s < kStreamLanesItems; s++) {
                 const int p = rd * kStreamRound + s * GSR_WAVE + lane;
                 const bool keep = p < n_inst && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf);
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+                unsafe |= __builtin_amdgcn_ballot_w64(keep && !stream_conic_is_safe(f1[s]));
                 const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 if (keep)
@@ -513,10 +526,18 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             // of wave masks: +6 us, costs an occupancy step; batches of 2 / 8.)
             // (Evaluating batch i + 1 ahead of the blend of batch i -- one basic block, ping-pong registers -- was
             // measured: +17 % replay time; the loop is bound by instruction count, not by exposed latency.)
-            for (int i = 0; i < n_surv; i += kBatch) {
-                if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
-                const StreamBatch b = stream_eval(list, i, pf2x, pf2y);
-                stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+            if (unsafe == 0ull) {
+                for (int i = 0; i < n_surv; i += kBatch) {
+                    if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+                    const StreamBatch b = stream_eval<false>(list, i, pf2x, pf2y);
+                    stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                }
+            } else {
+                for (int i = 0; i < n_surv; i += kBatch) {
+                    if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+                    const StreamBatch b = stream_eval<true>(list, i, pf2x, pf2y);
+                    stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                }
             }
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
