@@ -243,13 +243,19 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ quad_work) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
-    // order keys (last frame's cost of each tile) asked for first: they are needed last
     const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 8 * GSR_BLOCK;
-    uint32_t key[8];
+    // two workgroups: #0 turns the totals into ranges, #1 computes the cost order, which depends on nothing of this
+    // frame (without keys the order is by list length and has to follow the ranges in #0)
+    if (blockIdx.x == 1) {
+        if (!keyed) return;
+        uint32_t key[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int t = (int)threadIdx.x + i * GSR_BLOCK;
-        key[i] = (keyed && t < T) ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+        for (int i = 0; i < 8; i++) {
+            const int t = (int)threadIdx.x + i * GSR_BLOCK;
+            key[i] = t < T ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+        }
+        gsr_tile_order_block_keys(key, T, tile_order, s_bins, s_w);
+        return;
     }
     uint32_t sum = 0;
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) sum += totals[t];
@@ -275,12 +281,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
         hdr->overflow = overflow ? 1u : 0u;
         hdr->R = overflow ? 0u : grand;
     }
-    if (tile_order == nullptr) return;  // every tile resident at once in the compositor: no order needed
+    if (tile_order == nullptr || keyed) return;
     __syncthreads();  // this workgroup's range stores are visible to all of its threads
-    if (keyed)
-        gsr_tile_order_block_keys(key, T, tile_order, s_bins, s_w);
-    else
-        gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
+    gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
 }
 
 template <int NW>
@@ -522,7 +525,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
                        img.ranges, gsr_render_wants_tile_order(T) ? img.tile_order : (uint32_t *)nullptr,
                        (uint32_t *)nullptr, (const uint32_t *)img.quad_work);
     return gsr_check_launch("tile_starts", debug, stream);
