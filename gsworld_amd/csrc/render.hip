@@ -311,15 +311,18 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
 // Counters of variant 3 on the config-2 frame (profiles/round1/pmc): the 4 waves of a tile spend half their life
 // parked (workgroup barriers around every 256-instance round, lgkmcnt waits inside 4 serial blend steps, a scalar
 // walk over the survivor masks that issues as many SALU as VALU instructions), and the kernel ends with the few
-// longest tiles running alone.  Here the unit of work is one 8x8 QUADRANT = one wave, pulled from a queue of
-// 4 x tiles tickets; a wave shares nothing with the other waves of its workgroup:
+// longest tiles running alone.  Here the unit of work is one 8x8 QUADRANT = one wave (4 x tiles units, dealt
+// statically: every unit has its own resident wave when they fit, a longest-first snake otherwise); a wave shares
+// nothing with the other waves of its workgroup:
 //  * per round it gathers 64 instances (one per lane: index, then the 3 x 16 B record), one round ahead;
 //  * each lane runs quadrant_may_hit on its candidate; survivors are compacted (ballot + mbcnt rank) into
-//    the wave's private LDS list, in list order, with their list position in the record's spare slot;
-//  * the replay reads the list back 4 consecutive survivors at a time -- 12 ds_read_b128 off one base register
-//    with immediate offsets, one lgkmcnt wait per batch -- and composites exactly as variants 2/3 do.
-// No workgroup barrier, no scalar bit-walk, a quadrant retires the moment its 64 pixels saturate, and the queue
-// balances 4x finer units.  LDS traffic (3 b128 per survivor per wave) stays below the VALU time.
+//    the wave's private LDS list, in list order, pair-interleaved, with their list position alongside;
+//  * the replay reads the list back 4 consecutive survivors at a time -- 11 LDS reads off one base register
+//    with immediate offsets -- evaluates them two per packed instruction and composites in the same operation order
+//    as variants 0 / 2 / 3 (bit-identical image state).
+// No workgroup barrier, no scalar bit-walk, a quadrant retires the moment its 64 pixels saturate.  LDS traffic
+// (48 B per survivor per wave) stays below the VALU time.  Which tiles share a CU is decided by their cost in the
+// previous frame on the same renderer state (quad_work, tile_starts_kernel).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kStreamLanesItems = 1;                              // candidates per lane per round (A/B: 1 ~ 2 > 3;
                                                                   // 1 halves the LDS list: 13 KiB per workgroup)
