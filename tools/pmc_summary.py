@@ -11,7 +11,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-keys = ["render", "tile_place", "tile_count", "preprocess", "radix_scatter", "radix_hist", "rowscan", "compact", "scan_small", "tile_starts"]
+keys = ["render", "tile_place", "tile_count", "preprocess", "radix_scatter", "radix_hist", "rowscan", "compact", "scan_small", "tile_starts", "ssim"]
 for name in sorted(agg, key=lambda n: -sum(agg[n].get("SQ_WAVE_CYCLES", [0]))):
     if not any(k in name for k in keys):
         continue
