@@ -79,9 +79,9 @@ def main():
     # both for one frame and for 3 frames in flight (tools/sweep_bench.sh); the flag is for sweeps
     bpc = args.render_bpc
     if bpc:
-        import ctypes
-        lib().gsr_debug_set_render_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-        check(lib().gsr_debug_set_render_variant(4, bpc))
+        from gsworld_amd import debug as dbg
+
+        dbg.set_render_variant(4, bpc)
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
     fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1)

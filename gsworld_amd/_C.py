@@ -62,6 +62,7 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes."""
     dev = means3D.device
+    _lib.apply_tuning(settings)
     inp = GsrInputs(
         P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
         colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),

@@ -27,7 +27,21 @@ class GsrSettings(C.Structure):
         ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
         ("prefiltered", C.c_int32), ("antialiasing", C.c_int32), ("debug", C.c_int32),
         ("near_plane", C.c_float),
+        # A/B and test selectors, 0 = library default (include/gsr.h); they travel with every call
+        ("binning_path", C.c_int32), ("render_variant", C.c_int32), ("render_blocks_per_cu", C.c_int32),
     ]
+
+
+# Python-side defaults of the three selectors above (tests, tools/ab_render.py, bench.py --render-bpc): the shared
+# library itself keeps no mutable state, every GsrSettings built by this package copies these in.
+TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0}
+
+
+def apply_tuning(st: "GsrSettings") -> "GsrSettings":
+    st.binning_path = int(TUNING["binning_path"])
+    st.render_variant = int(TUNING["render_variant"])
+    st.render_blocks_per_cu = int(TUNING["render_blocks_per_cu"])
+    return st
 
 
 class GsrInputs(C.Structure):
@@ -118,8 +132,6 @@ def lib() -> C.CDLL:
     L.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.gsr_pack_rgb8.restype = C.c_int
     L.gsr_pack_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-    L.gsr_debug_set_binning_mode.restype = C.c_int
-    L.gsr_debug_set_binning_mode.argtypes = [C.c_int]
     L.gsr_profile_enable.restype = C.c_int
     L.gsr_profile_enable.argtypes = [C.c_int]
     L.gsr_profile_collect.restype = C.c_int

@@ -10,9 +10,6 @@
 
 namespace {
 thread_local char g_err[512] = "";
-// 1 = depth sort + counting placement (default: fastest at config 2), 2 = bin-then-sort (scales better with V and
-// tiles, its per-tile LDS sort is not tuned yet -- profiles/round1/binning_modes.md), 0 = depth sort + radix (fallback)
-int g_binning_mode = 1;
 
 // ---- optional stage timing with HIP events on the caller's stream (bench / profiling only) ----------------
 constexpr int kStages = GSR_PROFILE_STAGES;
@@ -23,7 +20,9 @@ struct Profiler {
     std::vector<hipEvent_t> ev;  // (kStages + 1) events per frame
     hipEvent_t &at(int frame, int k) { return ev[(size_t)frame * (kStages + 1) + k]; }
 };
-Profiler g_prof;
+// one recorder per calling thread: renderers driven from different threads (one per device in a multi-GPU process)
+// never share events or counters
+thread_local Profiler g_prof;
 
 inline void prof_mark(int k, hipStream_t stream) {
     if (g_prof.mode == 0 || g_prof.frames >= kMaxFrames) return;
@@ -104,6 +103,11 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
                 return GSR_E_INVALID;
             }
         }
+        if (st->binning_path < 0 || st->binning_path > 2 || st->render_variant < 0 || st->render_variant > 3 ||
+            st->render_blocks_per_cu < 0 || st->render_blocks_per_cu > 8) {
+            gsr_set_error("gsr_forward: binning_path must be 0..2, render_variant 0..3, render_blocks_per_cu 0..8");
+            return GSR_E_INVALID;
+        }
         if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
             gsr_set_error("gsr_forward: unknown bits in param_space");
             return GSR_E_INVALID;
@@ -157,7 +161,9 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     // binning path: 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
     // (tile grids above GSR_MAX_COUNT_TILES, or wider than 2048 tiles -- one band row of counters must fit 64 KiB of
     // LDS -- always take 0)
-    const int mode = GeomState::counting(tiles) && gsr_div_up(W, GSR_TILE) <= 2048 ? g_binning_mode : 0;
+    // GsrSettings.binning_path: 0 = default (mode 1), 1 = radix (mode 0), 2 = bin-then-sort (mode 2)
+    const int want = st->binning_path == 0 ? 1 : (st->binning_path == 1 ? 0 : 2);
+    const int mode = GeomState::counting(tiles) && gsr_div_up(W, GSR_TILE) <= 2048 ? want : 0;
     const bool exact = r_capacity <= 0;
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
@@ -223,15 +229,6 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(5, stream);
     prof_end_frame();
     return gsr_check_launch("render", debug, stream);
-}
-
-int gsr_debug_set_binning_mode(int mode) {
-    if (mode < 0 || mode > 2) {
-        gsr_set_error("gsr_debug_set_binning_mode: mode must be 0, 1 or 2");
-        return GSR_E_INVALID;
-    }
-    g_binning_mode = mode;
-    return GSR_OK;
 }
 
 int gsr_profile_enable(int mode) {
@@ -309,7 +306,7 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity,
         v->clamped = reinterpret_cast<const uint8_t *>(g.clamped);
         v->tiles_touched = g.tiles_touched;
         v->rects = reinterpret_cast<const uint16_t *>(g.rects);
-        v->depth_order = g_binning_mode == 2 && GeomState::counting(gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE)) ? nullptr : g.order;  // no global depth order on the default path
+        v->depth_order = g.order;  // (not written by the bin-then-sort path, GsrSettings.binning_path = 2)
     }
     if (binning) {
         const BinningState b = BinningState::carve((char *)binning, r_capacity);

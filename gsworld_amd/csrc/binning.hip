@@ -526,7 +526,7 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
     hipLaunchKernelGGL(tile_starts_kernel, dim3(2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
-                       img.ranges, gsr_render_wants_tile_order(T) ? img.tile_order : (uint32_t *)nullptr,
+                       img.ranges, gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr,
                        (uint32_t *)nullptr, (const uint32_t *)img.quad_work);
     return gsr_check_launch("tile_starts", debug, stream);
 }

@@ -204,7 +204,7 @@ int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug,
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
-bool gsr_render_wants_tile_order(int num_tiles);
+bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles);
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
                       uint8_t *out_rgb8, bool order_ready, hipStream_t stream);

@@ -12,8 +12,19 @@
 
 namespace {
 
-int g_render_variant = 4;
-int g_render_blocks_per_cu = 6;
+// compositing kernel selection comes with every call (GsrSettings.render_variant / render_blocks_per_cu): the library
+// keeps no mutable process state, so renderers on different threads / devices never see each other's choices
+constexpr int kDefaultBlocksPerCu = 6;
+struct RenderChoice {
+    int variant;        // 4 = wave-decoupled stream kernel (default), 0 = tile kernel, 2 / 3 = batched tile kernels
+    int blocks_per_cu;
+};
+inline RenderChoice render_choice(const GsrSettings &st) {
+    RenderChoice c;
+    c.variant = st.render_variant == 0 ? 4 : (st.render_variant == 1 ? 0 : st.render_variant);
+    c.blocks_per_cu = st.render_blocks_per_cu > 0 ? st.render_blocks_per_cu : kDefaultBlocksPerCu;
+    return c;
+}
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -633,8 +644,9 @@ static int render_num_cus() {
 // once (1200 tiles on 256 CUs x 6) the deal is the identity and the binning stage need not build the order.
 // The default compositor always takes an order: with every unit resident at once (tiles <= CUs x workgroups per CU) it
 // decides which tiles share a CU; beyond that it is the longest-first queue order.
-bool gsr_render_wants_tile_order(int num_tiles) {
-    return g_render_variant == 4 || (g_render_variant >= 2 && num_tiles > render_num_cus() * g_render_blocks_per_cu);
+bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
+    const RenderChoice c = render_choice(st);
+    return c.variant == 4 || (c.variant >= 2 && num_tiles > render_num_cus() * c.blocks_per_cu);
 }
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
@@ -643,19 +655,20 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     // the default kernel writes the uint8 frame itself; the A/B variants get a separate conversion pass
-    const bool pack_after = out_rgb8 != nullptr && g_render_variant != 4;
-    if (g_render_variant >= 2) {
+    const RenderChoice rc = render_choice(st);
+    const bool pack_after = out_rgb8 != nullptr && rc.variant != 4;
+    if (rc.variant >= 2) {
         const int T = gx * gy;
-        const bool ordered = gsr_render_wants_tile_order(T);
+        const bool ordered = gsr_render_wants_tile_order(st, T);
         const uint32_t *order = ordered ? img.tile_order : nullptr;
         if (ordered && !order_ready)
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
-        const int blocks = min(T, render_num_cus() * g_render_blocks_per_cu);
-        if (g_render_variant == 4)
+        const int blocks = min(T, render_num_cus() * rc.blocks_per_cu);
+        if (rc.variant == 4)
             hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
                                g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
                                img.n_contrib, out_rgb8, img.quad_work, render_num_cus());
-        else if (g_render_variant == 3)
+        else if (rc.variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
                                point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,
                                img.final_T, img.n_contrib);
@@ -675,15 +688,3 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     return GSR_OK;
 }
 
-// 0 = LDS-staged tile kernel (upstream's structure), 2 = batched tile kernel, 3 = the same with per-quadrant instance
-// culling, 4 = wave-decoupled culling kernel (default); the others are kept for within-process A/B measurements and
-// the bit-identity test.  (1 was a v_readlane broadcast kernel: measured slower than 0, removed.)  blocks_per_cu sizes the persistent grid of variants 2-4.
-extern "C" int gsr_debug_set_render_variant(int variant, int blocks_per_cu) {
-    if (variant < 0 || variant > 4 || variant == 1 || blocks_per_cu < 0 || blocks_per_cu > 8) {
-        gsr_set_error("gsr_debug_set_render_variant: variant must be 0, 2, 3 or 4; blocks_per_cu 0..8");
-        return GSR_E_INVALID;
-    }
-    g_render_variant = variant;
-    if (blocks_per_cu > 0) g_render_blocks_per_cu = blocks_per_cu;
-    return GSR_OK;
-}

@@ -5,7 +5,28 @@ import ctypes as C
 
 import torch
 
+from . import _lib
 from ._lib import GsrStateView, check, lib
+
+
+def set_binning_mode(mode: int) -> None:
+    """A/B and tests: 1 = global depth sort + counting placement (default), 0 = depth sort + emit + tile-id radix sort,
+    2 = unordered binning + per-tile LDS sort.  Sets the selector every later call of this package carries
+    (``GsrSettings.binning_path``); the shared library keeps no state."""
+    if mode not in (0, 1, 2):
+        raise ValueError("binning mode must be 0, 1 or 2")
+    _lib.TUNING["binning_path"] = {1: 0, 0: 1, 2: 2}[mode]
+
+
+def set_render_variant(variant: int, blocks_per_cu: int = 0) -> None:
+    """A/B and tests: 4 = wave-decoupled culling kernel (default), 0 = LDS-staged per tile (upstream's structure),
+    2 = batched tile kernel, 3 = the same with per-quadrant culling; ``blocks_per_cu`` 1..8 sizes the persistent grid
+    (0 = keep).  All variants produce bit-identical image state."""
+    if variant not in (0, 2, 3, 4) or not 0 <= blocks_per_cu <= 8:
+        raise ValueError("variant must be 0, 2, 3 or 4; blocks_per_cu 0..8")
+    _lib.TUNING["render_variant"] = {4: 0, 0: 1, 2: 2, 3: 3}[variant]
+    if blocks_per_cu > 0:
+        _lib.TUNING["render_blocks_per_cu"] = blocks_per_cu
 
 
 def _view(buf: torch.Tensor, ptr, count: int, dtype: torch.dtype) -> torch.Tensor:
@@ -39,7 +60,7 @@ def state_view(P: int, width: int, height: int, num_rendered: int, num_visible: 
     out["clamped"] = _view(geomBuffer, v.clamped, 4 * P, torch.uint8).view(P, 4)[:, :3]
     out["tiles_touched"] = _view(geomBuffer, v.tiles_touched, P, torch.int32)
     out["rects"] = _view(geomBuffer, v.rects, 4 * P, torch.int16).view(P, 4)
-    if v.depth_order:  # only the depth-sorted binning paths (modes 0 / 1) materialise a global depth order
+    if v.depth_order and _lib.TUNING["binning_path"] != 2:  # bin-then-sort builds no global depth order
         out["depth_order"] = _view(geomBuffer, v.depth_order, max(num_visible, 0), torch.int32)
     if binningBuffer is not None and num_rendered > 0:
         out["point_list"] = _view(binningBuffer, v.point_list, num_rendered, torch.int32)

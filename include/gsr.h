@@ -53,6 +53,18 @@ typedef struct GsrSettings {
     int32_t antialiasing;
     int32_t debug;        /* sync + error check after every kernel */
     float near_plane;     /* cull p_view.z <= near_plane; GSR_NEAR_PLANE for GSWorld */
+    /* A/B and test selectors; 0 = the library's default everywhere.  They travel with the call -- the library keeps
+     * no mutable process state, so renderers on different threads or devices cannot disturb each other.  Every
+     * choice produces the same point list and bit-identical image state.
+     * binning_path: 0 = global depth sort + counting placement, 1 = global depth sort + emit + tile-id radix sort
+     *   (always used for tile grids above 16384 tiles or wider than 2048 tiles), 2 = unordered binning + per-tile
+     *   (depth, index) sort in LDS.
+     * render_variant: 0 = wave-decoupled culling kernel, 1 = LDS-staged per tile (upstream's structure), 2 = batched
+     *   tile kernel, 3 = the same with per-quadrant instance culling.
+     * render_blocks_per_cu: 1..8 sizes the persistent grid of the compositing kernel (0 = 6). */
+    int32_t binning_path;
+    int32_t render_variant;
+    int32_t render_blocks_per_cu;
 } GsrSettings;
 
 typedef struct GsrInputs {
@@ -155,7 +167,8 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity_
  * Optional stage timing with HIP events recorded on the caller's stream (what bench.py's roofline uses).
  * mode 0 = off, 1 = the compositing kernel only (2 events / frame), 2 = every stage (6 events / frame).
  * Stages: 0 preprocess, 1 compaction + depth sort, 2 tile offsets (scan), 3 emit + tile sort + ranges, 4 render.
- * Not thread-safe; at most 4096 frames are recorded between two collects.
+ * The recorder is per calling thread (enable, render and collect from the same thread); at most 4096 frames
+ * are recorded between two collects.
  */
 #define GSR_PROFILE_STAGES 5
 typedef struct GsrProfile {
@@ -163,14 +176,6 @@ typedef struct GsrProfile {
     double stage_ms[GSR_PROFILE_STAGES]; /* summed over `frames` */
 } GsrProfile;
 int gsr_profile_enable(int mode);
-/* A/B measurements: compositing kernel 0 = LDS-staged per tile (upstream's structure), 2 = batched tile kernel,
- * 3 = the same with per-quadrant instance culling, 4 = wave-decoupled culling kernel (default).  blocks_per_cu
- * (1..8, 0 = keep) sizes the grid of variants 2-4.  All variants produce bit-identical image state. */
-int gsr_debug_set_render_variant(int variant, int blocks_per_cu);
-/* Tests / A-B: binning path.  1 = global depth sort + counting placement (default), 2 = unordered binning + per-tile
- * (depth, index) sort in LDS, 0 = global depth sort + emit + tile-id radix sort (always used for tile grids above
- * 16384 tiles or wider than 2048 tiles).  All three produce the same point list. */
-int gsr_debug_set_binning_mode(int mode);
 int gsr_profile_collect(GsrProfile *out);
 
 /*

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import helpers as hp
-from gsworld_amd import scenes
+from gsworld_amd import debug as dbg, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -106,15 +106,13 @@ def test_tabletop_config2_full(cuda_device):
 def test_alternative_binning_paths_match_too(cuda_device, mode):
     """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 16384 tiles use) and mode 2 (unordered
     binning + per-tile LDS sort) must give the same point list as the default mode 1 (depth sort + counting)."""
-    from gsworld_amd._lib import lib
-
     raw = scenes.random_scene_camera_frame(30_000, seed=14)
-    lib().gsr_debug_set_binning_mode(mode)
+    dbg.set_binning_mode(mode)
     try:
         _run(raw, scenes.identity_camera(200, 120, 60.0))   # 104 tiles: 1 radix pass (result side 1 -> copied)
         _run(raw, scenes.identity_camera(640, 480, 60.0))   # 1200 tiles: 2 passes
     finally:
-        lib().gsr_debug_set_binning_mode(1)
+        dbg.set_binning_mode(1)
 
 
 @pytest.mark.parametrize("scene", ["random", "tabletop", "thin"])
@@ -122,10 +120,6 @@ def test_compositing_variants_are_bit_identical(cuda_device, scene):
     """The default compositing kernel culls, per 8x8 quadrant, instances that cannot reach alpha >= 1/255 there.
     That must not change a single bit of the image state: compare with the plain tile kernel (variant 0) and the
     unculled queue kernel (variant 2)."""
-    import ctypes as C
-
-    from gsworld_amd._lib import check, lib
-
     if scene == "random":
         raw, cam = scenes.random_scene_camera_frame(60_000, seed=21), scenes.identity_camera(333, 201, 60.0)
     elif scene == "tabletop":
@@ -137,16 +131,14 @@ def test_compositing_variants_are_bit_identical(cuda_device, scene):
         raw.opacity -= 2.0
     inp, st = hp.np_inputs(raw, cam), hp.oracle_settings(cam)
     bg = np.asarray((0.1, 0.2, 0.3), np.float32)
-    L = lib()
-    L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
     outs = {}
     try:
         for variant in (0, 2, 3, 4):
-            check(L.gsr_debug_set_render_variant(variant, 0))
+            dbg.set_render_variant(variant, 0)
             g = hp.gpu_forward(inp, st, bg)
             outs[variant] = (g["color"], g["invdepth"], g["views"]["final_T"], g["views"]["n_contrib"])
     finally:
-        check(L.gsr_debug_set_render_variant(4, 0))
+        dbg.set_render_variant(4, 0)
     assert outs[0][3].max() > 0
     for variant in (2, 3, 4):
         for name, a, b in zip(("color", "invdepth", "final_T", "n_contrib"), outs[0], outs[variant]):
@@ -164,15 +156,13 @@ def test_large_tile_grid_and_long_tile_lists(cuda_device):
     rep = _run(scenes.random_scene_camera_frame(20_000, seed=18), scenes.identity_camera(33_000, 16, 60.0))
     assert rep["R"] > 0
     # tile lists longer than the 8192-key LDS sort: 30k big splats on a 64x64 image (16 tiles)
-    from gsworld_amd._lib import lib
-
     raw = scenes.random_scene_camera_frame(30_000, seed=16)
     raw.scaling += 3.0
-    lib().gsr_debug_set_binning_mode(2)
+    dbg.set_binning_mode(2)
     try:
         rep = _run(raw, scenes.identity_camera(64, 64, 60.0))
     finally:
-        lib().gsr_debug_set_binning_mode(1)
+        dbg.set_binning_mode(1)
     assert rep["R"] / 16 > 8192, rep["R"]
 
 

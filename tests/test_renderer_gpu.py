@@ -3,7 +3,7 @@ step concurrently) must reproduce the drop-in rasterizer bit for
 import pytest
 import torch
 
-from gsworld_amd import scenes
+from gsworld_amd import debug as dbg, scenes
 from gsworld_amd.camera import look_at_view
 
 pytestmark = pytest.mark.gpu
@@ -129,9 +129,6 @@ def test_frame_and_step_replay_from_a_hipgraph(cuda_device):
 def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
     """GsrOutputs.out_rgb8: written inside the default compositing kernel, by a conversion pass behind the A/B
     variants -- and always equal to GSWorld's own conversion of the float image (gs_world_wrapper.py:268-270)."""
-    import ctypes as C
-
-    from gsworld_amd._lib import check, lib
     from gsworld_amd.renderer import FrameRenderer
 
     dev = cuda_device
@@ -141,12 +138,10 @@ def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
     shs = shs.clone()
     shs[::3, 0] += 3.0  # a third of the splats far brighter than 1: exercises the clamp at 255
     bg = torch.tensor([0.9, 1.0, 0.4], device=dev)
-    L = lib()
-    L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
     frames = {}
     try:
         for variant in (4, 0, 3):
-            check(L.gsr_debug_set_render_variant(variant, 0))
+            dbg.set_render_variant(variant, 0)
             out = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
             color, _, _ = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg,
                                                     rgb8_out=out)
@@ -154,6 +149,6 @@ def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
             assert torch.equal(out, want), f"variant {variant}"
             frames[variant] = out
     finally:
-        check(L.gsr_debug_set_render_variant(4, 0))
+        dbg.set_render_variant(4, 0)
     assert torch.equal(frames[4], frames[0]) and torch.equal(frames[4], frames[3])
     assert int(frames[4].max()) == 255

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd import debug as dbg, scenes  # noqa: E402
 from gsworld_amd._lib import GsrProfile, PROFILE_STAGES, check, lib  # noqa: E402
 from gsworld_amd.renderer import FrameRenderer  # noqa: E402
 
@@ -20,7 +20,6 @@ cam = scenes.sensor_camera("xarm6_align").to(dev)
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
 r = FrameRenderer(dev)
 L = lib()
-L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
 
 
 def frame():
@@ -32,7 +31,7 @@ ref = None
 res = {}
 for rnd in range(5):
     for cfg in configs:
-        check(L.gsr_debug_set_render_variant(*cfg))
+        dbg.set_render_variant(*cfg)
         frame(); torch.cuda.synchronize()
         check(L.gsr_profile_enable(2))
         for _ in range(50):

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "gsworld_amd", "dropin"))
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 from fused_ssim import fused_ssim  # noqa: E402
-from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd import debug as dbg, scenes  # noqa: E402
 
 
 def main():
@@ -33,8 +33,7 @@ def main():
                          "inside the kernels) instead of upstream's torch packing")
     args = ap.parse_args()
     if args.binning_mode >= 0:
-        from gsworld_amd._lib import check, lib
-        check(lib().gsr_debug_set_binning_mode(args.binning_mode))
+        dbg.set_binning_mode(args.binning_mode)
     dev = torch.device("cuda:0")
     S = args.size
     cam = scenes.training_camera(S, S, 60.0).to(dev)

@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd import debug as dbg, scenes  # noqa: E402
 from gsworld_amd._lib import check, lib  # noqa: E402
 from oracle import gs_oracle as go  # noqa: E402
 from tests import helpers as hp  # noqa: E402
@@ -24,7 +24,6 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     L = lib()
-    L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
     t0 = time.time()
     worst_rgb, total_border, total_px = 0.0, 0, 0
     for it in range(iters):
@@ -54,11 +53,11 @@ def main():
         o = hp.oracle_forward(inp, st, bg)
         g = hp.gpu_forward(gin, st, bg, param_space=param_space)
         rep = hp.compare_forward(o, g, st)
-        check(L.gsr_debug_set_render_variant(0, 0))
+        dbg.set_render_variant(0, 0)
         try:
             g0 = hp.gpu_forward(gin, st, bg, param_space=param_space)
         finally:
-            check(L.gsr_debug_set_render_variant(4, 0))
+            dbg.set_render_variant(4, 0)
         for name in ("color", "invdepth"):
             assert np.array_equal(g[name].view(np.uint32), g0[name].view(np.uint32)), (it, name)
         if n > 0 and "views" in g:

@@ -7,7 +7,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd import debug as dbg, scenes  # noqa: E402
 from gsworld_amd._lib import check, lib  # noqa: E402
 from gsworld_amd.renderer import FrameRenderer  # noqa: E402
 
@@ -20,8 +20,7 @@ cam = scenes.sensor_camera("xarm6_align").to(dev)
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
 r = FrameRenderer(dev)
 L = lib()
-L.gsr_debug_set_render_variant.argtypes = [C.c_int, C.c_int]
-check(L.gsr_debug_set_render_variant(variant, bpc))
+dbg.set_render_variant(variant, bpc)
 for _ in range(frames):
     r.render(cam, means, op, shs=shs, scales=sc, rotations=rot)
 torch.cuda.synchronize()
