@@ -14,18 +14,42 @@ namespace {
 
 constexpr int kXf = 17;  // floats per transform: R (row-major 9), t (3), scale (1), q_R (w,x,y,z)
 
+// blockIdx.y = environment e: the same Gaussians under the e-th pose table, written to the e-th slice of the outputs
+// (the (B,N,.) shapes transform_gaussians returns for a batch of poses, gs_utils.py:283-385).  SCALING: also rewrite the
+// log-scale parameter of the parts flagged in `rescale` the way the reference does for a per-env scale vector
+// (gs_utils.py `scaling = inverse_sigmoid(torch.exp(scaling) * scale)`, log(x / (1 - x)) -- sic), copy it for the rest.
+template <bool SCALING>
 __global__ __launch_bounds__(GSR_BLOCK) void transform_kernel(int P, const float *__restrict__ xyz,
                                                               const float *__restrict__ rot,
+                                                              const float *__restrict__ scaling,
                                                               const float *__restrict__ semantics,
                                                               const int32_t *__restrict__ lut, int lut_size,
-                                                              const float *__restrict__ xf, int K,
-                                                              float *__restrict__ xyz_out, float *__restrict__ rot_out) {
+                                                              const float *__restrict__ xf_all, int K,
+                                                              const uint8_t *__restrict__ rescale,
+                                                              float *__restrict__ xyz_out_all,
+                                                              float *__restrict__ rot_out_all,
+                                                              float *__restrict__ scaling_out_all) {
     const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
     if (i >= P) return;
+    const size_t e = blockIdx.y;
+    const float *xf = xf_all + e * (size_t)K * kXf;
+    float *xyz_out = xyz_out_all + e * (size_t)P * 3, *rot_out = rot_out_all + e * (size_t)P * 4;
     float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
     float4 q = *reinterpret_cast<const float4 *>(rot + 4 * (size_t)i);
     const int label = (int)semantics[i];  // the reference compares labels after .long() (truncation)
     const int k = (label >= 0 && label < lut_size) ? lut[label] : -1;
+    if (SCALING) {
+        float s0 = scaling[3 * (size_t)i], s1 = scaling[3 * (size_t)i + 1], s2 = scaling[3 * (size_t)i + 2];
+        if (k >= 0 && k < K && rescale != nullptr && rescale[k]) {
+            const float s = xf[(size_t)k * kXf + 12];
+            const float x0 = expf(s0) * s, x1 = expf(s1) * s, x2 = expf(s2) * s;
+            s0 = logf(x0 / (1.0f - x0));
+            s1 = logf(x1 / (1.0f - x1));
+            s2 = logf(x2 / (1.0f - x2));
+        }
+        float *so = scaling_out_all + e * (size_t)P * 3 + 3 * (size_t)i;
+        so[0] = s0; so[1] = s1; so[2] = s2;
+    }
     if (k >= 0 && k < K) {
         const float *T = xf + (size_t)k * kXf;
         const float s = T[12];
@@ -104,23 +128,38 @@ extern "C" int gsr_pack_part_transforms(int32_t K, const float *matrices, const 
     return gsr_check_launch("pack_part_transforms", false, (hipStream_t)stream);
 }
 
-extern "C" int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const float *semantics,
-                                       const int32_t *lut, int32_t lut_size, const float *transforms, int32_t K,
-                                       float *xyz_out, float *rot_out, void *stream) {
-    if (P < 0 || K < 0 || lut_size < 0) {
-        gsr_set_error("gsr_transform_gaussians: negative size");
+extern "C" int gsr_transform_gaussians_batch(int32_t P, int32_t E, const float *xyz, const float *rot,
+                                             const float *scaling, const float *semantics, const int32_t *lut,
+                                             int32_t lut_size, const float *transforms, int32_t K,
+                                             const uint8_t *rescale, float *xyz_out, float *rot_out,
+                                             float *scaling_out, void *stream) {
+    if (P < 0 || K < 0 || lut_size < 0 || E < 0 || E > 65535) {
+        gsr_set_error("gsr_transform_gaussians: negative size (or more than 65535 environments)");
         return GSR_E_INVALID;
     }
-    if (P == 0) return GSR_OK;
-    if (!xyz || !rot || !semantics || !xyz_out || !rot_out || (lut_size > 0 && !lut) || (K > 0 && !transforms)) {
-        gsr_set_error("gsr_transform_gaussians: null pointer");
+    if (P == 0 || E == 0) return GSR_OK;
+    if (!xyz || !rot || !semantics || !xyz_out || !rot_out || (lut_size > 0 && !lut) || (K > 0 && !transforms) ||
+        ((scaling_out != nullptr) != (scaling != nullptr))) {
+        gsr_set_error("gsr_transform_gaussians: null pointer (scaling and scaling_out go together)");
         return GSR_E_INVALID;
     }
     if ((reinterpret_cast<uintptr_t>(rot) | reinterpret_cast<uintptr_t>(rot_out)) & 15u) {
         gsr_set_error("gsr_transform_gaussians: rotation buffers must be 16-byte aligned");
         return GSR_E_INVALID;
     }
-    hipLaunchKernelGGL(transform_kernel, dim3(gsr_div_up(P, GSR_BLOCK)), dim3(GSR_BLOCK), 0, (hipStream_t)stream, P, xyz,
-                       rot, semantics, lut, lut_size, transforms, K, xyz_out, rot_out);
+    const dim3 grid(gsr_div_up(P, GSR_BLOCK), E);
+    if (scaling_out)
+        hipLaunchKernelGGL(transform_kernel<true>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, P, xyz, rot, scaling,
+                           semantics, lut, lut_size, transforms, K, rescale, xyz_out, rot_out, scaling_out);
+    else
+        hipLaunchKernelGGL(transform_kernel<false>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, P, xyz, rot, scaling,
+                           semantics, lut, lut_size, transforms, K, rescale, xyz_out, rot_out, scaling_out);
     return gsr_check_launch("transform_gaussians", false, (hipStream_t)stream);
+}
+
+extern "C" int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const float *semantics,
+                                       const int32_t *lut, int32_t lut_size, const float *transforms, int32_t K,
+                                       float *xyz_out, float *rot_out, void *stream) {
+    return gsr_transform_gaussians_batch(P, 1, xyz, rot, nullptr, semantics, lut, lut_size, transforms, K, nullptr,
+                                         xyz_out, rot_out, nullptr, stream);
 }

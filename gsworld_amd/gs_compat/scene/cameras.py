@@ -46,7 +46,10 @@ class Camera(nn.Module):
         self.trans = trans
         self.scale = scale
         vp = view_params(np.asarray(R), np.asarray(T), FoVx, FoVy, self.image_width, self.image_height, trans, scale)
-        dev = self.data_device if (self.data_device.type != "cuda" or torch.cuda.is_available()) else "cpu"
+        # upstream puts the three matrices on the GPU whatever `data_device` says (`...transpose(0, 1).cuda()`): they
+        # are rasterizer arguments, only the images follow data_device (CPU-only hosts, i.e. the unit tests, keep them
+        # on the CPU)
+        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         self.world_view_transform = vp.world_view_transform.to(dev)
         self.projection_matrix = (self.world_view_transform.new_zeros(4, 4))
         from gsworld_amd.camera import get_projection_matrix

@@ -234,5 +234,7 @@ class GaussianModel:
     def load_ply(self, path, use_train_test_exp=False):
         from gsworld_amd.ply import read_gaussian_ply
 
-        read_gaussian_ply(path, self)
+        # the stock loader: trainable nn.Parameters, _opacity (N,1).  GSWorld's Semantic3DGSWrapper overrides load_ply
+        # (frozen tensors, (N,1,1) opacity, semantics) -- that flavour is read_gaussian_ply's default.
+        read_gaussian_ply(path, self, upstream=True)
         self.active_sh_degree = self.max_sh_degree

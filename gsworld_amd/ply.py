@@ -79,14 +79,26 @@ def gaussian_tensors(cols: dict, max_sh_degree: int = 3) -> dict:
                 semantics=sem)
 
 
-def read_gaussian_ply(path: str, model, device="cuda") -> None:
-    """Fills a GaussianModel-like object (``_xyz``, ``_features_dc`` ... ``_semantics``) from ``path``."""
+def read_gaussian_ply(path: str, model, device="cuda", upstream: bool = False) -> None:
+    """Fills a GaussianModel-like object (``_xyz``, ``_features_dc`` ... ) from ``path``.
+
+    Default: what GSWorld's ``Semantic3DGSWrapper.load_ply`` leaves behind
+    (semantic_3dgs_wrapper.py:151-167) -- frozen plain tensors, ``_opacity (N,1,1)``, ``_semantics (N,1)``.
+    ``upstream=True``: what the stock 3DGS ``GaussianModel.load_ply`` leaves behind -- ``nn.Parameter`` s that require
+    grad (training resumes from a saved PLY), ``_opacity (N,1)``, no semantics."""
     t = gaussian_tensors(read_ply(path), getattr(model, "max_sh_degree", 3))
     dev = device if (device != "cuda" or torch.cuda.is_available()) else "cpu"
     for attr, key in (("_xyz", "xyz"), ("_features_dc", "features_dc"), ("_features_rest", "features_rest"),
                       ("_opacity", "opacity"), ("_scaling", "scaling"), ("_rotation", "rotation"),
                       ("_semantics", "semantics")):
-        setattr(model, attr, torch.tensor(t[key], dtype=torch.float32, device=dev))
+        if upstream and key == "semantics":
+            continue
+        v = torch.tensor(t[key], dtype=torch.float32, device=dev)
+        if upstream:
+            if key == "opacity":
+                v = v.reshape(-1, 1)
+            v = torch.nn.Parameter(v.contiguous().requires_grad_(True))
+        setattr(model, attr, v)
 
 
 def write_gaussian_ply(path: str, model, with_semantics: bool | None = None) -> None:

