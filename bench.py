@@ -33,6 +33,10 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gather-every", type=int, default=16, help="frames per RCCL gather batch (N > 1)")
+    ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
+                    help="N > 1: gather-to-rank-0 (default, what north_star asks for) or all_gather of the uint8 frames")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (dense view, upstream packing, closed loop, torch-CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage event timing table to stderr")
@@ -84,7 +88,8 @@ def main():
         dbg.set_render_variant(4, bpc)
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
-    fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1)
+    fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1,
+                        collective=args.collective)
     n_slots = fg.num_slots
     rs_ = [FrameRenderer(dev) for _ in range(S)]
     lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
@@ -204,11 +209,20 @@ def main():
     if stats.overflow:
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
 
+    own_elapsed = elapsed
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = [own_elapsed]
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([own_elapsed], dtype=torch.float64, device=dev))
+        per_rank = [float(t.item()) for t in every]
     elapsed = float(t_max.item())
     fps = world * args.steps / elapsed
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg)
 
     if rank == 0:
         b_alg = stats.algorithmic_bytes(W, H)
@@ -216,11 +230,21 @@ def main():
         render_bytes = 40 * stats.num_rendered + 16 * W * H  # 40 B per composited instance + outputs
         ach = render_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
         traffic = valu_frac = None
+        traffic_source = "none"
         pmc = os.path.join(ROOT, "profiles", "pmc_render.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 traffic = rec.get("hbm_bytes_per_launch")
+                # NOT measured in this run (PMC counters need a rocprofv3 session): a committed counter run of the same
+                # frame.  The record carries the hash of render.hip it was taken with; a kernel edited since then is
+                # flagged instead of silently quoted.
+                import hashlib
+                sha = hashlib.sha256(open(os.path.join(ROOT, "gsworld_amd", "csrc", "render.hip"), "rb").read()).hexdigest()[:16]
+                stale = rec.get("render_hip_sha16") != sha
+                traffic_source = (f"committed rocprofv3 --pmc run {os.path.relpath(pmc, ROOT)} "
+                                  f"({rec.get('collected', 'undated')}; render.hip "
+                                  f"{'CHANGED since then: stale' if stale else 'unchanged since then'})")
                 # what actually bounds the compositor: VALU issue.  SQ_INSTS_VALU wave-instructions (committed PMC
                 # run of the same frame) x 4 cycles on 256 CUs x 4 SIMDs at 2.4 GHz, over the kernel time measured now
                 insts = rec.get("counters", {}).get("SQ_INSTS_VALU")
@@ -239,11 +263,16 @@ def main():
                 "num_gaussians": n, "num_visible": stats.num_visible, "num_rendered": stats.num_rendered,
                 "sh_degree": 3, "launch": "hipGraph replay" if graph is not None else "eager",
                 "frames_in_flight": S,
-                "frame_gather": f"RCCL all_gather of uint8 frames every {K_g} frames" if world > 1 else "none",
+                "frame_gather": (f"RCCL {args.collective} of uint8 frames every {K_g} frames "
+                                 f"(backend {dist.get_backend()}, {dist.get_world_size()} ranks)") if world > 1 else "none",
+                "world_size": world,
+                # every rank's own rate over the same K steps: sum ~ value when no rank is a straggler, and rank 0's
+                # figure is directly comparable with the N = 1 run
+                "per_rank_frames_per_s": [args.steps / t for t in per_rank],
             },
             "roofline": {
                 "bound": "hbm", "kernel": "render_stream_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
                 "valu_issue_frac": valu_frac,
                 "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
@@ -262,12 +291,180 @@ def main():
         }
         if args.breakdown:
             print("[bench] stage ms:", dict(zip(PROFILE_STAGES, stage_ms)), file=sys.stderr)
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(raw, cam_cpu, args.cpu_frames)
+            if not args.no_extras:
+                out["cpu_baseline_config0"] = cpu_baseline_config0()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _time_frames(torch, enqueue, steps, warmup=10):
+    for _ in range(warmup):
+        enqueue()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enqueue()
+    torch.cuda.synchronize()
+    return steps / (time.perf_counter() - t0)
+
+
+def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
+    """SURVEY.md 8d's second numbers, N = 1 only, outside the headline's timed region, each a few hundred frames:
+    * dense_view: the same scene and N from a camera that sees V = 0.6 N of it (8d's worked example; right_cam sees 0.12 N);
+    * upstream_packing: the rasterizer figure INCLUDING what upstream render() does per frame before it
+      (sigmoid / exp / normalize over the model + cat(dc, rest) -> (N,16,3)), and the same frame with those four passes
+      fused into preprocess (raw parameters + split SH, GsrInputs.param_space / shs_rest);
+    * closed_loop: BASELINE.json configs[2] surrogate -- 1 reset + 200 steps x 2 cameras through
+      gsworld_amd.closed_loop (pose upload, fused transform, both frames, one hipGraph replay per step)."""
+    import torch
+
+    from gsworld_amd import closed_loop as cl, scenes
+    from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+    from gsworld_amd.camera import look_at_view
+    from gsworld_amd.renderer import FrameRenderer
+
+    out = {}
+    W, H = args.width, args.height
+    steps = min(args.steps, 200)
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+
+    def graphed(fn):
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        return g
+
+    # ---- dense view ---------------------------------------------------------------------------------------------
+    cam_d = scenes.dense_view_camera(name, W, H).to(dev)
+    rd = FrameRenderer(dev)
+    fr = lambda: rd.render(cam_d, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=rgb8)  # noqa: E731
+    for _ in range(2):
+        fr()
+        st = rd.ensure_valid(fr)
+    g = graphed(fr)
+    f = _time_frames(torch, g.replay, steps)
+    st = rd.ensure_valid(fr)
+    b_alg = st.algorithmic_bytes(W, H)
+    out["dense_view"] = {
+        "frames_per_s": f, "frames_in_flight": 1, "num_visible": st.num_visible, "num_rendered": st.num_rendered,
+        "visible_fraction": st.num_visible / st.num_gaussians, "algorithmic_bytes_per_frame": b_alg,
+        "frac_of_8TBs": b_alg * f / 1e9 / HBM_PEAK_GBS,
+        "workload": f"same {st.num_gaussians} Gaussians, camera 1.5 m above the table centre looking down "
+                    "(gsworld_amd.scenes.dense_view_camera), one frame at a time, hipGraph replay"}
+    del rd, g
+    # ---- what upstream render() adds in front of the rasterizer -----------------------------------------------
+    rawd = raw.to(dev)
+    cam = scenes.sensor_camera(name, W, H).to(dev)
+    rp = FrameRenderer(dev)
+
+    def packed():
+        shs_ = torch.cat((rawd.features_dc, rawd.features_rest), dim=1)
+        rp.render(cam, rawd.xyz, torch.sigmoid(rawd.opacity), shs=shs_, scales=torch.exp(rawd.scaling),
+                  rotations=torch.nn.functional.normalize(rawd.rotation), bg=bg, rgb8_out=rgb8)
+
+    def fused():
+        rp.render(cam, rawd.xyz, rawd.opacity, shs=rawd.features_dc, shs_rest=rawd.features_rest, scales=rawd.scaling,
+                  rotations=rawd.rotation, bg=bg, rgb8_out=rgb8,
+                  param_space=RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS)
+
+    def plain():
+        rp.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=rgb8)
+
+    res = {}
+    for label, fn in (("pre_activated_inputs", plain), ("torch_sigmoid_exp_normalize_cat_per_frame", packed),
+                      ("activations_and_split_sh_fused_into_preprocess", fused)):
+        for _ in range(2):
+            fn()
+            rp.ensure_valid(fn)
+        g = graphed(fn)
+        res[label] = _time_frames(torch, g.replay, steps)
+        del g
+    out["upstream_packing"] = {"frames_per_s": res, "frames_in_flight": 1,
+                               "workload": "headline scene and camera, one frame at a time, hipGraph replay"}
+    del rp
+    # ---- closed loop (configs[2] surrogate) -------------------------------------------------------------------
+    cams = {"right_cam": scenes.sensor_camera(name, W, H),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
+    parts, actors = cl.xarm6_parts()
+    loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS if name.startswith("xarm") else scenes.SIM2GS_ARM_TRANS)
+    ep_len = 200
+    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=ep_len + 1, seed=0))
+    pinned = [(M.pin_memory(), s.pin_memory()) for M, s in poses]
+    loop.reset(*pinned[0])
+    loop.capture()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.step(*pinned[0])  # the episode's reset() frame pair
+    for M, s in pinned[1:]:
+        loop.step(M, s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    overflow = any(x.overflow for x in loop.ensure_valid())
+    out["closed_loop"] = {
+        "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
+        "frames": (ep_len + 1) * len(cams), "overflow": overflow,
+        "workload": f"BASELINE.json configs[2] surrogate: 1 reset + {ep_len} steps x {len(cams)} cameras {W}x{H}, "
+                    f"{raw.num} Gaussians, {len(parts)} moving parts (seeded random walk instead of PhysX), per step: "
+                    "pose upload + device-side pose table + fused transform + both frames, one hipGraph replay"}
+    return out
+
+
+def cpu_baseline_config0():
+    """BASELINE.json configs[0]: 100 k random Gaussians, one 256x256 camera -- north_star's "PyTorch-CPU fallback render
+    timed on the host cores": oracle/torch_cpu_render.py (vectorised PyTorch, CPU) and oracle/gs_oracle.c beside it.
+    torch threads are capped at 32: with every host thread of a 256-thread box the op-by-op torch render spends its time
+    in thread-pool hand-offs and does not finish in minutes."""
+    import numpy as np
+    import torch
+
+    from gsworld_amd import scenes
+    from oracle import gs_oracle as go
+    from oracle import torch_cpu_render as tcr
+
+    raw = scenes.random_scene_camera_frame(100_000, seed=0)
+    cam = scenes.identity_camera(256, 256, 60.0)
+    means, shs, op, sc, rot = raw.activated()
+    cores = os.cpu_count() or 1
+    threads = min(32, cores)
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        ts = []
+        for k in range(3):
+            t0 = time.perf_counter()
+            tcr.render(means, shs, op.reshape(-1), sc, rot, cam.world_view_transform, cam.full_proj_transform,
+                       cam.camera_center, torch.zeros(3), cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(old)
+    t_torch = sorted(ts[1:])[0]
+    st = go.Settings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy)
+    go.set_threads(cores)
+    a = (st, np.zeros(3, np.float32), means.numpy(), shs.numpy(), None, op.numpy().reshape(-1), sc.numpy(), rot.numpy(),
+         None, cam.world_view_transform.numpy().reshape(-1), cam.full_proj_transform.numpy().reshape(-1),
+         cam.camera_center.numpy())
+    go.forward(*a)
+    tc = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        go.forward(*a)
+        tc.append(time.perf_counter() - t0)
+    return {"workload": "BASELINE.json configs[0]: 100000 random Gaussians, 256x256",
+            "pytorch_cpu": {"value": 1.0 / t_torch, "unit": "frames/s", "cores": threads, "kind": "port",
+                            "sample": "best of 2 frames after 1 warm-up, oracle/torch_cpu_render.py"},
+            "c_openmp": {"value": 1.0 / sorted(tc)[len(tc) // 2], "unit": "frames/s", "cores": cores, "kind": "port",
+                         "sample": "median of 5 frames after 1 warm-up, oracle/gs_oracle.c"}}
 
 
 def cpu_baseline(raw, cam, frames):

@@ -1,0 +1,195 @@
+"""Render side of GSWorld's closed loop (BASELINE.json configs[2]) without the wrapper's per-step torch glue.
+
+``GSWorldWrapper.step`` / ``reset`` (/root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:176-198)
+do two things after the physics step: ``transform_gs_perlink`` (``:110-162``: one ``transform_gaussians`` per robot link
+and tracked actor) and ``_render_gsworld`` (``:232-275``: per camera and per environment a deep copy of the model, the
+masked write-back of every moved part, ``render()``, uint8 conversion).  :class:`ClosedLoopRenderer` is that pair for a
+scene held on one MI355X:
+
+* the pose table of the step is packed on the device (``gsr_pack_part_transforms``), one fused pass moves every labelled
+  Gaussian (``gsr_transform_gaussians_batch``; ``E`` environments at once),
+* all ``E x C`` frames of the step are enqueued on their own HIP streams with their own renderer state
+  (:class:`gsworld_amd.renderer.MultiCameraRenderer`), the compositor writes GSWorld's uint8 frames itself,
+* the whole GPU side of a step can be captured once and replayed as one hipGraph.
+
+Returns what ``_render_gsworld`` returns: ``{camera name: uint8 (num_envs, H, W, 3)}``.
+
+SAPIEN / PhysX do not run on a headless GPU box, so :func:`random_walk_poses` stands in for the simulator when the loop
+is measured (``bench.py``, ``tools/closed_loop_surrogate.py``): a seeded random walk of the part poses, i.e. the
+random-action rollout of /root/reference/examples/maniskill/gsworld_rand_action_tabletop.py:99-133 reduced to what
+reaches the renderer.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import transform as tf
+from ._lib import RAW_ROTATIONS, RAW_SCALES
+from .renderer import MultiCameraRenderer
+
+
+class ClosedLoopRenderer:
+    def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
+                 background=None):
+        """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
+        merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
+        the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
+        ``scaled_parts``: the tracked actors (their log-scales are rewritten per step as the reference does)."""
+        self.device = torch.device(device)
+        dev = self.device
+        self.num_envs = int(num_envs)
+        self.names = list(cameras.keys())
+        self.cameras = [cameras[n].to(dev) for n in self.names]
+        g = lambda a, b: getattr(raw, a) if hasattr(raw, a) else getattr(raw, b)  # noqa: E731
+        self.xyz = g("xyz", "_xyz").detach().to(dev, torch.float32).contiguous()
+        self.rotation = g("rotation", "_rotation").detach().to(dev, torch.float32).contiguous()
+        self.scaling = g("scaling", "_scaling").detach().to(dev, torch.float32).contiguous()
+        self.features_dc = g("features_dc", "_features_dc").detach().to(dev, torch.float32).contiguous()
+        self.features_rest = g("features_rest", "_features_rest").detach().to(dev, torch.float32).contiguous()
+        # opacity is never moved (new_opacity=None at both call sites of the wrapper): activate it once
+        self.opacity = torch.sigmoid(g("opacity", "_opacity").detach().to(dev, torch.float32).reshape(-1, 1)).contiguous()
+        semantics = g("semantics", "_semantics")
+        self.op = tf.FusedPartTransform(part_labels, semantics.to(dev), scaled_parts=scaled_parts)
+        self.rescaled = len(tuple(scaled_parts)) > 0
+        self.K = len(self.op.names)
+        H, W = self.cameras[0].image_height, self.cameras[0].image_width
+        self.frames = {n: torch.zeros((self.num_envs, c.image_height, c.image_width, 3), dtype=torch.uint8, device=dev)
+                       for n, c in zip(self.names, self.cameras)}
+        self.bg = torch.zeros(3, device=dev) if background is None else background.to(dev, torch.float32)
+        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev)
+        lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
+        # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
+        self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()
+        self.scales = torch.ones(lead, device=dev)
+        self._graph = None
+        self.image_size = (H, W)
+
+    # ---- one step ------------------------------------------------------------------------------------------------
+    def _gpu_step(self):
+        """Everything the GPU does per step: pose table, fused transform, E x C frames (reads self.matrices / scales)."""
+        if self.rescaled:
+            xyz, rot, scaling = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales, scaling=self.scaling)
+        else:
+            xyz, rot = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales)
+            scaling = self.scaling
+        E, C = self.num_envs, len(self.cameras)
+        # lane e * C + c renders environment e from camera c; the transformed quaternions keep their norm (reference
+        # semantics) and the scales stay logs: preprocess activates both on load
+        views, outs = [], []
+        for e in range(E):
+            for c in range(C):
+                views.append(self.cameras[c])
+                outs.append(self.frames[self.names[c]][e])
+        if E == 1:
+            self.multi.render(views, xyz, self.opacity, rgb8_out=outs, shs=self.features_dc,
+                              shs_rest=self.features_rest, scales=scaling, rotations=rot,
+                              param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg)
+        else:
+            per_lane = [dict(means3D=xyz[e], scales=(scaling[e] if scaling.dim() == 3 else scaling), rotations=rot[e])
+                        for e in range(E) for _ in range(C)]
+            self.multi.render(views, None, self.opacity, rgb8_out=outs, shs=self.features_dc,
+                              shs_rest=self.features_rest, param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg,
+                              per_lane=per_lane)
+
+    def set_poses(self, matrices: torch.Tensor, scales: torch.Tensor | None = None):
+        """Copies this step's part poses ((K,4,4) or (E,K,4,4), host or device; + uniform scales) into the persistent
+        device buffers the (possibly captured) step reads."""
+        if tuple(matrices.shape) != tuple(self.matrices.shape):
+            raise ValueError(f"expected poses of shape {tuple(self.matrices.shape)}, got {tuple(matrices.shape)}")
+        self.matrices.copy_(matrices.to(torch.float32), non_blocking=True)
+        if scales is not None:
+            self.scales.copy_(scales.to(torch.float32).reshape(self.scales.shape), non_blocking=True)
+
+    def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None) -> dict:
+        """-> {camera name: uint8 (num_envs, H, W, 3)} -- renderer-owned tensors, overwritten by the next step."""
+        if matrices is not None:
+            self.set_poses(matrices, scales)
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._gpu_step()
+        return self.frames
+
+    def reset(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None) -> dict:
+        """First frame(s): exact-mode render that sizes every lane's binning capacity, then the validity check."""
+        if matrices is not None:
+            self.set_poses(matrices, scales)
+        self._gpu_step()
+        self.multi.ensure_valid(self._gpu_step)
+        return self.frames
+
+    def ensure_valid(self):
+        """Overflow check of the last step (synchronises); re-renders exactly if a lane's capacity was exceeded.  A
+        captured graph is dropped in that case (its capacities are baked in): call :meth:`capture` again."""
+        def again():
+            self._graph = None
+            self._gpu_step()
+        return self.multi.ensure_valid(again)
+
+    def capture(self):
+        """Captures the GPU side of a step into one hipGraph (call after :meth:`reset`)."""
+        dev = self.device
+        self._graph = None
+        self._gpu_step()
+        self.multi.ensure_valid(self._gpu_step)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._gpu_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self._gpu_step()
+        self._graph = g
+        torch.cuda.synchronize(dev)
+        return g
+
+
+def small_rigid(gen: torch.Generator, k: int, angle: float = 0.05, shift: float = 0.01) -> torch.Tensor:
+    """``k`` random small rigid 4x4 increments (Rodrigues rotation of a N(0, angle^2) axis-angle + N(0, shift^2) shift)."""
+    w = torch.randn(k, 3, generator=gen) * angle
+    th = w.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    a = w / th
+    Kx = torch.zeros(k, 3, 3)
+    Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0] = -a[:, 2], a[:, 1], a[:, 2]
+    Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -a[:, 0], -a[:, 1], a[:, 0]
+    R = torch.eye(3) + torch.sin(th)[:, :, None] * Kx + (1 - torch.cos(th))[:, :, None] * (Kx @ Kx)
+    M = torch.eye(4).repeat(k, 1, 1)
+    M[:, :3, :3] = R
+    M[:, :3, 3] = torch.randn(k, 3, generator=gen) * shift
+    return M
+
+
+def random_walk_poses(sim2gs: torch.Tensor, num_parts: int, num_actors: int, steps: int, seed: int = 0,
+                      num_envs: int = 1):
+    """Seeded stand-in for the simulator of a random-action rollout: yields, per step, the part matrices the wrapper
+    would build -- ``sim2gs @ pose_now @ inv(pose_scan = I) @ inv(sim2gs)`` for links (gs_world_wrapper.py:120) and the
+    rigid part + uniform scale of the same product for the last ``num_actors`` parts (``:146-156``) -- as
+    ``(matrices (K,4,4) | (E,K,4,4), scales (K,) | (E,K))`` on the host."""
+    from .camera import extract_rigid_transform
+
+    gen = torch.Generator().manual_seed(seed)
+    K = num_parts
+    sim2gs = sim2gs.to(torch.float32)
+    inv = torch.linalg.inv(sim2gs)
+    now = torch.eye(4).repeat(num_envs, K, 1, 1)
+    for _ in range(steps):
+        now = now @ small_rigid(gen, num_envs * K).reshape(num_envs, K, 4, 4)
+        full = sim2gs @ now @ inv
+        rigid, scale, _, _ = extract_rigid_transform(full.reshape(-1, 4, 4))
+        rigid = rigid.reshape(num_envs, K, 4, 4)
+        scales = torch.ones(num_envs, K)
+        if num_actors:
+            scales[:, K - num_actors:] = scale.reshape(num_envs, K)[:, K - num_actors:]
+        if num_envs == 1:
+            yield rigid[0].contiguous(), scales[0].contiguous()
+        else:
+            yield rigid.contiguous(), scales.contiguous()
+
+
+def xarm6_parts():
+    """16 robot links (labels 1..16) and 2 tracked actors (labels 17, 18), the way ``xarm_gs_semantics`` /
+    ``obj_gs_semantics`` label the synthetic table-top scenes of :mod:`gsworld_amd.scenes`."""
+    parts = {f"link{k}": k for k in range(1, 17)}
+    parts.update({"005_tomato_soup_can": 17, "dtc_green_can": 18})
+    return parts, ("005_tomato_soup_can", "dtc_green_can")

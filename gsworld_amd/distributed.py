@@ -39,27 +39,40 @@ def scene_for_rank(rank: int, names) -> tuple[str, int]:
 
 
 class FrameGather:
-    """Batches ``batch`` frames of shape (H, W, 3) uint8 per rank and all-gathers them: result
+    """Batches ``batch`` frames of shape (H, W, 3) uint8 per rank and gathers them over the process group: result
     ``(world * batch, H, W, 3)`` ordered by rank, then by frame slot.
 
+    ``collective = "gather"`` (default): gather-to-root -- only rank ``dst`` receives the frames, which is what
+    north_star asks for ("RCCL over xGMI only to gather frames") and moves ``(world - 1) x batch x 0.92 MB`` into ONE
+    rank per batch instead of into every rank.  ``"all_gather"``: every rank receives every frame (8x the traffic on an
+    8-GPU node; for consumers that need all frames everywhere).
+
     ``buffers = 2`` double-buffers the frame slots (and the gathered result): while the collective of batch b runs on
-    the side stream, batch b + 1 is rendered into the other half, so nothing on the render streams waits for RCCL
-    (8 ranks x 16 frames x 0.92 MB = 118 MB per gather would otherwise stall every batch).  A stream that is about to
-    overwrite the slots of a batch calls :meth:`wait_reusable` first; that gather was issued a whole batch earlier."""
+    the side stream, batch b + 1 is rendered into the other half, so nothing on the render streams waits for RCCL.  A
+    stream that is about to overwrite the slots of a batch calls :meth:`wait_reusable` first (that collective was issued
+    a whole batch earlier); a consumer of the gathered frames calls :meth:`wait_gathered` before reading
+    :attr:`gathered`."""
 
     def __init__(self, height: int, width: int, batch: int = 16, device="cpu", world: int | None = None,
-                 buffers: int = 1):
+                 buffers: int = 1, collective: str = "gather", dst: int = 0):
+        if collective not in ("gather", "all_gather"):
+            raise ValueError("collective must be 'gather' or 'all_gather'")
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = dist.get_rank() if (self.world > 1 and dist.is_initialized()) else 0
+        self.collective = collective
+        self.dst = dst
         self.batch = max(1, int(batch))
         self.buffers = max(1, int(buffers))
         self.device = torch.device(device)
         self.frames = torch.empty((self.buffers * self.batch, height, width, 3), dtype=torch.uint8, device=self.device)
+        self.receives = self.world > 1 and (collective == "all_gather" or self.rank == dst)
         self._gathered = [torch.empty((self.world * self.batch, height, width, 3), dtype=torch.uint8,
-                                      device=self.device) if self.world > 1 else self._half(b)
+                                      device=self.device) if self.receives else self._half(b)
                           for b in range(self.buffers)]
-        self.gathered = self._gathered[0]  # result of the most recent gather
+        self.gathered = self._gathered[0]  # result of the most recent gather (this rank's own frames if it is not a receiver)
         self.stream = torch.cuda.Stream(self.device) if (self.world > 1 and self.device.type == "cuda") else None
-        self._done = [None] * self.buffers  # event after the gather that last read half b
+        self._done = [None] * self.buffers  # event after the collective that last read half b
+        self._last = None  # event of the most recent collective (what `gathered` waits for)
         self.num_gathers = 0
 
     def _half(self, b: int) -> torch.Tensor:
@@ -74,31 +87,59 @@ class FrameGather:
         return self.frames[i % self.num_slots]
 
     def wait_reusable(self, i: int, stream=None) -> None:
-        """Makes ``stream`` (default: current) wait until the gather that last read step ``i``'s half has finished."""
+        """Makes ``stream`` (default: current) wait until the collective that last read step ``i``'s half has finished."""
         ev = self._done[(i // self.batch) % self.buffers]
         if ev is not None:
             (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(ev)
 
+    def wait_gathered(self, stream=None) -> torch.Tensor:
+        """Makes ``stream`` (default: current) wait for the most recent collective and returns :attr:`gathered`: the
+        collective runs on a side stream, so a consumer must call this before it reads the frames."""
+        if self._last is not None:
+            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._last)
+        return self.gathered
+
+    def _collective(self, dst_buf: torch.Tensor, src: torch.Tensor) -> None:
+        if self.device.type == "cuda" and dist.get_backend() == "gloo":
+            # test hook only (GSWORLD_DIST_BACKEND=gloo, several ranks on one GPU): gloo moves host tensors
+            host = src.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.receives else None
+            if self.collective == "all_gather":
+                dist.all_gather(parts, host)
+            else:
+                dist.gather(host, gather_list=parts, dst=self.dst)
+            if self.receives:
+                dst_buf.copy_(torch.cat(parts))
+            return
+        if self.collective == "all_gather":
+            if self.device.type == "cuda":
+                dist.all_gather_into_tensor(dst_buf, src)
+            else:
+                dist.all_gather(list(dst_buf.view(self.world, *src.shape).unbind(0)), src)
+        else:
+            parts = list(dst_buf.view(self.world, *src.shape).unbind(0)) if self.rank == self.dst else None
+            dist.gather(src, gather_list=parts, dst=self.dst)
+
     def step_done(self, i: int) -> bool:
-        """Call after step ``i`` wrote its slot.  Launches the gather when the batch is full; returns True then."""
+        """Call after step ``i`` wrote its slot.  Launches the collective when the batch is full; returns True then."""
         if (i % self.batch) != self.batch - 1:
             return False
         b = (i // self.batch) % self.buffers
-        src, dst = self._half(b), self._gathered[b]
+        src, dst_buf = self._half(b), self._gathered[b]
         if self.world > 1:
             if self.stream is not None:
                 cur = torch.cuda.current_stream(self.device)
                 self.stream.wait_stream(cur)
                 with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(dst, src)
+                    self._collective(dst_buf, src)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
                 self._done[b] = ev
+                self._last = ev
                 if self.buffers == 1:
                     cur.wait_stream(self.stream)  # the next batch overwrites the same slots
             else:
-                parts = list(dst.view(self.world, *src.shape).unbind(0))
-                dist.all_gather(parts, src)
-        self.gathered = dst
+                self._collective(dst_buf, src)
+        self.gathered = dst_buf
         self.num_gathers += 1
         return True

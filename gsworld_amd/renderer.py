@@ -171,19 +171,24 @@ class MultiCameraRenderer:
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)]
 
-    def render(self, views, means3D, opacities, rgb8_out=None, **render_kw):
+    def render(self, views, means3D, opacities, rgb8_out=None, per_lane=None, **render_kw):
         """``views``: one :class:`gsworld_amd.camera.ViewParams` per camera.  Returns ``[(color, radii, invdepth)]``
         per camera (renderer-owned tensors, overwritten by the next call).  ``rgb8_out``: optional list of (H,W,3)
-        uint8 tensors that receive GSWorld's uint8 frame conversion on the same stream as the frame."""
-        if len(views) != len(self.lanes):
+        uint8 tensors that receive GSWorld's uint8 frame conversion on the same stream as the frame.
+        ``per_lane``: optional list of keyword overrides per lane (``means3D``, ``scales``, ``rotations`` ...): the
+        frames of one step over several ENVIRONMENTS read environment-specific geometry (slice e of the batched fused
+        transform) but share everything the step does not move (SH coefficients, opacity)."""
+        if len(views) != len(self.lanes) or (per_lane is not None and len(per_lane) != len(self.lanes)):
             raise ValueError(f"expected {len(self.lanes)} cameras, got {len(views)}")
         cur = torch.cuda.current_stream(self.device)
         outs = []
         for k, (lane, stream, view) in enumerate(zip(self.lanes, self.streams, views)):
+            kw = render_kw if per_lane is None else {**render_kw, **per_lane[k]}
+            m3d = kw.pop("means3D", means3D) if per_lane is not None else means3D
             stream.wait_stream(cur)  # the step's transformed Gaussians are ready
             with torch.cuda.stream(stream):
-                color, radii, invd = lane.render(view, means3D, opacities,
-                                                 rgb8_out=rgb8_out[k] if rgb8_out is not None else None, **render_kw)
+                color, radii, invd = lane.render(view, m3d, opacities,
+                                                 rgb8_out=rgb8_out[k] if rgb8_out is not None else None, **kw)
             outs.append((color, radii, invd))
         for stream in self.streams:
             cur.wait_stream(stream)  # join: the caller's stream sees every frame

@@ -213,9 +213,21 @@ def sensor_camera(name: str = "xarm6_align", width: int = 640, height: int = 480
     return cam_maniskill2gs(extrinsic_cv, torch.tensor(RS_D435I_RGB_K), width, height, rigid, scale)
 
 
+def dense_view_camera(name: str = "xarm6_align", width: int = 640, height: int = 480, height_m: float = 1.5) -> ViewParams:
+    """A second view of the same scene in which most of it is on screen: straight down on the table centre from
+    ``height_m`` metres (sim frame, mapped by the scene's sim2gs), same intrinsics as the sensor camera.  At 1.5 m the
+    xarm6_align-like scene has V = 0.60 N visible Gaussians -- the ratio SURVEY.md 8d's worked example assumes -- against
+    0.12 N from ``right_cam``, whose frustum holds only the part of the table in front of the robot."""
+    M = (SIM2GS_XARM_TRANS if name.startswith("xarm") else SIM2GS_ARM_TRANS).astype(np.float64)
+    to_gs = lambda p: M[:3, :3] @ np.asarray(p, dtype=np.float64) + M[:3, 3]  # noqa: E731
+    return look_at_view(to_gs([0.5, 0.0, height_m]), to_gs([0.5, 0.0, 0.0]), M[:3, :3] @ np.array([1.0, 0.0, 0.0]),
+                        0.9715089, 0.7551448, width, height)
+
+
 def training_camera(width: int = 800, height: int = 800, fov_deg: float = 60.0) -> ViewParams:
     return identity_camera(width, height, fov_deg)
 
 
 __all__ = ["RawGaussians", "random_scene_camera_frame", "identity_camera", "tabletop_scene", "sensor_camera",
+           "dense_view_camera",
            "training_camera", "SCENE_NAMES", "XARM6_ALIGN_NUM_GAUSSIANS", "look_at_view"]

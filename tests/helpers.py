@@ -77,8 +77,11 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def compare_forward(o, g, st, rgb_tol=RGB_TOL, check_image=True):
-    """Asserts stage-by-stage parity; returns a report dict (counts / max errors)."""
+def compare_forward(o, g, st, rgb_tol=RGB_TOL, check_image=True, all_pixel_tol=0.02):
+    """Asserts stage-by-stage parity; returns a report dict (counts / max errors).  ``all_pixel_tol``: bound on EVERY
+    pixel, borderline ones included (a borderline pixel may flip one alpha >= 1/255 or T >= 1e-4 decision under a
+    1-ulp exp() difference: 0.02 covers the worst case and is kept for fuzz inputs; the BASELINE configurations are held
+    to north_star's 1e-4 on all pixels)."""
     rep = {}
     geom, binning = o["geom"], o["binning"]
     vis = geom["radii"] > 0
@@ -136,7 +139,10 @@ def compare_forward(o, g, st, rgb_tol=RGB_TOL, check_image=True):
     rep["final_T_max_abs"] = float(dT[ok].max()) if ok.any() else 0.0
     assert rep["final_T_max_abs"] <= rgb_tol
     # borderline pixels may flip one contribution: bounded by alpha_min * T * c <= 1/255 (+ termination 1e-4)
-    assert rep["rgb_max_abs_all"] <= 0.02, f"borderline pixel error {rep['rgb_max_abs_all']}"
+    rep["invdepth_max_abs_all"] = float(dd.max())
+    assert rep["rgb_max_abs_all"] <= all_pixel_tol, f"all-pixel RGB error {rep['rgb_max_abs_all']} > {all_pixel_tol}"
+    if all_pixel_tol <= rgb_tol:
+        assert rep["invdepth_max_abs_all"] <= all_pixel_tol * scale, f"all-pixel invdepth {rep['invdepth_max_abs_all']}"
     assert rep["borderline_pixels"] <= max(8, 0.01 * border.size), "too many borderline pixels"
     return rep
 
