@@ -104,8 +104,8 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
             }
         }
         if (st->binning_path < 0 || st->binning_path > 2 || st->render_variant < 0 || st->render_variant > 3 ||
-            st->render_blocks_per_cu < 0 || st->render_blocks_per_cu > 8) {
-            gsr_set_error("gsr_forward: binning_path must be 0..2, render_variant 0..3, render_blocks_per_cu 0..8");
+            st->render_blocks_per_cu < 0 || st->render_blocks_per_cu > 8 || st->depth_sort < 0 || st->depth_sort > 1) {
+            gsr_set_error("gsr_forward: binning_path must be 0..2, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
             return GSR_E_INVALID;
         }
         if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
@@ -182,7 +182,11 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(1, stream);
     if (mode != 2) {
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
-        if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+        if (st->depth_sort == 1) {
+            if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+        } else {
+            if (int e = gsr_launch_sample_depth_sort(in->P, g, debug, stream)) return e;
+        }
     }
     prof_mark(2, stream);
     if (mode == 2) {

@@ -446,38 +446,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void bin_starts_kernel(const uint32_t *_
     gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w);
 }
 
-// Ascending-only bitonic network over `n` keys padded (virtually) to N = 2^k with +inf: every comparator puts the
-// minimum at the lower index, so padding slots never move and need not exist.  256 threads, barrier per stage.
-template <typename Ptr>
-__device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
-    // all sizes are powers of two: index arithmetic with shifts and masks only
-    for (int lk = 1; (1 << lk) <= N; lk++) {
-        const int k = 1 << lk, hk = k >> 1;
-        // flip step: i <-> mirror position inside each block of k
-        for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
-            const int off = p & (hk - 1);
-            const int blk0 = (p >> (lk - 1)) << lk;
-            const int i = blk0 + off, j = blk0 + k - 1 - off;
-            if (j < n) {
-                const uint64_t x = a[i], y = a[j];
-                if (x > y) { a[i] = y; a[j] = x; }
-            }
-        }
-        __syncthreads();
-        for (int ld = lk - 2; ld >= 0; ld--) {
-            const int d = 1 << ld;
-            for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
-                const int i = ((p >> ld) << (ld + 1)) | (p & (d - 1)), j = i + d;
-                if (j < n) {
-                    const uint64_t x = a[i], y = a[j];
-                    if (x > y) { a[i] = y; a[j] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 constexpr int kSortLds = 8192;  // keys held in LDS (64 KiB); longer tile lists are sorted in place in global memory
 
 __global__ __launch_bounds__(GSR_BLOCK) void tile_sort_kernel(const uint2 *__restrict__ ranges,

@@ -1,0 +1,427 @@
+// depthsort.hip -- depth order of the visible Gaussians in THREE launches (upstream: the depth half of
+// cub::DeviceRadixSort::SortPairs over the 64-bit (tile | depth) keys, rasterizer_impl.cu).
+//
+// What is sorted: V (depth bits, Gaussian index) records, ascending depth bits, ties by ascending index -- the order the
+// reference's stable key sort leaves inside every tile.  At config 2 V = 175 k: 1.4 MB, a problem of LATENCY, not
+// bandwidth.  The 3-pass LSD radix sort of round 1 (sort.hip: compaction + 3 x (histogram, row scan, scatter) = 10
+// launches of ~86 workgroups each) spent 95 us on it, 1 % of the HBM roofline.  Here a sample sort:
+//
+//   ss_compact   index-ordered compaction of the visible (key, index) records (per-workgroup offsets by redundant
+//                sums of the per-block counts preprocess left), AND, in the same pass: every workgroup sorts the same
+//                <= 4096 sampled keys in LDS, cuts them into B - 1 splitters, classifies its records by binary search
+//                and leaves its bucket histogram
+//   ss_partition every workgroup sums the histogram rows before its own (no scan kernel), then moves ITS segment into
+//                the buckets, stably (wave64 match-any ranks, as the radix scatter)
+//   ss_buckets   one workgroup per bucket: stable LSD radix sort in LDS on the bits that actually differ inside the
+//                bucket (typically 2 passes of 8 bits), result = the bare Gaussian indices in `order`
+//
+// Stability (index order on equal keys) is kept end to end: compaction in index order, stable partition, stable LSD
+// passes.  Samples are the first visible key of every preprocess block (256 Gaussians), thinned evenly to S; splitters
+// carry the top 24 key bits only, so records with equal depth never straddle a bucket boundary by accident of the
+// sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a bucket averages <= 512 records.
+// A bucket that does not fit the LDS (bad luck or adversarial depths: > 3584 records) is sorted by the same workgroup
+// in global memory with a bitonic network over the (key << 32 | index) composites -- slow, correct, never seen on
+// the BASELINE scenes.
+#include "gsr_internal.h"
+
+namespace {
+
+constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
+constexpr int kSamplesPerBucket = 4;
+constexpr int kMaxSamples = 4096;
+constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
+
+__device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
+    int B = 256;
+    while (B < bmax && (uint32_t)B * 512u < V) B <<= 1;
+    return B;
+}
+__device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
+
+// number of splitters <= tkey among split[0 .. B-2]  (split is ascending; B is a power of two)
+__device__ __forceinline__ uint32_t ss_bucket(const uint32_t *split, int B, uint32_t tkey) {
+    uint32_t lo = 0;
+    for (int step = B >> 1; step > 0; step >>= 1) {
+        const uint32_t probe = lo + (uint32_t)step;  // candidate count: splitters [0, probe) all <= tkey ?
+        if (split[probe - 1u] <= tkey) lo = probe;
+    }
+    return lo;  // in [0, B-1]  (split[B-1] is never probed: probe - 1 <= B - 2)
+}
+
+// wave64 match-any on the low `nbits` of d among the valid lanes: returns the mask of lanes holding the same value
+__device__ __forceinline__ uint64_t ss_match(uint32_t d, int nbits, bool valid) {
+    uint64_t same = __builtin_amdgcn_ballot_w64(valid);
+    for (int b = 0; b < nbits; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
+        same &= bit ? bal : ~bal;
+    }
+    return same;
+}
+
+// One stable LSD pass (8-bit digit at `shift`) over n records held in LDS.  Wave w owns the contiguous quarter
+// [w q, (w+1) q): counts per wave, cursors = digit start + earlier waves, then barrier-free ranking rounds (LDS
+// operations of one wave retire in order).  s_cur: 4 x 256 words, s_w: 4 words.
+template <bool PAIRS>
+__device__ __forceinline__ void lds_radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+                                               int n, int shift, uint32_t *s_cur, uint32_t *s_w) {
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
+    const int q = (((n + 3) >> 2) + 63) & ~63;
+    const int rounds = q >> 6, lo = wave * q;
+    const uint64_t lt = gsr_lanemask_lt();
+    for (int i = tid; i < 4 * 256; i += kT) s_cur[i] = 0u;
+    __syncthreads();
+    for (int r = 0; r < rounds; r++) {
+        const int i = lo + (r << 6) + lane;
+        if (i < n) atomicAdd(&s_cur[wave * 256 + (int)((kin[i] >> shift) & 255u)], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = s_cur[tid], c1 = s_cur[256 + tid], c2 = s_cur[512 + tid], c3 = s_cur[768 + tid];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t all;
+        const uint32_t excl = gsr_block_incl_scan(tot, s_w, all) - tot;
+        s_cur[tid] = excl;
+        s_cur[256 + tid] = excl + c0;
+        s_cur[512 + tid] = excl + c0 + c1;
+        s_cur[768 + tid] = excl + c0 + c1 + c2;
+    }
+    __syncthreads();
+    uint32_t *cur = s_cur + wave * 256;
+    for (int r = 0; r < rounds; r++) {
+        const int i = lo + (r << 6) + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? kin[i] : 0u;
+        const uint32_t val = (PAIRS && valid) ? vin[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        const uint64_t same = ss_match(d, 8, valid);
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        if (valid) {
+            const uint32_t pos = cur[d] + rank;
+            kout[pos] = key;
+            if (PAIRS) vout[pos] = val;
+        }
+        __builtin_amdgcn_wave_barrier();  // every lane has read its cursor before the group leader moves it
+        if (valid && rank == 0u) cur[d] += (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_compact: compaction + sampling + classification.  Workgroup b owns the preprocess blocks [b bpw, (b+1) bpw).
+// records are written as (index, key): the 64-bit little-endian view is key << 32 | index, the composite the
+// global-memory fallback of ss_buckets sorts.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw, int bmax,
+                                                        const uint32_t *__restrict__ vis_key,
+                                                        const uint32_t *__restrict__ block_counts,
+                                                        const uint32_t *__restrict__ block_cand,
+                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ splitters,
+                                                        uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_key = smem;                       // [2][kMaxSamples]
+    uint32_t *s_cur = s_key + 2 * kMaxSamples;    // [4][256]
+    uint32_t *s_split = s_cur + 4 * 256;          // [bmax]
+    uint32_t *s_hist = s_split + bmax;            // [bmax]
+    uint32_t *s_boff = s_hist + bmax;             // [bpw + 1]
+    __shared__ uint32_t s_w[4];
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
+    const int first = (int)blockIdx.x * bpw, nblk = max(0, min(nb1, first + bpw) - first);
+
+    // ---- V, this workgroup's first output slot, and the rank of every block among the blocks that have a sample
+    const int per = (nb1 + kT - 1) / kT;
+    const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
+    uint32_t all = 0, before = 0, valid_cnt = 0;
+    for (int j = j0; j < j1; j++) {
+        const uint32_t c = block_counts[j];
+        all += c;
+        if (j < first) before += c;
+        valid_cnt += c != 0u ? 1u : 0u;
+    }
+    uint32_t V, m, dummy;
+    (void)gsr_block_incl_scan(all, s_w, V);
+    before = gsr_block_incl_scan(before, s_w, dummy);  // inclusive over threads ...
+    before = dummy;                                     // ... the total is what is wanted
+    const uint32_t vrank0 = gsr_block_incl_scan(valid_cnt, s_w, m) - valid_cnt;
+    if (blockIdx.x == 0 && tid == 0) {  // first kernel of the frame that touches the header
+        hdr->V = V;
+        hdr->R = 0u;
+        hdr->overflow = 0u;
+        hdr->r_capacity = 0u;
+        hdr->R_raw = 0u;
+        hdr->tile_queue = 0u;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) seg_off[gridDim.x] = V;
+    if (tid == 0) seg_off[blockIdx.x] = before;
+    if (V == 0u) return;
+
+    // ---- samples: the valid block candidates, thinned evenly to S; top 24 key bits only
+    const int B = ss_num_buckets(V, bmax);
+    const uint32_t S = (uint32_t)min(kMaxSamples, kSamplesPerBucket * B);
+    const uint32_t S_eff = min(S, m);
+    {
+        uint32_t r = vrank0;
+        for (int j = j0; j < j1; j++) {
+            if (block_counts[j] == 0u) continue;
+            uint32_t slot = r;
+            bool take = true;
+            if (m > S) {
+                slot = (uint32_t)(((uint64_t)r * S) / m);
+                take = r == 0u || (uint32_t)(((uint64_t)(r - 1u) * S) / m) != slot;
+            }
+            if (take) s_key[slot] = block_cand[j] & 0xFFFFFF00u;
+            r++;
+        }
+    }
+    __syncthreads();
+    lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S_eff, 8, s_cur, s_w);
+    lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S_eff, 16, s_cur, s_w);
+    lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S_eff, 24, s_cur, s_w);
+    const uint32_t *sorted = s_key + kMaxSamples;
+    for (int i = tid; i < B; i += kT) {
+        const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S_eff) / (uint32_t)B);
+        const uint32_t sp = (i < B - 1 && q < S_eff) ? sorted[q] : 0xFFFFFFFFu;
+        s_split[i] = sp;
+        s_hist[i] = 0u;
+        if (blockIdx.x == 0) splitters[i] = sp;
+    }
+    // ---- exclusive offsets of this workgroup's blocks (bpw <= 1024: four consecutive blocks per thread)
+    {
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = tid * 4 + k;
+            c[k] = j < nblk ? block_counts[first + j] : 0u;
+            sum += c[k];
+        }
+        uint32_t tot;
+        uint32_t run = gsr_block_incl_scan(sum, s_w, tot) - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = tid * 4 + k;
+            if (j <= nblk) s_boff[j] = run;
+            run += c[k];
+        }
+        if (tid == kT - 1 && nblk == 4 * kT) s_boff[nblk] = run;
+    }
+    __syncthreads();
+    // ---- the walk: one wave per block of 256 Gaussians, no workgroup barrier inside
+    for (int k = wave; k < nblk; k += kT / GSR_WAVE) {
+        const uint32_t b0 = s_boff[k];
+        if (s_boff[k + 1] == b0) continue;  // nothing visible in this block
+        const int base_i = (first + k) * GSR_BLOCK;
+        uint32_t key[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = base_i + r * GSR_WAVE + lane;
+            key[r] = i < P ? vis_key[i] : 0u;
+        }
+        uint32_t pos = before + b0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool vis = key[r] != 0u;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
+            if (vis) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[r]);
+                atomicAdd(&s_hist[ss_bucket(s_split, B, key[r] & 0xFFFFFF00u)], 1u);
+            }
+            pos += (uint32_t)__popcll(mask);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < B; i += kT) table[(size_t)blockIdx.x * bmax + i] = s_hist[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_partition: bucket starts from the histogram rows, then the stable move of this workgroup's segment.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 *__restrict__ in,
+                                                          uint2 *__restrict__ out, const uint32_t *__restrict__ table,
+                                                          const uint32_t *__restrict__ splitters,
+                                                          const uint32_t *__restrict__ seg_off,
+                                                          uint32_t *__restrict__ bucket_start,
+                                                          const GsrHeader *__restrict__ hdr) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_split = smem;            // [bmax]
+    uint32_t *s_run = s_split + bmax;    // [bmax]  next free slot of every bucket for this workgroup
+    uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
+    __shared__ uint32_t s_w[4];
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
+    const uint32_t V = hdr->V;
+    if (V == 0u) return;
+    const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
+    const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
+    {
+        uint32_t tot[8], mine[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) tot[k] = mine[k] = 0u;
+        for (int r = 0; r < nbc; r++) {
+            const uint32_t *row = table + (size_t)r * bmax + tid * PER;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < PER) {
+                    const uint32_t c = row[k];
+                    tot[k] += c;
+                    if (r < me) mine[k] += c;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += tot[k];
+        uint32_t all;
+        uint32_t run = gsr_block_incl_scan(sum, s_w, all) - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < PER) {
+                const int d = tid * PER + k;
+                s_run[d] = run + mine[k];
+                s_split[d] = splitters[d];
+                if (me == 0) bucket_start[d] = run;
+                run += tot[k];
+            }
+        if (me == 0 && tid == 0) bucket_start[B] = V;
+    }
+    const uint32_t s0 = seg_off[me], s1 = seg_off[me + 1];
+    const uint64_t lt = gsr_lanemask_lt();
+    for (uint32_t tile = s0; tile < s1; tile += 4u * kT) {
+        for (int i = tid; i < 4 * B; i += kT) s_cnt[(i >> nbits) * bmax + (i & (B - 1))] = 0u;
+        __syncthreads();  // (also: s_run / s_split of the set-up above, cursors of the previous tile)
+        uint32_t idx[4], key[4], dig[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
+            const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
+            idx[r] = rec.x;
+            key[r] = rec.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
+            dig[r] = 0u;
+            if (i < s1) {
+                dig[r] = ss_bucket(s_split, B, key[r] & 0xFFFFFF00u);
+                atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < PER) {
+                const int d = tid * PER + k;
+                const uint32_t c0 = s_cnt[d], c1 = s_cnt[bmax + d], c2 = s_cnt[2 * bmax + d], c3 = s_cnt[3 * bmax + d];
+                const uint32_t start = s_run[d];
+                s_cnt[d] = start;
+                s_cnt[bmax + d] = start + c0;
+                s_cnt[2 * bmax + d] = start + c0 + c1;
+                s_cnt[3 * bmax + d] = start + c0 + c1 + c2;
+                s_run[d] = start + c0 + c1 + c2 + c3;
+            }
+        __syncthreads();
+        uint32_t *cur = s_cnt + wave * bmax;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
+            const bool valid = i < s1;
+            const uint64_t same = ss_match(dig[r], nbits, valid);
+            const uint32_t rank = (uint32_t)__popcll(same & lt);
+            if (valid) out[cur[dig[r]] + rank] = make_uint2(idx[r], key[r]);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0u) cur[dig[r]] += (uint32_t)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_buckets: one workgroup per bucket.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs,
+                                                        const uint32_t *__restrict__ bucket_start,
+                                                        uint32_t *__restrict__ order,
+                                                        const GsrHeader *__restrict__ hdr) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_k = smem;                      // [2][kBucketCap]
+    uint32_t *s_v = s_k + 2 * kBucketCap;      // [2][kBucketCap]
+    uint32_t *s_cur = s_v + 2 * kBucketCap;    // [4][256]
+    __shared__ uint32_t s_w[4];
+    const int tid = (int)threadIdx.x;
+    const uint32_t V = hdr->V;
+    if (V == 0u) return;
+    const int B = ss_num_buckets(V, bmax);
+    if ((int)blockIdx.x >= B) return;
+    const uint32_t s = bucket_start[blockIdx.x];
+    const int n = (int)(bucket_start[blockIdx.x + 1] - s);
+    if (n == 0) return;
+    uint2 *seg = recs + s;
+    if (n > kBucketCap) {
+        // does not fit the LDS: bitonic network over the (key << 32 | index) composites in global memory (one
+        // workgroup, barriers order the stages); unique composites, so the result is the stable order
+        int N = 2;
+        while (N < n) N <<= 1;
+        uint64_t *comp = reinterpret_cast<uint64_t *>(seg);
+        __syncthreads();
+        bitonic_sort_block(comp, n, N);
+        for (int i = tid; i < n; i += kT) order[s + i] = (uint32_t)comp[i];
+        return;
+    }
+    const uint32_t key0 = seg[0].y;
+    uint32_t diff = 0;
+    for (int i = tid; i < n; i += kT) {
+        const uint2 r = seg[i];
+        s_v[i] = r.x;
+        s_k[i] = r.y;
+        diff |= r.y ^ key0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o, 64);
+    if (gsr_lane() == 0) s_w[gsr_wave()] = diff;
+    __syncthreads();
+    diff = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+    __syncthreads();
+    const int bits = diff == 0u ? 0 : 32 - __builtin_clz(diff);
+    int src = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
+                             s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
+        src ^= 1;
+    }
+    for (int i = tid; i < n; i += kT) order[s + i] = s_v[src * kBucketCap + i];
+}
+
+}  // namespace
+
+// geometry of the sample sort for P Gaussians: compaction workgroups, preprocess blocks per workgroup, bucket capacity
+int gsr_ss_nbc(int32_t P) {
+    const int nb1 = GeomState::prep_blocks(P);
+    int nbc = gsr_div_up(nb1, 8);
+    if (nbc > 128) nbc = 128;
+    const int need = gsr_div_up(nb1, 1024);  // at most 1024 blocks per workgroup (LDS offsets)
+    return nbc > need ? nbc : need;
+}
+int gsr_ss_bmax(int32_t P) {
+    int b = 256;
+    while (b < 2048 && (int64_t)b * 512 < (int64_t)P) b <<= 1;
+    return b;
+}
+
+// preprocess left vis_key / block_counts / block_cand; the sorted depth order ends in g.order
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
+    const int nb1 = GeomState::prep_blocks(P);
+    const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
+    const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + bpw + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
+                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr);
+    if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
+    const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc), dim3(kT), lds2, stream, bmax, g.pair[0], g.pair[1], g.ss_table,
+                       g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr);
+    if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
+    const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
+                       g.order, g.hdr);
+    return gsr_check_launch("ss_buckets", debug, stream);
+}

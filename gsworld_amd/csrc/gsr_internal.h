@@ -35,6 +35,10 @@ static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 static inline size_t gsr_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int gsr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// sample sort geometry (depthsort.hip): compaction workgroups and bucket capacity for P Gaussians
+int gsr_ss_nbc(int32_t P);
+int gsr_ss_bmax(int32_t P);
+
 // ---- geometry state (per Gaussian) -------------------------------------------------------------------
 struct GeomState {
     GsrHeader *hdr;
@@ -55,6 +59,13 @@ struct GeomState {
     uint32_t *tile_bsum;      // [nb+1] tiles touched per 2048 depth-ordered Gaussians -> exclusive offsets
     uint32_t *tile_table;     // [tiles * prep_blocks]  per-workgroup tile histograms (counting placement)
     uint32_t *tile_totals;    // [tiles]
+    // sample sort of the depth keys (depthsort.hip)
+    uint32_t *vis_key;        // [P]   depth bits of a visible Gaussian, 0 otherwise
+    uint32_t *block_cand;     // [ceil(P/256)]  depth bits of the first visible Gaussian of every preprocess block
+    uint32_t *ss_table;       // [nbc * bmax]   bucket histogram of every compaction workgroup
+    uint32_t *ss_splitters;   // [bmax]
+    uint32_t *ss_bucket_start;// [bmax + 1]
+    uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -90,6 +101,12 @@ struct GeomState {
         const size_t tt = counting(tiles) ? (size_t)tiles : 0;
         g.tile_table = take<uint32_t>(p, tt * prep_blocks(P) + 1);
         g.tile_totals = take<uint32_t>(p, tt + 1);
+        g.vis_key = take<uint32_t>(p, n);
+        g.block_cand = take<uint32_t>(p, (size_t)prep_blocks(P));
+        g.ss_table = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) * gsr_ss_bmax(P));
+        g.ss_splitters = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
+        g.ss_bucket_start = take<uint32_t>(p, (size_t)gsr_ss_bmax(P) + 1);
+        g.ss_seg = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) + 1);
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
@@ -201,6 +218,7 @@ int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const Image
 int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
@@ -361,6 +379,37 @@ __device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[
     for (int i = 0; i < 8; i++) {
         const int t = (int)threadIdx.x + i * GSR_BLOCK;
         if (t < num_tiles) order[atomicAdd(&s_bins[63 - (int)((float)key[i] * scale)], 1u)] = (uint32_t)t;
+    }
+}
+// Ascending-only bitonic network over `n` keys padded (virtually) to N = 2^k with +inf: every comparator puts the
+// minimum at the lower index, so padding slots never move and need not exist.  256 threads, barrier per stage.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
+    // all sizes are powers of two: index arithmetic with shifts and masks only
+    for (int lk = 1; (1 << lk) <= N; lk++) {
+        const int k = 1 << lk, hk = k >> 1;
+        // flip step: i <-> mirror position inside each block of k
+        for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
+            const int off = p & (hk - 1);
+            const int blk0 = (p >> (lk - 1)) << lk;
+            const int i = blk0 + off, j = blk0 + k - 1 - off;
+            if (j < n) {
+                const uint64_t x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (int ld = lk - 2; ld >= 0; ld--) {
+            const int d = 1 << ld;
+            for (int p = (int)threadIdx.x; p < (N >> 1); p += GSR_BLOCK) {
+                const int i = ((p >> ld) << (ld + 1)) | (p & (d - 1)), j = i + d;
+                if (j < n) {
+                    const uint64_t x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 #endif  // __HIPCC__

@@ -26,6 +26,8 @@ struct PreprocessArgs {
     uint32_t *tiles_touched;
     uint2 *rects;
     uint32_t *block_counts;
+    uint32_t *vis_key;     // depth bits of a visible Gaussian, else 0 (depthsort.hip reads this instead of 48-B records)
+    uint32_t *block_cand;  // depth bits of the block's first visible Gaussian (sort sample)
     // bin-then-sort path: per-tile instance totals and the visible count are accumulated here
     int num_tiles;
     uint32_t *tile_accum;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
     const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
     bool visible = false;
     float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);  // xyz + radius, handed to the colour phase
-    uint32_t my_tiles = 0;
+    uint32_t my_tiles = 0, my_key = 0;
     uint2 my_rect = make_uint2(0u, 0u);
     if (COUNT_TILES) {
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         }
         a.radii[i] = radius;
         a.tiles_touched[i] = touched;
+        my_key = visible ? __float_as_uint(vz) : 0u;  // (vz > near_plane > 0: never the 0 pattern)
+        a.vis_key[i] = my_key;
     }
     // ---- phase 2: colour, on the block-compacted list of survivors ------------------------------------------
     // Typically only a fraction of the 256 lanes survive cull + rect; evaluating the SH (48 loads + ~110 VALU per
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
     if (visible) {
         s_pos[incl - 1u] = mypos;
         s_idx[incl - 1u] = i;
+        if (incl == 1u) a.block_cand[blockIdx.x] = my_key;
     }
     if (threadIdx.x == 0) {
         a.block_counts[blockIdx.x] = cnt;  // consumed by the index-ordered compaction (depth-sorted paths)
@@ -364,6 +369,8 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.tiles_touched = g.tiles_touched;
     a.rects = g.rects;
     a.block_counts = g.block_counts;
+    a.vis_key = g.vis_key;
+    a.block_cand = g.block_cand;
     a.num_tiles = a.gx * a.gy;
     a.tile_accum = g.tile_accum;
     a.hdr = g.hdr;

@@ -18,6 +18,13 @@ def set_binning_mode(mode: int) -> None:
     _lib.TUNING["binning_path"] = {1: 0, 0: 1, 2: 2}[mode]
 
 
+def set_depth_sort(variant: int) -> None:
+    """A/B and tests: 0 = sample sort (default), 1 = 3-pass LSD radix sort of the visible Gaussians."""
+    if variant not in (0, 1):
+        raise ValueError("depth sort variant must be 0 or 1")
+    _lib.TUNING["depth_sort"] = variant
+
+
 def set_render_variant(variant: int, blocks_per_cu: int = 0) -> None:
     """A/B and tests: 4 = wave-decoupled culling kernel (default), 0 = LDS-staged per tile (upstream's structure),
     2 = batched tile kernel, 3 = the same with per-quadrant culling; ``blocks_per_cu`` 1..8 sizes the persistent grid

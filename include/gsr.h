@@ -65,6 +65,9 @@ typedef struct GsrSettings {
     int32_t binning_path;
     int32_t render_variant;
     int32_t render_blocks_per_cu;
+    /* depth_sort: 0 = sample sort (3 launches: compaction + classification, stable partition, per-bucket LDS radix),
+     *   1 = 3-pass LSD radix sort over all visible Gaussians (10 launches).  Same depth order. */
+    int32_t depth_sort;
 } GsrSettings;
 
 typedef struct GsrInputs {

