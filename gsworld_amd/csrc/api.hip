@@ -278,6 +278,22 @@ int gsr_profile_collect(GsrProfile *out) {
     return GSR_OK;
 }
 
+// Tuning aid (libraries built with -DGSR_SS_TIMING): the 64 cycle stamps the depth-sort kernels left in the geometry
+// state.  Synchronises the device.
+int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *geom, uint64_t *out64) {
+    if (!geom || !out64) {
+        gsr_set_error("gsr_debug_ss_stamps: null argument");
+        return GSR_E_INVALID;
+    }
+    const GeomState g = GeomState::carve((char *)geom, P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE));
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(out64, g.ss_dbg, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        gsr_set_error("gsr_debug_ss_stamps: copy failed");
+        return GSR_E_HIP;
+    }
+    return GSR_OK;
+}
+
 int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream_) {
     if (!geom || !stats) {
         gsr_set_error("gsr_frame_stats: null argument");

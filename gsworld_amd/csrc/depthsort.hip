@@ -26,9 +26,17 @@
 
 namespace {
 
+#ifdef GSR_SS_TIMING
+#define SS_STAMP(buf, slot) do { __syncthreads(); if (blockIdx.x == (buf##_wg) && threadIdx.x == 0) (buf)[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SS_STAMP(buf, slot) do { } while (0)
+#endif
+
 constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
-constexpr int kSamplesPerBucket = 4;
+constexpr int kSamplesPerBucket = 2;
 constexpr int kMaxSamples = 4096;
+constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'
+constexpr uint32_t kReuseMaxSamples = 4 * kSamplesPerBucket;  // sample count per bucket that still passes for balanced
 constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
@@ -46,6 +54,25 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint32_t *split, int B, uint
         if (split[probe - 1u] <= tkey) lo = probe;
     }
     return lo;  // in [0, B-1]  (split[B-1] is never probed: probe - 1 <= B - 2)
+}
+
+// the same for W keys at once: W independent probe chains per step instead of W searches one after the other
+// (a search is log2(B) DEPENDENT LDS round trips; nothing else in these kernels costs as much)
+template <int W>
+__device__ __forceinline__ void ss_bucketN(const uint32_t *split, int B, const uint32_t (&tkey)[W], uint32_t (&out)[W]) {
+    uint32_t lo[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) lo[u] = 0u;
+    for (int step = B >> 1; step > 0; step >>= 1) {
+        uint32_t pv[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) pv[u] = split[lo[u] + (uint32_t)step - 1u];
+#pragma unroll
+        for (int u = 0; u < W; u++)
+            if (pv[u] <= tkey[u]) lo[u] += (uint32_t)step;
+    }
+#pragma unroll
+    for (int u = 0; u < W; u++) out[u] = lo[u];
 }
 
 // wave64 match-any on the low `nbits` of d among the valid lanes: returns the mask of lanes holding the same value
@@ -119,8 +146,11 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                                                         const uint32_t *__restrict__ block_cand,
                                                         uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ splitters,
-                                                        uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr) {
+                                                        uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
+                                                        uint64_t *__restrict__ dbg) {
     extern __shared__ uint32_t smem[];
+    const unsigned dbg_wg = 64; (void)dbg_wg;
+    SS_STAMP(dbg, 0);
     uint32_t *s_key = smem;                       // [2][kMaxSamples]
     uint32_t *s_cur = s_key + 2 * kMaxSamples;    // [4][256]
     uint32_t *s_split = s_cur + 4 * 256;          // [bmax]
@@ -130,21 +160,24 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const int first = (int)blockIdx.x * bpw, nblk = max(0, min(nb1, first + bpw) - first);
 
-    // ---- V, this workgroup's first output slot, and the rank of every block among the blocks that have a sample
-    const int per = (nb1 + kT - 1) / kT;
-    const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
-    uint32_t all = 0, before = 0, valid_cnt = 0;
-    for (int j = j0; j < j1; j++) {
-        const uint32_t c = block_counts[j];
-        all += c;
-        if (j < first) before += c;
-        valid_cnt += c != 0u ? 1u : 0u;
+    // ---- V and this workgroup's first output slot: every workgroup adds up the per-block counts itself (coalesced,
+    // eight independent loads per thread and step; no scan kernel in front)
+    uint32_t all = 0, before = 0;
+    for (int j = tid; j < nb1; j += 8 * kT) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = j + u * kT < nb1 ? block_counts[j + u * kT] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            all += c[u];
+            if (j + u * kT < first) before += c[u];
+        }
     }
-    uint32_t V, m, dummy;
+    SS_STAMP(dbg, 1);
+    uint32_t V, dummy;
     (void)gsr_block_incl_scan(all, s_w, V);
-    before = gsr_block_incl_scan(before, s_w, dummy);  // inclusive over threads ...
-    before = dummy;                                     // ... the total is what is wanted
-    const uint32_t vrank0 = gsr_block_incl_scan(valid_cnt, s_w, m) - valid_cnt;
+    (void)gsr_block_incl_scan(before, s_w, dummy);
+    before = dummy;  // block total of the partial sums
     if (blockIdx.x == 0 && tid == 0) {  // first kernel of the frame that touches the header
         hdr->V = V;
         hdr->R = 0u;
@@ -157,36 +190,79 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     if (tid == 0) seg_off[blockIdx.x] = before;
     if (V == 0u) return;
 
-    // ---- samples: the valid block candidates, thinned evenly to S; top 24 key bits only
+    // ---- samples: S preprocess blocks spread evenly over the model; a block contributes the key of its first visible
+    // Gaussian (top 24 bits), a block without one contributes nothing (key 0xFFFFFF00 -- no depth has that pattern --
+    // sorts behind every real sample).  Two batches of independent loads, no ranks, no compaction.
     const int B = ss_num_buckets(V, bmax);
-    const uint32_t S = (uint32_t)min(kMaxSamples, kSamplesPerBucket * B);
-    const uint32_t S_eff = min(S, m);
+    const uint32_t S = (uint32_t)min(min(kMaxSamples, kSamplesPerBucket * B), max(nb1, 1));
+    uint32_t present = 0;
     {
-        uint32_t r = vrank0;
-        for (int j = j0; j < j1; j++) {
-            if (block_counts[j] == 0u) continue;
-            uint32_t slot = r;
-            bool take = true;
-            if (m > S) {
-                slot = (uint32_t)(((uint64_t)r * S) / m);
-                take = r == 0u || (uint32_t)(((uint64_t)(r - 1u) * S) / m) != slot;
+        constexpr int kPer = kMaxSamples / kT;  // 16 sample slots per thread at most
+        const float blocks_per_sample = (float)nb1 / (float)S;  // (which block exactly does not matter)
+        uint32_t cnt[kPer], cand[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            const uint32_t sl = (uint32_t)(tid + u * kT);
+            const int j = min(nb1 - 1, (int)((float)sl * blocks_per_sample));
+            cnt[u] = sl < S ? block_counts[j] : 0u;
+            cand[u] = sl < S ? block_cand[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            const uint32_t sl = (uint32_t)(tid + u * kT);
+            if (sl < S) {
+                s_key[sl] = cnt[u] != 0u ? (cand[u] & 0xFFFFFF00u) : 0xFFFFFF00u;
+                present += cnt[u] != 0u ? 1u : 0u;
             }
-            if (take) s_key[slot] = block_cand[j] & 0xFFFFFF00u;
-            r++;
+        }
+    }
+    uint32_t S_eff;
+    (void)gsr_block_incl_scan(present, s_w, S_eff);
+    SS_STAMP(dbg, 2);
+    __syncthreads();
+    // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
+    // previous frame usually still cut THIS frame's samples evenly.  Check that (the table must be ascending -- a fresh
+    // state holds garbage -- and no bucket may draw more than kReuseMaxSamples of the samples) and skip the sample sort
+    // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
+    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S_eff >= (uint32_t)B;
+    if (reuse) {
+        uint32_t bad = 0;
+        for (int i = tid; i < B; i += kT) {
+            const uint32_t sp = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
+            s_split[i] = sp;
+            s_hist[i] = 0u;
+            if (i + 1 < B - 1 && splitters[i + 1] < sp) bad = 1u;
+        }
+        __syncthreads();
+        for (uint32_t i0 = (uint32_t)tid; i0 < S; i0 += 4u * kT) {
+            uint32_t tk[4], bk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) tk[u] = i0 + (uint32_t)(u * kT) < S ? s_key[i0 + (uint32_t)(u * kT)] : 0xFFFFFF00u;
+            ss_bucketN<4>(s_split, B, tk, bk);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (tk[u] != 0xFFFFFF00u) atomicAdd(&s_hist[bk[u]], 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < B; i += kT)
+            if (s_hist[i] > kReuseMaxSamples) bad = 1u;
+        reuse = __syncthreads_or((int)bad) == 0;
+    }
+    if (!reuse) {
+        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 8, s_cur, s_w);
+        lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 16, s_cur, s_w);
+        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
+        const uint32_t *sorted = s_key + kMaxSamples;
+        for (int i = tid; i < B; i += kT) {
+            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S_eff) / (uint32_t)B);
+            const uint32_t sp = (i < B - 1 && q < S_eff) ? sorted[q] : 0xFFFFFFFFu;
+            s_split[i] = sp;
+            if (blockIdx.x == 0) splitters[i] = sp;
         }
     }
     __syncthreads();
-    lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S_eff, 8, s_cur, s_w);
-    lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S_eff, 16, s_cur, s_w);
-    lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S_eff, 24, s_cur, s_w);
-    const uint32_t *sorted = s_key + kMaxSamples;
-    for (int i = tid; i < B; i += kT) {
-        const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S_eff) / (uint32_t)B);
-        const uint32_t sp = (i < B - 1 && q < S_eff) ? sorted[q] : 0xFFFFFFFFu;
-        s_split[i] = sp;
-        s_hist[i] = 0u;
-        if (blockIdx.x == 0) splitters[i] = sp;
-    }
+    for (int i = tid; i < B; i += kT) s_hist[i] = 0u;
+    SS_STAMP(dbg, 3);
     // ---- exclusive offsets of this workgroup's blocks (bpw <= 1024: four consecutive blocks per thread)
     {
         uint32_t c[4], sum = 0;
@@ -207,33 +283,94 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         if (tid == kT - 1 && nblk == 4 * kT) s_boff[nblk] = run;
     }
     __syncthreads();
-    // ---- the walk: one wave per block of 256 Gaussians, no workgroup barrier inside
-    for (int k = wave; k < nblk; k += kT / GSR_WAVE) {
-        const uint32_t b0 = s_boff[k];
-        if (s_boff[k + 1] == b0) continue;  // nothing visible in this block
-        const int base_i = (first + k) * GSR_BLOCK;
-        uint32_t key[4];
+    SS_STAMP(dbg, 4);
+    // ---- the walk: one wave per block of 256 Gaussians, no workgroup barrier inside.  A wave requests the keys of
+    // its next kWalk blocks in one go (4 kWalk loads in flight per lane) and only then ranks them: a wave is a chain of
+    // HBM round trips otherwise.
+    {
+        constexpr int NW = kT / GSR_WAVE, kWalk = 6;
+        for (int k0 = wave; k0 < nblk; k0 += NW * kWalk) {
+            uint32_t key[kWalk][4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int i = base_i + r * GSR_WAVE + lane;
-            key[r] = i < P ? vis_key[i] : 0u;
-        }
-        uint32_t pos = before + b0;
+            for (int w = 0; w < kWalk; w++) {
+                const int k = k0 + w * NW;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const bool vis = key[r] != 0u;
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
-            if (vis) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[r]);
-                atomicAdd(&s_hist[ss_bucket(s_split, B, key[r] & 0xFFFFFF00u)], 1u);
+                for (int r = 0; r < 4; r++) {
+                    const int i = (first + k) * GSR_BLOCK + r * GSR_WAVE + lane;
+                    key[w][r] = (k < nblk && i < P) ? vis_key[i] : 0u;
+                }
             }
-            pos += (uint32_t)__popcll(mask);
+#pragma unroll
+            for (int w = 0; w < kWalk; w++) {
+                const int k = k0 + w * NW;
+                if (k >= nblk) break;
+                const int base_i = (first + k) * GSR_BLOCK;
+                uint32_t pos = before + s_boff[k];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool vis = key[w][r] != 0u;
+                    const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
+                    if (vis) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[w][r]);
+                    }
+                    pos += (uint32_t)__popcll(mask);
+                }
+            }
         }
     }
+    SS_STAMP(dbg, 5);
+    __syncthreads();  // this workgroup's records are written: visible to all of its threads
+    // ---- classification, dense: every thread takes eight records of the segment per step (only ~12 % of the lanes of
+    // the walk hold a visible Gaussian -- searching there would run one serial search per 64 Gaussians)
+    {
+        const uint32_t seg0 = before, seg1 = before + s_boff[nblk];
+        for (uint32_t i0 = seg0 + (uint32_t)tid; i0 < seg1; i0 += 8u * kT) {
+            uint32_t tk[8], bk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + (uint32_t)(u * kT);
+                tk[u] = i < seg1 ? (pairs[i].y & 0xFFFFFF00u) : 0u;
+            }
+            ss_bucketN<8>(s_split, B, tk, bk);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + (uint32_t)(u * kT) < seg1) atomicAdd(&s_hist[bk[u]], 1u);
+        }
+    }
+    SS_STAMP(dbg, 6);
     __syncthreads();
     for (int i = tid; i < B; i += kT) table[(size_t)blockIdx.x * bmax + i] = s_hist[i];
+    SS_STAMP(dbg, 7);
+}
+
+// Partial column sums of the histogram rows this wave owns (rows wave*RS + [0, RS), + 4 RS, ...): lane l covers the
+// 4 NV buckets [4 NV l, 4 NV (l + 1)) of a row with NV 16-byte loads; 16 loads are in flight per step.
+template <int NV>
+__device__ __forceinline__ void ss_column_sums(const uint32_t *__restrict__ table, int bmax, int nbc, int me, int wave,
+                                               int lane, uint32_t (&tot)[32], uint32_t (&mine)[32]) {
+    constexpr int RS = 16 / NV;
+    for (int r0 = wave * RS; r0 < nbc; r0 += 4 * RS) {
+        uint4 c[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int r = r0 + u / NV;
+            c[u] = r < nbc ? reinterpret_cast<const uint4 *>(table + (size_t)r * bmax)[lane * NV + (u % NV)]
+                           : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const bool m = r0 + u / NV < me;
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int v = u % NV;
+            tot[4 * v + 0] += c[u].x; tot[4 * v + 1] += c[u].y; tot[4 * v + 2] += c[u].z; tot[4 * v + 3] += c[u].w;
+            if (m) {
+                mine[4 * v + 0] += c[u].x; mine[4 * v + 1] += c[u].y; mine[4 * v + 2] += c[u].z; mine[4 * v + 3] += c[u].w;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,8 +381,10 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
                                                           const uint32_t *__restrict__ splitters,
                                                           const uint32_t *__restrict__ seg_off,
                                                           uint32_t *__restrict__ bucket_start,
-                                                          const GsrHeader *__restrict__ hdr) {
+                                                          const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
     extern __shared__ uint32_t smem[];
+    uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
+    SS_STAMP(dbg, 0);
     uint32_t *s_split = smem;            // [bmax]
     uint32_t *s_run = s_split + bmax;    // [bmax]  next free slot of every bucket for this workgroup
     uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
@@ -256,55 +395,72 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
     const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
     {
-        uint32_t tot[8], mine[8], sum = 0;
+        // Column sums of the histogram rows (all rows -> bucket totals, rows before mine -> my first slot per bucket).
+        // The rows sit in other XCDs' L2s / HBM: a round trip is ~2 k cycles, so rows are spread over the waves and a
+        // lane keeps up to 16 wide loads in flight; the four partial sums meet in LDS.
+        const int NV = B / 256;                       // uint4 per lane and row: 1, 2, 4 or 8
+        uint32_t tot[32], mine[32];
 #pragma unroll
-        for (int k = 0; k < 8; k++) tot[k] = mine[k] = 0u;
-        for (int r = 0; r < nbc; r++) {
-            const uint32_t *row = table + (size_t)r * bmax + tid * PER;
+        for (int k = 0; k < 32; k++) tot[k] = mine[k] = 0u;
+        switch (NV) {
+            case 1: ss_column_sums<1>(table, bmax, nbc, me, wave, lane, tot, mine); break;
+            case 2: ss_column_sums<2>(table, bmax, nbc, me, wave, lane, tot, mine); break;
+            case 4: ss_column_sums<4>(table, bmax, nbc, me, wave, lane, tot, mine); break;
+            default: ss_column_sums<8>(table, bmax, nbc, me, wave, lane, tot, mine); break;
+        }
+        // lane l holds buckets [4 NV l, 4 NV (l+1)): partial sums of this wave -> LDS, then thread t sums its PER buckets
+        uint32_t sum = 0, T[8], M[8];
+        for (int phase = 0; phase < 2; phase++) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                if (k < 4 * NV) s_cnt[wave * bmax + lane * 4 * NV + k] = phase == 0 ? tot[k] : mine[k];
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (k < PER) {
-                    const uint32_t c = row[k];
-                    tot[k] += c;
-                    if (r < me) mine[k] += c;
+                    const int d = tid * PER + k;
+                    const uint32_t v = s_cnt[d] + s_cnt[bmax + d] + s_cnt[2 * bmax + d] + s_cnt[3 * bmax + d];
+                    if (phase == 0) T[k] = v; else M[k] = v;
                 }
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) sum += tot[k];
+        for (int k = 0; k < 8; k++)
+            if (k < PER) sum += T[k];
         uint32_t all;
         uint32_t run = gsr_block_incl_scan(sum, s_w, all) - sum;
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < PER) {
                 const int d = tid * PER + k;
-                s_run[d] = run + mine[k];
+                s_run[d] = run + M[k];
                 s_split[d] = splitters[d];
                 if (me == 0) bucket_start[d] = run;
-                run += tot[k];
+                run += T[k];
             }
         if (me == 0 && tid == 0) bucket_start[B] = V;
     }
+    SS_STAMP(dbg, 1);
     const uint32_t s0 = seg_off[me], s1 = seg_off[me + 1];
     const uint64_t lt = gsr_lanemask_lt();
-    for (uint32_t tile = s0; tile < s1; tile += 4u * kT) {
+    constexpr int kPR = 8;  // rounds per wave and tile: a tile is 4 x kPR x 64 = 2048 records (most segments: one tile)
+    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(4 * kPR * GSR_WAVE)) {
         for (int i = tid; i < 4 * B; i += kT) s_cnt[(i >> nbits) * bmax + (i & (B - 1))] = 0u;
         __syncthreads();  // (also: s_run / s_split of the set-up above, cursors of the previous tile)
-        uint32_t idx[4], key[4], dig[4];
+        uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
+        for (int r = 0; r < kPR; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
             const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
             idx[r] = rec.x;
             key[r] = rec.y;
+            tk[r] = rec.y & 0xFFFFFF00u;
         }
+        ss_bucketN<kPR>(s_split, B, tk, dig);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
-            dig[r] = 0u;
-            if (i < s1) {
-                dig[r] = ss_bucket(s_split, B, key[r] & 0xFFFFFF00u);
-                atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
-            }
+        for (int r = 0; r < kPR; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
+            if (i < s1) atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
         }
         __syncthreads();
 #pragma unroll
@@ -322,8 +478,8 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         __syncthreads();
         uint32_t *cur = s_cnt + wave * bmax;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kT + r * GSR_WAVE + lane);
+        for (int r = 0; r < kPR; r++) {
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
             const bool valid = i < s1;
             const uint64_t same = ss_match(dig[r], nbits, valid);
             const uint32_t rank = (uint32_t)__popcll(same & lt);
@@ -334,6 +490,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         }
         __syncthreads();
     }
+    SS_STAMP(dbg, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -341,9 +498,11 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs,
                                                         const uint32_t *__restrict__ bucket_start,
-                                                        uint32_t *__restrict__ order,
-                                                        const GsrHeader *__restrict__ hdr) {
+                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
+                                                        GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
     extern __shared__ uint32_t smem[];
+    uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
+    SS_STAMP(dbg, 0);
     uint32_t *s_k = smem;                      // [2][kBucketCap]
     uint32_t *s_v = s_k + 2 * kBucketCap;      // [2][kBucketCap]
     uint32_t *s_cur = s_v + 2 * kBucketCap;    // [4][256]
@@ -353,6 +512,10 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     if (V == 0u) return;
     const int B = ss_num_buckets(V, bmax);
     if ((int)blockIdx.x >= B) return;
+    if (blockIdx.x == 0 && tid == 0) {
+        hdr->ss_magic = kSplitMagic;
+        hdr->ss_buckets = (uint32_t)B;
+    }
     const uint32_t s = bucket_start[blockIdx.x];
     const int n = (int)(bucket_start[blockIdx.x + 1] - s);
     if (n == 0) return;
@@ -366,8 +529,13 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         __syncthreads();
         bitonic_sort_block(comp, n, N);
         for (int i = tid; i < n; i += kT) order[s + i] = (uint32_t)comp[i];
+        for (int i = tid; i < B - 1; i += kT) {  // next frame's splitters: exact quantiles (see below)
+            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
+            if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & 0xFFFFFF00u;
+        }
         return;
     }
+    SS_STAMP(dbg, 1);
     const uint32_t key0 = seg[0].y;
     uint32_t diff = 0;
     for (int i = tid; i < n; i += kT) {
@@ -382,14 +550,26 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     __syncthreads();
     diff = s_w[0] | s_w[1] | s_w[2] | s_w[3];
     __syncthreads();
+    SS_STAMP(dbg, 2);
     const int bits = diff == 0u ? 0 : 32 - __builtin_clz(diff);
+#ifdef GSR_SS_TIMING
+    if (blockIdx.x == dbg_wg && tid == 0) { dbg[8] = (uint64_t)bits; dbg[9] = (uint64_t)n; }
+#endif
     int src = 0;
     for (int shift = 0; shift < bits; shift += 8) {
         lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
                              s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
         src ^= 1;
     }
+    SS_STAMP(dbg, 3);
+    // next frame's splitters: the exact B-quantiles of this frame's depth order (top 24 bits), each written by the
+    // bucket that holds its rank
+    for (int i = tid; i < B - 1; i += kT) {
+        const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
+        if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & 0xFFFFFF00u;
+    }
     for (int i = tid; i < n; i += kT) order[s + i] = s_v[src * kBucketCap + i];
+    SS_STAMP(dbg, 4);
 }
 
 }  // namespace
@@ -414,14 +594,14 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipS
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + bpw + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
-                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr);
+                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc), dim3(kT), lds2, stream, bmax, g.pair[0], g.pair[1], g.ss_table,
-                       g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr);
+                       g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg);
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
-                       g.order, g.hdr);
+                       g.order, g.ss_splitters, g.hdr, g.ss_dbg);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

@@ -28,7 +28,9 @@ struct GsrHeader {
     uint32_t r_capacity;
     uint32_t R_raw;       // sum of tiles touched, even when it overflowed
     uint32_t tile_queue;  // ticket counter of the compositing kernel's tile queue (zeroed with the header)
-    uint32_t pad[58];
+    uint32_t ss_magic;    // depth sort: the splitters in the state are the exact quantiles of the last frame ...
+    uint32_t ss_buckets;  // ... for this bucket count (both survive from frame to frame; garbage on a fresh state)
+    uint32_t pad[56];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -66,6 +68,7 @@ struct GeomState {
     uint32_t *ss_splitters;   // [bmax]
     uint32_t *ss_bucket_start;// [bmax + 1]
     uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
+    uint64_t *ss_dbg;         // [64] cycle stamps of workgroup 0 (builds with -DGSR_SS_TIMING only)
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -107,6 +110,7 @@ struct GeomState {
         g.ss_splitters = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.ss_bucket_start = take<uint32_t>(p, (size_t)gsr_ss_bmax(P) + 1);
         g.ss_seg = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) + 1);
+        g.ss_dbg = take<uint64_t>(p, 64);
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }

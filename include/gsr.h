@@ -146,6 +146,9 @@ size_t gsr_image_bytes(int32_t width, int32_t height);
 int gsr_forward(const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
                 const GsrBuffers *buffers, int64_t r_capacity, GsrFrameStats *stats, void *stream);
 
+/* Tuning aid: cycle stamps of the depth-sort kernels (meaningful in builds with -DGSR_SS_TIMING only). */
+int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *geom, uint64_t *out64);
+
 /* Reads V / R / overflow of the frame whose geometry state is `geom` (synchronises `stream`). */
 int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream);
 
