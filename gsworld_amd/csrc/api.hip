@@ -57,7 +57,7 @@ const char *gsr_last_error(void) { return g_err; }
 const char *gsr_version(void) { return "gsworld_amd-gsr 0.1 (gfx950)"; }
 
 size_t gsr_geom_bytes(int32_t P, int32_t width, int32_t height) {
-    return GeomState::required(P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE));
+    return GeomState::required(P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE), gsr_div_up(width, GSR_TILE));
 }
 size_t gsr_binning_bytes(int64_t r_capacity) { return BinningState::required(r_capacity); }
 size_t gsr_image_bytes(int32_t width, int32_t height) { return ImageState::required(width, height); }
@@ -103,9 +103,9 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
                 return GSR_E_INVALID;
             }
         }
-        if (st->binning_path < 0 || st->binning_path > 2 || st->render_variant < 0 || st->render_variant > 3 ||
+        if (st->binning_path < 0 || st->binning_path > 3 || st->render_variant < 0 || st->render_variant > 3 ||
             st->render_blocks_per_cu < 0 || st->render_blocks_per_cu > 8 || st->depth_sort < 0 || st->depth_sort > 1) {
-            gsr_set_error("gsr_forward: binning_path must be 0..2, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
+            gsr_set_error("gsr_forward: binning_path must be 0..3, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
             return GSR_E_INVALID;
         }
         if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
@@ -149,21 +149,24 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         return GSR_E_INVALID;
     }
 
-    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles));
+    const int tiles_x = gsr_div_up(W, GSR_TILE);
+    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles, tiles_x));
     char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
     if (!geom_mem || !img_mem) {
         gsr_set_error("gsr_forward: resize callback returned NULL");
         return GSR_E_ALLOC;
     }
-    const GeomState g = GeomState::carve(geom_mem, in->P, tiles);
+    const GeomState g = GeomState::carve(geom_mem, in->P, tiles, nullptr, tiles_x);
     const ImageState img = ImageState::carve(img_mem, W, H);
 
     // binning path: 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
     // (tile grids above GSR_MAX_COUNT_TILES, or wider than 2048 tiles -- one band row of counters must fit 64 KiB of
     // LDS -- always take 0)
-    // GsrSettings.binning_path: 0 = default (mode 1), 1 = radix (mode 0), 2 = bin-then-sort (mode 2)
-    const int want = st->binning_path == 0 ? 1 : (st->binning_path == 1 ? 0 : 2);
-    const int mode = GeomState::counting(tiles) && gsr_div_up(W, GSR_TILE) <= 2048 ? want : 0;
+    // GsrSettings.binning_path: 0 = default (mode 1, by tile rows where the grid allows), 1 = radix (mode 0),
+    // 2 = bin-then-sort (mode 2), 3 = mode 1 by chunks of 256 depth ranks (round 1's counting placement)
+    const int want = (st->binning_path == 0 || st->binning_path == 3) ? 1 : (st->binning_path == 1 ? 0 : 2);
+    const int mode = GeomState::counting(tiles) && tiles_x <= 2048 ? want : 0;
+    const bool band = mode == 1 && st->binning_path == 0 && gsr_band_supported(tiles_x);
     const bool exact = r_capacity <= 0;
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
@@ -184,6 +187,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
         if (st->depth_sort == 1) {
             if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+            if (band)
+                if (int e = gsr_launch_gather_rects(in->P, g, debug, stream)) return e;
         } else {
             if (int e = gsr_launch_sample_depth_sort(in->P, g, debug, stream)) return e;
         }
@@ -191,6 +196,9 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(2, stream);
     if (mode == 2) {
         if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
+    } else if (band) {
+        if (int e = gsr_launch_band_count(*st, g, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
     } else {
@@ -220,6 +228,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const BinningState b = BinningState::carve(bin_mem, cap);
     if (mode == 2) {
         if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
+    } else if (band) {
+        if (int e = gsr_launch_band_place(*st, g, b, img, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_place(*st, in->P, g, b, img, debug, stream)) return e;
     } else {

@@ -1,0 +1,314 @@
+// bandplace.hip -- counting placement by tile rows: the point list (upstream duplicateWithKeys + SortPairs +
+// identifyTileRanges, rasterizer_impl.cu) without keys, without a sort of instances and
+// without LDS atomics.
+//
+// The Gaussians arrive depth-sorted (depthsort.hip) and a Gaussian touches DISTINCT tiles, so the slot of instance
+// (g, t) is  tile_start[t] + #{Gaussians before g in depth order that touch t}.  Round 1 evaluated that per chunk of 256
+// depth ranks against ALL tiles (binning.hip tile_count / tile_place: 38 KiB of LDS counters per workgroup, one returning
+// LDS atomic per instance in a serial walk per wave, 4-byte stores scattered over ~1000 tile lists per workgroup:
+// 57 us for a 15.8 MB list at config 2 and 4.1x write amplification).  Here the work is cut the other way:
+//
+//   grid = (NR depth-rank ranges) x (tile rows).  Workgroup (r, y) looks at the Gaussians of rank range r that overlap
+//   tile row y -- the depth-ordered rects are one coalesced 8-byte stream (rect_sorted, written by the depth sort) -- and
+//   compacts those (Gaussian, row) pairs, in order.  The row's cursors live in REGISTERS, one tile column per lane, and
+//   the wave takes its pairs one after the other: the lanes inside the pair's column span store the Gaussian at their
+//   cursor and advance it.  ~11 instructions per pair, no counters in LDS, no atomics; depth order = program order.
+//   (Measured alternatives on MI355X, same decomposition: a ballot per tile column and round of 64 pairs 59 us; lane
+//   bits ORed into per-column LDS masks + popcount ranks 29 us; the same staged in LDS and copied out in whole lines
+//   37 us -- the LDS atomics and the per-instance round trips cost more than the scattered stores they avoid.)
+//
+//   band_count   order-free: +1 / -1 at the ends of a pair's column range, running sum = pairs per column; per-wave
+//                column counts -> wtable, per-workgroup -> table[t][r]
+//   band_scan    exclusive scan of every tile's NR entries, totals[t]           (then tile_starts_kernel of binning.hip:
+//                ranges, R, capacity check, compositing order)
+//   band_place   cursors = ranges[t].x + table[t][r] + earlier waves of the workgroup, then the rounds with the stores
+//
+// A (tile, workgroup) run is R / (tiles x NR) ~ 50 consecutive slots at config 2 (200 B) and lanes of one store
+// instruction write consecutive words, so the list is written in whole lines.  Tile rows up to 256 tiles wide (4096 px);
+// wider grids use the older paths.
+#include "gsr_internal.h"
+
+namespace {
+
+constexpr int kBT = GSR_BLOCK;              // 256 threads = 4 waves
+constexpr int kBW = kBT / GSR_WAVE;
+constexpr int kRing = 128;                  // (Gaussian, row) pairs buffered per wave
+
+// rank range of global wave gw (of NR * 4): multiples of 64 ranks, ceil(V / waves) each
+__device__ __forceinline__ void band_wave_range(uint32_t V, uint32_t gw, uint32_t waves, uint32_t &lo, uint32_t &hi) {
+    const uint32_t per = (((V + waves - 1u) / waves) + 63u) & ~63u;
+    lo = min(V, gw * per);
+    hi = min(V, lo + per);
+}
+
+constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (704 ranks per wave at config 2: one batch)
+
+// Counting needs no order at all: a pair adds +1 at its first column and -1 behind its last one; the running sum over
+// the columns is the number of pairs covering each.  Two LDS atomics per pair, per-wave difference arrays.
+template <int NC>
+__global__ __launch_bounds__(kBT) void band_count_kernel(const uint2 *__restrict__ rect_sorted,
+                                                         const GsrHeader *__restrict__ hdr, int gx, int NR,
+                                                         uint32_t *__restrict__ table, uint32_t *__restrict__ wtable) {
+    __shared__ int s_diff[kBW][NC * 64 + 1];
+    __shared__ uint32_t s_tot[kBW][NC * 64];
+    const int lane = gsr_lane(), wave = gsr_wave();
+    const uint32_t V = hdr->V, r = blockIdx.x, y = blockIdx.y;
+    uint32_t lo, hi;
+    band_wave_range(V, r * kBW + (uint32_t)wave, (uint32_t)NR * kBW, lo, hi);
+    int *diff = s_diff[wave];
+#pragma unroll
+    for (int k = 0; k < NC; k++) diff[k * 64 + lane] = 0;
+    if (lane == 0) diff[NC * 64] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = lo; base < hi; base += (uint32_t)(kBatch * GSR_WAVE)) {
+        uint2 rc[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const uint32_t i = base + (uint32_t)(u * GSR_WAVE + lane);
+            rc[u] = i < hi ? rect_sorted[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const uint32_t miny = rc[u].x >> 16, maxy = rc[u].y >> 16;
+            if (miny <= y && y < maxy) {  // (an empty slot has maxy = 0)
+                atomicAdd(&diff[rc[u].x & 0xffffu], 1);
+                atomicAdd(&diff[rc[u].y & 0xffffu], -1);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // running sum over the columns: lane l of round k = column 64 k + l
+    uint32_t *wrow = wtable + ((size_t)(y * (uint32_t)NR + r) * kBW + (uint32_t)wave) * (NC * 64);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const uint32_t incl = gsr_wave_incl_scan((uint32_t)diff[k * 64 + lane]) + carry;
+        wrow[k * 64 + lane] = incl;
+        s_tot[wave][k * 64 + lane] = incl;
+        carry = (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    __syncthreads();
+    for (int x = (int)threadIdx.x; x < gx; x += kBT)
+        table[((size_t)y * gx + x) * NR + r] = s_tot[0][x] + s_tot[1][x] + s_tot[2][x] + s_tot[3][x];
+}
+
+// exclusive scan of every tile's NR (<= 64) entries by one wave; totals[t] = instances of tile t
+__global__ __launch_bounds__(kBT) void band_scan_kernel(uint32_t *__restrict__ table, int T,
+                                                        uint32_t *__restrict__ totals) {
+    constexpr int PL = (GSR_BAND_RANGES + GSR_WAVE - 1) / GSR_WAVE;  // consecutive entries per lane
+    const int t = (int)blockIdx.x * kBW + gsr_wave();
+    if (t >= T) return;
+    const int lane = gsr_lane();
+    uint32_t *row = table + (size_t)t * GSR_BAND_RANGES;
+    uint32_t v[PL], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PL; k++) {
+        v[k] = lane * PL + k < GSR_BAND_RANGES ? row[lane * PL + k] : 0u;
+        sum += v[k];
+    }
+    const uint32_t incl = gsr_wave_incl_scan(sum);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < PL; k++) {
+        if (lane * PL + k < GSR_BAND_RANGES) row[lane * PL + k] = run;
+        run += v[k];
+    }
+    if (lane == 63) totals[t] = incl;
+}
+
+// 64 x 64 bit-matrix transpose across the wave: lane l brings row R_l, lane x leaves with column x (bit l = bit x of
+// R_l).  Six butterfly steps (swap the off-diagonal s x s blocks, s = 32 .. 1), registers and cross-lane moves only.
+__device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t R) {
+    const uint32_t lane = (uint32_t)gsr_lane();
+    constexpr uint64_t kLow[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                                  0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int s = 32 >> i;
+        const uint64_t m = kLow[i];
+        const uint32_t tlo = (uint32_t)__shfl_xor((int)(uint32_t)R, s, 64);
+        const uint32_t thi = (uint32_t)__shfl_xor((int)(uint32_t)(R >> 32), s, 64);
+        const uint64_t t = ((uint64_t)thi << 32) | tlo;
+        R = (lane & (uint32_t)s) == 0u ? ((R & m) | ((t & m) << s)) : ((R & ~m) | ((t & ~m) >> s));
+    }
+    return R;
+}
+
+// One placing round: lanes [0, n) hold a (Gaussian, row) pair each, in depth order.  The pairs' column spans are the
+// rows of a 64 x gx bit matrix; its transpose gives every column the set of pairs that cover it, in lane = depth order,
+// so the slot of instance (pair l, column x) is cursor[x] + popcount(column_mask[x] below lane l).  The masks and cursors
+// go through a wave-private LDS row; a pair then walks its OWN columns (~5), four per step.
+template <int NC>
+__device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool valid, int gx, uint32_t *cur,
+                                                 unsigned long long *colmask, uint32_t *__restrict__ point_list) {
+    const int lane = gsr_lane();
+    const uint64_t lt = gsr_lanemask_lt();
+    const uint32_t minx = span & 0xffffu, maxx = span >> 16, w = valid ? maxx - minx : 0u;
+    uint32_t wmax = w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
+    wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+    uint32_t add[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const uint32_t lo = max(minx, (uint32_t)(64 * k)), hi = min(maxx, (uint32_t)(64 * k + 64));
+        uint64_t row = 0ull;
+        if (valid && hi > lo) row = (hi - lo == 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << (lo - (uint32_t)(64 * k));
+        const uint64_t col = wave_bit_transpose(row);
+        colmask[k * 64 + lane] = col;
+        add[k] = (uint32_t)__popcll(col);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j0 = 0; j0 < wmax; j0 += 4u) {
+        unsigned long long m[4];
+        uint32_t cx[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            m[u] = j0 + u < w ? colmask[minx + j0 + u] : 0ull;
+            cx[u] = j0 + u < w ? cur[minx + j0 + u] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+            if (j0 + u < w) {
+#if defined(BAND_EXP) && BAND_EXP == 4
+                asm volatile("" ::"v"(cx[u] + (uint32_t)__popcll(m[u] & lt)), "v"(g));
+#elif defined(BAND_EXP) && BAND_EXP == 5
+                point_list[(cx[u] + (uint32_t)__popcll(m[u] & lt)) & ~63u | (uint32_t)lane] = g;
+#else
+                point_list[cx[u] + (uint32_t)__popcll(m[u] & lt)] = g;
+#endif
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NC; k++) cur[k * 64 + lane] += add[k];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NC>
+__global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict__ rect_sorted,
+                                                         const uint32_t *__restrict__ order,
+                                                         const GsrHeader *__restrict__ hdr, int gx, int NR,
+                                                         const uint32_t *__restrict__ table,
+                                                         const uint32_t *__restrict__ wtable,
+                                                         const uint2 *__restrict__ ranges,
+                                                         uint32_t *__restrict__ point_list) {
+    __shared__ uint2 s_ring[kBW][kRing];
+    __shared__ unsigned long long s_mask[kBW][NC * 64];
+    __shared__ uint32_t s_cur[kBW][NC * 64];
+    const int lane = gsr_lane(), wave = gsr_wave();
+    if (hdr->overflow) return;
+    const uint32_t V = hdr->V, r = blockIdx.x, y = blockIdx.y;
+    uint32_t lo, hi;
+    band_wave_range(V, r * kBW + (uint32_t)wave, (uint32_t)NR * kBW, lo, hi);
+    if (lo >= hi) return;
+    uint2 *ring = s_ring[wave];
+    uint32_t *cur = s_cur[wave];
+    unsigned long long *colmask = s_mask[wave];
+    // cursors: first slot of the tile + rank ranges before mine + earlier waves of this workgroup
+    const uint32_t *wbase = wtable + (size_t)(y * (uint32_t)NR + r) * kBW * (NC * 64);
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int x = k * 64 + lane;
+        uint32_t s = 0u;
+        if (x < gx) {
+            const size_t tile = (size_t)y * gx + x;
+            s = ranges[tile].x + table[tile * NR + r];
+            for (int w = 0; w < wave; w++) s += wbase[w * (NC * 64) + x];
+        }
+        cur[x] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the stream: pairs of row y, in depth order, compacted through the ring; a round per 64 pairs
+    uint32_t head = 0, tail = 0;  // wave-uniform: pairs consumed / produced
+    for (uint32_t base = lo; base < hi; base += (uint32_t)(kBatch * GSR_WAVE)) {
+        uint2 rc[kBatch];
+        uint32_t g[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const uint32_t i = base + (uint32_t)(u * GSR_WAVE + lane);
+            rc[u] = i < hi ? rect_sorted[i] : make_uint2(0u, 0u);
+            g[u] = i < hi ? order[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const uint32_t miny = rc[u].x >> 16, maxy = rc[u].y >> 16;
+            const bool keep = miny <= y && y < maxy;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+            if (mask == 0ull) continue;
+            if (keep) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                ring[(tail + rank) & (kRing - 1)] = make_uint2((rc[u].x & 0xffffu) | (rc[u].y << 16), g[u]);
+            }
+            tail += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= (uint32_t)GSR_WAVE) {
+                const uint2 p = ring[(head + (uint32_t)lane) & (kRing - 1)];
+                __builtin_amdgcn_wave_barrier();
+                band_place_round<NC>(p.x, p.y, true, gx, cur, colmask, point_list);
+                head += (uint32_t)GSR_WAVE;
+            }
+        }
+    }
+    if (tail != head) {
+        const bool valid = (uint32_t)lane < tail - head;
+        const uint2 p = valid ? ring[(head + (uint32_t)lane) & (kRing - 1)] : make_uint2(0u, 0u);
+        band_place_round<NC>(p.x, p.y, valid, gx, cur, colmask, point_list);
+    }
+}
+
+// depth-ordered rects for depth sorts that do not write them themselves (the LSD radix variant)
+__global__ __launch_bounds__(kBT) void gather_rects_kernel(const uint32_t *__restrict__ order,
+                                                           const uint2 *__restrict__ rects,
+                                                           const GsrHeader *__restrict__ hdr,
+                                                           uint2 *__restrict__ rect_sorted) {
+    const uint32_t V = hdr->V;
+    for (uint32_t i = blockIdx.x * (uint32_t)kBT + threadIdx.x; i < V; i += gridDim.x * (uint32_t)kBT)
+        rect_sorted[i] = rects[order[i]];
+}
+
+}  // namespace
+
+bool gsr_band_supported(int gx) { return gx <= 256; }
+
+int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
+    const int blocks = GeomState::prep_blocks(P) < 1024 ? GeomState::prep_blocks(P) : 1024;
+    hipLaunchKernelGGL(gather_rects_kernel, dim3(blocks), dim3(kBT), 0, stream, g.order, g.rects, g.hdr, g.rect_sorted);
+    return gsr_check_launch("gather_rects", debug, stream);
+}
+
+// counts -> ranges, R (tile_starts_kernel lives in binning.hip)
+int gsr_launch_band_count(const GsrSettings &st, const GeomState &g, bool debug, hipStream_t stream) {
+    const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
+    const dim3 grid(GSR_BAND_RANGES, gy);
+    if (gx <= 64)
+        hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+                           g.band_table, g.band_wtable);
+    else if (gx <= 128)
+        hipLaunchKernelGGL(band_count_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+                           g.band_table, g.band_wtable);
+    else
+        hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+                           g.band_table, g.band_wtable);
+    if (int e = gsr_check_launch("band_count", debug, stream)) return e;
+    const int T = gx * gy;
+    hipLaunchKernelGGL(band_scan_kernel, dim3(gsr_div_up(T, kBW)), dim3(kBT), 0, stream, g.band_table, T, g.tile_totals);
+    return gsr_check_launch("band_scan", debug, stream);
+}
+
+int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
+                          bool debug, hipStream_t stream) {
+    const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
+    const dim3 grid(GSR_BAND_RANGES, gy);
+    if (gx <= 64)
+        hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+    else if (gx <= 128)
+        hipLaunchKernelGGL(band_place_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+    else
+        hipLaunchKernelGGL(band_place_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+    return gsr_check_launch("band_place", debug, stream);
+}

@@ -493,6 +493,13 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
+    return gsr_launch_tile_starts(st, g, img, r_capacity, debug, stream);
+}
+
+// per-tile totals -> ranges, R, capacity check, compositing order (shared by the two counting placements)
+int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
+                           bool debug, hipStream_t stream) {
+    const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
     hipLaunchKernelGGL(tile_starts_kernel, dim3(2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
                        img.ranges, gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr,
                        (uint32_t *)nullptr, (const uint32_t *)img.quad_work);

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
 __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs,
                                                         const uint32_t *__restrict__ bucket_start,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
+                                                        const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
@@ -528,7 +529,11 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         uint64_t *comp = reinterpret_cast<uint64_t *>(seg);
         __syncthreads();
         bitonic_sort_block(comp, n, N);
-        for (int i = tid; i < n; i += kT) order[s + i] = (uint32_t)comp[i];
+        for (int i = tid; i < n; i += kT) {
+            const uint32_t gi = (uint32_t)comp[i];
+            order[s + i] = gi;
+            rect_sorted[s + i] = rects[gi];
+        }
         for (int i = tid; i < B - 1; i += kT) {  // next frame's splitters: exact quantiles (see below)
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
             if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & 0xFFFFFF00u;
@@ -568,7 +573,11 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
         if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & 0xFFFFFF00u;
     }
-    for (int i = tid; i < n; i += kT) order[s + i] = s_v[src * kBucketCap + i];
+    for (int i = tid; i < n; i += kT) {  // depth order + the tile rects in that order (what the placement streams)
+        const uint32_t gi = s_v[src * kBucketCap + i];
+        order[s + i] = gi;
+        rect_sorted[s + i] = rects[gi];
+    }
     SS_STAMP(dbg, 4);
 }
 
@@ -602,6 +611,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipS
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
-                       g.order, g.ss_splitters, g.hdr, g.ss_dbg);
+                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.hdr, g.ss_dbg);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

@@ -17,6 +17,7 @@
 #define GSR_DEPTH_RADIX_BITS 11       // digit width of the 32-bit depth sort and the 30-bit Morton sort: 3 passes
 #define GSR_DEPTH_RADIX_BINS 2048
 #define GSR_BIN_SLOTS 16              // replicated per-tile counters of the bin-then-sort path
+#define GSR_BAND_RANGES 64            // band placement (bandplace.hip): depth-rank ranges per tile row
 #define GSR_MAX_COUNT_TILES 16384     // counting placement: tile_table is tiles x ceil(P/256) words (bands keep LDS <= 40 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch
@@ -69,6 +70,10 @@ struct GeomState {
     uint32_t *ss_bucket_start;// [bmax + 1]
     uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
     uint64_t *ss_dbg;         // [64] cycle stamps of workgroup 0 (builds with -DGSR_SS_TIMING only)
+    // band placement (bandplace.hip)
+    uint2 *rect_sorted;       // [P]   tile rects in depth order (written by the depth sort)
+    uint32_t *band_table;     // [tiles * GSR_BAND_RANGES]  instances per (tile, rank range) -> exclusive offsets
+    uint32_t *band_wtable;    // [tile rows * GSR_BAND_RANGES * 4 waves * padded row width]  per-wave column counts
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -80,7 +85,13 @@ struct GeomState {
         return r;
     }
     static bool counting(int tiles) { return tiles <= GSR_MAX_COUNT_TILES; }
-    static GeomState carve(char *base, int32_t P, int tiles, size_t *bytes = nullptr) {
+    // words of band_wtable for a grid `tiles_x` wide (0: band placement not used for this grid)
+    static size_t band_wtable_words(int tiles_x, int tiles) {
+        if (tiles_x <= 0 || tiles_x > 256) return 1;
+        const int rows = tiles / tiles_x, padded = tiles_x <= 64 ? 64 : (tiles_x <= 128 ? 128 : 256);
+        return (size_t)rows * GSR_BAND_RANGES * 4 * padded;
+    }
+    static GeomState carve(char *base, int32_t P, int tiles, size_t *bytes = nullptr, int tiles_x = 0) {
         GeomState g;
         char *p = base;
         const size_t n = (size_t)(P > 0 ? P : 1);
@@ -111,12 +122,15 @@ struct GeomState {
         g.ss_bucket_start = take<uint32_t>(p, (size_t)gsr_ss_bmax(P) + 1);
         g.ss_seg = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) + 1);
         g.ss_dbg = take<uint64_t>(p, 64);
+        g.rect_sorted = take<uint2>(p, n);
+        g.band_table = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES + 1);
+        g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
-    static size_t required(int32_t P, int tiles) {
+    static size_t required(int32_t P, int tiles, int tiles_x = 0) {
         size_t bytes = 0;
-        carve(nullptr, P, tiles, &bytes);
+        carve(nullptr, P, tiles, &bytes, tiles_x);
         return bytes;
     }
 };
@@ -223,6 +237,13 @@ int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const Geom
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+bool gsr_band_supported(int gx);
+int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_band_count(const GsrSettings &st, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
+                          bool debug, hipStream_t stream);
+int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
+                           bool debug, hipStream_t stream);
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);

@@ -56,9 +56,10 @@ typedef struct GsrSettings {
     /* A/B and test selectors; 0 = the library's default everywhere.  They travel with the call -- the library keeps
      * no mutable process state, so renderers on different threads or devices cannot disturb each other.  Every
      * choice produces the same point list and bit-identical image state.
-     * binning_path: 0 = global depth sort + counting placement, 1 = global depth sort + emit + tile-id radix sort
-     *   (always used for tile grids above 16384 tiles or wider than 2048 tiles), 2 = unordered binning + per-tile
-     *   (depth, index) sort in LDS.
+     * binning_path: 0 = global depth sort + counting placement by tile rows (rows up to 256 tiles; by chunks of depth
+     *   ranks beyond), 1 = global depth sort + emit + tile-id radix sort (always used for tile grids above 16384 tiles
+     *   or wider than 2048 tiles), 2 = unordered binning + per-tile (depth, index) sort in LDS, 3 = global depth sort +
+     *   counting placement by chunks of 256 depth ranks.
      * render_variant: 0 = wave-decoupled culling kernel, 1 = LDS-staged per tile (upstream's structure), 2 = batched
      *   tile kernel, 3 = the same with per-quadrant instance culling.
      * render_blocks_per_cu: 1..8 sizes the persistent grid of the compositing kernel (0 = 6). */

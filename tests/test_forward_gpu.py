@@ -155,7 +155,7 @@ def _full_size_properties(raw, cam, device="cuda"):
     assert np.array_equal(g3["views"]["point_list"], v["point_list"])
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_alternative_binning_paths_match_too(cuda_device, mode):
     """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 16384 tiles use) and mode 2 (unordered
     binning + per-tile LDS sort) must give the same point list as the default mode 1 (depth sort + counting)."""
