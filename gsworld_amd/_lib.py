@@ -29,13 +29,13 @@ class GsrSettings(C.Structure):
         ("near_plane", C.c_float),
         # A/B and test selectors, 0 = library default (include/gsr.h); they travel with every call
         ("binning_path", C.c_int32), ("render_variant", C.c_int32), ("render_blocks_per_cu", C.c_int32),
-        ("depth_sort", C.c_int32),
+        ("depth_sort", C.c_int32), ("render_split", C.c_int32),
     ]
 
 
 # Python-side defaults of the three selectors above (tests, tools/ab_render.py, bench.py --render-bpc): the shared
 # library itself keeps no mutable state, every GsrSettings built by this package copies these in.
-TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0, "depth_sort": 0}
+TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0, "depth_sort": 0, "render_split": 0}
 
 
 def apply_tuning(st: "GsrSettings") -> "GsrSettings":
@@ -43,6 +43,7 @@ def apply_tuning(st: "GsrSettings") -> "GsrSettings":
     st.render_variant = int(TUNING["render_variant"])
     st.render_blocks_per_cu = int(TUNING["render_blocks_per_cu"])
     st.depth_sort = int(TUNING["depth_sort"])
+    st.render_split = int(TUNING["render_split"])
     return st
 
 

@@ -238,7 +238,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(4, stream);
     // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
     if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth,
-                                  out->out_rgb8, mode != 0, stream))
+                                  out->out_rgb8, mode != 0, mode == 1, stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();

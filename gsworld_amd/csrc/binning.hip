@@ -240,14 +240,121 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 uint2 *__restrict__ ranges,
                                                                 uint32_t *__restrict__ tile_order,
                                                                 uint32_t *__restrict__ cursor_to_zero,
-                                                                const uint32_t *__restrict__ quad_work) {
+                                                                const uint32_t *__restrict__ quad_work,
+                                                                const uint32_t *__restrict__ quad_work_b,
+                                                                uint32_t *__restrict__ split_flag,
+                                                                uint32_t *__restrict__ split_list,
+                                                                uint32_t *__restrict__ split_count, int split_cap,
+                                                                uint32_t *__restrict__ quad_order) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
     const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 8 * GSR_BLOCK;
+    // workgroup #2: which quadrants the compositor cuts in two this frame -- the costliest ones of the previous frame
+    // on this state, as many as spare waves exist (split_cap), and only those clearly above the average.  A quadrant
+    // that WAS split reports its two halves separately; together they did about 1.5x the work of the whole (two cull
+    // rectangles, two candidate sweeps).  Depends on nothing of this frame; any choice gives the same image.
+    if (blockIdx.x == 2) {
+        if (split_flag == nullptr) return;
+        const int Q = 4 * T;
+        __shared__ uint32_t s_cnt, s_thr;
+        auto est = [&](int q) -> uint32_t {
+            const uint32_t a = min(quad_work[q], 1u << 24);
+            if (split_flag[q] == 0u) return a;  // (last frame's flags: read before they are rewritten below)
+            return (uint32_t)(((uint64_t)(a + min(quad_work_b[q], 1u << 24)) * 2u) / 3u);
+        };
+        uint32_t mx = 0, sum = 0;
+        for (int q = (int)threadIdx.x; q < Q; q += GSR_BLOCK) {
+            const uint32_t e = est(q);
+            mx = max(mx, e);
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        if (gsr_lane() == 0) s_w[gsr_wave()] = mx;
+        if (threadIdx.x < 64) s_bins[threadIdx.x] = 0u;
+        __syncthreads();
+        mx = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+        __syncthreads();
+        uint32_t total;
+        (void)gsr_block_incl_scan(sum, s_w, total);
+        const uint32_t floor_cost = (uint32_t)(((uint64_t)total * 115u) / (100u * (uint32_t)max(Q, 1)));  // 1.15 x mean
+        const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
+        for (int q = (int)threadIdx.x; q < Q; q += GSR_BLOCK) atomicAdd(&s_bins[(int)((float)est(q) * scale)], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // lowest bucket whose quadrants, with all costlier ones, still fit the spare waves
+            uint32_t acc = 0;
+            int b = 64;
+            while (b > 0 && acc + s_bins[b - 1] <= (uint32_t)max(split_cap, 0)) acc += s_bins[--b];
+            s_thr = (uint32_t)b;
+            s_cnt = 0u;
+        }
+        __syncthreads();
+        const uint32_t thr = s_thr;
+        uint32_t flags[32];  // (Q <= 32 x 256 on this path: T <= 2048)
+        int k = 0;
+        for (int q = (int)threadIdx.x; q < Q && k < 32; q += GSR_BLOCK, k++) {
+            const uint32_t e = est(q);
+            flags[k] = (split_cap > 0 && (uint32_t)((float)e * scale) >= thr && e > floor_cost && e > 0u) ? 1u : 0u;
+        }
+        __syncthreads();  // every estimate above used last frame's flags
+        k = 0;
+        for (int q = (int)threadIdx.x; q < Q && k < 32; q += GSR_BLOCK, k++) {
+            split_flag[q] = flags[k];
+            if (flags[k]) split_list[atomicAdd(&s_cnt, 1u)] = (uint32_t)q;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *split_count = s_cnt;
+        return;
+    }
     // two workgroups: #0 turns the totals into ranges, #1 computes the cost order, which depends on nothing of this
     // frame (without keys the order is by list length and has to follow the ranges in #0)
     if (blockIdx.x == 1) {
         if (!keyed) return;
+        if (quad_order != nullptr) {
+            // quadrants by descending cost (256-bucket counting sort, costs held in registers: Q <= 32 x 256): the
+            // compositor gives every workgroup four quadrants of nearly equal cost (render.hip)
+            __shared__ uint32_t s_qb[256];
+            const int Q = 4 * T;
+            uint32_t c[32], qmx = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int q = (int)threadIdx.x + k * GSR_BLOCK;
+                c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
+                qmx = max(qmx, c[k]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
+            if (gsr_lane() == 0) s_w[gsr_wave()] = qmx;
+            s_qb[threadIdx.x] = 0u;
+            __syncthreads();
+            qmx = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+            // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
+            const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
+            const uint32_t div = (qmx >> sh) + 1u;
+            const float inv = 256.0f / (float)div;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int q = (int)threadIdx.x + k * GSR_BLOCK;
+                c[k] = 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));
+                if (q < Q) atomicAdd(&s_qb[c[k]], 1u);
+            }
+            __syncthreads();
+            {
+                const uint32_t n = s_qb[threadIdx.x];
+                uint32_t tot;
+                const uint32_t incl = gsr_block_incl_scan(n, s_w, tot);
+                s_qb[threadIdx.x] = incl - n;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int q = (int)threadIdx.x + k * GSR_BLOCK;
+                if (q < Q) quad_order[atomicAdd(&s_qb[c[k]], 1u)] = (uint32_t)q;
+            }
+            __syncthreads();
+            return;  // (the tile-level order below is what the compositor uses when it has no quadrant order)
+        }
         uint32_t key[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -500,9 +607,13 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                            bool debug, hipStream_t stream) {
     const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T, g.hdr, r_capacity,
-                       img.ranges, gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr,
-                       (uint32_t *)nullptr, (const uint32_t *)img.quad_work);
+    const int split_blocks = T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : 2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T,
+                       g.hdr, r_capacity, img.ranges,
+                       gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr, (uint32_t *)nullptr,
+                       (const uint32_t *)img.quad_work, (const uint32_t *)img.quad_work_b, img.split_flag,
+                       img.split_list, img.split_count, split_blocks * (GSR_BLOCK / GSR_WAVE),
+                       gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

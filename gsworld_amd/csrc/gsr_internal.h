@@ -180,6 +180,11 @@ struct ImageState {
     uint32_t *tile_order; // [tiles] tile ids, longest instance list first (compositing queue order)
     uint32_t *quad_work;  // [4*tiles] cost of each 8x8 quadrant in the compositor's LAST frame on this state (order key of
                           // the next frame; garbage on a fresh state -- any key gives a valid permutation)
+    uint32_t *quad_work_b; // [4*tiles] cost of rows 4-7 of a quadrant that was split in the last frame
+    uint32_t *split_flag; // [4*tiles] 1: this frame the quadrant is composited as two 8x4 halves
+    uint32_t *split_list; // [4*tiles] quadrant ids (4 tile + quad) whose second half an extra wave takes
+    uint32_t *split_count;// [1]
+    uint32_t *quad_order; // [4*tiles] quadrant ids (4 tile + quad) sorted by descending cost in the last frame
     static ImageState carve(char *base, int32_t W, int32_t H, size_t *bytes = nullptr) {
         ImageState s;
         char *p = base;
@@ -187,6 +192,11 @@ struct ImageState {
         s.ranges = GeomState::take<uint2>(p, tiles);
         s.tile_order = GeomState::take<uint32_t>(p, tiles);
         s.quad_work = GeomState::take<uint32_t>(p, 4 * tiles);
+        s.quad_work_b = GeomState::take<uint32_t>(p, 4 * tiles);
+        s.split_flag = GeomState::take<uint32_t>(p, 4 * tiles);
+        s.split_list = GeomState::take<uint32_t>(p, 4 * tiles);
+        s.split_count = GeomState::take<uint32_t>(p, 64);
+        s.quad_order = GeomState::take<uint32_t>(p, 4 * tiles);
         s.final_T = GeomState::take<float>(p, (size_t)W * H);
         s.n_contrib = GeomState::take<uint32_t>(p, (size_t)W * H);
         if (bytes) *bytes = (size_t)(p - base);
@@ -248,9 +258,11 @@ int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, 
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
 bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles);
+int gsr_render_split_blocks(const GsrSettings &st, int num_tiles);
+bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
-                      uint8_t *out_rgb8, bool order_ready, hipStream_t stream);
+                      uint8_t *out_rgb8, bool order_ready, bool split_ready, hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

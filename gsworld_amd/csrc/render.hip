@@ -136,11 +136,12 @@ constexpr int kBatch = 4;
 // of the per-pixel evaluation (a few ulps of the largest term), and a conic that is not positive definite in
 // float is never culled.  A culled instance is one every pixel of the quadrant would have skipped (alpha < 1/255),
 // so the image, final_T and n_contrib are bit-identical with and without the test.
-__device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float4 q, float x0, float y0) {
+__device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float4 q, float x0, float y0,
+                                                 float yext = 7.0f) {
     const float A = q.x, B = q.y, C = q.z;
     // the same subtractions the corner pixels perform: every pixel's rounded offset lies in [dxl, dxh] x [dyl, dyh]
     const float dxh = cx - x0, dxl = cx - (x0 + 7.0f);
-    const float dyh = cy - y0, dyl = cy - (y0 + 7.0f);
+    const float dyh = cy - y0, dyl = cy - (y0 + yext);  // (yext = rows - 1: 7 for a quadrant, 3 for half of one)
     const float tau = -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * q.w);  // opacity 0 -> +inf
     const float ex = fminf(fmaxf(0.0f, dxl), dxh);
     const float ey = fminf(fmaxf(0.0f, dyl), dyh);
@@ -428,7 +429,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                                                   uint32_t *__restrict__ n_contrib,
                                                                   uint8_t *__restrict__ rgb8 /* optional */,
                                                                   uint32_t *__restrict__ quad_work /* optional */,
-                                                                  int num_cus) {
+                                                                  int num_cus, int main_blocks,
+                                                                  const uint32_t *__restrict__ split_flag,
+                                                                  const uint32_t *__restrict__ split_list,
+                                                                  const uint32_t *__restrict__ split_count,
+                                                                  uint32_t *__restrict__ quad_work_b,
+                                                                  const uint32_t *__restrict__ quad_order) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
@@ -448,12 +454,25 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
     // pay either (80-82 us): what the L2s gain in locality the XCDs lose in balance.
     // (snake order: pass 0 deals the longest units to waves 0..S-1, pass 1 deals the next ones to waves S-1..0, so a
     // wave that started with a long unit continues with a short one)
-    const uint32_t ticket_stride = gridDim.x * (uint32_t)(GSR_BLOCK / GSR_WAVE);
+    // Split quadrants.  The kernel lasts as long as its longest quadrant (a wave is one in-order instruction stream),
+    // and the costs spread 219 (mean) ... 369 survivors at config 2.  The quadrants that were costliest in the previous
+    // frame on this state (tile_starts_kernel, workgroup 2) are therefore cut in two 8 x 4 halves: the quadrant's own
+    // wave keeps rows 0-3 (its lanes 0-31), a wave of the EXTRA workgroups behind the main grid takes rows 4-7, each
+    // with its own, tighter cull rectangle.  Pixels are independent, so the image state does not change by a bit.
+    const bool extra = (int)blockIdx.x >= main_blocks;
+    uint32_t extra_q = 0;
+    if (extra) {
+        const uint32_t e = (blockIdx.x - (uint32_t)main_blocks) * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
+        if (split_count == nullptr || e >= *split_count) return;
+        extra_q = split_list[e];
+    }
+    const uint32_t ticket_stride = (uint32_t)main_blocks * (uint32_t)(GSR_BLOCK / GSR_WAVE);
     const uint32_t wave_global = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
-    for (uint32_t pass = 0, ticket = wave_global; ticket < num_tickets;
-         pass++, ticket = pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
+    for (uint32_t pass = 0, ticket = extra ? 0u : wave_global; ticket < num_tickets;
+         pass++, ticket = extra ? num_tickets
+                                : pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
         uint32_t unit = ticket >> 2;
-        if (tile_order != nullptr && gridDim.x >= (uint32_t)num_tiles) {
+        if (!extra && tile_order != nullptr && main_blocks >= num_tiles) {
             // Every tile resident at once: workgroups b, b + #CUs, b + 2 #CUs ... share a CU (observed placement on
             // MI355X: s_getreg HW_ID of every workgroup), so position p of the cost-sorted order goes to workgroup
             // p in even groups of #CUs and to the mirrored workgroup in odd ones: every CU gets one tile of each cost
@@ -462,13 +481,27 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             const uint32_t size = min((uint32_t)num_cus, (uint32_t)num_tiles - group * (uint32_t)num_cus);
             unit = group * (uint32_t)num_cus + ((group & 1u) ? size - 1u - idx : idx);
         }
-        const int tile = tile_order ? (int)tile_order[unit] : (int)unit;
-        const int quad = (int)(ticket & 3u);
-        const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3), qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3);
+        int tile = extra ? (int)(extra_q >> 2) : (tile_order ? (int)tile_order[unit] : (int)unit);
+        int quad = extra ? (int)(extra_q & 3u) : (int)(ticket & 3u);
+        if (!extra && quad_order != nullptr && main_blocks >= num_tiles) {
+            // Everything resident, quadrants sorted by their cost in the previous frame: workgroup position `unit` takes
+            // the four quadrants 4 unit .. 4 unit + 3 of that order, i.e. four of (nearly) EQUAL cost, whatever tiles they
+            // belong to.  The four waves of a workgroup go to the four SIMDs of its CU, so every SIMD of the CU then
+            // carries the same load; dealing tiles (four quadrants of unequal cost) left the SIMD loads a sum of
+            // five random quadrant costs each -- +-11 %, and the most loaded of 1024 SIMDs sets the kernel time.
+            const uint32_t q = quad_order[4u * unit + (ticket & 3u)];
+            tile = (int)(q >> 2);
+            quad = (int)(q & 3u);
+        }
+        // half: 0 = whole quadrant, 1 = its rows 0-3 (the other half runs elsewhere), 2 = its rows 4-7
+        const int half = extra ? 2 : ((split_flag != nullptr && split_flag[4 * tile + quad] != 0u) ? 1 : 0);
+        const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3);
+        const int qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3) + (half == 2 ? 4 : 0);
         const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-        const bool inside = px < W && py < H;
+        const bool inside = px < W && py < H && (half == 0 || lane < 32);
         const float pfx = (float)px, pfy = (float)py;
         const float qxf = (float)qx0, qyf = (float)qy0;
+        const float yext = half == 0 ? 7.0f : 3.0f;
         const uint2 range = ranges[tile];
         const int n_inst = (int)(range.y - range.x);
         const uint32_t *src = point_list + range.x;
@@ -505,7 +538,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
 #pragma unroll
             for (int s = 0; s < kStreamLanesItems; s++) {
                 const int p = rd * kStreamRound + s * GSR_WAVE + lane;
-                const bool keep = p < n_inst && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf);
+                const bool keep = p < n_inst && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext);
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
                 unsafe |= __builtin_amdgcn_ballot_w64(keep && !stream_conic_is_safe(f1[s]));
                 const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                                     __uint_as_float((uint32_t)p + 1u));
                 n_surv += (int)__builtin_popcountll(mask);
             }
-            work += (uint32_t)n_surv + 5u;
+            work += 8u;  // cull + compaction of a round of 64 candidates, in units of one replayed survivor
             if (lane < kBatch)  // alpha = 0 padding behind the last survivor
                 stream_list_put(list, n_surv + lane, zero4, zero4, zero4, 0.0f);
             // ---- next round's gathers go out before the replay so that they fly under it
@@ -545,17 +578,19 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                     if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
                     const StreamBatch b = stream_eval<false>(list, i, pf2x, pf2y);
                     stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                    work += (uint32_t)kBatch;  // survivors actually replayed (a saturated quadrant stops early)
                 }
             } else {
                 for (int i = 0; i < n_surv; i += kBatch) {
                     if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
                     const StreamBatch b = stream_eval<true>(list, i, pf2x, pf2y);
                     stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                    work += (uint32_t)kBatch;
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
-        if (quad_work != nullptr && lane == 0) quad_work[4 * tile + quad] = work;
+        if (quad_work != nullptr && lane == 0) (half == 2 ? quad_work_b : quad_work)[4 * tile + quad] = work;
         if (inside) {
             const size_t pid = (size_t)py * W + px;
             const size_t plane = (size_t)H * W;
@@ -644,6 +679,23 @@ static int render_num_cus() {
 // once (1200 tiles on 256 CUs x 6) the deal is the identity and the binning stage need not build the order.
 // The default compositor always takes an order: with every unit resident at once (tiles <= CUs x workgroups per CU) it
 // decides which tiles share a CU; beyond that it is the longest-first queue order.
+// Workgroups appended to the compositing grid for the second halves of split quadrants: whatever the chip can still
+// hold next to the main grid (all tiles resident: tiles < CUs x workgroups per CU), none otherwise.  The split list is
+// built by the counting placements (tile_starts_kernel); GsrSettings.render_split = 1 turns the splitting off.
+int gsr_render_split_blocks(const GsrSettings &st, int num_tiles) {
+    const RenderChoice c = render_choice(st);
+    if (c.variant != 4 || st.render_split != 1) return 0;  // (off by default: measured slower)
+    const int resident = render_num_cus() * c.blocks_per_cu;
+    return num_tiles < resident ? resident - num_tiles : 0;
+}
+
+// true when the default compositor keeps every tile resident at once AND takes its quadrants in the order of their
+// previous cost (quad_order, built by tile_starts_kernel instead of the tile-level order)
+bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles) {
+    const RenderChoice c = render_choice(st);
+    return c.variant == 4 && num_tiles <= 2048 && num_tiles <= render_num_cus() * c.blocks_per_cu;
+}
+
 bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
     const RenderChoice c = render_choice(st);
     return c.variant == 4 || (c.variant >= 2 && num_tiles > render_num_cus() * c.blocks_per_cu);
@@ -651,7 +703,7 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
                       const float *background, float *out_color, float *out_invdepth, uint8_t *out_rgb8,
-                      bool order_ready, hipStream_t stream) {
+                      bool order_ready, bool split_ready, hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     // the default kernel writes the uint8 frame itself; the A/B variants get a separate conversion pass
@@ -664,10 +716,16 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
         if (ordered && !order_ready)
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
         const int blocks = min(T, render_num_cus() * rc.blocks_per_cu);
-        if (rc.variant == 4)
-            hipLaunchKernelGGL(render_stream_kernel, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges, point_list,
-                               g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
-                               img.n_contrib, out_rgb8, img.quad_work, render_num_cus());
+        if (rc.variant == 4) {
+            // (the split list is built by tile_starts_kernel: counting placements, grids up to 2048 tiles)
+            const int extra = split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
+            hipLaunchKernelGGL(render_stream_kernel, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream, img.ranges,
+                               point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
+                               img.n_contrib, out_rgb8, img.quad_work, render_num_cus(), blocks,
+                               extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list, img.split_count,
+                               img.quad_work_b,
+                               (split_ready && gsr_render_uses_quad_order(st, T)) ? img.quad_order : (const uint32_t *)nullptr);
+        }
         else if (rc.variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
                                point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth,

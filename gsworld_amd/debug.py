@@ -25,6 +25,11 @@ def set_depth_sort(variant: int) -> None:
     _lib.TUNING["depth_sort"] = variant
 
 
+def set_render_split(on: bool) -> None:
+    """A/B and tests: the compositor cuts the costliest quadrants of the previous frame into two 8x4 halves (default off)."""
+    _lib.TUNING["render_split"] = 1 if on else 0
+
+
 def set_render_variant(variant: int, blocks_per_cu: int = 0) -> None:
     """A/B and tests: 4 = wave-decoupled culling kernel (default), 0 = LDS-staged per tile (upstream's structure),
     2 = batched tile kernel, 3 = the same with per-quadrant culling; ``blocks_per_cu`` 1..8 sizes the persistent grid

@@ -69,6 +69,9 @@ typedef struct GsrSettings {
     /* depth_sort: 0 = sample sort (3 launches: compaction + classification, stable partition, per-bucket LDS radix),
      *   1 = 3-pass LSD radix sort over all visible Gaussians (10 launches).  Same depth order. */
     int32_t depth_sort;
+    /* render_split: 1 = the costliest quadrants of the previous frame are composited as two 8x4 halves on two waves
+     *   (image state bit-identical; measured slower than the default 0 = never split, kept for A/B). */
+    int32_t render_split;
 } GsrSettings;
 
 typedef struct GsrInputs {

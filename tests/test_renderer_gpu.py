@@ -152,3 +152,37 @@ def test_uint8_frame_is_the_same_from_every_compositor_variant(cuda_device):
         dbg.set_render_variant(4, 0)
     assert torch.equal(frames[4], frames[0]) and torch.equal(frames[4], frames[3])
     assert int(frames[4].max()) == 255
+
+
+def test_split_quadrants_leave_the_image_state_bit_identical(cuda_device):
+    """With GsrSettings.render_split = 1 the compositor cuts the quadrants that were costliest in the PREVIOUS frame on the
+    same renderer state into two 8x4 halves on two waves (and by default it deals the quadrants to workgroups in the order
+    of that cost).  Frame after frame on one state (so the split list is the real one, not a fresh state's
+    arbitrary one), colour / inverse depth / uint8 frame must equal the unsplit render bit for bit."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    raw = scenes.tabletop_scene("xarm6_align", n=400_000, seed=3)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    bg = torch.tensor([0.1, 0.3, 0.2], device=dev)
+
+    def frames(n, split):
+        dbg.set_render_split(split)
+        try:
+            r = FrameRenderer(dev)
+            out = []
+            for _ in range(n):
+                rgb8 = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+                color, _, invd = r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=rgb8)
+                out.append((color.clone(), invd.clone(), rgb8))
+            assert not r.stats().overflow
+            return out
+        finally:
+            dbg.set_render_split(False)
+
+    ref = frames(1, False)[0]
+    for color, invd, rgb8 in frames(4, True):
+        assert torch.equal(color.view(torch.int32), ref[0].view(torch.int32))
+        assert torch.equal(invd.view(torch.int32), ref[1].view(torch.int32))
+        assert torch.equal(rgb8, ref[2])
