@@ -14,6 +14,25 @@ import torch
 from . import _lib
 from ._lib import (GsrBuffers, GsrFrameStats, GsrInputs, GsrOutputs, GsrSettings, RESIZE_FN, check, lib)
 
+# The compiled binding (csrc_torch/ext.cpp, built by gsworld_amd/build_ext.py): the `_C` pybind module upstream's
+# python package imports.  Used whenever it has been built; the ctypes path below drives the SAME shared library and
+# remains for environments without the torch headers (GSWORLD_AMD_CTYPES=1 forces it, e.g. to A/B the host overhead).
+import os as _os
+
+_ext = None
+if _os.environ.get("GSWORLD_AMD_CTYPES", "") != "1":
+    try:
+        from . import _C_ext as _ext  # noqa: F401
+    except ImportError:
+        _ext = None
+
+
+def _tuning_list():
+    t = _lib.TUNING
+    return [int(t["binning_path"]), int(t["render_variant"]), int(t["render_blocks_per_cu"]), int(t["depth_sort"]),
+            int(t["render_split"])]
+
+
 # GSWorld's edit of cuda_rasterizer/auxiliary.h (/root/reference/README.md:33).  Module-level so that a stock
 # 3DGS caller can restore 0.2 without touching the ABI.
 NEAR_PLANE = _lib.GSR_NEAR_PLANE
@@ -62,6 +81,21 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes."""
     dev = means3D.device
+    if _ext is not None:
+        st = settings
+        e = torch.empty(0, device=dev)
+        nv, nr, ov = _ext.forward_frame(
+            st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.scale_modifier, st.sh_degree, st.sh_coeffs,
+            bool(st.antialiasing), bool(st.debug), st.near_plane, background, means3D,
+            colors if colors is not None else e, opacity, scales if scales is not None else e,
+            rotations if rotations is not None else e, cov3D_precomp if cov3D_precomp is not None else e, viewmatrix,
+            projmatrix, sh if sh is not None else e, sh_rest if sh_rest is not None else e, campos, out_color,
+            out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
+            rgb8_out if rgb8_out is not None else torch.empty(0, dtype=torch.uint8, device=dev), int(r_capacity),
+            bool(want_stats), int(param_space), _tuning_list())
+        stats = GsrFrameStats()
+        stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
+        return stats
     _lib.apply_tuning(settings)
     inp = GsrInputs(
         P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
@@ -88,6 +122,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     (P,1,3), ``sh_rest`` = features_rest (P,M-1,3), read in place instead of a per-frame ``cat``; ``param_space`` --
     OR of ``_lib.RAW_*``: ``opacity`` / ``scales`` / ``rotations`` are the raw parameters and are activated inside
     preprocess."""
+    if _ext is not None:
+        return _ext.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier),
+                                        cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                        int(image_height), int(image_width), sh, int(degree), campos,
+                                        bool(prefiltered), bool(antialiasing), bool(debug), sh_rest, int(param_space),
+                                        float(NEAR_PLANE), _tuning_list())
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if sh_rest is not None and (sh.ndim != 3 or sh.size(1) != 1 or sh_rest.ndim != 3 or sh_rest.size(0) != sh.size(0)):
@@ -127,6 +167,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
                                  antialiasing, debug, sh_rest=None, param_space=0):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     [+ dL_dsh_rest with ``sh_rest``; opacity / scale / rotation gradients w.r.t. the raw parameters with ``param_space``]."""
+    if _ext is not None:
+        return tuple(_ext.rasterize_gaussians_backward(
+            background, means3D, radii, colors, opacities, scales, rotations, float(scale_modifier), cov3D_precomp,
+            viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color,
+            dL_dout_invdepth if dL_dout_invdepth is not None else None, sh, int(degree), campos, geomBuffer, int(R),
+            binningBuffer, imageBuffer, bool(antialiasing), bool(debug), sh_rest, int(param_space), float(NEAR_PLANE)))
     from . import _backward
 
     return _backward.rasterize_gaussians_backward(
@@ -137,6 +183,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     """-> bool (P,): Gaussians in front of the near plane (upstream markVisible; projmatrix is unused there too)."""
+    if _ext is not None:
+        return _ext.mark_visible(means3D, viewmatrix, projmatrix, float(NEAR_PLANE))
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P = means3D.size(0)

@@ -1,0 +1,293 @@
+// ext.cpp -- the compiled `_C` module of the drop-in `diff_gaussian_rasterization` package:
+// what upstream's ext.cpp / rasterize_points.cu export through pybind, over the C ABI of libgsr_hip.so
+// (include/gsr.h).  Same positional signatures, same return tuples, same error strings:
+//
+//   rasterize_gaussians            <->  RasterizeGaussiansCUDA           (rasterize_points.cu)
+//   rasterize_gaussians_backward   <->  RasterizeGaussiansBackwardCUDA
+//   mark_visible                   <->  markVisible
+//
+// plus `forward_frame`, the persistent-state entry gsworld_amd.renderer.FrameRenderer uses (caller-owned outputs and
+// state tensors, optional no-sync capacity mode): one native call per frame instead of a ctypes struct marshalling and
+// three Python resize callbacks.  No device code here -- this file is host glue; it is built by
+// gsworld_amd/build_ext.py (g++ against the torch headers, linked to ../libgsr_hip.so) and is optional: without it
+// gsworld_amd/_C.py falls back to the ctypes binding of the same library.
+#include <torch/extension.h>
+// (PyTorch-ROCm keeps the device type "cuda": the guard / stream types of that naming live in these headers)
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <tuple>
+
+#include "../../include/gsr.h"
+
+namespace {
+
+char *resize_cb(void *user, size_t bytes) {
+    auto *t = static_cast<torch::Tensor *>(user);
+    t->resize_({static_cast<long long>(bytes)});
+    return reinterpret_cast<char *>(t->data_ptr());
+}
+
+const float *fptr(const torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+
+// float32, on `dev`, dense -- what upstream's `.contiguous().data<float>()` implies
+torch::Tensor f32(const torch::Tensor &t, const torch::Device &dev, const char *what) {
+    if (t.numel() == 0) return t;
+    TORCH_CHECK(t.scalar_type() == torch::kFloat32, what, " must be float32");
+    return (t.device() == dev ? t : t.to(dev)).contiguous();
+}
+
+void require_gpu(const torch::Tensor &t, const char *what) {
+    TORCH_CHECK(t.is_cuda(), what, " is on ", t.device(),
+                ": the MI355X rasterizer has no CPU path (tensors must live on a HIP device)");
+}
+
+struct Tuning {
+    int binning_path = 0, render_variant = 0, render_blocks_per_cu = 0, depth_sort = 0, render_split = 0;
+};
+
+GsrSettings settings(int H, int W, float tanfovx, float tanfovy, float scale_modifier, int degree, int M,
+                     bool prefiltered, bool antialiasing, bool debug, float near_plane, const Tuning &tn) {
+    GsrSettings st{};
+    st.image_height = H;
+    st.image_width = W;
+    st.tanfovx = tanfovx;
+    st.tanfovy = tanfovy;
+    st.scale_modifier = scale_modifier;
+    st.sh_degree = degree;
+    st.sh_coeffs = M;
+    st.prefiltered = prefiltered;
+    st.antialiasing = antialiasing;
+    st.debug = debug;
+    st.near_plane = near_plane;
+    st.binning_path = tn.binning_path;
+    st.render_variant = tn.render_variant;
+    st.render_blocks_per_cu = tn.render_blocks_per_cu;
+    st.depth_sort = tn.depth_sort;
+    st.render_split = tn.render_split;
+    return st;
+}
+
+Tuning tuning_from(const std::vector<int> &v) {
+    Tuning t;
+    if (v.size() >= 5) {
+        t.binning_path = v[0];
+        t.render_variant = v[1];
+        t.render_blocks_per_cu = v[2];
+        t.depth_sort = v[3];
+        t.render_split = v[4];
+    }
+    return t;
+}
+
+void *current_stream(const torch::Device &dev) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
+
+// ---- one frame into caller-owned tensors (FrameRenderer) ---------------------------------------------------------
+std::tuple<int64_t, int64_t, int64_t> forward_frame(
+    int H, int W, double tanfovx, double tanfovy, double scale_modifier, int degree, int M, bool antialiasing,
+    bool debug, double near_plane, const torch::Tensor &bg, const torch::Tensor &means3D, const torch::Tensor &colors,
+    const torch::Tensor &opacity, const torch::Tensor &scales, const torch::Tensor &rotations,
+    const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix,
+    const torch::Tensor &sh, const torch::Tensor &sh_rest, const torch::Tensor &campos, torch::Tensor out_color,
+    torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
+    const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning) {
+    const auto dev = means3D.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    GsrSettings st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false,
+                              antialiasing, debug, (float)near_plane, tuning_from(tuning));
+    GsrInputs in{};
+    in.P = (int32_t)means3D.size(0);
+    in.background = fptr(bg);
+    in.means3D = fptr(means3D);
+    in.shs = fptr(sh);
+    in.colors_precomp = fptr(colors);
+    in.opacities = fptr(opacity);
+    in.scales = fptr(scales);
+    in.rotations = fptr(rotations);
+    in.cov3D_precomp = fptr(cov3D_precomp);
+    in.viewmatrix = fptr(viewmatrix);
+    in.projmatrix = fptr(projmatrix);
+    in.campos = fptr(campos);
+    in.shs_rest = fptr(sh_rest);
+    in.param_space = param_space;
+    GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(), radii.data_ptr<int32_t>(),
+                   rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
+    GsrBuffers buf{resize_cb, &geom, resize_cb, &binning, resize_cb, &image};
+    GsrFrameStats stats{};
+    const int rc = gsr_forward(&st, &in, &out, &buf, r_capacity, want_stats ? &stats : nullptr, current_stream(dev));
+    TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    return {stats.num_visible, stats.num_rendered, (int64_t)stats.overflow};
+}
+
+std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(geom.device());
+    GsrFrameStats s{};
+    const int rc = gsr_frame_stats(geom.data_ptr(), &s, current_stream(geom.device()));
+    TORCH_CHECK(rc == GSR_OK || rc == GSR_E_OVERFLOW, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    return {s.num_visible, s.num_rendered, (int64_t)s.overflow};
+}
+
+// ---- upstream's three functions ------------------------------------------------------------------------------------
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians(const torch::Tensor &background, const torch::Tensor &means3D, const torch::Tensor &colors,
+                    const torch::Tensor &opacity, const torch::Tensor &scales, const torch::Tensor &rotations,
+                    double scale_modifier, const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix,
+                    const torch::Tensor &projmatrix, double tan_fovx, double tan_fovy, int image_height,
+                    int image_width, const torch::Tensor &sh, int degree, const torch::Tensor &campos, bool prefiltered,
+                    bool antialiasing, bool debug, c10::optional<torch::Tensor> sh_rest, int param_space,
+                    double near_plane, std::vector<int> tuning) {
+    if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
+    require_gpu(means3D, "means3D");
+    const auto dev = means3D.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int P = (int)means3D.size(0), H = image_height, W = image_width;
+    auto fopt = means3D.options().dtype(torch::kFloat32);
+    auto bopt = means3D.options().dtype(torch::kByte);
+    torch::Tensor out_color = torch::zeros({3, H, W}, fopt), out_invdepth = torch::zeros({1, H, W}, fopt);
+    torch::Tensor radii = torch::zeros({P}, means3D.options().dtype(torch::kInt32));
+    torch::Tensor geom = torch::empty({0}, bopt), binning = torch::empty({0}, bopt), img = torch::empty({0}, bopt);
+    int rendered = 0;
+    if (P != 0) {
+        int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+        torch::Tensor rest;
+        if (sh_rest.has_value()) {
+            TORCH_CHECK(sh.ndimension() == 3 && sh.size(1) == 1 && sh_rest->ndimension() == 3 &&
+                            sh_rest->size(0) == sh.size(0),
+                        "sh_rest needs sh = features_dc of shape (num_points, 1, 3)");
+            rest = f32(*sh_rest, dev, "sh_rest");
+            M = 1 + (int)rest.size(1);
+        }
+        const torch::Tensor bg = f32(background, dev, "background"), m3 = f32(means3D, dev, "means3D"),
+                            col = f32(colors, dev, "colors"), op = f32(opacity, dev, "opacity"),
+                            sc = f32(scales, dev, "scales"), rot = f32(rotations, dev, "rotations"),
+                            cov = f32(cov3D_precomp, dev, "cov3D_precomp"), vm = f32(viewmatrix, dev, "viewmatrix"),
+                            pm = f32(projmatrix, dev, "projmatrix"), shc = f32(sh, dev, "sh"),
+                            cp = f32(campos, dev, "campos");
+        auto stats = forward_frame(H, W, tan_fovx, tan_fovy, scale_modifier, degree, M, antialiasing, debug,
+                                   near_plane, bg, m3, col, op, sc, rot, cov, vm, pm, shc,
+                                   rest.defined() ? rest : torch::Tensor(torch::empty({0}, fopt)), cp, out_color,
+                                   out_invdepth, radii, geom, binning, img, torch::empty({0}, bopt), 0, true,
+                                   param_space, tuning);
+        (void)prefiltered;
+        rendered = (int)std::get<1>(stats);
+    }
+    return {rendered, out_color, radii, geom, binning, img, out_invdepth};
+}
+
+std::vector<torch::Tensor> rasterize_gaussians_backward(
+    const torch::Tensor &background, const torch::Tensor &means3D, const torch::Tensor &radii,
+    const torch::Tensor &colors, const torch::Tensor &opacities, const torch::Tensor &scales,
+    const torch::Tensor &rotations, double scale_modifier, const torch::Tensor &cov3D_precomp,
+    const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix, double tan_fovx, double tan_fovy,
+    const torch::Tensor &dL_dout_color, c10::optional<torch::Tensor> dL_dout_invdepth, const torch::Tensor &sh,
+    int degree, const torch::Tensor &campos, const torch::Tensor &geomBuffer, int64_t R,
+    const torch::Tensor &binningBuffer, const torch::Tensor &imageBuffer, bool antialiasing, bool debug,
+    c10::optional<torch::Tensor> sh_rest, int param_space, double near_plane) {
+    const auto dev = means3D.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int64_t P = means3D.size(0);
+    const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
+    int64_t M = sh.numel() != 0 ? sh.size(1) : 0;
+    const bool split = sh_rest.has_value();
+    if (split) {
+        TORCH_CHECK(M == 1, "sh_rest needs sh = features_dc of shape (P,1,3)");
+        M = 1 + sh_rest->size(1);
+    }
+    // one uninitialised arena sliced into the gradient buffers (gsr_backward zeroes adjacent buffers with a single
+    // memset); (P,4)-shaped pieces first so that every slice stays 16-byte aligned
+    const int64_t n_rot = 4 * P, n_conic = 4 * P, n_sh = (split ? 1 : M) * 3 * P, n_rest = split ? (M - 1) * 3 * P : 0,
+                  n_cov = 6 * P, n3 = 3 * P, n1 = P;
+    auto arena = torch::empty({n_rot + n_conic + n_sh + n_rest + n_cov + 4 * n3 + 2 * n1},
+                              means3D.options().dtype(torch::kFloat32));
+    int64_t off = 0;
+    auto take = [&](int64_t n, std::vector<int64_t> shape) {
+        auto v = arena.narrow(0, off, n).view(shape);
+        off += n;
+        return v;
+    };
+    auto dL_drot = take(n_rot, {P, 4}), dL_dconic = take(n_conic, {P, 2, 2});
+    auto dL_dsh = take(n_sh, {P, split ? 1 : M, 3}), dL_dsh_rest = take(n_rest, {P, split ? M - 1 : 0, 3});
+    auto dL_dcov = take(n_cov, {P, 6}), dL_dm3 = take(n3, {P, 3}), dL_dm2 = take(n3, {P, 3}),
+         dL_dcol = take(n3, {P, 3}), dL_dsc = take(n3, {P, 3}), dL_dop = take(n1, {P, 1}), dL_dinv = take(n1, {P, 1});
+    if (P != 0) {
+        const torch::Tensor bg = f32(background, dev, "background"), m3 = f32(means3D, dev, "means3D"),
+                            col = f32(colors, dev, "colors"), op = f32(opacities, dev, "opacities"),
+                            sc = f32(scales, dev, "scales"), rot = f32(rotations, dev, "rotations"),
+                            cov = f32(cov3D_precomp, dev, "cov3D_precomp"), vm = f32(viewmatrix, dev, "viewmatrix"),
+                            pm = f32(projmatrix, dev, "projmatrix"), shc = f32(sh, dev, "sh"),
+                            cp = f32(campos, dev, "campos"), dLc = f32(dL_dout_color, dev, "dL_dout_color");
+        torch::Tensor rest, dLd;
+        if (split) rest = f32(*sh_rest, dev, "sh_rest");
+        if (dL_dout_invdepth.has_value() && dL_dout_invdepth->numel() != 0)
+            dLd = f32(*dL_dout_invdepth, dev, "dL_dout_invdepth");
+        GsrSettings st = settings(H, W, (float)tan_fovx, (float)tan_fovy, (float)scale_modifier, degree, (int)M, false,
+                                  antialiasing, debug, (float)near_plane, Tuning{});
+        GsrInputs in{};
+        in.P = (int32_t)P;
+        in.background = fptr(bg);
+        in.means3D = fptr(m3);
+        in.shs = fptr(shc);
+        in.colors_precomp = fptr(col);
+        in.opacities = fptr(op);
+        in.scales = fptr(sc);
+        in.rotations = fptr(rot);
+        in.cov3D_precomp = fptr(cov);
+        in.viewmatrix = fptr(vm);
+        in.projmatrix = fptr(pm);
+        in.campos = fptr(cp);
+        in.shs_rest = split ? fptr(rest) : nullptr;
+        in.param_space = param_space;
+        GsrBackwardInputs bw{fptr(dLc), dLd.defined() ? fptr(dLd) : nullptr, radii.data_ptr<int32_t>(), R,
+                             geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr()};
+        auto mp = [](torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
+        GsrGrads gr{mp(dL_dm2), mp(dL_dcol), mp(dL_dop), mp(dL_dm3), mp(dL_dcov), mp(dL_dsh), mp(dL_dsc), mp(dL_drot),
+                    mp(dL_dconic), mp(dL_dinv), split ? mp(dL_dsh_rest) : nullptr};
+        const int rc = gsr_backward(&st, &in, &bw, &gr, current_stream(dev));
+        TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    }
+    std::vector<torch::Tensor> out{dL_dm2, dL_dcol, dL_dop, dL_dm3, dL_dcov, dL_dsh, dL_dsc, dL_drot};
+    if (split) out.push_back(dL_dsh_rest);
+    return out;
+}
+
+torch::Tensor mark_visible(const torch::Tensor &means3D, const torch::Tensor &viewmatrix,
+                           const torch::Tensor &projmatrix, double near_plane) {
+    (void)projmatrix;  // unused upstream as well
+    require_gpu(means3D, "means3D");
+    const auto dev = means3D.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int64_t P = means3D.size(0);
+    auto present = torch::zeros({P}, means3D.options().dtype(torch::kBool));
+    if (P != 0) {
+        const torch::Tensor m3 = f32(means3D, dev, "means3D"), vm = f32(viewmatrix, dev, "viewmatrix");
+        const int rc = gsr_mark_visible((int32_t)P, fptr(m3), fptr(vm), (float)near_plane,
+                                        reinterpret_cast<uint8_t *>(present.data_ptr()), current_stream(dev));
+        TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    }
+    return present;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "compiled binding of libgsr_hip.so (MI355X 3DGS rasterizer) with upstream's _C signatures";
+    m.def("rasterize_gaussians", &rasterize_gaussians, py::arg("background"), py::arg("means3D"), py::arg("colors"),
+          py::arg("opacity"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"),
+          py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"),
+          py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"), py::arg("degree"),
+          py::arg("campos"), py::arg("prefiltered"), py::arg("antialiasing"), py::arg("debug"),
+          py::arg("sh_rest") = py::none(), py::arg("param_space") = 0, py::arg("near_plane") = GSR_NEAR_PLANE,
+          py::arg("tuning") = std::vector<int>{});
+    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"),
+          py::arg("radii"), py::arg("colors"), py::arg("opacities"), py::arg("scales"), py::arg("rotations"),
+          py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"),
+          py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("dL_dout_invdepth"),
+          py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"),
+          py::arg("binningBuffer"), py::arg("imageBuffer"), py::arg("antialiasing"), py::arg("debug"),
+          py::arg("sh_rest") = py::none(), py::arg("param_space") = 0, py::arg("near_plane") = GSR_NEAR_PLANE);
+    m.def("mark_visible", &mark_visible, py::arg("means3D"), py::arg("viewmatrix"), py::arg("projmatrix"),
+          py::arg("near_plane") = GSR_NEAR_PLANE);
+    m.def("forward_frame", &forward_frame);
+    m.def("frame_stats", &frame_stats);
+    m.def("version", []() { return std::string(gsr_version()); });
+}

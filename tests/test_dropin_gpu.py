@@ -150,3 +150,58 @@ def test_create_from_pcd_uses_distcuda2_and_ssim_imports(cuda_device, gs_paths):
     assert distCUDA2(torch.from_numpy(pts).to(cuda_device)).shape == (3000,)
     a = torch.rand(1, 3, 32, 32, device=cuda_device)
     assert abs(float(fused_ssim(a, a)) - 1.0) < 1e-6
+
+
+def test_compiled_C_extension_is_loaded_and_matches_the_ctypes_binding(cuda_device):
+    """the drop-in package's `_C` is a compiled torch extension (csrc_torch/ext.cpp) with upstream's
+    positional signatures.  It must be the binding in use on a GPU box, and forward / backward / mark_visible through it
+    must equal the ctypes binding of the same library bit for bit (same kernels, same arguments)."""
+    import numpy as np
+
+    from gsworld_amd import _C, scenes
+
+    assert _C._ext is not None, "gsworld_amd/_C_ext*.so was not built: run `python -m gsworld_amd.build_ext`"
+    assert "gfx950" in _C._ext.version()
+    dev = cuda_device
+    raw = scenes.random_scene_camera_frame(30_000, seed=77)
+    raw.scaling += 0.5
+    cam = scenes.identity_camera(200, 152, 60.0).to(dev)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    e = torch.empty(0, device=dev)
+    gen = torch.Generator().manual_seed(3)
+    dLc = torch.randn((3, 152, 200), generator=gen).to(dev)
+    dLd = torch.randn((1, 152, 200), generator=gen).to(dev)
+
+    def run():
+        out = _C.rasterize_gaussians(bg, means, e, op, sc, rot, 1.0, e, cam.world_view_transform,
+                                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 152, 200, shs, 3,
+                                     cam.camera_center, False, False, False)
+        R, color, radii, gB, bB, iB, invd = out
+        grads = _C.rasterize_gaussians_backward(bg, means, radii, e, op, sc, rot, 1.0, e, cam.world_view_transform,
+                                                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, dLc, dLd, shs, 3,
+                                                cam.camera_center, gB, R, bB, iB, False, False)
+        vis = _C.mark_visible(means, cam.world_view_transform, cam.full_proj_transform)
+        return R, color, radii, invd, grads, vis
+
+    a = run()
+    ext, _C._ext = _C._ext, None  # the ctypes binding of the same shared library
+    try:
+        b = run()
+    finally:
+        _C._ext = ext
+    assert a[0] == b[0] and a[0] > 0
+    for x, y in zip(a[1:4], b[1:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[5], b[5]) and a[5].dtype == torch.bool
+    assert len(a[4]) == len(b[4]) == 8
+    for x, y in zip(a[4], b[4]):  # float atomics: order differs from run to run
+        assert x.shape == y.shape
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-3, atol=1e-3 * float(y.abs().max()) + 1e-12)
+    # upstream's error behaviour through the compiled module
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        _C.rasterize_gaussians(bg, means.reshape(-1), e, op, sc, rot, 1.0, e, cam.world_view_transform,
+                               cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 152, 200, shs, 3, cam.camera_center,
+                               False, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _C.mark_visible(means.cpu(), cam.world_view_transform, cam.full_proj_transform)
