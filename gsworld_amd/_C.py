@@ -75,11 +75,13 @@ def _require_gpu(t: torch.Tensor, what: str):
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                 imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
-                rgb8_out=None):
+                rgb8_out=None, parts=None):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
-    inside preprocess instead of by three torch passes."""
+    inside preprocess instead of by three torch passes.
+    ``parts``: optional ``(labels (P,) float32, lut (L,) int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- the
+    per-frame rigid transform of labelled Gaussians applied inside preprocess (GsrInputs.part_*)."""
     dev = means3D.device
     if _ext is not None:
         st = settings
@@ -92,7 +94,10 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
             projmatrix, sh if sh is not None else e, sh_rest if sh_rest is not None else e, campos, out_color,
             out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
             rgb8_out if rgb8_out is not None else torch.empty(0, dtype=torch.uint8, device=dev), int(r_capacity),
-            bool(want_stats), int(param_space), _tuning_list())
+            bool(want_stats), int(param_space), _tuning_list(),
+            parts[0] if parts is not None else e, parts[1] if parts is not None else torch.empty(0, dtype=torch.int32, device=dev),
+            parts[2] if parts is not None else e,
+            parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev))
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
@@ -102,6 +107,11 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3D_precomp=_ptr(cov3D_precomp), viewmatrix=_ptr(viewmatrix), projmatrix=_ptr(projmatrix),
         campos=_ptr(campos), shs_rest=_ptr(sh_rest) if sh_rest is not None else None, param_space=int(param_space))
+    if parts is not None:
+        labels, lut, table, rescale = parts
+        inp.part_labels, inp.part_lut, inp.part_lut_size = _ptr(labels), _ptr(lut), int(lut.numel())
+        inp.part_transforms, inp.part_count = _ptr(table), int(table.shape[0])
+        inp.part_rescale = _ptr(rescale) if rescale is not None else None
     out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii),
                      _ptr(rgb8_out) if rgb8_out is not None else None)
     cbs = (_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer))

@@ -56,6 +56,9 @@ class GsrInputs(C.Structure):
         ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("shs_rest", C.c_void_p),  # optional features_rest (P,M-1,3): `shs` is then features_dc (forward only)
         ("param_space", C.c_int32),  # RAW_* flags: activations evaluated inside preprocess (forward only)
+        # optional per-frame rigid transform of labelled Gaussians inside preprocess (forward only)
+        ("part_labels", C.c_void_p), ("part_lut", C.c_void_p), ("part_lut_size", C.c_int32),
+        ("part_transforms", C.c_void_p), ("part_count", C.c_int32), ("part_rescale", C.c_void_p),
     ]
 
 

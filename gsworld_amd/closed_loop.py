@@ -30,11 +30,16 @@ from .renderer import MultiCameraRenderer
 
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
-                 background=None):
+                 background=None, fuse_transform: bool = True):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
-        ``scaled_parts``: the tracked actors (their log-scales are rewritten per step as the reference does)."""
+        ``scaled_parts``: the tracked actors (their log-scales are rewritten per step as the reference does).
+        ``fuse_transform`` (default): the step's rigid transforms are applied INSIDE each frame's preprocess
+        (``GsrInputs.part_*``): every (environment, camera) frame reads the one base model plus that environment's pose
+        table, and no transformed copy of the model is written -- per step that saves a 60 B/Gaussian pass per
+        environment (88 MB at 1.47 M) and, for ``num_envs`` > 1, the (E,P,.) buffers themselves.  ``False``: one
+        ``gsr_transform_gaussians_batch`` pass per step, frames read its outputs (same bytes out: tests)."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
@@ -51,6 +56,7 @@ class ClosedLoopRenderer:
         semantics = g("semantics", "_semantics")
         self.op = tf.FusedPartTransform(part_labels, semantics.to(dev), scaled_parts=scaled_parts)
         self.rescaled = len(tuple(scaled_parts)) > 0
+        self.fuse_transform = bool(fuse_transform)
         self.K = len(self.op.names)
         H, W = self.cameras[0].image_height, self.cameras[0].image_width
         self.frames = {n: torch.zeros((self.num_envs, c.image_height, c.image_width, 3), dtype=torch.uint8, device=dev)
@@ -67,12 +73,24 @@ class ClosedLoopRenderer:
     # ---- one step ------------------------------------------------------------------------------------------------
     def _gpu_step(self):
         """Everything the GPU does per step: pose table, fused transform, E x C frames (reads self.matrices / scales)."""
+        E, C = self.num_envs, len(self.cameras)
+        if self.fuse_transform:
+            parts = self.op.parts(self.matrices, self.scales)  # device-side pose table(s), nothing else
+            views, outs, per_lane = [], [], []
+            for e in range(E):
+                for c in range(C):
+                    views.append(self.cameras[c])
+                    outs.append(self.frames[self.names[c]][e])
+                    per_lane.append(dict(parts=parts if E == 1 else parts[e]))
+            self.multi.render(views, self.xyz, self.opacity, rgb8_out=outs, shs=self.features_dc,
+                              shs_rest=self.features_rest, scales=self.scaling, rotations=self.rotation,
+                              param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg, per_lane=per_lane)
+            return
         if self.rescaled:
             xyz, rot, scaling = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales, scaling=self.scaling)
         else:
             xyz, rot = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales)
             scaling = self.scaling
-        E, C = self.num_envs, len(self.cameras)
         # lane e * C + c renders environment e from camera c; the transformed quaternions keep their norm (reference
         # semantics) and the scales stay logs: preprocess activates both on load
         views, outs = [], []

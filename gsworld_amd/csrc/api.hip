@@ -112,6 +112,17 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
             gsr_set_error("gsr_forward: unknown bits in param_space");
             return GSR_E_INVALID;
         }
+        if (in->part_labels) {
+            if (!in->part_lut || in->part_lut_size <= 0 || in->part_count < 0 ||
+                (in->part_count > 0 && !in->part_transforms) || in->cov3D_precomp) {
+                gsr_set_error("gsr_forward: part_labels needs part_lut, part_transforms and scales / rotations");
+                return GSR_E_INVALID;
+            }
+            if (in->part_rescale && !(in->param_space & GSR_RAW_SCALES)) {
+                gsr_set_error("gsr_forward: part_rescale rewrites log-scales: it needs GSR_RAW_SCALES");
+                return GSR_E_INVALID;
+            }
+        }
         if (in->shs_rest && (!in->shs || st->sh_coeffs < 2)) {
             gsr_set_error("gsr_forward: shs_rest needs shs (= features_dc) and sh_coeffs >= 2");
             return GSR_E_INVALID;

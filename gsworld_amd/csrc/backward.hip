@@ -608,6 +608,10 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: unknown param_space bits");
         return GSR_E_INVALID;
     }
+    if (in->part_labels) {
+        gsr_set_error("gsr_backward: the in-preprocess part transform (GsrInputs.part_labels) is forward-only");
+        return GSR_E_INVALID;
+    }
     if ((in->param_space & (GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) && in->cov3D_precomp) {
         gsr_set_error("gsr_backward: raw scales / rotations cannot be combined with cov3D_precomp");
         return GSR_E_INVALID;

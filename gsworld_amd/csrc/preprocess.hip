@@ -19,6 +19,11 @@ struct PreprocessArgs {
     int param_space;  // GSR_RAW_* flags: activations evaluated here instead of three torch passes per frame
     const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;
+    // optional rigid transform of labelled Gaussians (GsrInputs.part_*): same arithmetic as transform.hip
+    const float *part_labels, *part_transforms;
+    const int32_t *part_lut;
+    const uint8_t *part_rescale;
+    int part_lut_size, part_count;
     int32_t *radii;
     float4 *splat;
     float *cov3D;
@@ -83,8 +88,24 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
     }
     if (i < a.P) {
-        const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1],
-                    pz = a.means3D[3 * (size_t)i + 2];
+        float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+        // moving part?  (label -> part through the LUT; the reference compares labels after .long(): truncation)
+        const float *xf = nullptr;
+        int part = -1;
+        if (a.part_labels != nullptr) {
+            const int label = (int)a.part_labels[i];
+            part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
+            if (part >= 0 && part < a.part_count) {
+                xf = a.part_transforms + (size_t)part * 17;
+                // xyz' = R (s xyz) + t, in the operation order of transform.hip (plain multiplies and adds)
+                const float s = xf[12];
+                px *= s; py *= s; pz *= s;
+                const float rx = xf[0] * px + xf[1] * py + xf[2] * pz + xf[9];
+                const float ry = xf[3] * px + xf[4] * py + xf[5] * pz + xf[10];
+                const float rz = xf[6] * px + xf[7] * py + xf[8] * pz + xf[11];
+                px = rx; py = ry; pz = rz;
+            }
+        }
         const float *m = a.view;
         // transformPoint4x3: M[r][c] = m[c*4+r]
         const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
@@ -108,6 +129,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
             } else {
                 float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
                 float sc0 = a.scales[3 * (size_t)i], sc1 = a.scales[3 * (size_t)i + 1], sc2 = a.scales[3 * (size_t)i + 2];
+                if (xf != nullptr) {
+                    // rot' = standardize(q_R (x) rot / |rot|) * |rot|  (gs_utils.py:242-249; transform.hip)
+                    const float norm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+                    const float bw = rq.x / norm, bx = rq.y / norm, by = rq.z / norm, bz = rq.w / norm;
+                    const float aw = xf[13], ax = xf[14], ay = xf[15], az = xf[16];
+                    float ow = aw * bw - ax * bx - ay * by - az * bz;
+                    float ox = aw * bx + ax * bw + ay * bz - az * by;
+                    float oy = aw * by - ax * bz + ay * bw + az * bx;
+                    float oz = aw * bz + ax * by - ay * bx + az * bw;
+                    if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }
+                    rq = make_float4(ow * norm, ox * norm, oy * norm, oz * norm);
+                    if (a.part_rescale != nullptr && a.part_rescale[part]) {
+                        // the reference's rewrite of a tracked actor's log-scales: inverse_sigmoid(exp(s) * scale)
+                        const float s = xf[12];
+                        const float x0 = expf(sc0) * s, x1 = expf(sc1) * s, x2 = expf(sc2) * s;
+                        sc0 = logf(x0 / (1.0f - x0));
+                        sc1 = logf(x1 / (1.0f - x1));
+                        sc2 = logf(x2 / (1.0f - x2));
+                    }
+                }
                 if (a.param_space & GSR_RAW_ROTATIONS) {  // F.normalize: q / max(|q|, 1e-12)
                     const float n2 = fma_(rq.w, rq.w, fma_(rq.z, rq.z, fma_(rq.y, rq.y, rq.x * rq.x)));
                     const float d = fmaxf(sqrtf(n2), 1e-12f);
@@ -362,6 +403,12 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.view = in.viewmatrix;
     a.proj = in.projmatrix;
     a.campos = in.campos;
+    a.part_labels = in.part_labels;
+    a.part_lut = in.part_lut;
+    a.part_lut_size = in.part_lut_size;
+    a.part_transforms = in.part_transforms;
+    a.part_count = in.part_count;
+    a.part_rescale = in.part_rescale;
     a.radii = radii;
     a.splat = g.splat;
     a.cov3D = g.cov3D;

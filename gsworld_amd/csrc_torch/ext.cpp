@@ -90,7 +90,9 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
     const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix,
     const torch::Tensor &sh, const torch::Tensor &sh_rest, const torch::Tensor &campos, torch::Tensor out_color,
     torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
-    const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning) {
+    const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning,
+    const torch::Tensor &part_labels, const torch::Tensor &part_lut, const torch::Tensor &part_table,
+    const torch::Tensor &part_rescale) {
     const auto dev = means3D.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     GsrSettings st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false,
@@ -110,6 +112,14 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
     in.campos = fptr(campos);
     in.shs_rest = fptr(sh_rest);
     in.param_space = param_space;
+    if (part_labels.numel() != 0) {  // rigid transform of labelled Gaussians inside preprocess (GsrInputs.part_*)
+        in.part_labels = part_labels.data_ptr<float>();
+        in.part_lut = part_lut.data_ptr<int32_t>();
+        in.part_lut_size = (int32_t)part_lut.numel();
+        in.part_transforms = fptr(part_table);
+        in.part_count = (int32_t)part_table.size(0);
+        in.part_rescale = part_rescale.numel() ? part_rescale.data_ptr<uint8_t>() : nullptr;
+    }
     GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(), radii.data_ptr<int32_t>(),
                    rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
     GsrBuffers buf{resize_cb, &geom, resize_cb, &binning, resize_cb, &image};
@@ -167,7 +177,9 @@ rasterize_gaussians(const torch::Tensor &background, const torch::Tensor &means3
                                    near_plane, bg, m3, col, op, sc, rot, cov, vm, pm, shc,
                                    rest.defined() ? rest : torch::Tensor(torch::empty({0}, fopt)), cp, out_color,
                                    out_invdepth, radii, geom, binning, img, torch::empty({0}, bopt), 0, true,
-                                   param_space, tuning);
+                                   param_space, tuning, torch::empty({0}, fopt),
+                                   torch::empty({0}, means3D.options().dtype(torch::kInt32)), torch::empty({0}, fopt),
+                                   torch::empty({0}, bopt));
         (void)prefiltered;
         rendered = (int)std::get<1>(stats);
     }

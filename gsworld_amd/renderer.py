@@ -53,7 +53,7 @@ class FrameRenderer:
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
                antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
-               param_space: int = 0, rgb8_out=None):
+               param_space: int = 0, rgb8_out=None, parts=None):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
         renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
         ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
@@ -62,7 +62,11 @@ class FrameRenderer:
         arguments are the model's RAW parameters (logits, log scales, un-normalised quaternions) and are activated
         inside preprocess (no sigmoid / exp / normalize passes per frame).
         ``rgb8_out``: optional (H,W,3) uint8 tensor that receives GSWorld's uint8 frame conversion directly from the
-        compositing kernel (same bytes as :meth:`pack_rgb8` of the returned colour image)."""
+        compositing kernel (same bytes as :meth:`pack_rgb8` of the returned colour image).
+        ``parts``: ``(labels (P,) float32, lut int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- this frame's
+        rigid transform of the labelled Gaussians, applied inside preprocess: ``means3D`` / ``rotations`` / ``scales``
+        are then the BASE model and no transformed copy is ever written (:class:`gsworld_amd.transform.FusedPartTransform`
+        builds the tuple; bit-identical to transforming first)."""
         dev = self.device
 
         def norm(t, what, allow_none=True):
@@ -115,7 +119,7 @@ class FrameRenderer:
             cov3D_precomp if cov3D_precomp is not None else empty, view_m,
             proj_m, shs if shs is not None else empty, campos, color, invd, radii,
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
-            param_space=param_space, rgb8_out=rgb8_out)
+            param_space=param_space, rgb8_out=rgb8_out, parts=parts)
         if cap == 0:
             self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
         return color, radii, invd

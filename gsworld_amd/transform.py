@@ -91,6 +91,7 @@ class FusedPartTransform:
                 if not 0 <= int(lab) < lut_size:
                     raise ValueError(f"label {lab} of part {name!r} outside the LUT (size {lut_size})")
                 lut[int(lab)] = k
+        scaled_parts = tuple(scaled_parts)
         unknown = [n for n in scaled_parts if n not in part_labels]
         if unknown:
             raise ValueError(f"scaled_parts names unknown parts: {unknown}")
@@ -99,6 +100,7 @@ class FusedPartTransform:
         self.semantics = semantics.reshape(-1).to(torch.float32).contiguous()
         self.rescale = torch.tensor([1 if n in set(scaled_parts) else 0 for n in self.names],
                                     dtype=torch.uint8).to(self.device)
+        self._any_rescale = len(tuple(scaled_parts)) > 0
         self._out = {}
         self._table = None
 
@@ -141,6 +143,20 @@ class FusedPartTransform:
                 n, C.c_void_p(matrices.data_ptr()), C.c_void_p(scales.data_ptr() if scales is not None else 0),
                 C.c_void_p(self._table.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return self._table
+
+    def parts(self, matrices: torch.Tensor, scales=None, env: int | None = None):
+        """-> the ``parts=`` tuple of :meth:`gsworld_amd.renderer.FrameRenderer.render` for this step's poses: the
+        transform is then applied inside preprocess and no transformed copy of the model is written.  ``matrices``
+        (K,4,4) or (E,K,4,4) on the DEVICE (+ ``scales``); for a batch, ``env`` selects the environment (None: a list with
+        one tuple per environment).  The pose table lives in a persistent buffer (capturable)."""
+        table = self.pack_on_device(matrices, scales) if matrices.is_cuda else \
+            self.pack(matrices, scales).to(self.device, non_blocking=True)
+        rescale = self.rescale if self._any_rescale else None
+        if table.dim() == 2:
+            return (self.semantics, self.lut, table, rescale)
+        if env is not None:
+            return (self.semantics, self.lut, table[env], rescale)
+        return [(self.semantics, self.lut, table[e], rescale) for e in range(table.shape[0])]
 
     def _buffer(self, name, shape, like):
         t = self._out.get(name)

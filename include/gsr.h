@@ -98,6 +98,18 @@ typedef struct GsrInputs {
      * the model) are then evaluated inside preprocess, in the float32 order fixed by oracle/gs_oracle.c
      * (gso_activate_params; exp = 2^n * Cephes polynomial, ~1 ulp).  0 = upstream contract (activated inputs). */
     int32_t param_space;
+    /* Optional rigid transform of labelled Gaussians applied INSIDE preprocess (forward only): what
+     * gsr_transform_gaussians computes, without materialising transformed (P,.) buffers -- a frame of environment e from
+     * camera c reads the one base model plus environment e's 17-float pose table (see gsr_transform_gaussians below for
+     * the table and the arithmetic; the results are bit-identical to transforming first and rendering the outputs).
+     * part_labels NULL = off.  part_rescale ((K) bytes or NULL) marks the parts whose log-scales the reference rewrites
+     * (needs GSR_RAW_SCALES). */
+    const float *part_labels;      /* (P) semantic label per Gaussian, or NULL */
+    const int32_t *part_lut;       /* (part_lut_size) label -> part index, -1 = not a moving part */
+    int32_t part_lut_size;
+    const float *part_transforms;  /* (part_count, 17) */
+    int32_t part_count;
+    const uint8_t *part_rescale;   /* (part_count) or NULL */
 } GsrInputs;
 
 #define GSR_RAW_OPACITY 1   /* opacities are logits:        opacity  = 1 / (1 + exp(-x)) */

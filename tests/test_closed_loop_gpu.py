@@ -20,12 +20,13 @@ from oracle import wrapper_glue_ref as ref
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, n, num_envs=1, seed=1):
+def _setup(dev, n, num_envs=1, seed=1, fuse_transform=True):
     raw = scenes.tabletop_scene("xarm6_align", n=n, seed=seed)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
     parts, actors = cl.xarm6_parts()
-    loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=num_envs, device=dev)
+    loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=num_envs, device=dev,
+                                 fuse_transform=fuse_transform)
     rawd = raw.to(dev)
     model = types.SimpleNamespace(_xyz=rawd.xyz, _scaling=rawd.scaling, _rotation=rawd.rotation,
                                   _opacity=rawd.opacity.reshape(-1, 1, 1), _semantics=rawd.semantics,
@@ -80,6 +81,26 @@ def test_fused_glue_reproduces_the_wrapper_glue_over_a_rollout(cuda_device):
         for name in want:
             assert torch.equal(frames[name], want[name]), f"graph replay differs from eager ({name})"
     assert not any(st.overflow for st in loop.ensure_valid())
+
+
+@pytest.mark.parametrize("num_envs", [1, 2])
+def test_transform_inside_preprocess_is_bit_identical_to_the_transform_pass(cuda_device, num_envs):
+    """the default closed loop applies the step's rigid transforms inside every frame's preprocess
+    (GsrInputs.part_*: no transformed copy of the model, one pose table per environment) -- the frames must be the very
+    bytes of the two-pass path (gsr_transform_gaussians_batch, then frames over its outputs): same arithmetic."""
+    dev = cuda_device
+    _, _, parts, actors, fused, _ = _setup(dev, 150_000, num_envs=num_envs, seed=2, fuse_transform=True)
+    _, _, _, _, twopass, _ = _setup(dev, 150_000, num_envs=num_envs, seed=2, fuse_transform=False)
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=5, seed=9, num_envs=num_envs))
+    fused.reset(*poses[0])
+    twopass.reset(*poses[0])
+    for M, s in poses:
+        a, b = fused.step(M, s), twopass.step(M, s)
+        torch.cuda.synchronize()
+        for name in a:
+            assert torch.equal(a[name], b[name]), f"{name}: in-preprocess transform differs from the transform pass"
+    assert int(a["right_cam"].max()) > 100
 
 
 def test_env_batch_matches_the_wrapper_glue(cuda_device):
