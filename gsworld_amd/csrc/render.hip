@@ -374,8 +374,8 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
         const v2f dx = v2f{qxy.x, qxy.y} - pf2x, dy = v2f{qxy.z, qxy.w} - pf2y;
         const v2f cA = {qac.x, qac.y}, cC = {qac.z, qac.w};
         const v2f cB = {qbo.x, qbo.y}, op = {qbo.z, qbo.w};
-        const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
-        const v2f power = __builtin_elementwise_fma(-(cB * dx), dy, v2f{-0.5f, -0.5f} * q);
+        const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);   // = -0.5 (A dx^2 + C dy^2): pre-scaled
+        const v2f power = __builtin_elementwise_fma(cB * dx, dy, q);             // cB = -B
         const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
         const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
         const float a0 = fminf(0.99f, a.x), a1 = fminf(0.99f, a.y);
@@ -410,9 +410,12 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
     float *f = reinterpret_cast<float *>(pr) + (rank & 1);
     f[0] = geo.x;
     f[2] = geo.y;
-    f[4] = conic_op.x;
-    f[6] = conic_op.z;
-    f[8] = conic_op.y;
+    // the quadratic form is stored pre-multiplied: -A/2, -C/2, -B.  Scaling by a power of two commutes with every
+    // rounding below, so power = fma((-B) dx, dy, fma((-C/2) dy, dy, ((-A/2) dx) dx)) has the bits of
+    // fma(-(B dx), dy, -0.5 fma(C dy, dy, (A dx) dx)) -- one packed multiply less per survivor pair
+    f[4] = -0.5f * conic_op.x;
+    f[6] = -0.5f * conic_op.z;
+    f[8] = -conic_op.y;
     f[10] = conic_op.w;
     pr[3 + (rank & 1)] = rgbd;
     f[20] = pos;
@@ -574,19 +577,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             // (Evaluating batch i + 1 ahead of the blend of batch i -- one basic block, ping-pong registers -- was
             // measured: +17 % replay time; the loop is bound by instruction count, not by exposed latency.)
             if (unsafe == 0ull) {
-                for (int i = 0; i < n_surv; i += kBatch) {
-                    if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+                // (one exit test, at the bottom: with a second exit at the top the accumulators were copied through
+                // six v_mov per iteration)
+                int i = 0;
+                if (n_surv > 0) do {
                     const StreamBatch b = stream_eval<false>(list, i, pf2x, pf2y);
                     stream_blend(b, T, acc_rg, acc_bd, last_contributor);
                     work += (uint32_t)kBatch;  // survivors actually replayed (a saturated quadrant stops early)
-                }
+                    i += kBatch;
+                } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);
             } else {
-                for (int i = 0; i < n_surv; i += kBatch) {
-                    if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+                int i = 0;
+                if (n_surv > 0) do {
                     const StreamBatch b = stream_eval<true>(list, i, pf2x, pf2y);
                     stream_blend(b, T, acc_rg, acc_bd, last_contributor);
                     work += (uint32_t)kBatch;
-                }
+                    i += kBatch;
+                } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);
             }
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
