@@ -122,6 +122,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
             const float ndc_x = hx * p_w, ndc_y = hy * p_w;
 
             // ---- 3D covariance: Sigma = R diag((mod*s)^2) R^T ------------------------------------------------
+            const float opacity_raw = a.opacities[i];  // (requested with the covariance inputs: one round trip, not two)
             float c0, c1, c2, c3, c4, c5;
             if (a.cov3D_precomp) {
                 const float *c = a.cov3D_precomp + 6 * (size_t)i;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
                 rmaxy = min(a.gy, max(0, rmaxy));
                 const int area = (rmaxx - rminx) * (rmaxy - rminy);
                 if (area != 0) {
-                    float opacity_in = a.opacities[i];
+                    float opacity_in = opacity_raw;
                     if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
                     const float opacity = opacity_in * h_scale;
                     float4 *rec = a.splat + 3 * (size_t)i;
