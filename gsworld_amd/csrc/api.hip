@@ -208,7 +208,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     if (mode == 2) {
         if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_count(*st, g, debug, stream)) return e;
+        if (int e = gsr_launch_band_count(*st, in->P, g, st->depth_sort != 1, debug, stream)) return e;
         if (int e = gsr_launch_tile_starts(*st, g, img, cap32, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;

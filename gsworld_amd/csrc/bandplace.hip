@@ -34,11 +34,59 @@ constexpr int kBT = GSR_BLOCK;              // 256 threads = 4 waves
 constexpr int kBW = kBT / GSR_WAVE;
 constexpr int kRing = 128;                  // (Gaussian, row) pairs buffered per wave
 
-// rank range of global wave gw (of NR * 4): multiples of 64 ranks, ceil(V / waves) each
-__device__ __forceinline__ void band_wave_range(uint32_t V, uint32_t gw, uint32_t waves, uint32_t &lo, uint32_t &hi) {
-    const uint32_t per = (((V + waves - 1u) / waves) + 63u) & ~63u;
-    lo = min(V, gw * per);
-    hi = min(V, lo + per);
+// First depth rank of every placement wave.  Equal RANK shares load the waves unevenly -- a wave's work is its
+// instances, and the nearest splats (first in depth order) are the largest on screen: at config 5 the 5000 near-band
+// splats cover the whole image and all sat in the first three waves of every row (290 us).  With the running sums the
+// depth sort leaves (tiles per bucket, running sum inside each bucket) the order is cut at equal cumulative INSTANCE
+// counts: wave j starts at the first rank whose inclusive running sum exceeds j R / waves.  One workgroup.
+__global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrHeader *__restrict__ hdr, int bmax,
+                                                          const uint32_t *__restrict__ bucket_start,
+                                                          const uint32_t *__restrict__ bucket_tiles,
+                                                          const uint32_t *__restrict__ tile_cum, int waves,
+                                                          uint32_t *__restrict__ wave_lo) {
+    __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
+    __shared__ uint32_t s_w[4];
+    const int tid = (int)threadIdx.x;
+    const uint32_t V = hdr->V;
+    if (tile_cum == nullptr || V == 0u) {  // no running sums (LSD radix variant of the depth sort): equal rank shares
+        const uint32_t per = (((V + (uint32_t)waves - 1u) / (uint32_t)waves) + 63u) & ~63u;
+        for (int j = tid; j <= waves; j += kBT) wave_lo[j] = min(V, (uint32_t)j * per);
+        return;
+    }
+    int B = 256;
+    while (B < bmax && (uint32_t)B * 512u < V) B <<= 1;  // (ss_num_buckets of depthsort.hip)
+    const int PER = B / kBT;
+    uint32_t t[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        t[k] = k < PER ? bucket_tiles[tid * PER + k] : 0u;
+        sum += t[k];
+    }
+    uint32_t total;
+    uint32_t run = gsr_block_incl_scan(sum, s_w, total) - sum;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k < PER) {
+            s_pre[tid * PER + k] = run;
+            run += t[k];
+        }
+    if (tid == 0) s_pre[B] = total;
+    __syncthreads();
+    for (int j = tid; j <= waves; j += kBT) {
+        const uint32_t target = (uint32_t)(((uint64_t)total * (uint32_t)j) / (uint32_t)waves);
+        // bucket that holds the crossing: the last one whose exclusive sum is <= target
+        int b = 0;
+        for (int step = B >> 1; step > 0; step >>= 1)
+            if (s_pre[b + step] <= target) b += step;
+        // ranks of that bucket whose inclusive running sum is <= target - exclusive sum
+        const uint32_t s0 = bucket_start[b], n = bucket_start[b + 1] - s0, rest = target - s_pre[b];
+        uint32_t lo = 0, hi = n;  // count of entries <= rest: first index with tile_cum > rest
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile_cum[s0 + mid] <= rest) lo = mid + 1u; else hi = mid;
+        }
+        wave_lo[j] = j == waves ? V : s0 + lo;
+    }
 }
 
 constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (704 ranks per wave at config 2: one batch)
@@ -47,14 +95,13 @@ constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (70
 // the columns is the number of pairs covering each.  Two LDS atomics per pair, per-wave difference arrays.
 template <int NC>
 __global__ __launch_bounds__(kBT) void band_count_kernel(const uint2 *__restrict__ rect_sorted,
-                                                         const GsrHeader *__restrict__ hdr, int gx, int NR,
+                                                         const uint32_t *__restrict__ wave_lo, int gx, int NR,
                                                          uint32_t *__restrict__ table, uint32_t *__restrict__ wtable) {
     __shared__ int s_diff[kBW][NC * 64 + 1];
     __shared__ uint32_t s_tot[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
-    const uint32_t V = hdr->V, r = blockIdx.x, y = blockIdx.y;
-    uint32_t lo, hi;
-    band_wave_range(V, r * kBW + (uint32_t)wave, (uint32_t)NR * kBW, lo, hi);
+    const uint32_t r = blockIdx.x, y = blockIdx.y;
+    const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
     int *diff = s_diff[wave];
 #pragma unroll
     for (int k = 0; k < NC; k++) diff[k * 64 + lane] = 0;
@@ -144,7 +191,12 @@ __device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool
     const int lane = gsr_lane();
     const uint64_t lt = gsr_lanemask_lt();
     const uint32_t minx = span & 0xffffu, maxx = span >> 16, w = valid ? maxx - minx : 0u;
-    uint32_t wmax = w;
+    // a pair walks up to kNarrow of its own columns; the rest of a WIDE pair (a splat spanning much of the row: 1 % of
+    // the Gaussians at config 5, but one of them sits in nearly every round of 64 pairs) is spread over the whole wave
+    // instead of keeping 63 idle lanes looping with it
+    constexpr uint32_t kNarrow = 16;
+    const uint32_t wn = min(w, kNarrow);
+    uint32_t wmax = wn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o, 64));
     wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
@@ -164,20 +216,22 @@ __device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool
         uint32_t cx[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; u++) {
-            m[u] = j0 + u < w ? colmask[minx + j0 + u] : 0ull;
-            cx[u] = j0 + u < w ? cur[minx + j0 + u] : 0u;
+            m[u] = j0 + u < wn ? colmask[minx + j0 + u] : 0ull;
+            cx[u] = j0 + u < wn ? cur[minx + j0 + u] : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; u++)
-            if (j0 + u < w) {
-#if defined(BAND_EXP) && BAND_EXP == 4
-                asm volatile("" ::"v"(cx[u] + (uint32_t)__popcll(m[u] & lt)), "v"(g));
-#elif defined(BAND_EXP) && BAND_EXP == 5
-                point_list[(cx[u] + (uint32_t)__popcll(m[u] & lt)) & ~63u | (uint32_t)lane] = g;
-#else
-                point_list[cx[u] + (uint32_t)__popcll(m[u] & lt)] = g;
-#endif
-            }
+            if (j0 + u < wn) point_list[cx[u] + (uint32_t)__popcll(m[u] & lt)] = g;
+    }
+    for (uint64_t wide = __builtin_amdgcn_ballot_w64(w > kNarrow); wide;) {
+        const int src = __ffsll((unsigned long long)wide) - 1;
+        wide &= wide - 1ull;
+        const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)w, src);
+        const uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)minx, src);
+        const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int)g, src);
+        const uint64_t below = (1ull << src) - 1ull;
+        for (uint32_t j = kNarrow + (uint32_t)lane; j < sw; j += 64u)
+            point_list[cur[sx + j] + (uint32_t)__popcll(colmask[sx + j] & below)] = sg;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -188,7 +242,8 @@ __device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool
 template <int NC>
 __global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict__ rect_sorted,
                                                          const uint32_t *__restrict__ order,
-                                                         const GsrHeader *__restrict__ hdr, int gx, int NR,
+                                                         const GsrHeader *__restrict__ hdr,
+                                                         const uint32_t *__restrict__ wave_lo, int gx, int NR,
                                                          const uint32_t *__restrict__ table,
                                                          const uint32_t *__restrict__ wtable,
                                                          const uint2 *__restrict__ ranges,
@@ -198,9 +253,8 @@ __global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict
     __shared__ uint32_t s_cur[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
     if (hdr->overflow) return;
-    const uint32_t V = hdr->V, r = blockIdx.x, y = blockIdx.y;
-    uint32_t lo, hi;
-    band_wave_range(V, r * kBW + (uint32_t)wave, (uint32_t)NR * kBW, lo, hi);
+    const uint32_t r = blockIdx.x, y = blockIdx.y;
+    const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
     if (lo >= hi) return;
     uint2 *ring = s_ring[wave];
     uint32_t *cur = s_cur[wave];
@@ -279,17 +333,22 @@ int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream
 }
 
 // counts -> ranges, R (tile_starts_kernel lives in binning.hip)
-int gsr_launch_band_count(const GsrSettings &st, const GeomState &g, bool debug, hipStream_t stream) {
+int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
+                          hipStream_t stream) {
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const dim3 grid(GSR_BAND_RANGES, gy);
+    hipLaunchKernelGGL(band_ranges_kernel, dim3(1), dim3(kBT), 0, stream, g.hdr, gsr_ss_bmax(P), g.ss_bucket_start,
+                       g.bucket_tiles, balanced ? g.tile_cum : (const uint32_t *)nullptr, GSR_BAND_RANGES * kBW,
+                       g.wave_lo);
+    if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
-        hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+        hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
                            g.band_table, g.band_wtable);
     else if (gx <= 128)
-        hipLaunchKernelGGL(band_count_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+        hipLaunchKernelGGL(band_count_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
                            g.band_table, g.band_wtable);
     else
-        hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.hdr, gx, GSR_BAND_RANGES,
+        hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
                            g.band_table, g.band_wtable);
     if (int e = gsr_check_launch("band_count", debug, stream)) return e;
     const int T = gx * gy;
@@ -302,13 +361,13 @@ int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const Binni
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
     const dim3 grid(GSR_BAND_RANGES, gy);
     if (gx <= 64)
-        hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+        hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
                            GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
     else if (gx <= 128)
-        hipLaunchKernelGGL(band_place_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+        hipLaunchKernelGGL(band_place_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
                            GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
     else
-        hipLaunchKernelGGL(band_place_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, gx,
+        hipLaunchKernelGGL(band_place_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
                            GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
     return gsr_check_launch("band_place", debug, stream);
 }

@@ -37,6 +37,8 @@ constexpr int kSamplesPerBucket = 2;
 constexpr int kMaxSamples = 4096;
 constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'
 constexpr uint32_t kReuseMaxSamples = 4 * kSamplesPerBucket;  // sample count per bucket that still passes for balanced
+// placement cost of one Gaussian = its instances + this many (every tile row streams and tests every rank of its share)
+constexpr uint32_t kRankCost = 40u;
 constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         const uint32_t *__restrict__ bucket_start,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
+                                                        uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
@@ -519,7 +522,10 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     }
     const uint32_t s = bucket_start[blockIdx.x];
     const int n = (int)(bucket_start[blockIdx.x + 1] - s);
-    if (n == 0) return;
+    if (n == 0) {
+        if (tid == 0) bucket_tiles[blockIdx.x] = 0u;
+        return;
+    }
     uint2 *seg = recs + s;
     if (n > kBucketCap) {
         // does not fit the LDS: bitonic network over the (key << 32 | index) composites in global memory (one
@@ -529,11 +535,23 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         uint64_t *comp = reinterpret_cast<uint64_t *>(seg);
         __syncthreads();
         bitonic_sort_block(comp, n, N);
-        for (int i = tid; i < n; i += kT) {
-            const uint32_t gi = (uint32_t)comp[i];
-            order[s + i] = gi;
-            rect_sorted[s + i] = rects[gi];
+        uint32_t carry = 0;
+        for (int i0 = 0; i0 < n; i0 += kT) {
+            const int i = i0 + tid;
+            uint32_t t = 0;
+            if (i < n) {
+                const uint32_t gi = (uint32_t)comp[i];
+                const uint2 rc = rects[gi];
+                order[s + i] = gi;
+                rect_sorted[s + i] = rc;
+                t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
+            }
+            uint32_t tot;
+            const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
+            if (i < n) tile_cum[s + i] = carry + incl;
+            carry += tot;
         }
+        if (tid == 0) bucket_tiles[blockIdx.x] = carry;
         for (int i = tid; i < B - 1; i += kT) {  // next frame's splitters: exact quantiles (see below)
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
             if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & 0xFFFFFF00u;
@@ -573,11 +591,25 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
         if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & 0xFFFFFF00u;
     }
-    for (int i = tid; i < n; i += kT) {  // depth order + the tile rects in that order (what the placement streams)
-        const uint32_t gi = s_v[src * kBucketCap + i];
-        order[s + i] = gi;
-        rect_sorted[s + i] = rects[gi];
+    // depth order, the tile rects in that order (what the placement streams), and the running sum of tiles touched
+    // inside the bucket (the placement cuts the depth order into shares of equal INSTANCE count with it)
+    uint32_t carry = 0;
+    for (int i0 = 0; i0 < n; i0 += kT) {
+        const int i = i0 + tid;
+        uint32_t t = 0;
+        if (i < n) {
+            const uint32_t gi = s_v[src * kBucketCap + i];
+            const uint2 rc = rects[gi];
+            order[s + i] = gi;
+            rect_sorted[s + i] = rc;
+            t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
+        }
+        uint32_t tot;
+        const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
+        if (i < n) tile_cum[s + i] = carry + incl;
+        carry += tot;
     }
+    if (tid == 0) bucket_tiles[blockIdx.x] = carry;
     SS_STAMP(dbg, 4);
 }
 
@@ -611,6 +643,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipS
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
-                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.hdr, g.ss_dbg);
+                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

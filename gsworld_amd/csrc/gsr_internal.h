@@ -74,6 +74,9 @@ struct GeomState {
     uint2 *rect_sorted;       // [P]   tile rects in depth order (written by the depth sort)
     uint32_t *band_table;     // [tiles * GSR_BAND_RANGES]  instances per (tile, rank range) -> exclusive offsets
     uint32_t *band_wtable;    // [tile rows * GSR_BAND_RANGES * 4 waves * padded row width]  per-wave column counts
+    uint32_t *tile_cum;       // [P]   tiles touched, inclusive running sum in depth order INSIDE each sort bucket
+    uint32_t *bucket_tiles;   // [bmax] tiles touched per sort bucket
+    uint32_t *wave_lo;        // [GSR_BAND_RANGES * 4 + 1] first depth rank of every placement wave (equal instance shares)
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -125,6 +128,9 @@ struct GeomState {
         g.rect_sorted = take<uint2>(p, n);
         g.band_table = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES + 1);
         g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));
+        g.tile_cum = take<uint32_t>(p, n);
+        g.bucket_tiles = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
+        g.wave_lo = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
@@ -249,7 +255,8 @@ int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug,
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-int gsr_launch_band_count(const GsrSettings &st, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
+                          hipStream_t stream);
 int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
                           bool debug, hipStream_t stream);
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
