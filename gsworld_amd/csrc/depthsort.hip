@@ -39,6 +39,8 @@ constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'
 constexpr uint32_t kReuseMaxSamples = 4 * kSamplesPerBucket;  // sample count per bucket that still passes for balanced
 // placement cost of one Gaussian = its instances + this many (every tile row streams and tests every rank of its share)
 constexpr uint32_t kRankCost = 40u;
+// compaction cost of one preprocess block (256 keys fetched and tested), in records
+constexpr uint32_t kBlockCost = 8u;
 constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
@@ -153,33 +155,57 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     extern __shared__ uint32_t smem[];
     const unsigned dbg_wg = 64; (void)dbg_wg;
     SS_STAMP(dbg, 0);
+#ifdef GSR_SS_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t *s_key = smem;                       // [2][kMaxSamples]
     uint32_t *s_cur = s_key + 2 * kMaxSamples;    // [4][256]
     uint32_t *s_split = s_cur + 4 * 256;          // [bmax]
     uint32_t *s_hist = s_split + bmax;            // [bmax]
-    uint32_t *s_boff = s_hist + bmax;             // [bpw + 1]
+    uint32_t *s_boff = s_hist + bmax;             // [4 kT + 1] offsets of up to 1024 blocks
     __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
-    const int first = (int)blockIdx.x * bpw, nblk = max(0, min(nb1, first + bpw) - first);
-
-    // ---- V and this workgroup's first output slot: every workgroup adds up the per-block counts itself (coalesced,
-    // eight independent loads per thread and step; no scan kernel in front)
-    uint32_t all = 0, before = 0;
-    for (int j = tid; j < nb1; j += 8 * kT) {
-        uint32_t c[8];
+    // ---- who owns what.  Thread t sums the counts of its contiguous slice of preprocess blocks; a block scan of the 256
+    // slice sums gives V and every slice's position in the running sum of VISIBLE Gaussians.  Workgroups own
+    // consecutive runs of blocks of equal cost (below), however the visible Gaussians are spread over the index range (a
+    // scan stored in spatial order has them all in a few thousand consecutive blocks; equal BLOCK shares then left the
+    // whole sort to a handful of workgroups: 328 us).  Samples are taken at equal steps of the running sum: uniform
+    // over the visible Gaussians.
+    const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
+    const int per = (nb1 + kT - 1) / kT;
+    const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
+    // the counts are staged in LDS (16 bits each, in the half of the sample buffer the sort only needs later) with
+    // coalesced loads: a thread reading its own contiguous slice straight from global memory touches a cache line per
+    // lane and load (that alone was 25 k cycles per workgroup)
+    uint16_t *s_cnt16 = reinterpret_cast<uint16_t *>(s_key + kMaxSamples);
+    constexpr int CB = 2 * kMaxSamples;  // blocks staged at a time (8192: 2.1 M Gaussians)
+    auto stage = [&](int cb) {
+        const int n = min(CB, nb1 - cb);
+        for (int i = tid; i < n; i += 8 * kT) {
+            uint32_t c[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) c[u] = j + u * kT < nb1 ? block_counts[j + u * kT] : 0u;
+            for (int u = 0; u < 8; u++) c[u] = i + u * kT < n ? block_counts[cb + i + u * kT] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            all += c[u];
-            if (j + u * kT < first) before += c[u];
+            for (int u = 0; u < 8; u++)
+                if (i + u * kT < n) s_cnt16[i + u * kT] = (uint16_t)c[u];
         }
+    };
+    uint32_t mine = 0;
+    for (int cb = 0; cb < nb1; cb += CB) {
+        if (cb > 0) __syncthreads();
+        stage(cb);
+        __syncthreads();
+        for (int j = max(j0, cb); j < min(j1, cb + CB); j++) mine += s_cnt16[j - cb];
     }
     SS_STAMP(dbg, 1);
-    uint32_t V, dummy;
-    (void)gsr_block_incl_scan(all, s_w, V);
-    (void)gsr_block_incl_scan(before, s_w, dummy);
-    before = dummy;  // block total of the partial sums
+    uint32_t V;
+    const uint32_t p_incl = gsr_block_incl_scan(mine, s_w, V), p_excl = p_incl - mine;
+    __shared__ uint32_t s_range[4];  // first block, records before it, end block, (unused)
+    if (tid == 0) {
+        s_range[0] = 0u;
+        s_range[1] = 0u;
+        s_range[2] = (uint32_t)nb1;
+    }
     if (blockIdx.x == 0 && tid == 0) {  // first kernel of the frame that touches the header
         hdr->V = V;
         hdr->R = 0u;
@@ -188,38 +214,84 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         hdr->R_raw = 0u;
         hdr->tile_queue = 0u;
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) seg_off[gridDim.x] = V;
-    if (tid == 0) seg_off[blockIdx.x] = before;
-    if (V == 0u) return;
-
-    // ---- samples: S preprocess blocks spread evenly over the model; a block contributes the key of its first visible
-    // Gaussian (top 24 bits), a block without one contributes nothing (key 0xFFFFFF00 -- no depth has that pattern --
-    // sorts behind every real sample).  Two batches of independent loads, no ranks, no compaction.
+    if (V == 0u) {
+        if (tid == 0) seg_off[me] = 0u;
+        if (me == nbc - 1 && tid == 0) seg_off[nbc] = 0u;
+        return;
+    }
+    __syncthreads();
     const int B = ss_num_buckets(V, bmax);
-    const uint32_t S = (uint32_t)min(min(kMaxSamples, kSamplesPerBucket * B), max(nb1, 1));
-    uint32_t present = 0;
+    const uint32_t S = (uint32_t)min(kMaxSamples, kSamplesPerBucket * B);
     {
-        constexpr int kPer = kMaxSamples / kT;  // 16 sample slots per thread at most
-        const float blocks_per_sample = (float)nb1 / (float)S;  // (which block exactly does not matter)
-        uint32_t cnt[kPer], cand[kPer];
-#pragma unroll
-        for (int u = 0; u < kPer; u++) {
-            const uint32_t sl = (uint32_t)(tid + u * kT);
-            const int j = min(nb1 - 1, (int)((float)sl * blocks_per_sample));
-            cnt[u] = sl < S ? block_counts[j] : 0u;
-            cand[u] = sl < S ? block_cand[j] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < kPer; u++) {
-            const uint32_t sl = (uint32_t)(tid + u * kT);
-            if (sl < S) {
-                s_key[sl] = cnt[u] != 0u ? (cand[u] & 0xFFFFFF00u) : 0xFFFFFF00u;
-                present += cnt[u] != 0u ? 1u : 0u;
+        // Ownership follows a COST: a block costs its visible Gaussians (records to classify and move) + kBlockCost
+        // (its 256 keys have to be fetched and tested whatever they hold) -- equal record shares alone hand a
+        // workgroup in an empty stretch of the model a thousand blocks to sweep.  The cost before block j is
+        // (records before j) + kBlockCost j; the owner of the slice in which it crosses a share boundary walks it.
+        const uint32_t W = V + kBlockCost * (uint32_t)nb1;
+        // (boundaries in binary64: products below 2^53 are exact, and the only requirement is that share b's upper
+        // boundary and share b + 1's lower one are the same number -- they are the same expression)
+        const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
+        const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
+        const uint32_t w_excl = p_excl + kBlockCost * (uint32_t)j0, w_incl = p_incl + kBlockCost * (uint32_t)j1;
+        const bool has_lo = me > 0 && w_excl <= t_lo && t_lo < w_incl;
+        const bool has_hi = me + 1 < nbc && w_excl <= t_hi && t_hi < w_incl;
+        // samples s with  p_excl <= s V / S < p_incl  are mine:  s in [ceil(p_excl S / V), ceil(p_incl S / V))
+        // (targets advance by V / S in 32.32 fixed point: one division per thread, none per sample; a target only picks
+        // WHICH block of the slice lends its key, so its last bit does not matter)
+        const uint64_t step = ((uint64_t)V << 32) >> ss_log2((int)S);  // (S is a power of two)
+        const uint32_t s_lo = min(S, (uint32_t)__builtin_ceil((double)p_excl * (double)S / (double)V));
+        const uint32_t s_hi = min(S, (uint32_t)__builtin_ceil((double)p_incl * (double)S / (double)V));
+        uint64_t acc = step * s_lo;
+        uint32_t run = p_excl, smp = s_lo;
+        for (int cb = 0; cb < nb1; cb += CB) {
+            if (nb1 > CB) {  // (a single chunk is still staged from the first pass)
+                __syncthreads();
+                stage(cb);
+                __syncthreads();
+            }
+            if (!(has_lo || has_hi || s_lo < s_hi)) continue;
+            for (int j = max(j0, cb); j < min(j1, cb + CB); j++) {
+                const uint32_t c = s_cnt16[j - cb];
+                const uint32_t wrun = run + kBlockCost * (uint32_t)j;
+                if (has_lo && wrun <= t_lo && t_lo < wrun + c + kBlockCost) {
+                    s_range[0] = (uint32_t)j;
+                    s_range[1] = run;
+                }
+                if (has_hi && wrun <= t_hi && t_hi < wrun + c + kBlockCost) s_range[2] = (uint32_t)j;
+                if (c == 0u) continue;
+                const bool last_live = run + c == p_incl;  // the slice's last block with records takes the rest
+                while (smp < s_hi && ((uint32_t)(acc >> 32) < run + c || last_live)) {
+                    s_key[smp] = (uint32_t)j;  // the block that lends its key; the keys are fetched together below
+                    smp++;
+                    acc += step;
+                }
+                run += c;
             }
         }
     }
-    uint32_t S_eff;
-    (void)gsr_block_incl_scan(present, s_w, S_eff);
+    __syncthreads();
+    {  // sample slot -> key (top 24 bits): every gather of the thread in flight at once (S <= 16 kT)
+        static_assert(kMaxSamples <= 16 * kT, "one batch of gathers covers the samples");
+        uint32_t k[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint32_t i = (uint32_t)(tid + u * kT);
+            k[u] = i < S ? block_cand[s_key[i]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint32_t i = (uint32_t)(tid + u * kT);
+            if (i < S) s_key[i] = k[u] & 0xFFFFFF00u;
+        }
+    }
+    __syncthreads();
+    const int first = (int)s_range[0], last = (int)s_range[2];
+    const uint32_t before = s_range[1];
+    if (me == nbc - 1 && tid == 0) seg_off[nbc] = V;
+    if (tid == 0) seg_off[me] = before;
+    const uint32_t present = 0u;
+    (void)present;
+    const uint32_t S_eff = S;  // (every sample slot is filled: V > 0)
     SS_STAMP(dbg, 2);
     __syncthreads();
     // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
@@ -265,69 +337,76 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     __syncthreads();
     for (int i = tid; i < B; i += kT) s_hist[i] = 0u;
     SS_STAMP(dbg, 3);
-    // ---- exclusive offsets of this workgroup's blocks (bpw <= 1024: four consecutive blocks per thread)
-    {
-        uint32_t c[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = tid * 4 + k;
-            c[k] = j < nblk ? block_counts[first + j] : 0u;
-            sum += c[k];
-        }
+    // ---- the walk over this workgroup's blocks [first, last), at most 1024 at a time (their offsets sit in LDS): one
+    // wave per block of 256 Gaussians, no workgroup barrier inside.  A wave requests the keys of its next kWalk blocks
+    // in one go (4 kWalk loads in flight per lane) and only then ranks them: a wave is a chain of HBM round trips
+    // otherwise.  Blocks without a visible Gaussian are skipped on their count.
+    uint32_t chunk_before = before;
+    for (int c0 = first; c0 < last; c0 += 4 * kT) {
+        const int nblk = min(4 * kT, last - c0);
         uint32_t tot;
-        uint32_t run = gsr_block_incl_scan(sum, s_w, tot) - sum;
+        {
+            uint32_t c[4], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = tid * 4 + k;
-            if (j <= nblk) s_boff[j] = run;
-            run += c[k];
-        }
-        if (tid == kT - 1 && nblk == 4 * kT) s_boff[nblk] = run;
-    }
-    __syncthreads();
-    SS_STAMP(dbg, 4);
-    // ---- the walk: one wave per block of 256 Gaussians, no workgroup barrier inside.  A wave requests the keys of
-    // its next kWalk blocks in one go (4 kWalk loads in flight per lane) and only then ranks them: a wave is a chain of
-    // HBM round trips otherwise.
-    {
-        constexpr int NW = kT / GSR_WAVE, kWalk = 6;
-        for (int k0 = wave; k0 < nblk; k0 += NW * kWalk) {
-            uint32_t key[kWalk][4];
-#pragma unroll
-            for (int w = 0; w < kWalk; w++) {
-                const int k = k0 + w * NW;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int i = (first + k) * GSR_BLOCK + r * GSR_WAVE + lane;
-                    key[w][r] = (k < nblk && i < P) ? vis_key[i] : 0u;
-                }
+            for (int k = 0; k < 4; k++) {
+                const int j = tid * 4 + k;
+                c[k] = j < nblk ? block_counts[c0 + j] : 0u;
+                sum += c[k];
             }
+            uint32_t run = gsr_block_incl_scan(sum, s_w, tot) - sum;
 #pragma unroll
-            for (int w = 0; w < kWalk; w++) {
-                const int k = k0 + w * NW;
-                if (k >= nblk) break;
-                const int base_i = (first + k) * GSR_BLOCK;
-                uint32_t pos = before + s_boff[k];
+            for (int k = 0; k < 4; k++) {
+                const int j = tid * 4 + k;
+                if (j <= nblk) s_boff[j] = run;
+                run += c[k];
+            }
+            if (tid == kT - 1 && nblk == 4 * kT) s_boff[nblk] = run;
+        }
+        __syncthreads();
+        SS_STAMP(dbg, 4);
+        {
+            constexpr int NW = kT / GSR_WAVE, kWalk = 6;
+            for (int k0 = wave; k0 < nblk; k0 += NW * kWalk) {
+                uint32_t key[kWalk][4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool vis = key[w][r] != 0u;
-                    const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
-                    if (vis) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                        pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[w][r]);
+                for (int w = 0; w < kWalk; w++) {
+                    const int k = k0 + w * NW;
+                    const bool live = k < nblk && s_boff[k + 1] != s_boff[k];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = (c0 + k) * GSR_BLOCK + r * GSR_WAVE + lane;
+                        key[w][r] = (live && i < P) ? vis_key[i] : 0u;
                     }
-                    pos += (uint32_t)__popcll(mask);
+                }
+#pragma unroll
+                for (int w = 0; w < kWalk; w++) {
+                    const int k = k0 + w * NW;
+                    if (k >= nblk) break;
+                    const int base_i = (c0 + k) * GSR_BLOCK;
+                    uint32_t pos = chunk_before + s_boff[k];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool vis = key[w][r] != 0u;
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
+                        if (vis) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[w][r]);
+                        }
+                        pos += (uint32_t)__popcll(mask);
+                    }
                 }
             }
         }
+        __syncthreads();  // (the offsets are rewritten by the next chunk)
+        chunk_before += tot;
     }
     SS_STAMP(dbg, 5);
     __syncthreads();  // this workgroup's records are written: visible to all of its threads
     // ---- classification, dense: every thread takes eight records of the segment per step (only ~12 % of the lanes of
     // the walk hold a visible Gaussian -- searching there would run one serial search per 64 Gaussians)
     {
-        const uint32_t seg0 = before, seg1 = before + s_boff[nblk];
+        const uint32_t seg0 = before, seg1 = chunk_before;
         for (uint32_t i0 = seg0 + (uint32_t)tid; i0 < seg1; i0 += 8u * kT) {
             uint32_t tk[8], bk[8];
 #pragma unroll
@@ -345,6 +424,14 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     __syncthreads();
     for (int i = tid; i < B; i += kT) table[(size_t)blockIdx.x * bmax + i] = s_hist[i];
     SS_STAMP(dbg, 7);
+#ifdef GSR_SS_TIMING
+    if (tid == 0) {
+        const unsigned long long el = __builtin_amdgcn_s_memtime() - t_start;
+        const unsigned long long old = atomicMax((unsigned long long *)&dbg[10], el);
+        if (el > old) { dbg[11] = blockIdx.x; dbg[12] = (unsigned long long)(last - first); dbg[13] = chunk_before - before; }
+        if (blockIdx.x == 0) { dbg[14] = el; }
+    }
+#endif
 }
 
 // Partial column sums of the histogram rows this wave owns (rows wave*RS + [0, RS), + 4 RS, ...): lane l covers the
@@ -633,7 +720,7 @@ int gsr_ss_bmax(int32_t P) {
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
-    const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + bpw + 1) * sizeof(uint32_t);
+    const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;

@@ -168,7 +168,8 @@ def test_alternative_binning_paths_match_too(cuda_device, mode):
         dbg.set_binning_mode(1)
 
 
-@pytest.mark.parametrize("case", ["lsd_radix_variant", "all_equal_depth", "two_depths", "one_million_visible", "tiny"])
+@pytest.mark.parametrize("case", ["lsd_radix_variant", "all_equal_depth", "two_depths", "one_million_visible", "tiny",
+                                  "index_coherent"])
 def test_depth_sort_paths(cuda_device, case):
     """The depth order (ascending depth bits, ties by index) from every path of the depth sort: the default sample sort
     with buckets of every size class (LDS radix; a bucket too large for the LDS -> global-memory bitonic fallback;
@@ -181,6 +182,16 @@ def test_depth_sort_paths(cuda_device, case):
             _run(scenes.tabletop_scene("xarm6_align", n=300_000, seed=5), scenes.sensor_camera("xarm6_align"))
         finally:
             dbg.set_depth_sort(0)
+        return
+    if case == "index_coherent":
+        # a model stored in spatial order (as real scans often are): every visible Gaussian sits in a few thousand
+        # consecutive preprocess blocks -- the sort's work shares follow the VISIBLE counts, not the block index
+        raw = scenes.tabletop_scene("xarm6_align", n=400_000, seed=6)
+        perm = torch.argsort(raw.xyz[:, 0] * 3.0 + raw.xyz[:, 2])
+        raw = scenes.RawGaussians(*[None if t is None else t[perm].contiguous() for t in (
+            raw.xyz, raw.features_dc, raw.features_rest, raw.opacity, raw.scaling, raw.rotation, raw.semantics)])
+        rep = _run(raw, scenes.sensor_camera("xarm6_align"))
+        assert rep["V"] > 20_000
         return
     if case == "one_million_visible":
         raw = scenes.random_scene_camera_frame(1_100_000, seed=31, near_fraction=0.0)

@@ -82,17 +82,32 @@ def main():
         loss, radii = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    # algorithmic bytes of the step: forward 48 N + 280 V + 64 R + 16 W H; backward: twice the forward's
+    # instance traffic (128 R) + the gradient bytes 4 (3+3+1+3+6+48+3+4) V = 284 V + the image gradient read (16 W H)
+    from gsworld_amd import _C
+    with torch.no_grad():
+        shs_ = torch.cat((raw.features_dc, raw.features_rest), dim=1)
+        R = _C.rasterize_gaussians(bg, raw.xyz.detach(), torch.empty(0, device=dev), torch.sigmoid(raw.opacity.detach()),
+                                   torch.exp(raw.scaling.detach()), torch.nn.functional.normalize(raw.rotation.detach()),
+                                   1.0, torch.empty(0, device=dev), cam.world_view_transform, cam.full_proj_transform,
+                                   cam.tanfovx, cam.tanfovy, S, S, shs_.detach(), 3, cam.camera_center, False, False,
+                                   False)[0]
+    N, V = args.num_gaussians, int((radii > 0).sum().item())
+    b_alg = (48 * N + 280 * V + 64 * R + 16 * S * S) + (128 * R + 284 * V + 16 * S * S)
     finite = all(torch.isfinite(p.grad).all().item() for p in (raw.xyz, raw.features_dc, raw.features_rest,
                                                                raw.opacity, raw.scaling, raw.rotation))
     print(json.dumps({
         "metric": "training iterations/sec (forward + backward, fused-ssim loss)", "value": 1.0 / dt,
         "unit": "it/s", "ms_per_step": dt * 1e3, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
         "data": "synthetic",
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(b_alg), "achieved": b_alg / dt / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": b_alg / dt / 1e9 / 8000.0,
+                     "note": "whole step (forward + backward + loss) against the HBM peak; SURVEY.md 8d byte model"},
         "config": {"workload": f"{args.num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
                                "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step "
                                "(BASELINE.json configs[4])",
                    "parameter_packing": "fused (raw parameters, split SH)" if args.fused else "upstream (torch)",
-                   "num_visible": int((radii > 0).sum().item()), "loss": float(loss.item()),
+                   "num_visible": V, "num_rendered": int(R), "loss": float(loss.item()),
                    "grads_finite": bool(finite)}}))
 
 
