@@ -61,23 +61,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
         if M != 1:
             raise RuntimeError("sh_rest needs sh = features_dc of shape (P,1,3)")
         M = 1 + sh_rest.size(1)
-    # One uninitialised arena sliced into the ten gradient buffers: gsr_backward zeroes adjacent buffers with a
-    # single memset on the stream.  (P,4)-shaped pieces first so that every slice stays 16-byte aligned.
-    shapes = [("dL_drotations", (P, 4)), ("dL_dconic", (P, 2, 2)), ("dL_dsh", (P, 1 if split else M, 3)),
-              ("dL_dsh_rest", (P, M - 1 if split else 0, 3)), ("dL_dcov3D", (P, 6)),
-              ("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)), ("dL_dcolors", (P, 3)), ("dL_dscales", (P, 3)),
-              ("dL_dopacity", (P, 1)), ("dL_dinvdepths", (P, 1))]
+    # One uninitialised arena sliced into the gradient buffers.  The SH gradients come first (16-byte aligned: the SH
+    # backward kernel then writes every word of them itself, through whole lines); behind them, without gaps, the
+    # buffers gsr_backward clears -- adjacent buffers cost ONE memset on the stream.
+    shapes = [("dL_dsh_rest", (P, M - 1 if split else 0, 3)), ("dL_dsh", (P, 1 if split else M, 3)),
+              ("dL_drotations", (P, 4)), ("dL_dcov3D", (P, 6)), ("dL_dmeans3D", (P, 3)), ("dL_dmeans2D", (P, 3)),
+              ("dL_dcolors", (P, 3)), ("dL_dscales", (P, 3)), ("dL_dopacity", (P, 1))]
     sizes = [max(1, int(torch.tensor(s).prod())) if 0 not in s else 0 for _, s in shapes]
-    arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    steps = [(sz + 3) // 4 * 4 if name in ("dL_dsh_rest", "dL_dsh") else sz for (name, _), sz in zip(shapes, sizes)]
+    arena = torch.empty(sum(steps), dtype=torch.float32, device=dev)
     views, off = {}, 0
-    for (name, shape), sz in zip(shapes, sizes):
+    for (name, shape), sz, step in zip(shapes, sizes, steps):
         views[name] = arena[off:off + sz].view(shape)
-        off += sz
-    dL_drotations, dL_dconic, dL_dsh, dL_dcov3D = (views[k] for k in ("dL_drotations", "dL_dconic", "dL_dsh",
-                                                                       "dL_dcov3D"))
+        off += step
+    dL_drotations, dL_dsh, dL_dcov3D = (views[k] for k in ("dL_drotations", "dL_dsh", "dL_dcov3D"))
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dscales = (views[k] for k in ("dL_dmeans3D", "dL_dmeans2D",
                                                                            "dL_dcolors", "dL_dscales"))
-    dL_dopacity, dL_dinvdepths = views["dL_dopacity"], views["dL_dinvdepths"]
+    dL_dopacity = views["dL_dopacity"]
     dL_dsh_rest = views["dL_dsh_rest"]
     if P != 0:
         tensors = [_f32(t, dev) for t in (background, means3D, colors, opacities, scales, rotations, cov3D_precomp,
@@ -99,7 +99,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
         bw = GsrBackwardInputs(_ptr(dL_dout_color), _ptr(dLd), _ptr(radii), int(R), _ptr(geomBuffer),
                                _ptr(binningBuffer), _ptr(imageBuffer))
         gr = GsrGrads(_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                      _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dconic), _ptr(dL_dinvdepths),
+                      _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), None, None,
                       _ptr(dL_dsh_rest) if split else None)
         with torch.cuda.device(dev):
             check(L.gsr_backward(C.byref(st), C.byref(inp), C.byref(bw), C.byref(gr),

@@ -37,6 +37,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 #endif
 }
 
+constexpr int kGradRec = 12;  // words of a Gaussian's record in GeomState::grad_rec (kGrad sums + 2 unused)
 constexpr int kGrad = 10;  // mean2D.x, mean2D.y, conic.xx, conic.xy(half), conic.yy, opacity, r, g, b, invdepth
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -82,14 +83,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, const float4 *__restrict__ splat,
     int W, int H, int gx, const float *__restrict__ bg, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
-    const float *__restrict__ dL_dinvdepth_pix, float *__restrict__ dL_dmean2D /*(P,3)*/,
-    float *__restrict__ dL_dconic /*(P,4): xx, xy, -, yy*/, float *__restrict__ dL_dopacity,
-    float *__restrict__ dL_dcolors /*(P,3)*/, float *__restrict__ dL_dinvdepths /*(P)*/) {
+    const float *__restrict__ dL_dinvdepth_pix, float *__restrict__ grad_rec /*(P,12): the kGrad sums + 2 unused*/) {
     __shared__ float4 s_rec0[GSR_BLOCK];
     __shared__ float4 s_rec1[GSR_BLOCK];
     __shared__ float4 s_rec2[GSR_BLOCK];
     __shared__ uint32_t s_id[GSR_BLOCK];
-    __shared__ float s_grad[GSR_BLOCK * kGrad];
+    __shared__ float s_grad[GSR_BLOCK * kGradRec];  // [staged instance][component]
     __shared__ uint32_t s_max[4];
 
     const int tile = (int)blockIdx.x;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             s_rec2[threadIdx.x] = rec[2];
         }
 #pragma unroll
-        for (int c = 0; c < kGrad; c++) s_grad[c * GSR_BLOCK + threadIdx.x] = 0.f;
+        for (int c = 0; c < kGradRec; c++) s_grad[c * GSR_BLOCK + threadIdx.x] = 0.f;
         __syncthreads();
         const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
         for (int j = 0; j < cnt; j++) {
@@ -204,29 +203,21 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             if (__ballot(hit) == 0ull) continue;  // nothing in this wave touches the instance
             const float gv[kGrad] = {g_mx, g_my, g_cxx, g_cxy, g_cyy, g_op, g_r, g_g, g_b, g_d};
             const float total = wave_reduce10(gv);
-            if (my_comp >= 0) atomicAdd(&s_grad[my_comp * GSR_BLOCK + j], total);  // LDS: at most 4 waves per address
+            if (my_comp >= 0) atomicAdd(&s_grad[j * kGradRec + my_comp], total);  // LDS: at most 4 waves per address
         }
         __syncthreads();
-        // flush: thread j owns staged instance j
-        // (measured: without this flush the kernel takes 137 instead of 214 us at config 5 -- a third of it is the
-        // device-scope float atomics)
-        if ((int)threadIdx.x < cnt) {
-            const uint32_t g = s_id[threadIdx.x];
-            const float v0 = s_grad[0 * GSR_BLOCK + threadIdx.x], v1 = s_grad[1 * GSR_BLOCK + threadIdx.x];
-            const float v2 = s_grad[2 * GSR_BLOCK + threadIdx.x], v3 = s_grad[3 * GSR_BLOCK + threadIdx.x];
-            const float v4 = s_grad[4 * GSR_BLOCK + threadIdx.x], v5 = s_grad[5 * GSR_BLOCK + threadIdx.x];
-            const float v6 = s_grad[6 * GSR_BLOCK + threadIdx.x], v7 = s_grad[7 * GSR_BLOCK + threadIdx.x];
-            const float v8 = s_grad[8 * GSR_BLOCK + threadIdx.x], v9 = s_grad[9 * GSR_BLOCK + threadIdx.x];
-            if (v0 != 0.f) atomicAdd(&dL_dmean2D[3 * (size_t)g], v0);
-            if (v1 != 0.f) atomicAdd(&dL_dmean2D[3 * (size_t)g + 1], v1);
-            if (v2 != 0.f) atomicAdd(&dL_dconic[4 * (size_t)g], v2);
-            if (v3 != 0.f) atomicAdd(&dL_dconic[4 * (size_t)g + 1], v3);
-            if (v4 != 0.f) atomicAdd(&dL_dconic[4 * (size_t)g + 3], v4);
-            if (v5 != 0.f) atomicAdd(&dL_dopacity[g], v5);
-            if (v6 != 0.f) atomicAdd(&dL_dcolors[3 * (size_t)g], v6);
-            if (v7 != 0.f) atomicAdd(&dL_dcolors[3 * (size_t)g + 1], v7);
-            if (v8 != 0.f) atomicAdd(&dL_dcolors[3 * (size_t)g + 2], v8);
-            if (v9 != 0.f) atomicAdd(&dL_dinvdepths[g], v9);
+        // flush: ONE device-scope atomic per (tile, instance, component), issued TRANSPOSED -- twelve consecutive lanes
+        // own the twelve words of one instance's record, so the ten sums of a Gaussian leave as one request to one
+        // 48-byte record instead of ten requests to five arrays (the atomics resolve memory-side: what they cost is
+        // requests, not words; thread-per-instance flushing into separate arrays was a third of this kernel)
+#pragma unroll
+        for (int u = 0; u < kGradRec; u++) {
+            const int e = u * GSR_BLOCK + (int)threadIdx.x;
+            const int j = e / kGradRec, c = e - j * kGradRec;
+            if (j < cnt && c < kGrad) {
+                const float v = s_grad[e];
+                if (v != 0.f) atomicAdd(&grad_rec[(size_t)kGradRec * s_id[j] + c], v);
+            }
         }
     }
 }
@@ -248,15 +239,20 @@ struct BwdArgs {
     const int32_t *radii;
     const float *cov3D;        // precomputed input or the forward's stored copy
     const uint32_t *clamped;
-    const float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dinvdepths;
+    const float *grad_rec;     // (P,12) the compositor's sums (render_backward_kernel)
+    float *dL_dmean2D, *dL_dcolors;  // written from the record (API outputs)
     float *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
     float *dL_dsh_rest;        // with shs_rest: dL_dsh is the dc part
 };
 
-// per-Gaussian chain rule; one thread per Gaussian
-__global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const BwdArgs a) {
+// Per-Gaussian chain rule, one thread per Gaussian, in two kernels: the geometry (2D mean, EWA covariance, 3D
+// covariance -> scale / quaternion, opacity) here, the SH colour below.  As one kernel it held 180 VGPRs (two waves per
+// SIMD) and moved every Gaussian's 2 x 180 bytes of SH through per-lane strided accesses.
+__global__ __launch_bounds__(GSR_BLOCK) void geometry_backward_kernel(const BwdArgs a) {
     const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
     if (i >= a.P || a.radii[i] <= 0) return;
+    const float4 *rec = reinterpret_cast<const float4 *>(a.grad_rec) + 3 * (size_t)i;
+    const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2];  // (mx, my, cxx, cxy) (cyy, opacity, r, g) (b, 1/depth, -, -)
     const float *m = a.view;
     const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
     const float *c6 = a.cov3D + 6 * (size_t)i;
@@ -296,7 +292,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     const bool raw_opacity = (a.param_space & GSR_RAW_OPACITY) != 0;
     float opacity_act = 0.f;
     if (a.antialiasing || raw_opacity) opacity_act = raw_opacity ? sigmoid_canonical(a.opacities[i]) : a.opacities[i];
-    if (raw_opacity && !a.antialiasing) a.dL_dopacity[i] *= opacity_act * (1.0f - opacity_act);
+    const float dL_dop = g1.y;
+    float dL_dop_out = raw_opacity ? dL_dop * (opacity_act * (1.0f - opacity_act)) : dL_dop;
     if (a.antialiasing) {
         const float det_cov = fma_(-cb, cb, ca * cc);
         ca += h_var;
@@ -304,9 +301,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
         const float det_plus = fma_(-cb, cb, ca * cc);
         const float ratio = det_cov / det_plus;
         const float h_scale = sqrtf(fmaxf(0.000025f, ratio));
-        const float dL_dop = a.dL_dopacity[i];
         const float d_h = dL_dop * opacity_act;
-        a.dL_dopacity[i] = raw_opacity ? (dL_dop * h_scale) * (opacity_act * (1.0f - opacity_act)) : dL_dop * h_scale;
+        dL_dop_out = raw_opacity ? (dL_dop * h_scale) * (opacity_act * (1.0f - opacity_act)) : dL_dop * h_scale;
         const float d_root = ratio <= 0.000025f ? 0.f : d_h / (2.f * h_scale);
         const float inv2 = 1.f / (det_plus * det_plus);
         dL_da_aa = d_root * ((cc - h_var) * det_plus - det_cov * cc) * inv2;
@@ -316,7 +312,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
         ca += h_var;
         cc += h_var;
     }
-    const float Lx = a.dL_dconic[4 * (size_t)i], Ly = a.dL_dconic[4 * (size_t)i + 1], Lz = a.dL_dconic[4 * (size_t)i + 3];
+    a.dL_dopacity[i] = dL_dop_out;
+    a.dL_dmean2D[3 * (size_t)i] = g0.x;
+    a.dL_dmean2D[3 * (size_t)i + 1] = g0.y;
+    a.dL_dcolors[3 * (size_t)i] = g1.z;
+    a.dL_dcolors[3 * (size_t)i + 1] = g1.w;
+    a.dL_dcolors[3 * (size_t)i + 2] = g2.x;
+    const float Lx = g0.z, Ly = g0.w, Lz = g1.x;
     const float denom = fma_(-cb, cb, ca * cc);
     const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
     float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     const float dtx = x_grad_mul * -fx * itz2 * dJ02;
     const float dty = y_grad_mul * -fy * itz2 * dJ12;
     float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + (2.f * fx * tx) * itz3 * dJ02 + (2.f * fy * ty) * itz3 * dJ12;
-    if (a.have_invdepth) dtz -= a.dL_dinvdepths[i] / (tz * tz);
+    if (a.have_invdepth) dtz -= g2.y / (tz * tz);
     float dmean[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) dmean[j] = m[j * 4 + 0] * dtx + m[j * 4 + 1] * dty + m[j * 4 + 2] * dtz;
@@ -365,152 +367,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
     const float m_w = 1.0f / (hw + 0.0000001f);
     const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
-    const float g2x = a.dL_dmean2D[3 * (size_t)i], g2y = a.dL_dmean2D[3 * (size_t)i + 1];
+    const float g2x = g0.x, g2y = g0.y;
     dmean[0] += (q[0] * m_w - q[3] * mul1) * g2x + (q[1] * m_w - q[3] * mul2) * g2y;
     dmean[1] += (q[4] * m_w - q[7] * mul1) * g2x + (q[5] * m_w - q[7] * mul2) * g2y;
     dmean[2] += (q[8] * m_w - q[11] * mul1) * g2x + (q[9] * m_w - q[11] * mul2) * g2y;
-    // SH -> colour
-    if (!a.colors_precomp) {
-        const float ox = px - a.campos[0], oy = py - a.campos[1], oz = pz - a.campos[2];
-        const float len = sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
-        const float x = ox / len, y = oy / len, z = oz / len;
-        const uint32_t cl = a.clamped[i];
-        float dRGB[3];
-        dRGB[0] = (cl & 0xffu) ? 0.f : a.dL_dcolors[3 * (size_t)i];
-        dRGB[1] = (cl & 0xff00u) ? 0.f : a.dL_dcolors[3 * (size_t)i + 1];
-        dRGB[2] = (cl & 0xff0000u) ? 0.f : a.dL_dcolors[3 * (size_t)i + 2];
-        float bas[16], bx[16], by[16], bz[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) bas[k] = bx[k] = by[k] = bz[k] = 0.f;
-        const int D = a.D;
-        bas[0] = kC0;
-        if (D > 0) {
-            bas[1] = -(kC1 * y); bas[2] = kC1 * z; bas[3] = -(kC1 * x);
-            by[1] = -kC1; bz[2] = kC1; bx[3] = -kC1;
-            if (D > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                bas[4] = kC2[0] * xy; bas[5] = kC2[1] * yz; bas[6] = kC2[2] * (fma_(2.f, zz, -xx) - yy);
-                bas[7] = kC2[3] * xz; bas[8] = kC2[4] * (xx - yy);
-                bx[4] = kC2[0] * y; by[4] = kC2[0] * x;
-                by[5] = kC2[1] * z; bz[5] = kC2[1] * y;
-                bx[6] = kC2[2] * -2.f * x; by[6] = kC2[2] * -2.f * y; bz[6] = kC2[2] * 4.f * z;
-                bx[7] = kC2[3] * z; bz[7] = kC2[3] * x;
-                bx[8] = kC2[4] * 2.f * x; by[8] = kC2[4] * -2.f * y;
-                if (D > 2) {
-                    bas[9] = (kC3[0] * y) * fma_(3.f, xx, -yy);
-                    bas[10] = (kC3[1] * xy) * z;
-                    bas[11] = (kC3[2] * y) * (fma_(4.f, zz, -xx) - yy);
-                    bas[12] = (kC3[3] * z) * fma_(-3.f, yy, fma_(-3.f, xx, 2.f * zz));
-                    bas[13] = (kC3[4] * x) * (fma_(4.f, zz, -xx) - yy);
-                    bas[14] = (kC3[5] * z) * (xx - yy);
-                    bas[15] = (kC3[6] * x) * fma_(-3.f, yy, xx);
-                    bx[9] = kC3[0] * 6.f * x * y; by[9] = kC3[0] * (3.f * xx - 3.f * yy);
-                    bx[10] = kC3[1] * y * z; by[10] = kC3[1] * x * z; bz[10] = kC3[1] * x * y;
-                    bx[11] = kC3[2] * -2.f * x * y; by[11] = kC3[2] * (4.f * zz - xx - 3.f * yy);
-                    bz[11] = kC3[2] * 8.f * y * z;
-                    bx[12] = kC3[3] * -6.f * x * z; by[12] = kC3[3] * -6.f * y * z;
-                    bz[12] = kC3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
-                    bx[13] = kC3[4] * (4.f * zz - 3.f * xx - yy); by[13] = kC3[4] * -2.f * x * y;
-                    bz[13] = kC3[4] * 8.f * x * z;
-                    bx[14] = kC3[5] * 2.f * x * z; by[14] = kC3[5] * -2.f * y * z; bz[14] = kC3[5] * (xx - yy);
-                    bx[15] = kC3[6] * (3.f * xx - 3.f * yy); by[15] = kC3[6] * -6.f * x * y;
-                }
-            }
-        }
-        const int nb = (D + 1) * (D + 1);
-        const float *sh = a.shs + (size_t)i * a.M * 3;
-        float *dsh = a.dL_dsh + (size_t)i * a.M * 3;
-        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-        if (a.shs_rest) {
-            // split storage (features_dc | features_rest): coefficient 0 in one pair of arrays, 1.. in the other
-            const float *dc = a.shs + 3 * (size_t)i;
-            float *ddc = a.dL_dsh + 3 * (size_t)i;
-            const float *rest = a.shs_rest + (size_t)i * (a.M - 1) * 3;
-            float *drest = a.dL_dsh_rest + (size_t)i * (a.M - 1) * 3;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                ddc[ch] = bas[0] * dRGB[ch];
-                const float sv = dc[ch] * dRGB[ch];
-                ddx += bx[0] * sv;
-                ddy += by[0] * sv;
-                ddz += bz[0] * sv;
-            }
-            if (D == 3 && a.M == 16) {
-                // 45 floats in, 45 out, every load ahead of every store: 15 + 15 dwordx3 accesses
-                const float3 *rest3 = reinterpret_cast<const float3 *>(rest);
-                float3 *drest3 = reinterpret_cast<float3 *>(drest);
-                float3 f[15], o[15];
-#pragma unroll
-                for (int k = 0; k < 15; k++) f[k] = rest3[k];
-#pragma unroll
-                for (int k = 1; k < 16; k++) {
-                    o[k - 1] = make_float3(bas[k] * dRGB[0], bas[k] * dRGB[1], bas[k] * dRGB[2]);
-                    const float s0 = f[k - 1].x * dRGB[0], s1 = f[k - 1].y * dRGB[1], s2 = f[k - 1].z * dRGB[2];
-                    ddx += bx[k] * s0; ddy += by[k] * s0; ddz += bz[k] * s0;
-                    ddx += bx[k] * s1; ddy += by[k] * s1; ddz += bz[k] * s1;
-                    ddx += bx[k] * s2; ddy += by[k] * s2; ddz += bz[k] * s2;
-                }
-#pragma unroll
-                for (int k = 0; k < 15; k++) drest3[k] = o[k];
-            } else {
-#pragma unroll
-                for (int k = 1; k < 16; k++) {
-                    if (k < nb) {
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            drest[3 * (k - 1) + ch] = bas[k] * dRGB[ch];
-                            const float sv = rest[3 * (k - 1) + ch] * dRGB[ch];
-                            ddx += bx[k] * sv;
-                            ddy += by[k] * sv;
-                            ddz += bz[k] * sv;
-                        }
-                    }
-                }
-            }
-        } else if (D == 3 && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.dL_dsh)) & 15u) == 0) {
-            // 48 contiguous floats in, 48 out: 12 + 12 dwordx4 accesses instead of 96 dword ones
-            float4 v[12], o[12];
-            const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
-#pragma unroll
-            for (int q = 0; q < 12; q++) v[q] = sh4[q];
-            const float *f = reinterpret_cast<const float *>(v);
-            float *of = reinterpret_cast<float *>(o);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    of[3 * k + ch] = bas[k] * dRGB[ch];
-                    const float sv = f[3 * k + ch] * dRGB[ch];
-                    ddx += bx[k] * sv;
-                    ddy += by[k] * sv;
-                    ddz += bz[k] * sv;
-                }
-            }
-            float4 *dsh4 = reinterpret_cast<float4 *>(dsh);
-#pragma unroll
-            for (int q = 0; q < 12; q++) dsh4[q] = o[q];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k < nb) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        dsh[3 * k + ch] = bas[k] * dRGB[ch];
-                        const float sv = sh[3 * k + ch] * dRGB[ch];
-                        ddx += bx[k] * sv;
-                        ddy += by[k] * sv;
-                        ddz += bz[k] * sv;
-                    }
-                }
-            }
-        }
-        const float sum2 = ox * ox + oy * oy + oz * oz;
-        const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-        dmean[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * inv32;
-        dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * inv32;
-        dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * inv32;
-    }
-    a.dL_dmeans3D[3 * (size_t)i] = dmean[0];
+    a.dL_dmeans3D[3 * (size_t)i] = dmean[0];  // (sh_backward_kernel adds the view-direction term of the colour)
     a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
     a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     // 3D covariance -> scale, quaternion
@@ -572,6 +433,216 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_backward_kernel(const Bw
     }
 }
 
+// SH basis of degree D at the unit direction (x, y, z) and its derivatives w.r.t. x, y, z
+struct ShBasis {
+    float v[16], dx[16], dy[16], dz[16];
+};
+__device__ __forceinline__ void sh_basis(int D, float x, float y, float z, ShBasis &b) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) b.v[k] = b.dx[k] = b.dy[k] = b.dz[k] = 0.f;
+    b.v[0] = kC0;
+    if (D > 0) {
+        b.v[1] = -(kC1 * y); b.v[2] = kC1 * z; b.v[3] = -(kC1 * x);
+        b.dy[1] = -kC1; b.dz[2] = kC1; b.dx[3] = -kC1;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b.v[4] = kC2[0] * xy; b.v[5] = kC2[1] * yz; b.v[6] = kC2[2] * (fma_(2.f, zz, -xx) - yy);
+            b.v[7] = kC2[3] * xz; b.v[8] = kC2[4] * (xx - yy);
+            b.dx[4] = kC2[0] * y; b.dy[4] = kC2[0] * x;
+            b.dy[5] = kC2[1] * z; b.dz[5] = kC2[1] * y;
+            b.dx[6] = kC2[2] * -2.f * x; b.dy[6] = kC2[2] * -2.f * y; b.dz[6] = kC2[2] * 4.f * z;
+            b.dx[7] = kC2[3] * z; b.dz[7] = kC2[3] * x;
+            b.dx[8] = kC2[4] * 2.f * x; b.dy[8] = kC2[4] * -2.f * y;
+            if (D > 2) {
+                b.v[9] = (kC3[0] * y) * fma_(3.f, xx, -yy);
+                b.v[10] = (kC3[1] * xy) * z;
+                b.v[11] = (kC3[2] * y) * (fma_(4.f, zz, -xx) - yy);
+                b.v[12] = (kC3[3] * z) * fma_(-3.f, yy, fma_(-3.f, xx, 2.f * zz));
+                b.v[13] = (kC3[4] * x) * (fma_(4.f, zz, -xx) - yy);
+                b.v[14] = (kC3[5] * z) * (xx - yy);
+                b.v[15] = (kC3[6] * x) * fma_(-3.f, yy, xx);
+                b.dx[9] = kC3[0] * 6.f * x * y; b.dy[9] = kC3[0] * (3.f * xx - 3.f * yy);
+                b.dx[10] = kC3[1] * y * z; b.dy[10] = kC3[1] * x * z; b.dz[10] = kC3[1] * x * y;
+                b.dx[11] = kC3[2] * -2.f * x * y; b.dy[11] = kC3[2] * (4.f * zz - xx - 3.f * yy);
+                b.dz[11] = kC3[2] * 8.f * y * z;
+                b.dx[12] = kC3[3] * -6.f * x * z; b.dy[12] = kC3[3] * -6.f * y * z;
+                b.dz[12] = kC3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                b.dx[13] = kC3[4] * (4.f * zz - 3.f * xx - yy); b.dy[13] = kC3[4] * -2.f * x * y;
+                b.dz[13] = kC3[4] * 8.f * x * z;
+                b.dx[14] = kC3[5] * 2.f * x * z; b.dy[14] = kC3[5] * -2.f * y * z; b.dz[14] = kC3[5] * (xx - yy);
+                b.dx[15] = kC3[6] * (3.f * xx - 3.f * yy); b.dy[15] = kC3[6] * -6.f * x * y;
+            }
+        }
+    }
+}
+
+// SH colour -> coefficient gradients and the view-direction term of dL/dmean.  CNT = floats per Gaussian of the array
+// that goes through LDS: 45 = features_rest of the split storage (the dc triple is read per thread), 48 = packed
+// (P,16,3); a workgroup's 256 Gaussians are CNT x 256 CONTIGUOUS floats in, and as many out, so they move as whole
+// lines (float4 per lane, consecutive lanes consecutive addresses) through an LDS image with an odd row stride, and
+// each thread works on its own row.  The kernel writes EVERY coefficient gradient of its 256 Gaussians -- zeros for
+// culled ones and for coefficients above the active degree -- so the caller does not clear those arrays.
+// CNT = 0: any other SH layout, per-thread accesses, arrays cleared by the caller.
+template <int CNT>
+__global__ __launch_bounds__(GSR_BLOCK) void sh_backward_kernel(const BwdArgs a) {
+    constexpr int STRIDE = CNT | 1;                                      // odd: a wave's rows start in 32 distinct banks
+    constexpr int IT = CNT ? (GSR_BLOCK * CNT + 4 * GSR_BLOCK - 1) / (4 * GSR_BLOCK) : 1;  // float4 per thread
+    constexpr int DIV = CNT ? CNT : 1;
+    __shared__ __attribute__((aligned(16))) float s_sh[CNT ? GSR_BLOCK * STRIDE + 4 : 4];
+    const int tid = (int)threadIdx.x;
+    const int base = blockIdx.x * GSR_BLOCK;
+    const int i = base + tid;
+    const bool vis = i < a.P && a.radii[i] > 0;
+    const bool split = CNT == 45 || (CNT == 0 && a.shs_rest != nullptr);
+    const float *src = nullptr;
+    float *dst = nullptr;
+    int n = 0;
+    if (CNT) {
+        src = (CNT == 45 ? a.shs_rest : a.shs) + (size_t)base * CNT;
+        dst = (CNT == 45 ? a.dL_dsh_rest : a.dL_dsh) + (size_t)base * CNT;
+        n = min(GSR_BLOCK, a.P - base) * CNT;  // (a multiple of 4 except possibly in the last workgroup)
+        const bool any = __syncthreads_or(vis) != 0;
+        if (any) {
+            // every load of the thread in flight before the first LDS write (a dozen dependent round trips otherwise)
+            float4 t[IT];
+#pragma unroll
+            for (int u = 0; u < IT; u++) {
+                const int e = 4 * (u * GSR_BLOCK + tid);
+                if (e + 3 < n) {
+                    t[u] = *reinterpret_cast<const float4 *>(src + e);
+                } else {
+                    t[u].x = e < n ? src[e] : 0.f;
+                    t[u].y = e + 1 < n ? src[e + 1] : 0.f;
+                    t[u].z = e + 2 < n ? src[e + 2] : 0.f;
+                    t[u].w = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IT; u++) {
+                const int e = 4 * (u * GSR_BLOCK + tid);
+                if (e >= n) continue;
+                if (STRIDE == CNT) {  // the image is the array itself
+                    *reinterpret_cast<float4 *>(s_sh + e) = t[u];
+                } else {
+                    const float v[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                    const int g = e / DIV, k = e - g * CNT;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int kk = k + q, over = kk >= CNT ? 1 : 0;  // (a float4 straddles at most one row boundary)
+                        if (e + q < n) s_sh[(g + over) * STRIDE + kk - over * CNT] = v[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!vis) {
+#pragma unroll
+            for (int k = 0; k < CNT; k++) s_sh[tid * STRIDE + k] = 0.f;
+            if (CNT == 45 && i < a.P) {
+                a.dL_dsh[3 * (size_t)i] = 0.f;
+                a.dL_dsh[3 * (size_t)i + 1] = 0.f;
+                a.dL_dsh[3 * (size_t)i + 2] = 0.f;
+            }
+        }
+    } else if (!vis) {
+        return;
+    }
+    if (vis) {
+        const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+        const float ox = px - a.campos[0], oy = py - a.campos[1], oz = pz - a.campos[2];
+        const float len = sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
+        const float x = ox / len, y = oy / len, z = oz / len;
+        const uint32_t cl = a.clamped[i];
+        const float *rec = a.grad_rec + 12 * (size_t)i;
+        float dRGB[3];
+        dRGB[0] = (cl & 0xffu) ? 0.f : rec[6];
+        dRGB[1] = (cl & 0xff00u) ? 0.f : rec[7];
+        dRGB[2] = (cl & 0xff0000u) ? 0.f : rec[8];
+        ShBasis b;
+        sh_basis(a.D, x, y, z, b);
+        const int nb = (a.D + 1) * (a.D + 1);
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        // coefficient k, channel ch: in at *in, gradient out at *out
+        auto term = [&](int k, int ch, const float *in, float *out) {
+            const float sv = *in * dRGB[ch];  // (read first: in the LDS image `in` and `out` are the same word)
+            *out = b.v[k] * dRGB[ch];
+            ddx += b.dx[k] * sv;
+            ddy += b.dy[k] * sv;
+            ddz += b.dz[k] * sv;
+        };
+        if (split) {
+            const float *dc = a.shs + 3 * (size_t)i;
+            float *ddc = a.dL_dsh + 3 * (size_t)i;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) term(0, ch, dc + ch, ddc + ch);
+        }
+        if (CNT) {
+            float *row = s_sh + tid * STRIDE;
+            constexpr int K0 = CNT == 45 ? 1 : 0;
+#pragma unroll
+            for (int k = K0; k < 16; k++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float *slot = row + 3 * (k - K0) + ch;
+                    if (k < nb) term(k, ch, slot, slot);
+                    else *slot = 0.f;
+                }
+            }
+        } else if (split) {
+            const float *rest = a.shs_rest + (size_t)i * (a.M - 1) * 3;
+            float *drest = a.dL_dsh_rest + (size_t)i * (a.M - 1) * 3;
+#pragma unroll
+            for (int k = 1; k < 16; k++)
+                if (k < nb) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) term(k, ch, rest + 3 * (k - 1) + ch, drest + 3 * (k - 1) + ch);
+                }
+        } else {
+            const float *sh = a.shs + (size_t)i * a.M * 3;
+            float *dsh = a.dL_dsh + (size_t)i * a.M * 3;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nb) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) term(k, ch, sh + 3 * k + ch, dsh + 3 * k + ch);
+                }
+        }
+        const float sum2 = ox * ox + oy * oy + oz * oz;
+        const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        float *dm = a.dL_dmeans3D + 3 * (size_t)i;
+        dm[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * inv32;
+        dm[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * inv32;
+        dm[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * inv32;
+    }
+    if (CNT) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const int e = 4 * (u * GSR_BLOCK + tid);
+            if (e >= n) continue;
+            float v[4];
+            if (STRIDE == CNT) {
+                const float4 t = *reinterpret_cast<const float4 *>(s_sh + e);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                const int g = e / DIV, k = e - g * CNT;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int kk = k + q, over = kk >= CNT ? 1 : 0;
+                    v[q] = e + q < n ? s_sh[(g + over) * STRIDE + kk - over * CNT] : 0.f;
+                }
+            }
+            if (e + 3 < n) {
+                *reinterpret_cast<float4 *>(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (e + q < n) dst[e + q] = v[q];
+            }
+        }
+    }
+}
+
 __global__ void wave_sum_selftest_kernel(const float *in, float *out) {
     // out[w] = sum of in[w*64 .. w*64+63] for each wave of the block
     const float v = in[threadIdx.x];
@@ -624,8 +695,7 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: bad sizes");
         return GSR_E_INVALID;
     }
-    if (!gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dmeans3D || !gr->dL_dcov3D ||
-        !gr->dL_dconic || !gr->dL_dinvdepths) {
+    if (!gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dmeans3D || !gr->dL_dcov3D) {
         gsr_set_error("gsr_backward: gradient buffers missing");
         return GSR_E_INVALID;
     }
@@ -635,18 +705,25 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         gsr_set_error("gsr_backward: dL_dsh / dL_dscales / dL_drots required for this input combination");
         return GSR_E_INVALID;
     }
-    // zero every gradient buffer; buffers that are adjacent in memory (one arena sliced by the caller, as
-    // gsworld_amd/_backward.py does) are cleared by ONE memset instead of ten launches
+    // Which SH layout goes through sh_backward_kernel's LDS image (it then writes every coefficient gradient itself).
+    const bool sh_aligned = ((reinterpret_cast<uintptr_t>(in->shs) | reinterpret_cast<uintptr_t>(gr->dL_dsh) |
+                              reinterpret_cast<uintptr_t>(in->shs_rest) | reinterpret_cast<uintptr_t>(gr->dL_dsh_rest)) & 15u) == 0;
+    const int sh_cnt = (colors_precomp || M != 16 || !sh_aligned) ? 0 : (in->shs_rest ? 45 : 48);
+    const bool work = P > 0 && bw->num_rendered > 0;
+    const bool sh_self_clearing = work && sh_cnt != 0;
+    // zero the gradient buffers the kernels only write for visible Gaussians; buffers that are adjacent in memory (one
+    // arena sliced by the caller, as gsworld_amd/_backward.py does) are cleared by ONE memset instead of ten launches.
+    // dL_dconic / dL_dinvdepths are not touched any more (the compositor's sums live in the state's record array).
     {
         const size_t n = (size_t)(P > 0 ? P : 0);
         const size_t m_dc = in->shs_rest ? 1u : (size_t)M, m_rest = in->shs_rest ? (size_t)M - 1u : 0u;
-        constexpr int NR = 11;
+        constexpr int NR = 9;
         struct Range { char *p; size_t bytes; } r[NR] = {
             {(char *)gr->dL_dmeans2D, 3 * n * 4}, {(char *)gr->dL_dcolors, 3 * n * 4}, {(char *)gr->dL_dopacity, n * 4},
             {(char *)gr->dL_dmeans3D, 3 * n * 4}, {(char *)gr->dL_dcov3D, 6 * n * 4},
-            {(char *)gr->dL_dsh, 3 * n * m_dc * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
-            {(char *)gr->dL_drots, 4 * n * 4}, {(char *)gr->dL_dconic, 4 * n * 4}, {(char *)gr->dL_dinvdepths, n * 4},
-            {(char *)(in->shs_rest ? gr->dL_dsh_rest : nullptr), 3 * n * m_rest * 4}};
+            {(char *)(sh_self_clearing ? nullptr : gr->dL_dsh), 3 * n * m_dc * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
+            {(char *)gr->dL_drots, 4 * n * 4},
+            {(char *)(in->shs_rest && !sh_self_clearing ? gr->dL_dsh_rest : nullptr), 3 * n * m_rest * 4}};
         for (int i = 1; i < NR; i++)  // insertion sort by address
             for (int j = i; j > 0 && r[j].p < r[j - 1].p; j--) {
                 const Range t = r[j];
@@ -674,10 +751,13 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
     const BinningState b = BinningState::carve((char *)bw->binning, bw->num_rendered);
     const ImageState img = ImageState::carve((char *)bw->image, W, H);
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
+    if (hipMemsetAsync(g.grad_rec, 0, (size_t)P * kGradRec * sizeof(float), stream) != hipSuccess) {
+        gsr_set_error("gsr_backward: hipMemsetAsync failed");
+        return GSR_E_HIP;
+    }
     hipLaunchKernelGGL(render_backward_kernel, dim3(gx * gy), dim3(GSR_BLOCK), 0, stream, img.ranges, b.gidx[0],
                        g.splat, W, H, gx, in->background, img.final_T, img.n_contrib, bw->dL_dout_color,
-                       bw->dL_dout_invdepth, gr->dL_dmeans2D, gr->dL_dconic, gr->dL_dopacity, gr->dL_dcolors,
-                       gr->dL_dinvdepths);
+                       bw->dL_dout_invdepth, g.grad_rec);
     if (int e = gsr_check_launch("render_backward", debug, stream)) return e;
     BwdArgs a;
     a.P = P; a.D = st->sh_degree; a.M = M; a.W = W; a.H = H;
@@ -692,10 +772,16 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
     a.radii = bw->radii;
     a.cov3D = cov_precomp ? in->cov3D_precomp : g.cov3D;
     a.clamped = g.clamped;
-    a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dconic = gr->dL_dconic; a.dL_dcolors = gr->dL_dcolors;
-    a.dL_dinvdepths = gr->dL_dinvdepths;
+    a.grad_rec = g.grad_rec;
+    a.dL_dmean2D = gr->dL_dmeans2D; a.dL_dcolors = gr->dL_dcolors;
     a.dL_dopacity = gr->dL_dopacity; a.dL_dmeans3D = gr->dL_dmeans3D; a.dL_dcov3D = gr->dL_dcov3D;
     a.dL_dsh = gr->dL_dsh; a.dL_dscales = gr->dL_dscales; a.dL_drots = gr->dL_drots;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(gsr_div_up(P, GSR_BLOCK)), dim3(GSR_BLOCK), 0, stream, a);
-    return gsr_check_launch("preprocess_backward", debug, stream);
+    const dim3 grid(gsr_div_up(P, GSR_BLOCK));
+    hipLaunchKernelGGL(geometry_backward_kernel, grid, dim3(GSR_BLOCK), 0, stream, a);
+    if (int e = gsr_check_launch("geometry_backward", debug, stream)) return e;
+    if (colors_precomp) return GSR_OK;
+    if (sh_cnt == 45) hipLaunchKernelGGL(sh_backward_kernel<45>, grid, dim3(GSR_BLOCK), 0, stream, a);
+    else if (sh_cnt == 48) hipLaunchKernelGGL(sh_backward_kernel<48>, grid, dim3(GSR_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL(sh_backward_kernel<0>, grid, dim3(GSR_BLOCK), 0, stream, a);
+    return gsr_check_launch("sh_backward", debug, stream);
 }

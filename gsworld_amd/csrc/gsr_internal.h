@@ -52,6 +52,8 @@ struct GeomState {
                               //       rec2 = (r, g, b, radius as float)
     float *cov3D;             // [6P]
     uint32_t *clamped;        // [P]   byte c = SH clamp flag of channel c
+    float *grad_rec;          // [12P] backward only: the compositor's ten per-Gaussian sums as ONE 48-byte record
+                              //       (mean2D.xy, conic xx xy yy, opacity, rgb, 1/depth, 2 unused) -- see backward.hip
     uint32_t *tiles_touched;  // [P]
     uint2 *rects;             // [P]   x = min.x | min.y<<16, y = max.x | max.y<<16
     uint32_t *block_counts;   // [ceil(P/256)+1]  visible per preprocess block -> exclusive offsets
@@ -106,6 +108,7 @@ struct GeomState {
         g.splat = take<float4>(p, 3 * n);
         g.cov3D = take<float>(p, 6 * n);
         g.clamped = take<uint32_t>(p, n);
+        g.grad_rec = take<float>(p, 12 * n);
         g.tiles_touched = take<uint32_t>(p, n);
         g.rects = take<uint2>(p, n);
         g.block_counts = take<uint32_t>(p, (size_t)prep_blocks(P) + 1);

@@ -205,22 +205,24 @@ std::vector<torch::Tensor> rasterize_gaussians_backward(
         TORCH_CHECK(M == 1, "sh_rest needs sh = features_dc of shape (P,1,3)");
         M = 1 + sh_rest->size(1);
     }
-    // one uninitialised arena sliced into the gradient buffers (gsr_backward zeroes adjacent buffers with a single
-    // memset); (P,4)-shaped pieces first so that every slice stays 16-byte aligned
-    const int64_t n_rot = 4 * P, n_conic = 4 * P, n_sh = (split ? 1 : M) * 3 * P, n_rest = split ? (M - 1) * 3 * P : 0,
-                  n_cov = 6 * P, n3 = 3 * P, n1 = P;
-    auto arena = torch::empty({n_rot + n_conic + n_sh + n_rest + n_cov + 4 * n3 + 2 * n1},
+    // One uninitialised arena sliced into the gradient buffers.  The SH gradients come first (16-byte aligned: the SH
+    // backward kernel then writes every word of them itself, through whole lines); behind them, without gaps, the
+    // buffers gsr_backward clears -- adjacent buffers cost ONE memset on the stream.
+    auto pad4 = [](int64_t n) { return (n + 3) / 4 * 4; };
+    const int64_t n_rot = 4 * P, n_sh = (split ? 1 : M) * 3 * P, n_rest = split ? (M - 1) * 3 * P : 0, n_cov = 6 * P,
+                  n3 = 3 * P, n1 = P;
+    auto arena = torch::empty({pad4(n_rest) + pad4(n_sh) + n_rot + n_cov + 4 * n3 + n1},
                               means3D.options().dtype(torch::kFloat32));
     int64_t off = 0;
-    auto take = [&](int64_t n, std::vector<int64_t> shape) {
+    auto take = [&](int64_t n, std::vector<int64_t> shape, bool pad) {
         auto v = arena.narrow(0, off, n).view(shape);
-        off += n;
+        off += pad ? pad4(n) : n;
         return v;
     };
-    auto dL_drot = take(n_rot, {P, 4}), dL_dconic = take(n_conic, {P, 2, 2});
-    auto dL_dsh = take(n_sh, {P, split ? 1 : M, 3}), dL_dsh_rest = take(n_rest, {P, split ? M - 1 : 0, 3});
-    auto dL_dcov = take(n_cov, {P, 6}), dL_dm3 = take(n3, {P, 3}), dL_dm2 = take(n3, {P, 3}),
-         dL_dcol = take(n3, {P, 3}), dL_dsc = take(n3, {P, 3}), dL_dop = take(n1, {P, 1}), dL_dinv = take(n1, {P, 1});
+    auto dL_dsh_rest = take(n_rest, {P, split ? M - 1 : 0, 3}, true), dL_dsh = take(n_sh, {P, split ? 1 : M, 3}, true);
+    auto dL_drot = take(n_rot, {P, 4}, false), dL_dcov = take(n_cov, {P, 6}, false), dL_dm3 = take(n3, {P, 3}, false),
+         dL_dm2 = take(n3, {P, 3}, false), dL_dcol = take(n3, {P, 3}, false), dL_dsc = take(n3, {P, 3}, false),
+         dL_dop = take(n1, {P, 1}, false);
     if (P != 0) {
         const torch::Tensor bg = f32(background, dev, "background"), m3 = f32(means3D, dev, "means3D"),
                             col = f32(colors, dev, "colors"), op = f32(opacities, dev, "opacities"),
@@ -253,7 +255,7 @@ std::vector<torch::Tensor> rasterize_gaussians_backward(
                              geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr()};
         auto mp = [](torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
         GsrGrads gr{mp(dL_dm2), mp(dL_dcol), mp(dL_dop), mp(dL_dm3), mp(dL_dcov), mp(dL_dsh), mp(dL_dsc), mp(dL_drot),
-                    mp(dL_dconic), mp(dL_dinv), split ? mp(dL_dsh_rest) : nullptr};
+                    nullptr, nullptr, split ? mp(dL_dsh_rest) : nullptr};
         const int rc = gsr_backward(&st, &in, &bw, &gr, current_stream(dev));
         TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
     }

@@ -222,8 +222,8 @@ typedef struct GsrGrads {
     float *dL_dsh;        /* (P,M,3) or NULL with colors_precomp */
     float *dL_dscales;    /* (P,3) or NULL with cov3D_precomp */
     float *dL_drots;      /* (P,4) or NULL with cov3D_precomp */
-    float *dL_dconic;     /* (P,4) scratch: xx, xy (half, upstream convention), -, yy */
-    float *dL_dinvdepths; /* (P)   scratch */
+    float *dL_dconic;     /* unused (may be NULL): the compositor's per-Gaussian sums live in the geometry state */
+    float *dL_dinvdepths; /* unused (may be NULL) */
     float *dL_dsh_rest;   /* (P,M-1,3) with GsrInputs.shs_rest (dL_dsh is then the (P,1,3) dc part), else NULL */
 } GsrGrads;
 
