@@ -95,7 +95,7 @@ class GsrProfile(C.Structure):
     _fields_ = [("frames", C.c_int32), ("stage_ms", C.c_double * 5)]
 
 
-PROFILE_STAGES = ("preprocess", "compact+depth_sort", "tile_offsets", "emit+tile_sort+ranges", "render")
+PROFILE_STAGES = ("preprocess", "depth_sort", "tile_counts+ranges", "placement", "render")
 
 
 class GsrError(RuntimeError):

@@ -179,6 +179,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const int mode = GeomState::counting(tiles) && tiles_x <= 2048 ? want : 0;
     const bool band = mode == 1 && st->binning_path == 0 && gsr_band_supported(tiles_x);
     const bool exact = r_capacity <= 0;
+    // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
+    const bool order_early = band && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
 
@@ -201,7 +203,9 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             if (band)
                 if (int e = gsr_launch_gather_rects(in->P, g, debug, stream)) return e;
         } else {
-            if (int e = gsr_launch_sample_depth_sort(in->P, g, debug, stream)) return e;
+            if (int e = gsr_launch_sample_depth_sort(in->P, g, order_early ? img.quad_work : (const uint32_t *)nullptr,
+                                                     4 * tiles, img.quad_order, debug, stream))
+                return e;
         }
     }
     prof_mark(2, stream);
@@ -209,7 +213,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
     } else if (band) {
         if (int e = gsr_launch_band_count(*st, in->P, g, st->depth_sort != 1, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, order_early, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
     } else {

@@ -312,47 +312,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     if (blockIdx.x == 1) {
         if (!keyed) return;
         if (quad_order != nullptr) {
-            // quadrants by descending cost (256-bucket counting sort, costs held in registers: Q <= 32 x 256): the
-            // compositor gives every workgroup four quadrants of nearly equal cost (render.hip)
-            __shared__ uint32_t s_qb[256];
-            const int Q = 4 * T;
-            uint32_t c[32], qmx = 0;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const int q = (int)threadIdx.x + k * GSR_BLOCK;
-                c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
-                qmx = max(qmx, c[k]);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
-            if (gsr_lane() == 0) s_w[gsr_wave()] = qmx;
-            s_qb[threadIdx.x] = 0u;
-            __syncthreads();
-            qmx = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
-            // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
-            const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
-            const uint32_t div = (qmx >> sh) + 1u;
-            const float inv = 256.0f / (float)div;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const int q = (int)threadIdx.x + k * GSR_BLOCK;
-                c[k] = 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));
-                if (q < Q) atomicAdd(&s_qb[c[k]], 1u);
-            }
-            __syncthreads();
-            {
-                const uint32_t n = s_qb[threadIdx.x];
-                uint32_t tot;
-                const uint32_t incl = gsr_block_incl_scan(n, s_w, tot);
-                s_qb[threadIdx.x] = incl - n;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const int q = (int)threadIdx.x + k * GSR_BLOCK;
-                if (q < Q) quad_order[atomicAdd(&s_qb[c[k]], 1u)] = (uint32_t)q;
-            }
-            __syncthreads();
+            gsr_quad_order_block(quad_work, 4 * T, quad_order, s_w);
             return;  // (the tile-level order below is what the compositor uses when it has no quadrant order)
         }
         uint32_t key[8];
@@ -600,20 +560,22 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     if (int e = gsr_check_launch("tile_count", debug, stream)) return e;
     // one table column per 256 depth ranks: the live row length is ceil(V / 256)
     if (int e = gsr_launch_rowscan(g.tile_table, &g.hdr->V, nb, GSR_BLOCK, T, g.tile_totals, debug, stream)) return e;
-    return gsr_launch_tile_starts(st, g, img, r_capacity, debug, stream);
+    return gsr_launch_tile_starts(st, g, img, r_capacity, false, debug, stream);
 }
 
 // per-tile totals -> ranges, R, capacity check, compositing order (shared by the two counting placements)
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
-                           bool debug, hipStream_t stream) {
+                           bool order_done, bool debug, hipStream_t stream) {
     const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
     const int split_blocks = T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : 2), dim3(GSR_BLOCK), 0, stream, g.tile_totals, T,
-                       g.hdr, r_capacity, img.ranges,
-                       gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr, (uint32_t *)nullptr,
+    // (order_done: the compositing order was computed earlier in the frame, beside the depth sort's partition pass)
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : (order_done ? 1 : 2)), dim3(GSR_BLOCK), 0, stream,
+                       g.tile_totals, T, g.hdr, r_capacity, img.ranges,
+                       !order_done && gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr,
+                       (uint32_t *)nullptr,
                        (const uint32_t *)img.quad_work, (const uint32_t *)img.quad_work_b, img.split_flag,
                        img.split_list, img.split_count, split_blocks * (GSR_BLOCK / GSR_WAVE),
-                       gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr);
+                       !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr);
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

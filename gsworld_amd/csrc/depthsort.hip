@@ -470,19 +470,25 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
                                                           const uint32_t *__restrict__ splitters,
                                                           const uint32_t *__restrict__ seg_off,
                                                           uint32_t *__restrict__ bucket_start,
-                                                          const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
+                                                          const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
+                                                          int nbc, const uint32_t *__restrict__ quad_work, int num_quads,
+                                                          uint32_t *__restrict__ quad_order) {
     extern __shared__ uint32_t smem[];
+    __shared__ uint32_t s_w[4];
+    if ((int)blockIdx.x == nbc) {  // the spare workgroup: the compositor's quadrant order (see gsr_quad_order_block)
+        gsr_quad_order_block(quad_work, num_quads, quad_order, s_w);
+        return;
+    }
     uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
     uint32_t *s_split = smem;            // [bmax]
     uint32_t *s_run = s_split + bmax;    // [bmax]  next free slot of every bucket for this workgroup
     uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
-    __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint32_t V = hdr->V;
     if (V == 0u) return;
     const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
-    const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
+    const int me = (int)blockIdx.x;
     {
         // Column sums of the histogram rows (all rows -> bucket totals, rows before mine -> my first slot per bucket).
         // The rows sit in other XCDs' L2s / HBM: a round trip is ~2 k cycles, so rows are spread over the waves and a
@@ -717,7 +723,8 @@ int gsr_ss_bmax(int32_t P) {
 }
 
 // preprocess left vis_key / block_counts / block_cand; the sorted depth order ends in g.order
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const uint32_t *quad_work, int num_quads,
+                                 uint32_t *quad_order, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
@@ -725,8 +732,9 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipS
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc), dim3(kT), lds2, stream, bmax, g.pair[0], g.pair[1], g.ss_table,
-                       g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg);
+    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
+                       g.pair[1], g.ss_table, g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work,
+                       num_quads, quad_order);
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,

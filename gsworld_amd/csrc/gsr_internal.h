@@ -255,7 +255,9 @@ int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const Image
 int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+// (quad_work != nullptr: a spare workgroup of the partition pass also sorts the num_quads quadrant costs -> quad_order)
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const uint32_t *quad_work, int num_quads,
+                                 uint32_t *quad_order, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
@@ -263,7 +265,7 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
 int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
                           bool debug, hipStream_t stream);
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
-                           bool debug, hipStream_t stream);
+                           bool order_done, bool debug, hipStream_t stream);
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
@@ -314,6 +316,52 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t *s_
     total = w0 + w1 + w2 + w3;
     __syncthreads();
     return incl + add;
+}
+
+// One workgroup (256 threads): the image's Q <= 32 x 256 quadrants by descending cost of the previous frame (256-bucket
+// counting sort, costs held in registers); the compositor gives every workgroup four quadrants of nearly equal cost
+// (render.hip).  Depends on nothing of the current frame, so it runs wherever a spare workgroup costs nothing.
+// Any permutation gives the same image: a fresh state (garbage costs) only balances badly.
+__device__ __forceinline__ void gsr_quad_order_block(const uint32_t *__restrict__ quad_work, int Q,
+                                                     uint32_t *__restrict__ quad_order, uint32_t *s_w /*[4]*/) {
+    __shared__ uint32_t s_qb[256];
+    uint32_t c[32], qmx = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int q = (int)threadIdx.x + k * GSR_BLOCK;
+        c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
+        qmx = max(qmx, c[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = qmx;
+    s_qb[threadIdx.x] = 0u;
+    __syncthreads();
+    qmx = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+    // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
+    const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
+    const uint32_t div = (qmx >> sh) + 1u;
+    const float inv = 256.0f / (float)div;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int q = (int)threadIdx.x + k * GSR_BLOCK;
+        c[k] = 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));
+        if (q < Q) atomicAdd(&s_qb[c[k]], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t n = s_qb[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = gsr_block_incl_scan(n, s_w, tot);
+        s_qb[threadIdx.x] = incl - n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int q = (int)threadIdx.x + k * GSR_BLOCK;
+        if (q < Q) quad_order[atomicAdd(&s_qb[c[k]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();
 }
 // Visits every tile of this lane's rect (t = tiles touched, rc = packed rect; t == 0 for lanes without a
 // Gaussian).  Lists of up to 32 tiles are walked by the owning lane; longer ones are spread over the whole wave,

@@ -188,7 +188,9 @@ int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity_
 /*
  * Optional stage timing with HIP events recorded on the caller's stream (what bench.py's roofline uses).
  * mode 0 = off, 1 = the compositing kernel only (2 events / frame), 2 = every stage (6 events / frame).
- * Stages: 0 preprocess, 1 compaction + depth sort, 2 tile offsets (scan), 3 emit + tile sort + ranges, 4 render.
+ * Stages: 0 preprocess, 1 depth sort (compaction, partition, buckets), 2 tile counts -> ranges (band ranges, count,
+ * scan, tile starts; the fallback paths: tile offsets), 3 placement of the instances (fallback: emit + tile sort +
+ * ranges), 4 render.
  * The recorder is per calling thread (enable, render and collect from the same thread); at most 4096 frames
  * are recorded between two collects.
  */
