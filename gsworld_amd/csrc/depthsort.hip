@@ -16,9 +16,13 @@
 //                bucket (typically 2 passes of 8 bits), result = the bare Gaussian indices in `order`
 //
 // Stability (index order on equal keys) is kept end to end: compaction in index order, stable partition, stable LSD
-// passes.  Samples are the first visible key of every preprocess block (256 Gaussians), thinned evenly to S; splitters
-// carry the top 24 key bits only, so records with equal depth never straddle a bucket boundary by accident of the
-// sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a bucket averages <= 512 records.
+// passes.  Samples are uniform over the VISIBLE Gaussians: sample s is the first visible key of the preprocess block
+// (256 Gaussians) that holds visible Gaussian s V / S -- uniform over the blocks would starve the dense part of an
+// index-coherent model.  Splitters carry the top 24 key bits only, so records with equal depth never straddle a bucket
+// boundary by accident of the sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a
+// bucket averages <= 512 records.  ss_buckets leaves the exact quantiles of the frame in the state; the next frame on
+// that state only validates them against its samples and skips the sample sort (any splitters give the same order).
+// Compaction workgroups share the blocks by COST (records + kBlockCost per block), not by count: see ss_compact_kernel.
 // A bucket that does not fit the LDS (bad luck or adversarial depths: > 3584 records) is sorted by the same workgroup
 // in global memory with a bitonic network over the (key << 32 | index) composites -- slow, correct, never seen on
 // the BASELINE scenes.
