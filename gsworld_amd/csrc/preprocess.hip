@@ -76,6 +76,281 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// Position of Gaussian i after the optional rigid part transform (GsrInputs.part_*); xf = its pose row or nullptr.
+__device__ __forceinline__ void prep_position(const PreprocessArgs &a, int i, float &px_, float &py_, float &pz_,
+                                              const float *&xf_, int &part_) {
+    float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+    // moving part?  (label -> part through the LUT; the reference compares labels after .long(): truncation)
+    const float *xf = nullptr;
+    int part = -1;
+    if (a.part_labels != nullptr) {
+        const int label = (int)a.part_labels[i];
+        part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
+        if (part >= 0 && part < a.part_count) {
+            xf = a.part_transforms + (size_t)part * 17;
+            // xyz' = R (s xyz) + t, in the operation order of transform.hip (plain multiplies and adds)
+            const float s = xf[12];
+            px *= s; py *= s; pz *= s;
+            const float rx = xf[0] * px + xf[1] * py + xf[2] * pz + xf[9];
+            const float ry = xf[3] * px + xf[4] * py + xf[5] * pz + xf[10];
+            const float rz = xf[6] * px + xf[7] * py + xf[8] * pz + xf[11];
+            px = rx; py = ry; pz = rz;
+        }
+    }
+    px_ = px; py_ = py; pz_ = pz; xf_ = xf; part_ = part;
+}
+
+struct GeomOut {
+    bool visible;
+    float4 pos;      // xyz (after the part transform) + radius as float, handed to the colour phase
+    uint32_t tiles;  // tiles touched
+    uint32_t key;    // depth bits of a visible Gaussian, 0 otherwise
+    uint2 rect;
+    int radius;
+};
+
+// The exact per-Gaussian geometry: cull, projection, covariances, conic, radius, rect.
+// Writes rec0 / rec1 / cov3D / rects of a visible Gaussian; the caller writes radii, tiles_touched and vis_key.
+__device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i) {
+    bool visible = false;
+    float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 my_rect = make_uint2(0u, 0u);
+    float px, py, pz;
+    const float *xf;
+    int part;
+    prep_position(a, i, px, py, pz, xf, part);
+    const float *m = a.view;
+    // transformPoint4x3: M[r][c] = m[c*4+r]
+    const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
+    const float vy = fma_(m[9], pz, fma_(m[5], py, m[1] * px)) + m[13];
+    const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
+    int radius = 0;
+    uint32_t touched = 0;
+    if (vz > a.near_plane) {  // in_frustum with GSWorld's near plane
+        const float *q = a.proj;
+        const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
+        const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
+        const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+        // ---- 3D covariance: Sigma = R diag((mod*s)^2) R^T ------------------------------------------------
+        const float opacity_raw = a.opacities[i];  // (requested with the covariance inputs: one round trip, not two)
+        float c0, c1, c2, c3, c4, c5;
+        if (a.cov3D_precomp) {
+            const float *c = a.cov3D_precomp + 6 * (size_t)i;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+        } else {
+            float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
+            float sc0 = a.scales[3 * (size_t)i], sc1 = a.scales[3 * (size_t)i + 1], sc2 = a.scales[3 * (size_t)i + 2];
+            if (xf != nullptr) {
+                // rot' = standardize(q_R (x) rot / |rot|) * |rot|  (gs_utils.py:242-249; transform.hip)
+                const float norm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+                const float bw = rq.x / norm, bx = rq.y / norm, by = rq.z / norm, bz = rq.w / norm;
+                const float aw = xf[13], ax = xf[14], ay = xf[15], az = xf[16];
+                float ow = aw * bw - ax * bx - ay * by - az * bz;
+                float ox = aw * bx + ax * bw + ay * bz - az * by;
+                float oy = aw * by - ax * bz + ay * bw + az * bx;
+                float oz = aw * bz + ax * by - ay * bx + az * bw;
+                if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }
+                rq = make_float4(ow * norm, ox * norm, oy * norm, oz * norm);
+                if (a.part_rescale != nullptr && a.part_rescale[part]) {
+                    // the reference's rewrite of a tracked actor's log-scales: inverse_sigmoid(exp(s) * scale)
+                    const float s = xf[12];
+                    const float x0 = expf(sc0) * s, x1 = expf(sc1) * s, x2 = expf(sc2) * s;
+                    sc0 = logf(x0 / (1.0f - x0));
+                    sc1 = logf(x1 / (1.0f - x1));
+                    sc2 = logf(x2 / (1.0f - x2));
+                }
+            }
+            if (a.param_space & GSR_RAW_ROTATIONS) {  // F.normalize: q / max(|q|, 1e-12)
+                const float n2 = fma_(rq.w, rq.w, fma_(rq.z, rq.z, fma_(rq.y, rq.y, rq.x * rq.x)));
+                const float d = fmaxf(sqrtf(n2), 1e-12f);
+                rq = make_float4(rq.x / d, rq.y / d, rq.z / d, rq.w / d);
+            }
+            if (a.param_space & GSR_RAW_SCALES) {
+                sc0 = exp_canonical(sc0);
+                sc1 = exp_canonical(sc1);
+                sc2 = exp_canonical(sc2);
+            }
+            const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
+            const float s0 = a.scale_modifier * sc0;
+            const float s1 = a.scale_modifier * sc1;
+            const float s2 = a.scale_modifier * sc2;
+            const float R00 = fma_(-2.f, fma_(z, z, y * y), 1.f);
+            const float R01 = 2.f * fma_(-r, z, x * y);
+            const float R02 = 2.f * fma_(r, y, x * z);
+            const float R10 = 2.f * fma_(r, z, x * y);
+            const float R11 = fma_(-2.f, fma_(z, z, x * x), 1.f);
+            const float R12 = 2.f * fma_(-r, x, y * z);
+            const float R20 = 2.f * fma_(-r, y, x * z);
+            const float R21 = 2.f * fma_(r, x, y * z);
+            const float R22 = fma_(-2.f, fma_(y, y, x * x), 1.f);
+            // M[k][j] = s_k * R[j][k]
+            const float M00 = s0 * R00, M01 = s0 * R10, M02 = s0 * R20;
+            const float M10 = s1 * R01, M11 = s1 * R11, M12 = s1 * R21;
+            const float M20 = s2 * R02, M21 = s2 * R12, M22 = s2 * R22;
+            c0 = fma_(M20, M20, fma_(M10, M10, M00 * M00));
+            c1 = fma_(M20, M21, fma_(M10, M11, M00 * M01));
+            c2 = fma_(M20, M22, fma_(M10, M12, M00 * M02));
+            c3 = fma_(M21, M21, fma_(M11, M11, M01 * M01));
+            c4 = fma_(M21, M22, fma_(M11, M12, M01 * M02));
+            c5 = fma_(M22, M22, fma_(M12, M12, M02 * M02));
+        }
+
+        // ---- EWA 2D covariance: (J W) Sigma (J W)^T ---------------------------------------------------------
+        const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        const float J00 = a.fx / vz, J02 = -(a.fx * tx) / (vz * vz);
+        const float J11 = a.fy / vz, J12 = -(a.fy * ty) / (vz * vz);
+        // A = J W with W[i][j] = m[j*4+i]
+        const float A00 = fma_(J02, m[2], J00 * m[0]);
+        const float A01 = fma_(J02, m[6], J00 * m[4]);
+        const float A02 = fma_(J02, m[10], J00 * m[8]);
+        const float A10 = fma_(J12, m[2], J11 * m[1]);
+        const float A11 = fma_(J12, m[6], J11 * m[5]);
+        const float A12 = fma_(J12, m[10], J11 * m[9]);
+        // B = A Sigma
+        const float B00 = fma_(A02, c2, fma_(A01, c1, A00 * c0));
+        const float B01 = fma_(A02, c4, fma_(A01, c3, A00 * c1));
+        const float B02 = fma_(A02, c5, fma_(A01, c4, A00 * c2));
+        const float B10 = fma_(A12, c2, fma_(A11, c1, A10 * c0));
+        const float B11 = fma_(A12, c4, fma_(A11, c3, A10 * c1));
+        const float B12 = fma_(A12, c5, fma_(A11, c4, A10 * c2));
+        float cxx = fma_(B02, A02, fma_(B01, A01, B00 * A00));
+        const float cxy = fma_(B02, A12, fma_(B01, A11, B00 * A10));
+        float cyy = fma_(B12, A12, fma_(B11, A11, B10 * A10));
+
+        const float det_cov = fma_(-cxy, cxy, cxx * cyy);
+        cxx += 0.3f;
+        cyy += 0.3f;
+        const float det = fma_(-cxy, cxy, cxx * cyy);
+        float h_scale = 1.0f;
+        if (a.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conic_x = cyy * det_inv, conic_y = -cxy * det_inv, conic_z = cxx * det_inv;
+            const float mid = 0.5f * (cxx + cyy);
+            const float root = sqrtf(fmaxf(0.1f, fma_(mid, mid, -det)));
+            const float lambda1 = mid + root, lambda2 = mid - root;
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix is binary64 upstream (double literals)
+            const float pix_x = (float)((((double)ndc_x + 1.0) * (double)a.W - 1.0) * 0.5);
+            const float pix_y = (float)((((double)ndc_y + 1.0) * (double)a.H - 1.0) * 0.5);
+            const int ir = (int)my_radius;
+            const float fr = (float)ir;
+            int rminx = (int)((pix_x - fr) / (float)GSR_TILE);
+            int rminy = (int)((pix_y - fr) / (float)GSR_TILE);
+            int rmaxx = (int)((pix_x + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
+            int rmaxy = (int)((pix_y + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
+            rminx = min(a.gx, max(0, rminx));
+            rminy = min(a.gy, max(0, rminy));
+            rmaxx = min(a.gx, max(0, rmaxx));
+            rmaxy = min(a.gy, max(0, rmaxy));
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) {
+                float opacity_in = opacity_raw;
+                if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
+                const float opacity = opacity_in * h_scale;
+                float4 *rec = a.splat + 3 * (size_t)i;
+                rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
+                rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
+                float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
+                cv[0] = make_float2(c0, c1);
+                cv[1] = make_float2(c2, c3);
+                cv[2] = make_float2(c4, c5);
+                my_rect = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
+                                     (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+                a.rects[i] = my_rect;
+                radius = ir;
+                touched = (uint32_t)area;
+                visible = true;
+                mypos = make_float4(px, py, pz, fr);
+            }
+        }
+    }
+    GeomOut o;
+    o.visible = visible;
+    o.pos = mypos;
+    o.tiles = touched;
+    o.key = visible ? __float_as_uint(vz) : 0u;  // (vz > near_plane > 0: never the 0 pattern)
+    o.rect = my_rect;
+    o.radius = radius;
+    return o;
+}
+
+// SH -> RGB (or the precomputed colour) of visible Gaussian g at position pp.xyz; writes rec2 and the clamp flags.
+template <bool FAST_SH16>
+__device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g, const float4 pp) {
+    float cr, cg, cb;
+    uint32_t clamp_bits = 0;
+    if (a.colors_precomp) {
+        cr = a.colors_precomp[3 * (size_t)g];
+        cg = a.colors_precomp[3 * (size_t)g + 1];
+        cb = a.colors_precomp[3 * (size_t)g + 2];
+    } else {
+        float dx = pp.x - a.campos[0], dy = pp.y - a.campos[1], dz = pp.z - a.campos[2];
+        const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        float b[16];
+        sh_basis(a.D, dx, dy, dz, b);
+        if (a.shs_rest) {
+            // split storage (features_dc | features_rest): coefficient 0 from one array, 1.. from the other
+            const float *dc = a.shs + 3 * (size_t)g;
+            const float *rest = a.shs_rest + (size_t)g * (a.M - 1) * 3;
+            const int nb = (a.D + 1) * (a.D + 1);
+            cr = b[0] * dc[0]; cg = b[0] * dc[1]; cb = b[0] * dc[2];
+            if (a.D == 3) {
+                float f[45];
+#pragma unroll
+                for (int k = 0; k < 45; k++) f[k] = rest[k];  // 15 x dwordx3, all in flight together
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    cr = fma_(b[k], f[3 * k - 3], cr);
+                    cg = fma_(b[k], f[3 * k - 2], cg);
+                    cb = fma_(b[k], f[3 * k - 1], cb);
+                }
+            } else {
+                for (int k = 1; k < nb; k++) {
+                    cr = fma_(b[k], rest[3 * k - 3], cr);
+                    cg = fma_(b[k], rest[3 * k - 2], cg);
+                    cb = fma_(b[k], rest[3 * k - 1], cb);
+                }
+            }
+        } else if (FAST_SH16) {
+            // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
+            const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
+            float4 v[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[k] = sh4[k];
+            const float *f = reinterpret_cast<const float *>(v);
+            cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                cr = fma_(b[k], f[3 * k], cr);
+                cg = fma_(b[k], f[3 * k + 1], cg);
+                cb = fma_(b[k], f[3 * k + 2], cb);
+            }
+        } else {
+            const float *sh = a.shs + (size_t)g * a.M * 3;
+            const int nb = (a.D + 1) * (a.D + 1);
+            cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
+            for (int k = 1; k < nb; k++) {
+                cr = fma_(b[k], sh[3 * k], cr);
+                cg = fma_(b[k], sh[3 * k + 1], cg);
+                cb = fma_(b[k], sh[3 * k + 2], cb);
+            }
+        }
+        cr += 0.5f; cg += 0.5f; cb += 0.5f;
+        clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
+        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+    }
+    a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, pp.w);
+    a.clamped[g] = clamp_bits;
+}
+
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
@@ -88,180 +363,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
     }
     if (i < a.P) {
-        float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
-        // moving part?  (label -> part through the LUT; the reference compares labels after .long(): truncation)
-        const float *xf = nullptr;
-        int part = -1;
-        if (a.part_labels != nullptr) {
-            const int label = (int)a.part_labels[i];
-            part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
-            if (part >= 0 && part < a.part_count) {
-                xf = a.part_transforms + (size_t)part * 17;
-                // xyz' = R (s xyz) + t, in the operation order of transform.hip (plain multiplies and adds)
-                const float s = xf[12];
-                px *= s; py *= s; pz *= s;
-                const float rx = xf[0] * px + xf[1] * py + xf[2] * pz + xf[9];
-                const float ry = xf[3] * px + xf[4] * py + xf[5] * pz + xf[10];
-                const float rz = xf[6] * px + xf[7] * py + xf[8] * pz + xf[11];
-                px = rx; py = ry; pz = rz;
-            }
-        }
-        const float *m = a.view;
-        // transformPoint4x3: M[r][c] = m[c*4+r]
-        const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
-        const float vy = fma_(m[9], pz, fma_(m[5], py, m[1] * px)) + m[13];
-        const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
-        int radius = 0;
-        uint32_t touched = 0;
-        if (vz > a.near_plane) {  // in_frustum with GSWorld's near plane
-            const float *q = a.proj;
-            const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
-            const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
-            const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
-            const float p_w = 1.0f / (hw + 0.0000001f);
-            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
-
-            // ---- 3D covariance: Sigma = R diag((mod*s)^2) R^T ------------------------------------------------
-            const float opacity_raw = a.opacities[i];  // (requested with the covariance inputs: one round trip, not two)
-            float c0, c1, c2, c3, c4, c5;
-            if (a.cov3D_precomp) {
-                const float *c = a.cov3D_precomp + 6 * (size_t)i;
-                c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
-            } else {
-                float4 rq = *reinterpret_cast<const float4 *>(a.rotations + 4 * (size_t)i);
-                float sc0 = a.scales[3 * (size_t)i], sc1 = a.scales[3 * (size_t)i + 1], sc2 = a.scales[3 * (size_t)i + 2];
-                if (xf != nullptr) {
-                    // rot' = standardize(q_R (x) rot / |rot|) * |rot|  (gs_utils.py:242-249; transform.hip)
-                    const float norm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
-                    const float bw = rq.x / norm, bx = rq.y / norm, by = rq.z / norm, bz = rq.w / norm;
-                    const float aw = xf[13], ax = xf[14], ay = xf[15], az = xf[16];
-                    float ow = aw * bw - ax * bx - ay * by - az * bz;
-                    float ox = aw * bx + ax * bw + ay * bz - az * by;
-                    float oy = aw * by - ax * bz + ay * bw + az * bx;
-                    float oz = aw * bz + ax * by - ay * bx + az * bw;
-                    if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }
-                    rq = make_float4(ow * norm, ox * norm, oy * norm, oz * norm);
-                    if (a.part_rescale != nullptr && a.part_rescale[part]) {
-                        // the reference's rewrite of a tracked actor's log-scales: inverse_sigmoid(exp(s) * scale)
-                        const float s = xf[12];
-                        const float x0 = expf(sc0) * s, x1 = expf(sc1) * s, x2 = expf(sc2) * s;
-                        sc0 = logf(x0 / (1.0f - x0));
-                        sc1 = logf(x1 / (1.0f - x1));
-                        sc2 = logf(x2 / (1.0f - x2));
-                    }
-                }
-                if (a.param_space & GSR_RAW_ROTATIONS) {  // F.normalize: q / max(|q|, 1e-12)
-                    const float n2 = fma_(rq.w, rq.w, fma_(rq.z, rq.z, fma_(rq.y, rq.y, rq.x * rq.x)));
-                    const float d = fmaxf(sqrtf(n2), 1e-12f);
-                    rq = make_float4(rq.x / d, rq.y / d, rq.z / d, rq.w / d);
-                }
-                if (a.param_space & GSR_RAW_SCALES) {
-                    sc0 = exp_canonical(sc0);
-                    sc1 = exp_canonical(sc1);
-                    sc2 = exp_canonical(sc2);
-                }
-                const float r = rq.x, x = rq.y, y = rq.z, z = rq.w;
-                const float s0 = a.scale_modifier * sc0;
-                const float s1 = a.scale_modifier * sc1;
-                const float s2 = a.scale_modifier * sc2;
-                const float R00 = fma_(-2.f, fma_(z, z, y * y), 1.f);
-                const float R01 = 2.f * fma_(-r, z, x * y);
-                const float R02 = 2.f * fma_(r, y, x * z);
-                const float R10 = 2.f * fma_(r, z, x * y);
-                const float R11 = fma_(-2.f, fma_(z, z, x * x), 1.f);
-                const float R12 = 2.f * fma_(-r, x, y * z);
-                const float R20 = 2.f * fma_(-r, y, x * z);
-                const float R21 = 2.f * fma_(r, x, y * z);
-                const float R22 = fma_(-2.f, fma_(y, y, x * x), 1.f);
-                // M[k][j] = s_k * R[j][k]
-                const float M00 = s0 * R00, M01 = s0 * R10, M02 = s0 * R20;
-                const float M10 = s1 * R01, M11 = s1 * R11, M12 = s1 * R21;
-                const float M20 = s2 * R02, M21 = s2 * R12, M22 = s2 * R22;
-                c0 = fma_(M20, M20, fma_(M10, M10, M00 * M00));
-                c1 = fma_(M20, M21, fma_(M10, M11, M00 * M01));
-                c2 = fma_(M20, M22, fma_(M10, M12, M00 * M02));
-                c3 = fma_(M21, M21, fma_(M11, M11, M01 * M01));
-                c4 = fma_(M21, M22, fma_(M11, M12, M01 * M02));
-                c5 = fma_(M22, M22, fma_(M12, M12, M02 * M02));
-            }
-
-            // ---- EWA 2D covariance: (J W) Sigma (J W)^T ---------------------------------------------------------
-            const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
-            const float txtz = vx / vz, tytz = vy / vz;
-            const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
-            const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
-            const float J00 = a.fx / vz, J02 = -(a.fx * tx) / (vz * vz);
-            const float J11 = a.fy / vz, J12 = -(a.fy * ty) / (vz * vz);
-            // A = J W with W[i][j] = m[j*4+i]
-            const float A00 = fma_(J02, m[2], J00 * m[0]);
-            const float A01 = fma_(J02, m[6], J00 * m[4]);
-            const float A02 = fma_(J02, m[10], J00 * m[8]);
-            const float A10 = fma_(J12, m[2], J11 * m[1]);
-            const float A11 = fma_(J12, m[6], J11 * m[5]);
-            const float A12 = fma_(J12, m[10], J11 * m[9]);
-            // B = A Sigma
-            const float B00 = fma_(A02, c2, fma_(A01, c1, A00 * c0));
-            const float B01 = fma_(A02, c4, fma_(A01, c3, A00 * c1));
-            const float B02 = fma_(A02, c5, fma_(A01, c4, A00 * c2));
-            const float B10 = fma_(A12, c2, fma_(A11, c1, A10 * c0));
-            const float B11 = fma_(A12, c4, fma_(A11, c3, A10 * c1));
-            const float B12 = fma_(A12, c5, fma_(A11, c4, A10 * c2));
-            float cxx = fma_(B02, A02, fma_(B01, A01, B00 * A00));
-            const float cxy = fma_(B02, A12, fma_(B01, A11, B00 * A10));
-            float cyy = fma_(B12, A12, fma_(B11, A11, B10 * A10));
-
-            const float det_cov = fma_(-cxy, cxy, cxx * cyy);
-            cxx += 0.3f;
-            cyy += 0.3f;
-            const float det = fma_(-cxy, cxy, cxx * cyy);
-            float h_scale = 1.0f;
-            if (a.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
-            if (det != 0.0f) {
-                const float det_inv = 1.f / det;
-                const float conic_x = cyy * det_inv, conic_y = -cxy * det_inv, conic_z = cxx * det_inv;
-                const float mid = 0.5f * (cxx + cyy);
-                const float root = sqrtf(fmaxf(0.1f, fma_(mid, mid, -det)));
-                const float lambda1 = mid + root, lambda2 = mid - root;
-                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-                // ndc2Pix is binary64 upstream (double literals)
-                const float pix_x = (float)((((double)ndc_x + 1.0) * (double)a.W - 1.0) * 0.5);
-                const float pix_y = (float)((((double)ndc_y + 1.0) * (double)a.H - 1.0) * 0.5);
-                const int ir = (int)my_radius;
-                const float fr = (float)ir;
-                int rminx = (int)((pix_x - fr) / (float)GSR_TILE);
-                int rminy = (int)((pix_y - fr) / (float)GSR_TILE);
-                int rmaxx = (int)((pix_x + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
-                int rmaxy = (int)((pix_y + fr + (float)(GSR_TILE - 1)) / (float)GSR_TILE);
-                rminx = min(a.gx, max(0, rminx));
-                rminy = min(a.gy, max(0, rminy));
-                rmaxx = min(a.gx, max(0, rmaxx));
-                rmaxy = min(a.gy, max(0, rmaxy));
-                const int area = (rmaxx - rminx) * (rmaxy - rminy);
-                if (area != 0) {
-                    float opacity_in = opacity_raw;
-                    if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
-                    const float opacity = opacity_in * h_scale;
-                    float4 *rec = a.splat + 3 * (size_t)i;
-                    rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
-                    rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
-                    float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
-                    cv[0] = make_float2(c0, c1);
-                    cv[1] = make_float2(c2, c3);
-                    cv[2] = make_float2(c4, c5);
-                    my_rect = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
-                                         (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
-                    a.rects[i] = my_rect;
-                    radius = ir;
-                    touched = (uint32_t)area;
-                    my_tiles = touched;
-                    visible = true;
-                    mypos = make_float4(px, py, pz, fr);
-                }
-            }
-        }
-        a.radii[i] = radius;
-        a.tiles_touched[i] = touched;
-        my_key = visible ? __float_as_uint(vz) : 0u;  // (vz > near_plane > 0: never the 0 pattern)
+        const GeomOut o = prep_geometry(a, i);
+        visible = o.visible;
+        mypos = o.pos;
+        my_tiles = o.tiles;
+        my_rect = o.rect;
+        a.radii[i] = o.radius;
+        a.tiles_touched[i] = o.tiles;
+        my_key = o.key;
         a.vis_key[i] = my_key;
     }
     // ---- phase 2: colour, on the block-compacted list of survivors ------------------------------------------
@@ -294,73 +403,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         }
     }
     if (threadIdx.x < cnt) {
-        const int g = s_idx[threadIdx.x];
-        const float4 pp = s_pos[threadIdx.x];
-        float cr, cg, cb;
-        uint32_t clamp_bits = 0;
-        if (a.colors_precomp) {
-            cr = a.colors_precomp[3 * (size_t)g];
-            cg = a.colors_precomp[3 * (size_t)g + 1];
-            cb = a.colors_precomp[3 * (size_t)g + 2];
-        } else {
-            float dx = pp.x - a.campos[0], dy = pp.y - a.campos[1], dz = pp.z - a.campos[2];
-            const float len = sqrtf(fma_(dz, dz, fma_(dy, dy, dx * dx)));
-            dx = dx / len; dy = dy / len; dz = dz / len;
-            float b[16];
-            sh_basis(a.D, dx, dy, dz, b);
-            if (a.shs_rest) {
-                // split storage (features_dc | features_rest): coefficient 0 from one array, 1.. from the other
-                const float *dc = a.shs + 3 * (size_t)g;
-                const float *rest = a.shs_rest + (size_t)g * (a.M - 1) * 3;
-                const int nb = (a.D + 1) * (a.D + 1);
-                cr = b[0] * dc[0]; cg = b[0] * dc[1]; cb = b[0] * dc[2];
-                if (a.D == 3) {
-                    float f[45];
-#pragma unroll
-                    for (int k = 0; k < 45; k++) f[k] = rest[k];  // 15 x dwordx3, all in flight together
-#pragma unroll
-                    for (int k = 1; k < 16; k++) {
-                        cr = fma_(b[k], f[3 * k - 3], cr);
-                        cg = fma_(b[k], f[3 * k - 2], cg);
-                        cb = fma_(b[k], f[3 * k - 1], cb);
-                    }
-                } else {
-                    for (int k = 1; k < nb; k++) {
-                        cr = fma_(b[k], rest[3 * k - 3], cr);
-                        cg = fma_(b[k], rest[3 * k - 2], cg);
-                        cb = fma_(b[k], rest[3 * k - 1], cb);
-                    }
-                }
-            } else if (FAST_SH16) {
-                // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
-                const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
-                float4 v[12];
-#pragma unroll
-                for (int k = 0; k < 12; k++) v[k] = sh4[k];
-                const float *f = reinterpret_cast<const float *>(v);
-                cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
-#pragma unroll
-                for (int k = 1; k < 16; k++) {
-                    cr = fma_(b[k], f[3 * k], cr);
-                    cg = fma_(b[k], f[3 * k + 1], cg);
-                    cb = fma_(b[k], f[3 * k + 2], cb);
-                }
-            } else {
-                const float *sh = a.shs + (size_t)g * a.M * 3;
-                const int nb = (a.D + 1) * (a.D + 1);
-                cr = b[0] * sh[0]; cg = b[0] * sh[1]; cb = b[0] * sh[2];
-                for (int k = 1; k < nb; k++) {
-                    cr = fma_(b[k], sh[3 * k], cr);
-                    cg = fma_(b[k], sh[3 * k + 1], cg);
-                    cb = fma_(b[k], sh[3 * k + 2], cb);
-                }
-            }
-            cr += 0.5f; cg += 0.5f; cb += 0.5f;
-            clamp_bits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 0x100u : 0u) | (cb < 0.f ? 0x10000u : 0u);
-            cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
-        }
-        a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, pp.w);
-        a.clamped[g] = clamp_bits;
+        prep_colour<FAST_SH16>(a, s_idx[threadIdx.x], s_pos[threadIdx.x]);
     }
 }
 

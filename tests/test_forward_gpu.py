@@ -211,6 +211,16 @@ def test_depth_sort_paths(cuda_device, case):
     assert rep["V"] > 0
 
 
+def test_cull_and_rect_on_stress_inputs(cuda_device):
+    """Cull / radius / rect on stress inputs: most of the cloud off screen with a band of it across every image edge,
+    huge and tiny scales, splats right at the near plane.  Every output of the frame must equal the oracle's."""
+    for seed, near_fraction, dscale in ((40, 0.3, 0.0), (41, 0.0, 2.5), (42, 0.05, -3.0)):
+        raw = scenes.random_scene_camera_frame(40_000, seed=seed, near_fraction=near_fraction)
+        raw.scaling += dscale
+        raw.xyz[:, :2] *= 3.0  # most of the cloud off screen, a band of it across every edge
+        _run(raw, scenes.identity_camera(208, 144, 70.0))
+
+
 @pytest.mark.parametrize("scene", ["random", "tabletop", "thin"])
 def test_compositing_variants_are_bit_identical(cuda_device, scene):
     """The default compositing kernel culls, per 8x8 quadrant, instances that cannot reach alpha >= 1/255 there.
