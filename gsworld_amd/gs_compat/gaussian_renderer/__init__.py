@@ -12,6 +12,25 @@ import torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_GETTERS = ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features", "get_features_dc",
+            "get_features_rest")
+
+
+def _stock_getters(pc) -> bool:
+    """True when ``pc`` renders exactly its stored ``_xyz`` ... through the base GaussianModel's getters."""
+    try:
+        from scene.gaussian_model import GaussianModel as Base
+    except ImportError:  # (package imported as gsworld_amd.gs_compat... rather than through sys.path)
+        from ..scene.gaussian_model import GaussianModel as Base
+    cls = type(pc)
+    if not isinstance(pc, Base):
+        from gsworld_amd.gs_compat.scene.gaussian_model import GaussianModel as Base2
+        if not isinstance(pc, Base2):
+            return False
+        Base = Base2
+    return all(getattr(cls, n, None) is getattr(Base, n) for n in _GETTERS)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, separate_sh=False,
            override_color=None, use_trained_exp=False):
     # gradient carrier for the 2D means (densification statistics read its .grad)
@@ -48,7 +67,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # traffic at 1.47 M Gaussians, as much as the whole frame).  Same image bit for bit (tests/test_dropin_gpu.py).
     raw = tuple(getattr(pc, n, None) for n in ("_xyz", "_opacity", "_scaling", "_rotation", "_features_dc",
                                               "_features_rest"))
-    no_grad = not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in raw)
+    # The shortcut reads the stored tensors, not the getters: it is only taken for a model whose getters are the stock
+    # ones (a subclass that overrides get_xyz / get_features / ... -- deformation, pose or scale optimisation -- may
+    # render something else than its raw attributes, and may be differentiable while they are frozen).
+    no_grad = _stock_getters(pc) and (not torch.is_grad_enabled()
+                                      or not any(t is not None and t.requires_grad for t in raw))
     fast = (no_grad and override_color is None and not getattr(pipe, "convert_SHs_python", False)
             and raw[5] is not None and raw[5].shape[1] > 0 and raw[4].is_contiguous() and raw[5].is_contiguous())
     # opt-in on top of it (pipe.fused_activations): hand over the RAW parameters and let preprocess apply sigmoid /

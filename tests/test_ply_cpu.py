@@ -135,3 +135,31 @@ def test_stock_load_ply_resumes_training(tmp_path):
     assert torch.equal(g._features_rest.detach().cpu(), m._features_rest) and g.active_sh_degree == 3
     (g.get_opacity.sum() + g.get_scaling.sum()).backward()
     assert g._opacity.grad is not None and g._scaling.grad is not None
+
+
+def test_inference_shortcut_only_for_stock_getters():
+    """gaussian_renderer.render hands the STORED tensors to the rasterizer when nothing needs grad; a subclass whose
+    getters compute something else (deformation, pose / scale optimisation) must not take that shortcut."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub in ("gs_compat", "dropin"):
+        path = os.path.join(root, "gsworld_amd", sub)
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import gaussian_renderer as gr
+    from scene.gaussian_model import GaussianModel
+
+    class Deformed(GaussianModel):
+        @property
+        def get_xyz(self):
+            return self._xyz + 1.0
+
+    class Labelled(GaussianModel):  # adds state, keeps the getters (GSWorld's semantic model is of this kind)
+        def get_semantics(self):
+            return None
+
+    assert gr._stock_getters(GaussianModel(3)) and gr._stock_getters(Labelled(3))
+    assert not gr._stock_getters(Deformed(3))
+    assert not gr._stock_getters(types.SimpleNamespace(_xyz=None))
