@@ -33,6 +33,8 @@ namespace {
 constexpr int kBT = GSR_BLOCK;              // 256 threads = 4 waves
 constexpr int kBW = kBT / GSR_WAVE;
 constexpr int kRing = 128;                  // (Gaussian, row) pairs buffered per wave
+constexpr uint32_t kSplit2 = 1024u, kSplit4 = 2048u;  // instances of a (share, row) unit above which 2 / 4 waves place it
+constexpr int kMaxSegments = 4;
 
 // First depth rank of every placement wave.  Equal RANK shares load the waves unevenly -- a wave's work is its
 // instances, and the nearest splats (first in depth order) are the largest on screen: at config 5 the 5000 near-band
@@ -239,8 +241,12 @@ __device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool
     __builtin_amdgcn_wave_barrier();
 }
 
+// 64-rank rows requested together by the placement: 6, not the 12 of the counting pass -- with 60 VGPRs eight waves fit
+// a SIMD and all 7 680+ waves of config 2 are resident at once (12 rows: 82 VGPRs, five waves, two rounds)
+constexpr int kPlaceBatch = 6;
+
 template <int NC>
-__global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict__ rect_sorted,
+__global__ __launch_bounds__(kBT, 8) void band_place_kernel(const uint2 *__restrict__ rect_sorted,
                                                          const uint32_t *__restrict__ order,
                                                          const GsrHeader *__restrict__ hdr,
                                                          const uint32_t *__restrict__ wave_lo, int gx, int NR,
@@ -253,14 +259,54 @@ __global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict
     __shared__ uint32_t s_cur[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
     if (hdr->overflow) return;
-    const uint32_t r = blockIdx.x, y = blockIdx.y;
+    const uint32_t r = blockIdx.x, y = blockIdx.y, seg = blockIdx.z;
     const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
     if (lo >= hi) return;
     uint2 *ring = s_ring[wave];
     uint32_t *cur = s_cur[wave];
     unsigned long long *colmask = s_mask[wave];
-    // cursors: first slot of the tile + rank ranges before mine + earlier waves of this workgroup
     const uint32_t *wbase = wtable + (size_t)(y * (uint32_t)NR + r) * kBW * (NC * 64);
+    // Column segments.  The shares are cut at equal cost over the whole image, but depth correlates with the image row
+    // (a table top recedes upwards), so a share's instances pile up in a few rows: at config 2 a (share, row) unit
+    // holds 514 instances on average and 3 683 at most, and the kernel lasted as long as that one wave.  The counting
+    // pass left every unit's instances per column, so a heavy unit is cut into 2 or 4 column segments of equal
+    // instance count, each placed by its own wave (grid z): the cursors are per column, so a wave that only takes
+    // the pairs overlapping its columns, clipped to them, writes exactly the slots the whole unit's wave would.
+    uint32_t x0 = 0u, x1 = (uint32_t)gx;
+    {
+        uint32_t mine[NC], total = 0u;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const int x = k * 64 + lane;
+            mine[k] = x < gx ? wbase[wave * (NC * 64) + x] : 0u;
+            total += mine[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_xor((int)total, o, 64);
+        // (measured: thresholds of 768 / 1536 the same, 512 / 1024 and 350 / 700 slower -- more waves repeat the filter)
+        const uint32_t nseg = total > kSplit4 ? 4u : (total > kSplit2 ? 2u : 1u);
+        if (seg >= nseg) return;
+        if (nseg > 1u) {
+            // column x belongs to segment floor(instances before x * nseg / total): contiguous, equal-count segments
+            uint32_t before = 0u, first = 0xFFFFFFFFu, last = 0u;
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const uint32_t incl = gsr_wave_incl_scan(mine[k]);
+                const uint32_t excl = before + incl - mine[k];
+                const bool in = k * 64 + lane < gx && (uint32_t)(((uint64_t)excl * nseg) / total) == seg;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(in);
+                if (m != 0ull) {
+                    first = min(first, (uint32_t)(k * 64 + __builtin_ctzll(m)));
+                    last = max(last, (uint32_t)(k * 64 + 64 - __builtin_clzll(m)));
+                }
+                before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            if (first == 0xFFFFFFFFu) return;  // (no column falls into this segment)
+            x0 = first;
+            x1 = last;
+        }
+    }
+    // cursors: first slot of the tile + rank ranges before mine + earlier waves of this workgroup
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         const int x = k * 64 + lane;
@@ -275,25 +321,26 @@ __global__ __launch_bounds__(kBT) void band_place_kernel(const uint2 *__restrict
     __builtin_amdgcn_wave_barrier();
     // the stream: pairs of row y, in depth order, compacted through the ring; a round per 64 pairs
     uint32_t head = 0, tail = 0;  // wave-uniform: pairs consumed / produced
-    for (uint32_t base = lo; base < hi; base += (uint32_t)(kBatch * GSR_WAVE)) {
-        uint2 rc[kBatch];
-        uint32_t g[kBatch];
+    for (uint32_t base = lo; base < hi; base += (uint32_t)(kPlaceBatch * GSR_WAVE)) {
+        uint2 rc[kPlaceBatch];
+        uint32_t g[kPlaceBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
+        for (int u = 0; u < kPlaceBatch; u++) {
             const uint32_t i = base + (uint32_t)(u * GSR_WAVE + lane);
             rc[u] = i < hi ? rect_sorted[i] : make_uint2(0u, 0u);
             g[u] = i < hi ? order[i] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
+        for (int u = 0; u < kPlaceBatch; u++) {
             const uint32_t miny = rc[u].x >> 16, maxy = rc[u].y >> 16;
-            const bool keep = miny <= y && y < maxy;
+            const uint32_t minx = max(rc[u].x & 0xffffu, x0), maxx = min(rc[u].y & 0xffffu, x1);
+            const bool keep = miny <= y && y < maxy && minx < maxx;
             const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
             if (mask == 0ull) continue;
             if (keep) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                ring[(tail + rank) & (kRing - 1)] = make_uint2((rc[u].x & 0xffffu) | (rc[u].y << 16), g[u]);
+                ring[(tail + rank) & (kRing - 1)] = make_uint2(minx | (maxx << 16), g[u]);
             }
             tail += (uint32_t)__popcll(mask);
             __builtin_amdgcn_wave_barrier();
@@ -359,7 +406,7 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
 int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
                           bool debug, hipStream_t stream) {
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    const dim3 grid(GSR_BAND_RANGES, gy);
+    const dim3 grid(GSR_BAND_RANGES, gy, kMaxSegments);
     if (gx <= 64)
         hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
                            GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
