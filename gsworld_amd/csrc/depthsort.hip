@@ -194,16 +194,25 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                 if (i + u * kT < n) s_cnt16[i + u * kT] = (uint16_t)c[u];
         }
     };
+    // (up to CB blocks -- 2.1 M Gaussians -- every count fits the LDS at once: the slice's counts are turned into their
+    // running sums in place and everything below is binary searches; larger models walk their slices chunk by chunk)
+    const bool all_staged = nb1 <= CB;
     uint32_t mine = 0;
     for (int cb = 0; cb < nb1; cb += CB) {
         if (cb > 0) __syncthreads();
         stage(cb);
         __syncthreads();
-        for (int j = max(j0, cb); j < min(j1, cb + CB); j++) mine += s_cnt16[j - cb];
+        for (int j = max(j0, cb); j < min(j1, cb + CB); j++) {
+            mine += s_cnt16[j - cb];
+            if (all_staged) s_cnt16[j] = (uint16_t)mine;  // (a slice holds <= 32 blocks x 256: fits 16 bits)
+        }
     }
     SS_STAMP(dbg, 1);
     uint32_t V;
     const uint32_t p_incl = gsr_block_incl_scan(mine, s_w, V), p_excl = p_incl - mine;
+    uint32_t *s_pex = s_cur;  // [kT + 1] visible Gaussians before every thread's slice (the cursors are not in use yet)
+    s_pex[tid] = p_excl;
+    if (tid == 0) s_pex[kT] = V;
     __shared__ uint32_t s_range[4];  // first block, records before it, end block, (unused)
     if (tid == 0) {
         s_range[0] = 0u;
@@ -226,33 +235,96 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     __syncthreads();
     const int B = ss_num_buckets(V, bmax);
     const uint32_t S = (uint32_t)min(kMaxSamples, kSamplesPerBucket * B);
-    {
-        // Ownership follows a COST: a block costs its visible Gaussians (records to classify and move) + kBlockCost
-        // (its 256 keys have to be fetched and tested whatever they hold) -- equal record shares alone hand a
-        // workgroup in an empty stretch of the model a thousand blocks to sweep.  The cost before block j is
-        // (records before j) + kBlockCost j; the owner of the slice in which it crosses a share boundary walks it.
-        const uint32_t W = V + kBlockCost * (uint32_t)nb1;
-        // (boundaries in binary64: products below 2^53 are exact, and the only requirement is that share b's upper
-        // boundary and share b + 1's lower one are the same number -- they are the same expression)
-        const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
-        const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
+    // Ownership follows a COST: a block costs its visible Gaussians (records to classify and move) + kBlockCost (its 256
+    // keys have to be fetched and tested whatever they hold) -- equal record shares alone hand a workgroup in an empty
+    // stretch of the model a thousand blocks to sweep.  The cost before block j is (records before j) + kBlockCost j;
+    // a workgroup's run starts at the block in which that crosses its share boundary.
+    // (boundaries in binary64: products below 2^53 are exact, and the only requirement is that share b's upper boundary
+    // and share b + 1's lower one are the same number -- they are the same expression)
+    const uint32_t W = V + kBlockCost * (uint32_t)nb1;
+    const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
+    const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
+    const int logS = ss_log2((int)S);  // (S is a power of two)
+    if (all_staged) {
+        // Sample s is the first visible key of the block that holds visible Gaussian floor(s V / S): uniform over the
+        // VISIBLE Gaussians.  Two binary searches per sample -- the thread slice (s_pex), then the block inside it
+        // (the slice's running sums) -- four samples side by side; walking the slices instead was 15 k cycles.
+#pragma unroll 1
+        for (int q0 = 0; q0 < 16; q0 += 4) {
+            if ((uint32_t)(q0 * kT) >= S) break;
+            uint32_t tgt[4], u[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
+                tgt[q] = (uint32_t)(((uint64_t)min(smp, S - 1u) * V) >> logS);
+                u[q] = 0u;
+            }
+#pragma unroll
+            for (int st = kT / 2; st > 0; st >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (s_pex[u[q] + (uint32_t)st] <= tgt[q]) u[q] += (uint32_t)st;  // last slice that starts at or before
+            }
+            uint32_t pos[4], base[4], n[4], lt[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                base[q] = min((uint32_t)nb1, u[q] * (uint32_t)per);
+                n[q] = min((uint32_t)nb1, base[q] + (uint32_t)per) - base[q];
+                lt[q] = tgt[q] - s_pex[u[q]];
+                pos[q] = 0u;
+            }
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {  // first block of the slice whose running sum exceeds lt (per <= 32)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (pos[q] + (uint32_t)st <= n[q] && (uint32_t)s_cnt16[base[q] + pos[q] + (uint32_t)st - 1u] <= lt[q])
+                        pos[q] += (uint32_t)st;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
+                if (smp < S) s_key[smp] = base[q] + min(pos[q], n[q] - 1u);  // the block that lends its key
+            }
+        }
+        // the two ends of my run of blocks: one lane each
+        if ((tid == 0 && me > 0) || (tid == GSR_WAVE && me + 1 < nbc)) {
+            const uint32_t t = tid == 0 ? t_lo : t_hi;
+            uint32_t us = 0u;  // last slice whose cost-before is <= t
+#pragma unroll
+            for (int st = kT / 2; st > 0; st >>= 1)
+                if (s_pex[us + (uint32_t)st] + kBlockCost * min((uint32_t)nb1, (us + (uint32_t)st) * (uint32_t)per) <= t)
+                    us += (uint32_t)st;
+            const uint32_t jb = min((uint32_t)nb1, us * (uint32_t)per), je = min((uint32_t)nb1, jb + (uint32_t)per);
+            uint32_t pos = 0u;  // last block of the slice whose cost-before is <= t (the slice's first one qualifies)
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {
+                const uint32_t k = jb + pos + (uint32_t)st;
+                if (k < je && s_pex[us] + (uint32_t)s_cnt16[k - 1u] + kBlockCost * k <= t) pos += (uint32_t)st;
+            }
+            const uint32_t j = jb + pos, before_j = s_pex[us] + (pos > 0u ? (uint32_t)s_cnt16[j - 1u] : 0u);
+            if (tid == 0) {
+                s_range[0] = j;
+                s_range[1] = before_j;
+            } else {
+                s_range[2] = j;
+            }
+        }
+    } else {
         const uint32_t w_excl = p_excl + kBlockCost * (uint32_t)j0, w_incl = p_incl + kBlockCost * (uint32_t)j1;
         const bool has_lo = me > 0 && w_excl <= t_lo && t_lo < w_incl;
         const bool has_hi = me + 1 < nbc && w_excl <= t_hi && t_hi < w_incl;
         // samples s with  p_excl <= s V / S < p_incl  are mine:  s in [ceil(p_excl S / V), ceil(p_incl S / V))
         // (targets advance by V / S in 32.32 fixed point: one division per thread, none per sample; a target only picks
         // WHICH block of the slice lends its key, so its last bit does not matter)
-        const uint64_t step = ((uint64_t)V << 32) >> ss_log2((int)S);  // (S is a power of two)
+        const uint64_t step = ((uint64_t)V << 32) >> logS;
         const uint32_t s_lo = min(S, (uint32_t)__builtin_ceil((double)p_excl * (double)S / (double)V));
         const uint32_t s_hi = min(S, (uint32_t)__builtin_ceil((double)p_incl * (double)S / (double)V));
         uint64_t acc = step * s_lo;
         uint32_t run = p_excl, smp = s_lo;
         for (int cb = 0; cb < nb1; cb += CB) {
-            if (nb1 > CB) {  // (a single chunk is still staged from the first pass)
-                __syncthreads();
-                stage(cb);
-                __syncthreads();
-            }
+            __syncthreads();
+            stage(cb);
+            __syncthreads();
             if (!(has_lo || has_hi || s_lo < s_hi)) continue;
             for (int j = max(j0, cb); j < min(j1, cb + CB); j++) {
                 const uint32_t c = s_cnt16[j - cb];
@@ -273,6 +345,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
             }
         }
     }
+    SS_STAMP(dbg, 21);
     __syncthreads();
     {  // sample slot -> key (top 24 bits): every gather of the thread in flight at once (S <= 16 kT)
         static_assert(kMaxSamples <= 16 * kT, "one batch of gathers covers the samples");

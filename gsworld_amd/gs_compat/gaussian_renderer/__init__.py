@@ -33,13 +33,15 @@ def _stock_getters(pc) -> bool:
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, separate_sh=False,
            override_color=None, use_trained_exp=False):
-    # gradient carrier for the 2D means (densification statistics read its .grad)
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
-                                          device=pc.get_xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:  # noqa: BLE001
-        pass
+    # gradient carrier for the 2D means (densification statistics read its .grad); the no-grad shortcut below creates it
+    # only when somebody reads it from the result
+    def make_screenspace_points():
+        pts = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
+        try:
+            pts.retain_grad()
+        except Exception:  # noqa: BLE001
+            pass
+        return pts
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
@@ -59,7 +61,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means3D = pc.get_xyz
-    means2D = screenspace_points
 
     # Inference fast path: when no gradient can flow -- GSWorld renders a detached deepcopy of a
     # frozen model -- the two SH parameters are handed to the rasterizer as they are stored instead of being
@@ -82,6 +83,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                 and getattr(pc, "scaling_activation", None) is torch.exp
                 and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
     fused = fast and fused_ok
+    screenspace_points = None if fast else make_screenspace_points()
+    means2D = screenspace_points
     # the same opt-in while TRAINING: raw parameters and the two SH tensors go through the autograd Function as they
     # are stored; activations and their chain rule run inside the preprocess kernels (no sigmoid / exp / normalize /
     # cat passes and none of their backward passes per step)
@@ -118,24 +121,30 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         renderer = _frame_renderer(means3D.device)
         view = _View(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.viewmatrix, rs.projmatrix, rs.campos)
 
+        P = means3D.shape[0]
+        f32 = dict(dtype=torch.float32, device=means3D.device)
+        # the frame is written straight into tensors the caller keeps (no copies out of renderer-owned buffers)
+        outs = (torch.empty((3, rs.image_height, rs.image_width), **f32),
+                torch.empty((1, rs.image_height, rs.image_width), **f32),
+                torch.empty((P,), dtype=torch.int32, device=means3D.device))
+
         def enqueue():
             return renderer.render(
                 view, means3D, opacity, shs=pc._features_dc, shs_rest=pc._features_rest, scales=scales,
                 rotations=rotations, cov3D_precomp=cov3D_precomp, bg=rs.bg, sh_degree=rs.sh_degree,
                 scale_modifier=rs.scale_modifier, antialiasing=rs.antialiasing, debug=rs.debug,
-                param_space=(RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS) if fused else 0)
+                param_space=(RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS) if fused else 0, outputs=outs)
 
         with torch.no_grad():
-            if means3D.shape[0] == 0:  # upstream: no launch, zero image
+            if P == 0:  # upstream: no launch, zero image
                 rendered_image = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
                 radii = torch.zeros((0,), dtype=torch.int32, device=means3D.device)
                 depth_image = torch.zeros((1, rs.image_height, rs.image_width), device=means3D.device)
             else:
-                color, radii, depth_image = enqueue()
+                rendered_image, radii, depth_image = enqueue()
                 renderer.ensure_valid(enqueue)
-                # the renderer owns its outputs and overwrites them on the next call; callers keep frames
-                rendered_image, radii, depth_image = color.clone(), radii.clone(), depth_image.clone()
-        return _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp)
+        return _finish(rendered_image, radii, depth_image, make_screenspace_points, viewpoint_camera, pc,
+                       use_trained_exp, lazy=True)
 
     shs = colors_precomp = None
     if override_color is None:
@@ -181,13 +190,48 @@ def _frame_renderer(device):
     return r
 
 
-def _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp):
+class _LazyResult(dict):
+    """upstream's result dict whose rarely read entries are computed on first access: GSWorld reads ["render"] only, and
+    `(radii > 0).nonzero()` alone is a compaction kernel plus a host synchronisation per frame.  Any access that is not a
+    plain lookup of an eager key (iteration, ``in``, ``get``, ``len``, ...) materialises everything first, so the object
+    is indistinguishable from the eager dict."""
+
+    def __init__(self, eager: dict, lazy: dict):
+        super().__init__(eager)
+        self._lazy = lazy
+
+    def _all(self):
+        for k in list(self._lazy):
+            dict.__setitem__(self, k, self._lazy.pop(k)())
+
+    def __getitem__(self, k):
+        if k in self._lazy:
+            dict.__setitem__(self, k, self._lazy.pop(k)())
+        return dict.__getitem__(self, k)
+
+    def _materialised(name):  # noqa: N805
+        def f(self, *a, **kw):
+            self._all()
+            return getattr(dict, name)(self, *a, **kw)
+        return f
+
+    for _n in ("__contains__", "__iter__", "__len__", "__repr__", "__eq__", "get", "keys", "values", "items", "copy",
+               "pop", "setdefault", "update", "__reduce_ex__"):
+        locals()[_n] = _materialised(_n)
+    del _n, _materialised
+
+
+def _finish(rendered_image, radii, depth_image, screenspace_points, viewpoint_camera, pc, use_trained_exp, lazy=False):
     if use_trained_exp:
         exposure = pc.get_exposure_from_name(viewpoint_camera.image_name)
         rendered_image = torch.matmul(rendered_image.permute(1, 2, 0), exposure[:3, :3]).permute(2, 0, 1) + \
             exposure[:3, 3, None, None]
 
     rendered_image = rendered_image.clamp(0, 1)
+    if lazy:  # (`screenspace_points` is then the function that makes them)
+        return _LazyResult({"render": rendered_image, "radii": radii, "depth": depth_image},
+                           {"viewspace_points": screenspace_points,
+                            "visibility_filter": lambda: (radii > 0).nonzero()})
     return {
         "render": rendered_image,
         "viewspace_points": screenspace_points,

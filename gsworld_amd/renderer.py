@@ -53,7 +53,7 @@ class FrameRenderer:
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
                antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
-               param_space: int = 0, rgb8_out=None, parts=None):
+               param_space: int = 0, rgb8_out=None, parts=None, outputs=None):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
         renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
         ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
@@ -66,7 +66,9 @@ class FrameRenderer:
         ``parts``: ``(labels (P,) float32, lut int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- this frame's
         rigid transform of the labelled Gaussians, applied inside preprocess: ``means3D`` / ``rotations`` / ``scales``
         are then the BASE model and no transformed copy is ever written (:class:`gsworld_amd.transform.FusedPartTransform`
-        builds the tuple; bit-identical to transforming first)."""
+        builds the tuple; bit-identical to transforming first).
+        ``outputs``: optional caller-owned ``(color (3,H,W) f32, invdepth (1,H,W) f32, radii (P,) i32)`` on this device,
+        written instead of the renderer's own buffers (every element is written)."""
         dev = self.device
 
         def norm(t, what, allow_none=True):
@@ -100,7 +102,16 @@ class FrameRenderer:
             raise ValueError("means3D must have dimensions (num_points, 3)")
         P = means3D.shape[0]
         H, W = view.image_height, view.image_width
-        color, invd, radii = self._outputs(P, H, W)
+        if outputs is not None:
+            color, invd, radii = outputs
+            if (color.shape != (3, H, W) or invd.shape != (1, H, W) or radii.shape != (P,) or color.dtype != torch.float32
+                    or invd.dtype != torch.float32 or radii.dtype != torch.int32
+                    or not (color.is_contiguous() and invd.is_contiguous() and radii.is_contiguous())
+                    or color.device != dev or invd.device != dev or radii.device != dev):
+                raise ValueError("outputs must be dense (3,H,W) float32, (1,H,W) float32, (P,) int32 tensors on the "
+                                 "renderer's device")
+        else:
+            color, invd, radii = self._outputs(P, H, W)
         self._P = P
         if bg is None:
             bg = torch.zeros(3, device=dev)

@@ -69,6 +69,9 @@ def test_render_through_gs_compat_matches_oracle(cuda_device, gs_paths):
     assert out_ag["render"].requires_grad
     assert torch.equal(out_ag["render"].detach(), out["render"]) and torch.equal(out_ag["radii"], out["radii"])
     assert torch.equal(out_ag["depth"].detach(), out["depth"])
+    # (the shortcut computes the entries GSWorld never reads on first access: same values as upstream's eager dict)
+    assert torch.equal(out["visibility_filter"], out_ag["visibility_filter"])
+    assert out["viewspace_points"].shape == out_ag["viewspace_points"].shape and out["viewspace_points"].requires_grad
     # the fast path renders through a cached renderer: returned frames must not alias its buffers, and a scene that
     # outgrows the instance capacity remembered from the previous frame must be re-rendered, not truncated
     keep = {k: out[k].clone() for k in ("render", "radii", "depth")}
