@@ -203,7 +203,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             if (band)
                 if (int e = gsr_launch_gather_rects(in->P, g, debug, stream)) return e;
         } else {
-            if (int e = gsr_launch_sample_depth_sort(in->P, g, order_early ? img.quad_work : (const uint32_t *)nullptr,
+            if (int e = gsr_launch_sample_depth_sort(in->P, g, in->viewmatrix,
+                                                     order_early ? img.quad_work : (const uint32_t *)nullptr,
                                                      4 * tiles, img.quad_order, debug, stream))
                 return e;
         }

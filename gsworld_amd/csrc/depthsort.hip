@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                                                         uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ splitters,
                                                         uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
-                                                        uint64_t *__restrict__ dbg) {
+                                                        uint64_t *__restrict__ dbg, const float *__restrict__ view) {
     extern __shared__ uint32_t smem[];
     const unsigned dbg_wg = 64; (void)dbg_wg;
     SS_STAMP(dbg, 0);
@@ -245,13 +245,22 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
     const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
     const int logS = ss_log2((int)S);  // (S is a power of two)
+    // A fixed sensor camera (GSWorld's right_cam and the like): the view matrix is bit for bit the one the splitters in
+    // the state were built under, so they are taken as they are -- no samples, no check.  Splitters only decide the
+    // BALANCE of the buckets, never the order; ss_buckets flags a bucket that came out far above its share (the scene
+    // changed under a static camera) and the next frame samples again.
+    bool same_view = true;
+#pragma unroll
+    for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
+    const bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
+                       hdr->ss_bad == 0u;
     if (all_staged) {
         // Sample s is the first visible key of the block that holds visible Gaussian floor(s V / S): uniform over the
         // VISIBLE Gaussians.  Two binary searches per sample -- the thread slice (s_pex), then the block inside it
         // (the slice's running sums) -- four samples side by side; walking the slices instead was 15 k cycles.
 #pragma unroll 1
         for (int q0 = 0; q0 < 16; q0 += 4) {
-            if ((uint32_t)(q0 * kT) >= S) break;
+            if (blind || (uint32_t)(q0 * kT) >= S) break;
             uint32_t tgt[4], u[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     }
     SS_STAMP(dbg, 21);
     __syncthreads();
-    {  // sample slot -> key (top 24 bits): every gather of the thread in flight at once (S <= 16 kT)
+    if (!blind) {  // sample slot -> key (top 24 bits): every gather of the thread in flight at once (S <= 16 kT)
         static_assert(kMaxSamples <= 16 * kT, "one batch of gathers covers the samples");
         uint32_t k[16];
 #pragma unroll
@@ -376,7 +385,9 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // state holds garbage -- and no bucket may draw more than kReuseMaxSamples of the samples) and skip the sample sort
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
     bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S_eff >= (uint32_t)B;
-    if (reuse) {
+    if (blind) {
+        for (int i = tid; i < B; i += kT) s_split[i] = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
+    } else if (reuse) {
         uint32_t bad = 0;
         for (int i = tid; i < B; i += kT) {
             const uint32_t sp = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
             if (s_hist[i] > kReuseMaxSamples) bad = 1u;
         reuse = __syncthreads_or((int)bad) == 0;
     }
-    if (!reuse) {
+    if (!reuse && !blind) {
         lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 8, s_cur, s_w);
         lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 16, s_cur, s_w);
         lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
                                                           const uint32_t *__restrict__ splitters,
                                                           const uint32_t *__restrict__ seg_off,
                                                           uint32_t *__restrict__ bucket_start,
-                                                          const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
+                                                          GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
                                                           int nbc, const uint32_t *__restrict__ quad_work, int num_quads,
                                                           uint32_t *__restrict__ quad_order) {
     extern __shared__ uint32_t smem[];
@@ -563,6 +574,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint32_t V = hdr->V;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->ss_bad = 0u;  // (read by every compaction workgroup, set again by ss_buckets)
     if (V == 0u) return;
     const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
     const int me = (int)blockIdx.x;
@@ -673,7 +685,8 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
-                                                        GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
+                                                        GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
+                                                        const float *__restrict__ view) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -690,8 +703,11 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         hdr->ss_magic = kSplitMagic;
         hdr->ss_buckets = (uint32_t)B;
     }
+    if (blockIdx.x == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
     const uint32_t s = bucket_start[blockIdx.x];
     const int n = (int)(bucket_start[blockIdx.x + 1] - s);
+    // far above the bucket's share (V / B): whatever splitters the compaction used, the next frame draws new ones
+    if (tid == 0 && (uint32_t)n > 4u * (V / (uint32_t)B) + 64u) hdr->ss_bad = 1u;
     if (n == 0) {
         if (tid == 0) bucket_tiles[blockIdx.x] = 0u;
         return;
@@ -800,13 +816,14 @@ int gsr_ss_bmax(int32_t P) {
 }
 
 // preprocess left vis_key / block_counts / block_cand; the sorted depth order ends in g.order
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const uint32_t *quad_work, int num_quads,
-                                 uint32_t *quad_order, bool debug, hipStream_t stream) {
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
+                                 int num_quads, uint32_t *quad_order, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
-                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg);
+                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg,
+                       viewmatrix);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
@@ -815,6 +832,7 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const uint32_t *
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
-                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg);
+                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
+                       viewmatrix);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

@@ -31,7 +31,9 @@ struct GsrHeader {
     uint32_t tile_queue;  // ticket counter of the compositing kernel's tile queue (zeroed with the header)
     uint32_t ss_magic;    // depth sort: the splitters in the state are the exact quantiles of the last frame ...
     uint32_t ss_buckets;  // ... for this bucket count (both survive from frame to frame; garbage on a fresh state)
-    uint32_t pad[56];
+    uint32_t ss_bad;      // a bucket of the last frame came out far above its share: sample again
+    uint32_t ss_view[16]; // bits of the view matrix the splitters were built under
+    uint32_t pad[39];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -256,8 +258,8 @@ int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const Geom
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 // (quad_work != nullptr: a spare workgroup of the partition pass also sorts the num_quads quadrant costs -> quad_order)
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const uint32_t *quad_work, int num_quads,
-                                 uint32_t *quad_order, bool debug, hipStream_t stream);
+int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
+                                 int num_quads, uint32_t *quad_order, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,

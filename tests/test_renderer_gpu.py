@@ -186,3 +186,33 @@ def test_split_quadrants_leave_the_image_state_bit_identical(cuda_device):
         assert torch.equal(color.view(torch.int32), ref[0].view(torch.int32))
         assert torch.equal(invd.view(torch.int32), ref[1].view(torch.int32))
         assert torch.equal(rgb8, ref[2])
+
+
+def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
+    """Under a bit-identical view matrix the depth sort takes the splitters the state holds without sampling
+    (depthsort.hip).  Splitters only balance the buckets, never decide the order: a scene that changes completely under
+    the static camera -- other Gaussians, other depth range, all depths equal (one bucket larger than the LDS: the
+    global-memory fallback) -- must still come out as a fresh renderer renders it, bit for bit, and the frames after
+    it (the sort samples again once a bucket came out far above its share) as well."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    cam = scenes.identity_camera(320, 240, 60.0).to(dev)
+    n = 120_000
+
+    def scene(seed, squash=None, shift=0.0):
+        raw = scenes.random_scene_camera_frame(n, seed=seed, near_fraction=0.0)
+        raw.scaling -= 1.5
+        if squash is not None:
+            raw.xyz[:, 2] = squash  # identity view: depth = z
+        raw.xyz[:, 2] += shift
+        return [t.to(dev) for t in raw.activated()]
+
+    scenes_ = [scene(50), scene(51, shift=3.0), scene(52, squash=2.5), scene(53), scene(53)]
+    r = FrameRenderer(dev)
+    for k, (means, shs, op, sc, rot) in enumerate(scenes_):
+        got = [t.clone() for t in r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, exact=True)]
+        want = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, exact=True)
+        for a, b, what in zip(got, want, ("color", "radii", "invdepth")):
+            assert torch.equal(a, b), f"frame {k}: {what} differs from a fresh renderer's"
+        assert int(got[1].count_nonzero()) > 10_000
