@@ -41,11 +41,18 @@ constexpr int kMaxSegments = 4;
 // splats cover the whole image and all sat in the first three waves of every row (290 us).  With the running sums the
 // depth sort leaves (tiles per bucket, running sum inside each bucket) the order is cut at equal cumulative INSTANCE
 // counts: wave j starts at the first rank whose inclusive running sum exceeds j R / waves.  One workgroup.
-__global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrHeader *__restrict__ hdr, int bmax,
+// While the camera rests (the depth sort took its splitters unchecked: hdr->ss_blind) the cuts of the last exact
+// computation are kept, rescaled to this frame's V, for up to kCutsMaxAge frames: the searches below are a chain of
+// dependent global round trips on the frame's critical path, and any monotone cut gives the same point list.
+constexpr uint32_t kCutsMagic = 0x43555453u;  // 'CUTS'
+constexpr uint32_t kCutsMaxAge = 15u;
+
+__global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict__ hdr, int bmax,
                                                           const uint32_t *__restrict__ bucket_start,
                                                           const uint32_t *__restrict__ bucket_tiles,
                                                           const uint32_t *__restrict__ tile_cum, int waves,
-                                                          uint32_t *__restrict__ wave_lo) {
+                                                          uint32_t *__restrict__ wave_lo,
+                                                          uint32_t *__restrict__ wave_lo_base) {
     __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
     __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x;
@@ -53,6 +60,13 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrHeader *__res
     if (tile_cum == nullptr || V == 0u) {  // no running sums (LSD radix variant of the depth sort): equal rank shares
         const uint32_t per = (((V + (uint32_t)waves - 1u) / (uint32_t)waves) + 63u) & ~63u;
         for (int j = tid; j <= waves; j += kBT) wave_lo[j] = min(V, (uint32_t)j * per);
+        return;
+    }
+    const uint32_t base_V = hdr->br_V, age = hdr->br_age;
+    if (hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && age < kCutsMaxAge && base_V != 0u) {
+        for (int j = tid; j <= waves; j += kBT)
+            wave_lo[j] = j == waves ? V : (uint32_t)(((uint64_t)wave_lo_base[j] * V) / base_V);
+        if (tid == 0) hdr->br_age = age + 1u;
         return;
     }
     int B = 256;
@@ -87,7 +101,14 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrHeader *__res
             const uint32_t mid = (lo + hi) >> 1;
             if (tile_cum[s0 + mid] <= rest) lo = mid + 1u; else hi = mid;
         }
-        wave_lo[j] = j == waves ? V : s0 + lo;
+        const uint32_t cut = j == waves ? V : s0 + lo;
+        wave_lo[j] = cut;
+        wave_lo_base[j] = cut;
+    }
+    if (tid == 0) {
+        hdr->br_magic = kCutsMagic;
+        hdr->br_V = V;
+        hdr->br_age = 0u;
     }
 }
 
@@ -386,7 +407,7 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const dim3 grid(GSR_BAND_RANGES, gy);
     hipLaunchKernelGGL(band_ranges_kernel, dim3(1), dim3(kBT), 0, stream, g.hdr, gsr_ss_bmax(P), g.ss_bucket_start,
                        g.bucket_tiles, balanced ? g.tile_cum : (const uint32_t *)nullptr, GSR_BAND_RANGES * kBW,
-                       g.wave_lo);
+                       g.wave_lo, g.wave_lo_base);
     if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
         hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
     const bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
                        hdr->ss_bad == 0u;
+    if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
     if (all_staged) {
         // Sample s is the first visible key of the block that holds visible Gaussian floor(s V / S): uniform over the
         // VISIBLE Gaussians.  Two binary searches per sample -- the thread slice (s_pex), then the block inside it

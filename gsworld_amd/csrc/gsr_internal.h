@@ -33,7 +33,11 @@ struct GsrHeader {
     uint32_t ss_buckets;  // ... for this bucket count (both survive from frame to frame; garbage on a fresh state)
     uint32_t ss_bad;      // a bucket of the last frame came out far above its share: sample again
     uint32_t ss_view[16]; // bits of the view matrix the splitters were built under
-    uint32_t pad[39];
+    uint32_t ss_blind;    // this frame's compaction took the splitters unchecked (static camera)
+    uint32_t br_magic;    // band placement: wave_lo_base holds exact equal-cost cuts of a depth order of ...
+    uint32_t br_V;        // ... this many visible Gaussians, computed ...
+    uint32_t br_age;      // ... this many frames ago
+    uint32_t pad[35];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -80,7 +84,8 @@ struct GeomState {
     uint32_t *band_wtable;    // [tile rows * GSR_BAND_RANGES * 4 waves * padded row width]  per-wave column counts
     uint32_t *tile_cum;       // [P]   tiles touched, inclusive running sum in depth order INSIDE each sort bucket
     uint32_t *bucket_tiles;   // [bmax] tiles touched per sort bucket
-    uint32_t *wave_lo;        // [GSR_BAND_RANGES * 4 + 1] first depth rank of every placement wave (equal instance shares)
+    uint32_t *wave_lo;        // [GSR_BAND_RANGES * 4 + 1] first depth rank of every placement wave (equal cost shares)
+    uint32_t *wave_lo_base;   // [GSR_BAND_RANGES * 4 + 1] the last exactly computed cuts (rescaled while the camera rests)
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -136,6 +141,7 @@ struct GeomState {
         g.tile_cum = take<uint32_t>(p, n);
         g.bucket_tiles = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.wave_lo = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
+        g.wave_lo_base = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
