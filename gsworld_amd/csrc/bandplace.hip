@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
                                                           const uint32_t *__restrict__ bucket_tiles,
                                                           const uint32_t *__restrict__ tile_cum, int waves,
                                                           uint32_t *__restrict__ wave_lo,
-                                                          uint32_t *__restrict__ wave_lo_base) {
+                                                          uint32_t *__restrict__ wave_lo_base, int P) {
     __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
     __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x;
@@ -63,7 +63,16 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
         return;
     }
     const uint32_t base_V = hdr->br_V, age = hdr->br_age;
-    if (hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && age < kCutsMaxAge && base_V != 0u) {
+    bool keep = hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && hdr->br_P == (uint32_t)P && age < kCutsMaxAge &&
+                base_V != 0u;
+    if (keep) {
+        // (the kept table is checked before it is used -- ascending from 0 to base_V -- see ss_compact_kernel)
+        uint32_t bad = 0u;
+        for (int j = tid; j < waves; j += kBT) bad |= wave_lo_base[j] > wave_lo_base[j + 1] ? 1u : 0u;
+        if (tid == 0) bad |= (wave_lo_base[0] != 0u || wave_lo_base[waves] != base_V) ? 1u : 0u;
+        keep = __syncthreads_or((int)bad) == 0;
+    }
+    if (keep) {
         for (int j = tid; j <= waves; j += kBT)
             wave_lo[j] = j == waves ? V : (uint32_t)(((uint64_t)wave_lo_base[j] * V) / base_V);
         if (tid == 0) hdr->br_age = age + 1u;
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
     }
     if (tid == 0) {
         hdr->br_magic = kCutsMagic;
+        hdr->br_P = (uint32_t)P;
         hdr->br_V = V;
         hdr->br_age = 0u;
     }
@@ -407,7 +417,7 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const dim3 grid(GSR_BAND_RANGES, gy);
     hipLaunchKernelGGL(band_ranges_kernel, dim3(1), dim3(kBT), 0, stream, g.hdr, gsr_ss_bmax(P), g.ss_bucket_start,
                        g.bucket_tiles, balanced ? g.tile_cum : (const uint32_t *)nullptr, GSR_BAND_RANGES * kBW,
-                       g.wave_lo, g.wave_lo_base);
+                       g.wave_lo, g.wave_lo_base, P);
     if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
         hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,

@@ -252,8 +252,19 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     bool same_view = true;
 #pragma unroll
     for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
-    const bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
-                       hdr->ss_bad == 0u;
+    bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
+                 hdr->ss_bad == 0u && hdr->ss_P == (uint32_t)P;
+    if (blind) {
+        // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
+        // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
+        uint32_t bad = 0u;
+        for (int i = tid; i < B; i += kT) {
+            const uint32_t sp = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
+            s_split[i] = sp;
+            if (i + 1 < B - 1 && splitters[i + 1] < sp) bad = 1u;
+        }
+        blind = __syncthreads_or((int)bad) == 0;
+    }
     if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
     if (all_staged) {
         // Sample s is the first visible key of the block that holds visible Gaussian floor(s V / S): uniform over the
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
     bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S_eff >= (uint32_t)B;
     if (blind) {
-        for (int i = tid; i < B; i += kT) s_split[i] = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
+        // (s_split was filled when the table was checked)
     } else if (reuse) {
         uint32_t bad = 0;
         for (int i = tid; i < B; i += kT) {
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
-                                                        const float *__restrict__ view) {
+                                                        const float *__restrict__ view, int P) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -703,6 +714,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     if (blockIdx.x == 0 && tid == 0) {
         hdr->ss_magic = kSplitMagic;
         hdr->ss_buckets = (uint32_t)B;
+        hdr->ss_P = (uint32_t)P;
     }
     if (blockIdx.x == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
     const uint32_t s = bucket_start[blockIdx.x];
@@ -834,6 +846,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
                        g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
-                       viewmatrix);
+                       viewmatrix, P);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

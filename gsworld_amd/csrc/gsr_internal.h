@@ -37,7 +37,9 @@ struct GsrHeader {
     uint32_t br_magic;    // band placement: wave_lo_base holds exact equal-cost cuts of a depth order of ...
     uint32_t br_V;        // ... this many visible Gaussians, computed ...
     uint32_t br_age;      // ... this many frames ago
-    uint32_t pad[35];
+    uint32_t ss_P;        // model size the splitters / cuts belong to (the arrays move with P; a recycled buffer may
+    uint32_t br_P;        //   carry an old header over new garbage: both users also check what they read)
+    uint32_t pad[33];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 

@@ -216,3 +216,13 @@ def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
         for a, b, what in zip(got, want, ("color", "radii", "invdepth")):
             assert torch.equal(a, b), f"frame {k}: {what} differs from a fresh renderer's"
         assert int(got[1].count_nonzero()) > 10_000
+    # a model of another size on the same state: the header survives in the buffer, every array behind it moves
+    for n2 in (70_000, 150_000, 70_000):
+        raw = scenes.random_scene_camera_frame(n2, seed=60 + n2 % 7, near_fraction=0.0)
+        raw.scaling -= 1.5
+        means, shs, op, sc, rot = [t.to(dev) for t in raw.activated()]
+        for _ in range(2):
+            got = [t.clone() for t in r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, exact=True)]
+        want = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, exact=True)
+        for a, b, what in zip(got, want, ("color", "radii", "invdepth")):
+            assert torch.equal(a, b), f"model of {n2}: {what} differs from a fresh renderer's"
