@@ -245,7 +245,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ split_flag,
                                                                 uint32_t *__restrict__ split_list,
                                                                 uint32_t *__restrict__ split_count, int split_cap,
-                                                                uint32_t *__restrict__ quad_order) {
+                                                                uint32_t *__restrict__ quad_order, int cus_per_xcd) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
     const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 8 * GSR_BLOCK;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     if (blockIdx.x == 1) {
         if (!keyed) return;
         if (quad_order != nullptr) {
-            gsr_quad_order_block(quad_work, 4 * T, quad_order, s_w);
+            gsr_quad_order_block(quad_work, 4 * T, quad_order, s_w, cus_per_xcd);
             return;  // (the tile-level order below is what the compositor uses when it has no quadrant order)
         }
         uint32_t key[8];
@@ -575,7 +575,8 @@ int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const Imag
                        (uint32_t *)nullptr,
                        (const uint32_t *)img.quad_work, (const uint32_t *)img.quad_work_b, img.split_flag,
                        img.split_list, img.split_count, split_blocks * (GSR_BLOCK / GSR_WAVE),
-                       !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr);
+                       !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr,
+                       gsr_render_cus_per_xcd());
     return gsr_check_launch("tile_starts", debug, stream);
 }
 

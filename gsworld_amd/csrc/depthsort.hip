@@ -572,11 +572,11 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
                                                           uint32_t *__restrict__ bucket_start,
                                                           GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
                                                           int nbc, const uint32_t *__restrict__ quad_work, int num_quads,
-                                                          uint32_t *__restrict__ quad_order) {
+                                                          uint32_t *__restrict__ quad_order, int cus_per_xcd) {
     extern __shared__ uint32_t smem[];
     __shared__ uint32_t s_w[4];
     if ((int)blockIdx.x == nbc) {  // the spare workgroup: the compositor's quadrant order (see gsr_quad_order_block)
-        gsr_quad_order_block(quad_work, num_quads, quad_order, s_w);
+        gsr_quad_order_block(quad_work, num_quads, quad_order, s_w, cus_per_xcd);
         return;
     }
     uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
@@ -841,7 +841,7 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
                        g.pair[1], g.ss_table, g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work,
-                       num_quads, quad_order);
+                       num_quads, quad_order, gsr_render_cus_per_xcd());
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,

@@ -265,7 +265,7 @@ int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const Image
 int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-// (quad_work != nullptr: a spare workgroup of the partition pass also sorts the num_quads quadrant costs -> quad_order)
+// (quad_work != nullptr: a spare workgroup of the partition pass also deals the num_quads quadrants -> quad_order)
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
                                  int num_quads, uint32_t *quad_order, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
@@ -282,6 +282,7 @@ int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomSt
 bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles);
 int gsr_render_split_blocks(const GsrSettings &st, int num_tiles);
 bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
+int gsr_render_cus_per_xcd();  // CUs of one XCD (the quadrant deal of gsr_quad_order_block)
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
                       uint8_t *out_rgb8, bool order_ready, bool split_ready, hipStream_t stream);
@@ -328,13 +329,27 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t *s_
     return incl + add;
 }
 
-// One workgroup (256 threads): the image's Q <= 32 x 256 quadrants by descending cost of the previous frame (256-bucket
-// counting sort, costs held in registers); the compositor gives every workgroup four quadrants of nearly equal cost
-// (render.hip).  Depends on nothing of the current frame, so it runs wherever a spare workgroup costs nothing.
-// Any permutation gives the same image: a fresh state (garbage costs) only balances badly.
+// One workgroup (256 threads): which compositing workgroup takes which of the image's Q <= 32 x 256 quadrants.
+// quad_order[4 b + j], j = 0..3, are the quadrants of workgroup b (render.hip: one quadrant per wave, the four waves of
+// a workgroup on the four SIMDs of one CU).  Three things are balanced at once, from the quadrants' costs in the
+// previous frame on this state:
+//   * a tile's four quadrants read the same instance list, so they stay on ONE XCD (one L2): tile t belongs to XCD
+//     t mod 8, and workgroup b runs on XCD b mod 8 (round-robin dispatch) -- dealing the quadrants over the whole chip
+//     made every L2 fetch the lists for itself (HBM-side traffic 79 -> 153 MB per frame);
+//   * inside an XCD the quadrants are sorted by cost (256-bucket counting sort) and a workgroup takes four consecutive
+//     ones, i.e. four of (nearly) equal cost: the SIMDs of a CU carry the same load;
+//   * workgroups k, k + cus, k + 2 cus ... of an XCD share a CU (observed placement), so the sorted groups of four go
+//     to the CUs in a snake: every CU gets one group of each cost class, the costliest of one with the cheapest of the
+//     next.
+// Depends on nothing of the current frame, so it runs wherever a spare workgroup costs nothing.  Any permutation gives
+// the same image: a fresh state (garbage costs) only balances badly.
+#define GSR_XCDS 8
 __device__ __forceinline__ void gsr_quad_order_block(const uint32_t *__restrict__ quad_work, int Q,
-                                                     uint32_t *__restrict__ quad_order, uint32_t *s_w /*[4]*/) {
-    __shared__ uint32_t s_qb[256];
+                                                     uint32_t *__restrict__ quad_order, uint32_t *s_w /*[4]*/,
+                                                     int cus_per_xcd) {
+    __shared__ uint32_t s_qb[GSR_XCDS * 256];
+    __shared__ uint32_t s_xbase[GSR_XCDS];
+    const int T = Q >> 2;
     uint32_t c[32], qmx = 0;
 #pragma unroll
     for (int k = 0; k < 32; k++) {
@@ -345,7 +360,8 @@ __device__ __forceinline__ void gsr_quad_order_block(const uint32_t *__restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
     if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = qmx;
-    s_qb[threadIdx.x] = 0u;
+#pragma unroll
+    for (int k = 0; k < GSR_XCDS; k++) s_qb[k * GSR_BLOCK + (int)threadIdx.x] = 0u;
     __syncthreads();
     qmx = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
     // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
@@ -355,21 +371,42 @@ __device__ __forceinline__ void gsr_quad_order_block(const uint32_t *__restrict_
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         const int q = (int)threadIdx.x + k * GSR_BLOCK;
-        c[k] = 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));
+        const uint32_t xcd = (uint32_t)(q >> 2) % GSR_XCDS;
+        c[k] = xcd * 256u + 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));  // bin = (XCD, cost class)
         if (q < Q) atomicAdd(&s_qb[c[k]], 1u);
     }
     __syncthreads();
-    {
-        const uint32_t n = s_qb[threadIdx.x];
+    {  // exclusive running sum over the 2048 bins: thread t owns bins 8 t .. 8 t + 7 (XCD t / 32)
+        uint32_t v[GSR_XCDS], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < GSR_XCDS; k++) {
+            v[k] = s_qb[GSR_XCDS * (int)threadIdx.x + k];
+            sum += v[k];
+        }
         uint32_t tot;
-        const uint32_t incl = gsr_block_incl_scan(n, s_w, tot);
-        s_qb[threadIdx.x] = incl - n;
+        uint32_t run = gsr_block_incl_scan(sum, s_w, tot) - sum;
+        if ((threadIdx.x & 31u) == 0u) s_xbase[threadIdx.x >> 5] = run;  // first slot of the XCD's list
+#pragma unroll
+        for (int k = 0; k < GSR_XCDS; k++) {
+            s_qb[GSR_XCDS * (int)threadIdx.x + k] = run;
+            run += v[k];
+        }
     }
     __syncthreads();
+    const uint32_t cus = (uint32_t)max(cus_per_xcd, 1);
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         const int q = (int)threadIdx.x + k * GSR_BLOCK;
-        if (q < Q) quad_order[atomicAdd(&s_qb[c[k]], 1u)] = (uint32_t)q;
+        if (q < Q) {
+            const uint32_t xcd = c[k] >> 8;
+            const uint32_t p = atomicAdd(&s_qb[c[k]], 1u) - s_xbase[xcd];        // position in the XCD's sorted list
+            const uint32_t nwg = ((uint32_t)T - 1u - xcd) / GSR_XCDS + 1u;         // workgroups (= tiles) of this XCD
+            const uint32_t slot = p >> 2, round = slot / cus, idx = slot - round * cus;
+            const uint32_t size = min(cus, nwg - round * cus);
+            const uint32_t cu = (round & 1u) ? size - 1u - idx : idx;
+            const uint32_t b = GSR_XCDS * (round * cus + cu) + xcd;
+            quad_order[4u * b + (p & 3u)] = (uint32_t)q;
+        }
     }
     __syncthreads();
 }

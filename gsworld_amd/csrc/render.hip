@@ -475,7 +475,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
          pass++, ticket = extra ? num_tickets
                                 : pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
         uint32_t unit = ticket >> 2;
-        if (!extra && tile_order != nullptr && main_blocks >= num_tiles) {
+        if (!extra && tile_order != nullptr && quad_order == nullptr && main_blocks >= num_tiles) {
             // Every tile resident at once: workgroups b, b + #CUs, b + 2 #CUs ... share a CU (observed placement on
             // MI355X: s_getreg HW_ID of every workgroup), so position p of the cost-sorted order goes to workgroup
             // p in even groups of #CUs and to the mirrored workgroup in odd ones: every CU gets one tile of each cost
@@ -487,11 +487,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         int tile = extra ? (int)(extra_q >> 2) : (tile_order ? (int)tile_order[unit] : (int)unit);
         int quad = extra ? (int)(extra_q & 3u) : (int)(ticket & 3u);
         if (!extra && quad_order != nullptr && main_blocks >= num_tiles) {
-            // Everything resident, quadrants sorted by their cost in the previous frame: workgroup position `unit` takes
-            // the four quadrants 4 unit .. 4 unit + 3 of that order, i.e. four of (nearly) EQUAL cost, whatever tiles they
-            // belong to.  The four waves of a workgroup go to the four SIMDs of its CU, so every SIMD of the CU then
-            // carries the same load; dealing tiles (four quadrants of unequal cost) left the SIMD loads a sum of
-            // five random quadrant costs each -- +-11 %, and the most loaded of 1024 SIMDs sets the kernel time.
+            // Everything resident: workgroup `unit` (= blockIdx.x) takes the four quadrants the deal of
+            // gsr_quad_order_block assigned to it -- four of (nearly) equal cost in the previous frame, from tiles of
+            // this workgroup's XCD.  The four waves of a workgroup go to the four SIMDs of its CU, so every SIMD of the CU
+            // carries the same load; dealing tiles (four quadrants of unequal cost) left the SIMD loads a sum of five
+            // random quadrant costs each -- +-11 %, and the most loaded of 1024 SIMDs sets the kernel time.
             const uint32_t q = quad_order[4u * unit + (ticket & 3u)];
             tile = (int)(q >> 2);
             quad = (int)(q & 3u);
@@ -681,6 +681,8 @@ static int render_num_cus() {
     }
     return num_cus;
 }
+
+int gsr_render_cus_per_xcd() { return render_num_cus() / GSR_XCDS > 0 ? render_num_cus() / GSR_XCDS : 1; }
 
 // The longest-first tile order only matters when workgroups take more than one tile: with every tile resident at
 // once (1200 tiles on 256 CUs x 6) the deal is the identity and the binning stage need not build the order.
