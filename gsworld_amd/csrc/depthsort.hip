@@ -4,7 +4,8 @@
 // What is sorted: V (depth bits, Gaussian index) records, ascending depth bits, ties by ascending index -- the order the
 // reference's stable key sort leaves inside every tile.  At config 2 V = 175 k: 1.4 MB, a problem of LATENCY, not
 // bandwidth.  The 3-pass LSD radix sort of round 1 (sort.hip: compaction + 3 x (histogram, row scan, scatter) = 10
-// launches of ~86 workgroups each) spent 95 us on it, 1 % of the HBM roofline.  Here a sample sort:
+// launches of ~86 workgroups each) spent 95 us on it, 1 % of the HBM roofline.  Here a sample sort (48 us; 25 + 16
+// + 12 when it samples, 19 + 17 + 12 while the camera rests):
 //
 //   ss_compact   index-ordered compaction of the visible (key, index) records (per-workgroup offsets by redundant
 //                sums of the per-block counts preprocess left), AND, in the same pass: every workgroup sorts the same
@@ -21,7 +22,9 @@
 // index-coherent model.  Splitters carry the top 24 key bits only, so records with equal depth never straddle a bucket
 // boundary by accident of the sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a
 // bucket averages <= 512 records.  ss_buckets leaves the exact quantiles of the frame in the state; the next frame on
-// that state only validates them against its samples and skips the sample sort (any splitters give the same order).
+// that state only validates them against its samples and skips the sample sort (any splitters give the same order);
+// under a bit-identical view matrix (a fixed sensor camera) it takes them without drawing samples at all, and a
+// bucket that comes out far above its share makes the following frame sample again.
 // Compaction workgroups share the blocks by COST (records + kBlockCost per block), not by count: see ss_compact_kernel.
 // A bucket that does not fit the LDS (bad luck or adversarial depths: > 3584 records) is sorted by the same workgroup
 // in global memory with a bitonic network over the (key << 32 | index) composites -- slow, correct, never seen on
@@ -387,16 +390,13 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     const uint32_t before = s_range[1];
     if (me == nbc - 1 && tid == 0) seg_off[nbc] = V;
     if (tid == 0) seg_off[me] = before;
-    const uint32_t present = 0u;
-    (void)present;
-    const uint32_t S_eff = S;  // (every sample slot is filled: V > 0)
     SS_STAMP(dbg, 2);
     __syncthreads();
     // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
     // previous frame usually still cut THIS frame's samples evenly.  Check that (the table must be ascending -- a fresh
     // state holds garbage -- and no bucket may draw more than kReuseMaxSamples of the samples) and skip the sample sort
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
-    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S_eff >= (uint32_t)B;
+    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B;
     if (blind) {
         // (s_split was filled when the table was checked)
     } else if (reuse) {
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
         const uint32_t *sorted = s_key + kMaxSamples;
         for (int i = tid; i < B; i += kT) {
-            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S_eff) / (uint32_t)B);
-            const uint32_t sp = (i < B - 1 && q < S_eff) ? sorted[q] : 0xFFFFFFFFu;
+            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
+            const uint32_t sp = (i < B - 1 && q < S) ? sorted[q] : 0xFFFFFFFFu;
             s_split[i] = sp;
             if (blockIdx.x == 0) splitters[i] = sp;
         }
