@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #pragma unroll
     for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
     bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
-                 hdr->ss_bad == 0u && hdr->ss_P == (uint32_t)P;
+                 (hdr->ss_bad == 0u || (hdr->ss_wait != 0u && hdr->ss_wait <= 64u)) && hdr->ss_P == (uint32_t)P;
     if (blind) {
         // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
         // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
@@ -396,6 +396,8 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // previous frame usually still cut THIS frame's samples evenly.  Check that (the table must be ascending -- a fresh
     // state holds garbage -- and no bucket may draw more than kReuseMaxSamples of the samples) and skip the sample sort
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
+    // (the largest of B Poisson(2) sample counts grows with B: 8 passes for 512 buckets 9 times out of 10, 12 for 2048)
+    const uint32_t reuse_max = kReuseMaxSamples + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
     bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B;
     if (blind) {
         // (s_split was filled when the table was checked)
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         }
         __syncthreads();
         for (int i = tid; i < B; i += kT)
-            if (s_hist[i] > kReuseMaxSamples) bad = 1u;
+            if (s_hist[i] > reuse_max) bad = 1u;
         reuse = __syncthreads_or((int)bad) == 0;
     }
     if (!reuse && !blind) {
@@ -586,7 +588,24 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint32_t V = hdr->V;
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->ss_bad = 0u;  // (read by every compaction workgroup, set again by ss_buckets)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // The imbalance flag of the last frame was read by every compaction workgroup; ss_buckets sets it again.  New
+        // samples do not always help -- depth ties (a flat table seen from straight above) cannot be split by ANY
+        // splitters, and the exact quantiles the state holds are already the best table there is -- so a sampling
+        // frame that still ends unbalanced doubles the number of frames the flag is ignored afterwards (1 .. 64).
+        const uint32_t was_bad = hdr->ss_bad, wait = hdr->ss_wait, backoff = hdr->ss_backoff;
+        if (was_bad == 0u) {
+            hdr->ss_wait = 0u;
+            hdr->ss_backoff = 1u;
+        } else if (hdr->ss_blind != 0u) {
+            hdr->ss_wait = (wait != 0u && wait <= 64u) ? wait - 1u : 0u;
+        } else {
+            const uint32_t b = (backoff == 0u || backoff > 64u) ? 1u : backoff;
+            hdr->ss_wait = b;
+            hdr->ss_backoff = b >= 64u ? 64u : 2u * b;
+        }
+        hdr->ss_bad = 0u;
+    }
     if (V == 0u) return;
     const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
     const int me = (int)blockIdx.x;

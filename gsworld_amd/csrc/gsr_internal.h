@@ -39,7 +39,9 @@ struct GsrHeader {
     uint32_t br_age;      // ... this many frames ago
     uint32_t ss_P;        // model size the splitters / cuts belong to (the arrays move with P; a recycled buffer may
     uint32_t br_P;        //   carry an old header over new garbage: both users also check what they read)
-    uint32_t pad[33];
+    uint32_t ss_wait;     // frames left in which a flagged imbalance does NOT trigger new samples ...
+    uint32_t ss_backoff;  // ... and the wait after the next sampling that still ends unbalanced (1, 2, 4 .. 64)
+    uint32_t pad[31];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
