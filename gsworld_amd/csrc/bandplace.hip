@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
         return;
     }
     int B = 256;
-    while (B < bmax && (uint32_t)B * 512u < V) B <<= 1;  // (ss_num_buckets of depthsort.hip)
+    while (B < bmax && (uint32_t)B * (uint32_t)GSR_SS_PER_BUCKET < V) B <<= 1;  // (ss_num_buckets of depthsort.hip)
     const int PER = B / kBT;
     uint32_t t[8], sum = 0;
 #pragma unroll

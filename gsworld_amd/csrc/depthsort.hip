@@ -41,9 +41,9 @@ namespace {
 
 constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
 constexpr int kSamplesPerBucket = 2;
+constexpr int kMinSamples = 2048;
 constexpr int kMaxSamples = 4096;
 constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'
-constexpr uint32_t kReuseMaxSamples = 4 * kSamplesPerBucket;  // sample count per bucket that still passes for balanced
 // placement cost of one Gaussian = its instances + this many (every tile row streams and tests every rank of its share)
 constexpr uint32_t kRankCost = 40u;
 // compaction cost of one preprocess block (256 keys fetched and tested), in records
@@ -52,7 +52,7 @@ constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
     int B = 256;
-    while (B < bmax && (uint32_t)B * 512u < V) B <<= 1;
+    while (B < bmax && (uint32_t)B * (uint32_t)GSR_SS_PER_BUCKET < V) B <<= 1;
     return B;
 }
 __device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     }
     __syncthreads();
     const int B = ss_num_buckets(V, bmax);
-    const uint32_t S = (uint32_t)min(kMaxSamples, kSamplesPerBucket * B);
+    // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
+    // in a few hundred frames outgrows the LDS)
+    const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
     // Ownership follows a COST: a block costs its visible Gaussians (records to classify and move) + kBlockCost (its 256
     // keys have to be fetched and tested whatever they hold) -- equal record shares alone hand a workgroup in an empty
     // stretch of the model a thousand blocks to sweep.  The cost before block j is (records before j) + kBlockCost j;
@@ -394,10 +396,10 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     __syncthreads();
     // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
     // previous frame usually still cut THIS frame's samples evenly.  Check that (the table must be ascending -- a fresh
-    // state holds garbage -- and no bucket may draw more than kReuseMaxSamples of the samples) and skip the sample sort
+    // state holds garbage -- and no bucket may draw more than four times its share of the samples) and skip the sample sort
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
     // (the largest of B Poisson(2) sample counts grows with B: 8 passes for 512 buckets 9 times out of 10, 12 for 2048)
-    const uint32_t reuse_max = kReuseMaxSamples + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
+    const uint32_t reuse_max = 4u * (S / (uint32_t)B) + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
     bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B;
     if (blind) {
         // (s_split was filled when the table was checked)
