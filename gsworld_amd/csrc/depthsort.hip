@@ -181,6 +181,17 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
     const int per = (nb1 + kT - 1) / kT;
     const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
+    // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself
+    // (up to 8 entries per thread): by the time the counts are summed it has all arrived, instead of costing three
+    // dependent round trips (header, view, table) in the middle of the kernel.
+    const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_wait = hdr->ss_wait,
+                   h_P = hdr->ss_P;
+    bool same_view = true;
+#pragma unroll
+    for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
+    uint32_t pre_sp[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) pre_sp[k] = tid + k * kT < bmax - 1 ? splitters[tid + k * kT] : 0xFFFFFFFFu;
     // the counts are staged in LDS (16 bits each, in the half of the sample buffer the sort only needs later) with
     // coalesced loads: a thread reading its own contiguous slice straight from global memory touches a cache line per
     // lane and load (that alone was 25 k cycles per workgroup)
@@ -254,20 +265,19 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // the state were built under, so they are taken as they are -- no samples, no check.  Splitters only decide the
     // BALANCE of the buckets, never the order; ss_buckets flags a bucket that came out far above its share (the scene
     // changed under a static camera) and the next frame samples again.
-    bool same_view = true;
-#pragma unroll
-    for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
-    bool blind = all_staged && same_view && hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B &&
-                 (hdr->ss_bad == 0u || (hdr->ss_wait != 0u && hdr->ss_wait <= 64u)) && hdr->ss_P == (uint32_t)P;
+    bool blind = all_staged && same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
+                 (h_bad == 0u || (h_wait != 0u && h_wait <= 64u)) && h_P == (uint32_t)P;
     if (blind) {
         // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
         // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
-        uint32_t bad = 0u;
-        for (int i = tid; i < B; i += kT) {
-            const uint32_t sp = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
-            s_split[i] = sp;
-            if (i + 1 < B - 1 && splitters[i + 1] < sp) bad = 1u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = tid + k * kT;
+            if (i < B) s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
         }
+        __syncthreads();
+        uint32_t bad = 0u;
+        for (int i = tid; i + 1 < B - 1; i += kT) bad |= s_split[i + 1] < s_split[i] ? 1u : 0u;
         blind = __syncthreads_or((int)bad) == 0;
     }
     if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
