@@ -401,13 +401,29 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     ep_len = 200
     poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=ep_len + 1, seed=0))
     pinned = [(M.pin_memory(), s.pin_memory()) for M, s in poses]
+
+    # the wrist camera rides on the arm: the wrapper recomputes its cameras on every render (gs_world_wrapper.py:238),
+    # so the surrogate moves it too (10 cm sweep over the episode) -- its frames then take the sampling path of the depth
+    # sort every step, the fixed right_cam keeps its splitters
+    def wrist_at(k):
+        import math as _m
+
+        a = 2.0 * _m.pi * k / ep_len
+        v = look_at_view([0.55 - 0.10 * _m.sin(a), 0.35, 0.25 + 0.05 * _m.sin(2.0 * a)], [0.35, 0.05, 0.05], [0, 0, 1],
+                         0.9715089, 0.7551448, W, H)
+        v.world_view_transform = v.world_view_transform.pin_memory()
+        v.full_proj_transform = v.full_proj_transform.pin_memory()
+        v.camera_center = v.camera_center.pin_memory()
+        return v
+
+    wrists = [wrist_at(k) for k in range(ep_len + 1)]
     loop.reset(*pinned[0])
     loop.capture()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loop.step(*pinned[0])  # the episode's reset() frame pair
-    for M, s in pinned[1:]:
-        loop.step(M, s)
+    loop.step(*pinned[0], cameras={"wrist_cam": wrists[0]})  # the episode's reset() frame pair
+    for (M, s), w in zip(pinned[1:], wrists[1:]):
+        loop.step(M, s, cameras={"wrist_cam": w})
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     overflow = any(x.overflow for x in loop.ensure_valid())
@@ -416,7 +432,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         "workload": f"BASELINE.json configs[2] surrogate: 1 reset + {ep_len} steps x {len(cams)} cameras {W}x{H}, "
                     f"{raw.num} Gaussians, {len(parts)} moving parts (seeded random walk instead of PhysX), per step: "
-                    "pose upload + device-side pose table + fused transform + both frames, one hipGraph replay"}
+                    "pose + wrist-camera upload (the wrist camera moves every step), device-side pose table, rigid transform inside "
+                    "preprocess, both frames, one hipGraph replay"}
     return out
 
 

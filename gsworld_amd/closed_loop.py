@@ -44,7 +44,7 @@ class ClosedLoopRenderer:
         dev = self.device
         self.num_envs = int(num_envs)
         self.names = list(cameras.keys())
-        self.cameras = [cameras[n].to(dev) for n in self.names]
+        self.cameras = [self._own(cameras[n], dev) for n in self.names]
         g = lambda a, b: getattr(raw, a) if hasattr(raw, a) else getattr(raw, b)  # noqa: E731
         self.xyz = g("xyz", "_xyz").detach().to(dev, torch.float32).contiguous()
         self.rotation = g("rotation", "_rotation").detach().to(dev, torch.float32).contiguous()
@@ -69,6 +69,15 @@ class ClosedLoopRenderer:
         self.scales = torch.ones(lead, device=dev)
         self._graph = None
         self.image_size = (H, W)
+
+    @staticmethod
+    def _own(cam, dev):
+        """A private, dense device copy of a camera (set_cameras writes into it in place)."""
+        from .camera import ViewParams
+
+        c = lambda t: t.detach().to(dev, torch.float32).clone().contiguous()  # noqa: E731
+        return ViewParams(cam.image_width, cam.image_height, cam.FoVx, cam.FoVy, c(cam.world_view_transform),
+                          c(cam.full_proj_transform), c(cam.camera_center))
 
     # ---- one step ------------------------------------------------------------------------------------------------
     def _gpu_step(self):
@@ -118,10 +127,30 @@ class ClosedLoopRenderer:
         if scales is not None:
             self.scales.copy_(scales.to(torch.float32).reshape(self.scales.shape), non_blocking=True)
 
-    def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None) -> dict:
+    def set_cameras(self, cameras: dict):
+        """This step's camera poses: ``{name: ViewParams}`` for any subset of the cameras given at construction -- the
+        wrapper recomputes them from the simulator's sensor parameters on every render
+        (gs_world_wrapper.py:238 ``self.gs_cam = self.cam_maniskill2gs(self.base_env.get_sensor_params(), ...)``), which
+        is how a wrist-mounted camera follows the arm.  The matrices are copied INTO the device tensors the (possibly
+        captured) step reads; image size and field of view are part of the launch and must not change."""
+        for name, cam in cameras.items():
+            if name not in self.names:
+                raise KeyError(f"unknown camera {name!r} (known: {self.names})")
+            mine = self.cameras[self.names.index(name)]
+            if (cam.image_width, cam.image_height) != (mine.image_width, mine.image_height) or \
+                    abs(cam.FoVx - mine.FoVx) > 1e-9 or abs(cam.FoVy - mine.FoVy) > 1e-9:
+                raise ValueError(f"camera {name!r}: image size / field of view are fixed at construction")
+            mine.world_view_transform.copy_(cam.world_view_transform.to(torch.float32), non_blocking=True)
+            mine.full_proj_transform.copy_(cam.full_proj_transform.to(torch.float32), non_blocking=True)
+            mine.camera_center.copy_(cam.camera_center.to(torch.float32), non_blocking=True)
+
+    def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None,
+             cameras: dict | None = None) -> dict:
         """-> {camera name: uint8 (num_envs, H, W, 3)} -- renderer-owned tensors, overwritten by the next step."""
         if matrices is not None:
             self.set_poses(matrices, scales)
+        if cameras:
+            self.set_cameras(cameras)
         if self._graph is not None:
             self._graph.replay()
         else:

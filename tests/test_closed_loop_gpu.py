@@ -142,3 +142,33 @@ def test_full_size_rollout_200_steps(cuda_device):
     assert len(set(sums)) == len(sums), "frames stopped changing"
     M, s = poses[-1]
     _compare(last, ref.render_step(model, parts, cams, M, s, _rasterize, actors), "step 200")
+
+
+def test_moving_wrist_camera_follows_through_eager_steps_and_graph_replay(cuda_device):
+    """The wrapper recomputes its cameras on every render (gs_world_wrapper.py:238), so a wrist camera moves with the
+    arm.  ClosedLoopRenderer.set_cameras copies the new matrices into the tensors the step reads -- also the CAPTURED
+    step: every frame of a rollout with a moving wrist camera must equal the wrapper glue's for that step's camera."""
+    dev = cuda_device
+    raw, cams, parts, actors, loop, model = _setup(dev, 120_000, seed=4)
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=7, seed=3))
+
+    def wrist(k):
+        return look_at_view([0.55 - 0.02 * k, 0.35, 0.25 + 0.01 * k], [0.35, 0.05 + 0.01 * k, 0.05], [0, 0, 1],
+                            0.9715089, 0.7551448, 640, 480)
+
+    loop.reset(*poses[0])
+    loop.capture()
+    seen = []
+    for k, (M, s) in enumerate(poses[1:]):
+        w = wrist(k)
+        frames = loop.step(M, s, cameras={"wrist_cam": w})
+        torch.cuda.synchronize()
+        want_cams = dict(cams, wrist_cam=w.to(dev))
+        _compare({n: v.clone() for n, v in frames.items()},
+                 ref.render_step(model, parts, want_cams, M, s, _rasterize, actors), f"step {k}")
+        seen.append(frames["wrist_cam"].clone())
+    assert not torch.equal(seen[0], seen[-1])
+    assert not any(st.overflow for st in loop.ensure_valid())
+    with pytest.raises(ValueError):
+        loop.set_cameras({"wrist_cam": look_at_view([0.5, 0.3, 0.2], [0.3, 0.0, 0.0], [0, 0, 1], 0.9, 0.7, 320, 240)})
