@@ -174,3 +174,43 @@ def test_frame_stats_algorithmic_bytes():
     s = FrameStats(1_468_850, 881_310, 3_525_240, False)
     # SURVEY.md 8d worked example: 70.5 + 246.8 + 225.6 + 4.9 = 548 MB
     assert abs(s.algorithmic_bytes(640, 480) / 1e6 - 547.8) < 0.5
+
+
+def test_tuning_env_selects_the_ab_paths_and_rejects_unknown_names():
+    """GSWORLD_AMD_TUNING="depth_sort=1,binning_path=3" presets the A/B selectors every GsrSettings of this package
+    carries (tools and bench.py runs without editing them); an unknown selector is an error, not a silent no-op."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from gsworld_amd import _lib; print(_lib.TUNING['depth_sort'], _lib.TUNING['binning_path'])"
+    env = dict(os.environ, GSWORLD_AMD_TUNING="depth_sort=1,binning_path=3", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "3"]
+    env["GSWORLD_AMD_TUNING"] = "no_such_selector=1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root)
+    assert out.returncode != 0 and "unknown selector" in out.stderr
+
+
+def test_closed_loop_pose_generator_is_seeded_and_shaped():
+    """The stand-in for the simulator (closed_loop.random_walk_poses): same seed -> same poses, (K,4,4) / (E,K,4,4)
+    matrices with unit scales for links and a per-step scale for the tracked actors, rigid up to that scale."""
+    import torch
+
+    from gsworld_amd import closed_loop as cl, scenes
+
+    parts, actors = cl.xarm6_parts()
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    a = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=4, seed=3))
+    b = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=4, seed=3))
+    c = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=4, seed=4))
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b))
+    assert not torch.equal(a[-1][0], c[-1][0])
+    M, s = a[1]
+    assert M.shape == (len(parts), 4, 4) and s.shape[0] == len(parts)
+    assert torch.allclose(M[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(len(parts), 4))
+    E = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=2, seed=3, num_envs=3))
+    assert E[0][0].shape == (3, len(parts), 4, 4)
+    assert not torch.equal(a[0][0], a[-1][0])  # the poses do walk
