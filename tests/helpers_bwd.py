@@ -42,6 +42,12 @@ def gpu_forward_backward(inp, st, bg, dL_dcolor, dL_dinvdepth, device="cuda", co
     return {k: v.cpu().numpy() for k, v in zip(GRAD_NAMES, grads)}, color.cpu().numpy()
 
 
+# the fixed-seed cases of tests/test_backward_gpu.py: every element within 2e-3 relative (observed: all of them, worst
+# normalised error 5e-4 -- float atomics in another order than the oracle's sums); the randomised sweeps keep the
+# wider defaults below
+SUITE_TOLERANCES = dict(frac_ok=0.9995, max_norm_err=5e-3)
+
+
 def compare_grads(ref: dict, got: dict, names=GRAD_NAMES, rtol=2e-3, frac_ok=0.999, max_norm_err=2e-2):
     rep = {}
     for k in names:
@@ -61,7 +67,9 @@ def compare_grads(ref: dict, got: dict, names=GRAD_NAMES, rtol=2e-3, frac_ok=0.9
 
 
 def run_case(n, W, H, seed, device="cuda", aa=False, deg=3, bg=(0.3, 0.1, 0.6), scale_boost=0.5, with_invdepth=True,
-             raw=None, cam=None):
+             raw=None, cam=None, **tolerances):
+    """``tolerances``: rtol / frac_ok / max_norm_err of :func:`compare_grads` (its defaults are the randomised sweep's
+    bounds; the fixed-seed suite tests pass the tighter SUITE_TOLERANCES)."""
     raw = raw if raw is not None else scenes.random_scene_camera_frame(n, seed=seed)
     if scale_boost:
         raw.scaling += scale_boost
@@ -76,7 +84,7 @@ def run_case(n, W, H, seed, device="cuda", aa=False, deg=3, bg=(0.3, 0.1, 0.6), 
     ref = go.backward(st, fwd, inp, bg, dLc, dLd)
     got, color = gpu_forward_backward(inp, st, bg, dLc, dLd, device=device)
     assert np.abs(color - fwd["color"]).max() < 1e-3
-    return compare_grads(ref, got)
+    return compare_grads(ref, got, **tolerances)
 
 
 def smoke_backward(device="cuda:0"):
