@@ -56,6 +56,20 @@ class ClosedLoopRenderer:
         semantics = g("semantics", "_semantics")
         self.op = tf.FusedPartTransform(part_labels, semantics.to(dev), scaled_parts=scaled_parts)
         self.rescaled = len(tuple(scaled_parts)) > 0
+        if self.num_envs > 1:
+            # A part with EXACTLY num_envs Gaussians takes a degenerate branch in the reference (gs_utils.py:331
+            # `rot_mat.size(0) == xyz.size(0)`: Gaussian g is rotated by environment g's matrix; the wrapper's
+            # `shape[0] == num_envs` write-back then broadcasts row i over the part -- recorded from the reference
+            # itself in tests/golden/wrapper_glue.npz).  That is an accident of shapes, not a behaviour anyone relies
+            # on; it is not mirrored here: every part moves rigidly under its environment's pose.  Say so, loudly.
+            lab = semantics.reshape(-1).long()
+            for name, labels in part_labels.items():
+                ids = torch.as_tensor(labels if isinstance(labels, (list, tuple)) else [labels], device=lab.device)
+                if int(torch.isin(lab, ids.long()).sum()) == self.num_envs:
+                    import warnings
+
+                    warnings.warn(f"part {name!r} has exactly num_envs = {self.num_envs} Gaussians: the reference's "
+                                  "shape tests mis-broadcast such a part; it is moved rigidly here", stacklevel=2)
         self.fuse_transform = bool(fuse_transform)
         self.K = len(self.op.names)
         H, W = self.cameras[0].image_height, self.cameras[0].image_width
@@ -190,6 +204,48 @@ class ClosedLoopRenderer:
         self._graph = g
         torch.cuda.synchronize(dev)
         return g
+
+
+def part_poses_from_sim(sim2gs_arm: torch.Tensor, link_now: torch.Tensor, link_scan: torch.Tensor, link_offset=None,
+                         actor_now: torch.Tensor | None = None, sim2gs_obj: torch.Tensor | None = None,
+                         actor_offset: torch.Tensor | None = None, actor_scale: torch.Tensor | None = None):
+    """The per-part matrices of one simulation step, from what a ManiSkill env exposes -- the host-side arithmetic of
+    ``GSWorldWrapper.transform_gs_perlink`` (gs_world_wrapper.py:114-120, 139-156) in its float32 operation order, so a
+    caller holding the simulator state gets exactly the ``rot_mat`` / ``translation`` / ``scale`` the reference hands
+    to ``transform_gaussians`` (pinned by tests/golden/wrapper_glue.npz, which records those arguments from the
+    reference's own run).
+
+    ``link_now`` (E,L,4,4): ``link.pose.to_transformation_matrix()`` of every robot link; ``link_scan`` (L,4,4): the same
+    at the qpos the robot was scanned in (``gs_link_pose_mats``, ``__init__`` :94-103); ``link_offset`` (3,): the
+    ``object_offset["xarm_arm"]`` shift added to every link position for xarm robots (:117-119) or None;
+    ``actor_now`` (E,A,4,4): tracked actor poses; ``sim2gs_obj`` (A,4,4): their ``sim2gs_object_transforms``;
+    ``actor_offset`` (A,3) and ``actor_scale`` (A,): ``object_offset`` / ``object_scale`` of each (zeros / ones when an
+    actor has no entry).  -> ``(matrices (E,L+A,4,4), scales (E,L+A))`` in link-then-actor order, the layout
+    :class:`ClosedLoopRenderer` takes (links carry scale 1 and are not rescaled)."""
+    from .camera import extract_rigid_transform
+
+    f32 = torch.float32
+    sim2gs_arm = sim2gs_arm.to(f32)
+    inv_arm = torch.linalg.inv(sim2gs_arm)
+    link_mat = link_now.to(f32).clone()
+    E, L = link_mat.shape[:2]
+    if link_offset is not None:
+        link_mat[:, :, :3, 3] += torch.as_tensor(link_offset, dtype=f32)
+    mats, scales = [], []
+    for k in range(L):  # (:120) sim2gs @ link_now @ inv(link_scan) @ inv(sim2gs), left to right
+        mats.append(sim2gs_arm @ link_mat[:, k] @ torch.linalg.inv(link_scan[k].to(f32)) @ inv_arm)
+        scales.append(torch.ones(E))
+    if actor_now is not None:
+        A = actor_now.shape[1]
+        for a in range(A):
+            mat = actor_now[:, a].to(f32).clone()
+            if actor_offset is not None:
+                mat[:, :3, 3] += actor_offset[a].to(f32)
+            full = sim2gs_arm @ mat @ torch.linalg.inv(sim2gs_obj[a].to(f32))  # (:147)
+            rigid, scale, _, _ = extract_rigid_transform(full)                  # (:150)
+            mats.append(rigid)
+            scales.append(scale * (1.0 if actor_scale is None else actor_scale[a]))
+    return torch.stack(mats, 1).contiguous(), torch.stack(scales, 1).to(f32).contiguous()
 
 
 def small_rigid(gen: torch.Generator, k: int, angle: float = 0.05, shift: float = 0.01) -> torch.Tensor:

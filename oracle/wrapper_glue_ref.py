@@ -63,12 +63,17 @@ def render_step(model, part_labels: dict, cameras: dict, matrices, scales, raste
     for cam_name, view in cameras.items():
         frames = []
         for e in range(E):
-            gs = assemble_env(model, part_labels, moved, e, E)
-            n = gs._xyz.shape[0]
-            color = rasterize(view, gs._xyz, torch.cat((gs._features_dc, gs._features_rest), dim=1),
-                              torch.sigmoid(gs._opacity).reshape(n, 1), torch.exp(gs._scaling),
-                              torch.nn.functional.normalize(gs._rotation), bg)
-            img = color.clamp(0, 1).permute(1, 2, 0).unsqueeze(0)  # render()["render"] is clamped to [0, 1]
-            frames.append((img * 255).clamp(0, 255).to(torch.uint8))  # :268-270
+            frames.append(render_model(assemble_env(model, part_labels, moved, e, E), view, rasterize, bg))
         out[cam_name] = torch.vstack(frames)
     return out
+
+
+def render_model(gs, view, rasterize, bg):
+    """What the wrapper does with one ``gs4render`` (:266-270): upstream ``render()`` (activations, SH concat,
+    rasterizer, clamp to [0, 1]) and the uint8 conversion.  -> uint8 (1,H,W,3)."""
+    n = gs._xyz.shape[0]
+    color = rasterize(view, gs._xyz, torch.cat((gs._features_dc, gs._features_rest), dim=1),
+                      torch.sigmoid(gs._opacity).reshape(n, 1), torch.exp(gs._scaling),
+                      torch.nn.functional.normalize(gs._rotation), bg)
+    img = color.clamp(0, 1).permute(1, 2, 0).unsqueeze(0)  # render()["render"] is clamped to [0, 1]
+    return (img * 255).clamp(0, 255).to(torch.uint8)  # :268-270
