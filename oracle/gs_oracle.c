@@ -36,6 +36,15 @@
 #include <omp.h>
 #endif
 
+/* Exposure builds (oracle/Makefile `variants`, tools/fma_exposure.py): the SAME file with the
+ * contraction choice changed, to MEASURE how much of the output depends on it.  GSO_FMA_NONE: nothing fuses (nvcc
+ * -fmad=false); GSO_FMA_COMPILER: every a * b + c is left to the compiler under -ffp-contract=fast (the closest thing
+ * here to "whatever nvcc -fmad=true picked").  Neither is the canonical build and no test uses them as a checker. */
+#if defined(GSO_FMA_NONE) || defined(GSO_FMA_COMPILER)
+#undef fmaf
+#define fmaf(a, b, c) ((a) * (b) + (c))
+#endif
+
 #define GSO_BLOCK_X 16
 #define GSO_BLOCK_Y 16
 #define GSO_NEAR_DEFAULT 0.05f /* /root/reference/README.md:33 (stock upstream: 0.2f) */
@@ -816,15 +825,15 @@ float gso_expf(float x) {
     if (x > 88.72283905206835f) return INFINITY;
     if (x < -103.972084045410f) return 0.0f;
     const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693359375f, x);
-    r = fmaf(n, 2.12194440e-4f, r);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    const float y = fmaf(p, r * r, r) + 1.0f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
     return ldexpf(y, (int)n);
 }
 

@@ -17,7 +17,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgs_oracle.so")
+# GS_ORACLE_LIB: an exposure build of the same source (tools/fma_exposure.py only; never a checker)
+_LIB_PATH = os.environ.get("GS_ORACLE_LIB") or os.path.join(_HERE, "libgs_oracle.so")
 _lib = None
 
 
@@ -38,6 +39,8 @@ class GsoSettings(C.Structure):
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gs_oracle.c")
+    if os.environ.get("GS_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)
     ):
