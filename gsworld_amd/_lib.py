@@ -36,7 +36,7 @@ class GsrSettings(C.Structure):
 # Python-side defaults of the three selectors above (tests, tools/ab_render.py, bench.py --render-bpc): the shared
 # library itself keeps no mutable state, every GsrSettings built by this package copies these in.
 TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0, "depth_sort": 0, "render_split": 0}
-# GSWORLD_AMD_TUNING="preprocess_path=1,depth_sort=1": A/B runs of the tools and bench.py without editing them
+# GSWORLD_AMD_TUNING="binning_path=4,depth_sort=1": A/B runs of the tools and bench.py without editing them
 for _kv in filter(None, os.environ.get("GSWORLD_AMD_TUNING", "").split(",")):
     _k, _, _v = _kv.partition("=")
     if _k.strip() not in TUNING:

@@ -103,9 +103,9 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
                 return GSR_E_INVALID;
             }
         }
-        if (st->binning_path < 0 || st->binning_path > 3 || st->render_variant < 0 || st->render_variant > 3 ||
+        if (st->binning_path < 0 || st->binning_path > 4 || st->render_variant < 0 || st->render_variant > 3 ||
             st->render_blocks_per_cu < 0 || st->render_blocks_per_cu > 8 || st->depth_sort < 0 || st->depth_sort > 1) {
-            gsr_set_error("gsr_forward: binning_path must be 0..3, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
+            gsr_set_error("gsr_forward: binning_path must be 0..4, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
             return GSR_E_INVALID;
         }
         if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
@@ -175,12 +175,15 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     // LDS -- always take 0)
     // GsrSettings.binning_path: 0 = default (mode 1, by tile rows where the grid allows), 1 = radix (mode 0),
     // 2 = bin-then-sort (mode 2), 3 = mode 1 by chunks of 256 depth ranks (round 1's counting placement)
-    const int want = (st->binning_path == 0 || st->binning_path == 3) ? 1 : (st->binning_path == 1 ? 0 : 2);
+    const int want = (st->binning_path == 0 || st->binning_path >= 3) ? 1 : (st->binning_path == 1 ? 0 : 2);
     const int mode = GeomState::counting(tiles) && tiles_x <= 2048 ? want : 0;
-    const bool band = mode == 1 && st->binning_path == 0 && gsr_band_supported(tiles_x);
+    // 4 = placement by chunks of the depth order (chunkplace.hip); grids it does not take fall back to the band placement
+    const bool chunk = mode == 1 && st->binning_path == 4 && gsr_chunk_supported(tiles_x, tiles / tiles_x);
+    const bool band = mode == 1 && (st->binning_path == 0 || (st->binning_path == 4 && !chunk)) &&
+                      gsr_band_supported(tiles_x);
     const bool exact = r_capacity <= 0;
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
-    const bool order_early = band && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
+    const bool order_early = (band || chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
 
@@ -200,7 +203,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
         if (st->depth_sort == 1) {
             if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
-            if (band)
+            if (band || chunk)
                 if (int e = gsr_launch_gather_rects(in->P, g, debug, stream)) return e;
         } else {
             if (int e = gsr_launch_sample_depth_sort(in->P, g, in->viewmatrix,
@@ -212,6 +215,9 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(2, stream);
     if (mode == 2) {
         if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
+    } else if (chunk) {
+        if (int e = gsr_launch_chunk_count(*st, in->P, g, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, order_early, debug, stream)) return e;
     } else if (band) {
         if (int e = gsr_launch_band_count(*st, in->P, g, st->depth_sort != 1, debug, stream)) return e;
         if (int e = gsr_launch_tile_starts(*st, g, img, cap32, order_early, debug, stream)) return e;
@@ -244,6 +250,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const BinningState b = BinningState::carve(bin_mem, cap);
     if (mode == 2) {
         if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
+    } else if (chunk) {
+        if (int e = gsr_launch_chunk_place(*st, in->P, g, b, img, debug, stream)) return e;
     } else if (band) {
         if (int e = gsr_launch_band_place(*st, g, b, img, debug, stream)) return e;
     } else if (mode == 1) {

@@ -280,6 +280,11 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
                           hipStream_t stream);
 int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
                           bool debug, hipStream_t stream);
+// placement by chunks of the depth order (chunkplace.hip)
+bool gsr_chunk_supported(int gx, int gy);
+int gsr_launch_chunk_count(const GsrSettings &st, int32_t P, const GeomState &g, bool debug, hipStream_t stream);
+int gsr_launch_chunk_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
+                           const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                            bool order_done, bool debug, hipStream_t stream);
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);

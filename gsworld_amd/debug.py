@@ -11,11 +11,12 @@ from ._lib import GsrStateView, check, lib
 
 def set_binning_mode(mode: int) -> None:
     """A/B and tests: 1 = global depth sort + counting placement (default), 0 = depth sort + emit + tile-id radix sort,
-    2 = unordered binning + per-tile LDS sort.  Sets the selector every later call of this package carries
+    2 = unordered binning + per-tile LDS sort, 3 = round 1's counting placement by rank chunks, 4 = placement by chunks
+    of the depth order with per-tile rank masks (chunkplace.hip).  Sets the selector every later call of this package carries
     (``GsrSettings.binning_path``); the shared library keeps no state."""
-    if mode not in (0, 1, 2, 3):
-        raise ValueError("binning mode must be 0, 1, 2 or 3")
-    _lib.TUNING["binning_path"] = {1: 0, 0: 1, 2: 2, 3: 3}[mode]  # 3 = counting placement by rank chunks (round 1)
+    if mode not in (0, 1, 2, 3, 4):
+        raise ValueError("binning mode must be 0, 1, 2, 3 or 4")
+    _lib.TUNING["binning_path"] = {1: 0, 0: 1, 2: 2, 3: 3, 4: 4}[mode]  # 3 = counting placement by rank chunks (round 1)
 
 
 def set_depth_sort(variant: int) -> None:

@@ -155,7 +155,7 @@ def _full_size_properties(raw, cam, device="cuda"):
     assert np.array_equal(g3["views"]["point_list"], v["point_list"])
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
 def test_alternative_binning_paths_match_too(cuda_device, mode):
     """Mode 0 (depth sort + emit + tile radix sort; also what tile grids above 16384 tiles use) and mode 2 (unordered
     binning + per-tile LDS sort) must give the same point list as the default mode 1 (depth sort + counting)."""
@@ -209,6 +209,38 @@ def test_depth_sort_paths(cuda_device, case):
         raw.xyz[n // 2:, 2] = 2.0
     rep = _run(raw, scenes.identity_camera(160, 160, 60.0))
     assert rep["V"] > 0
+
+
+@pytest.mark.parametrize("case", ["tabletop", "huge_splats_800", "wide_strip", "tiny", "lsd_radix_order"])
+def test_chunk_placement(cuda_device, case):
+    """chunkplace.hip (GsrSettings.binning_path = 4): point list, ranges and keys bit for bit -- a table-top frame (340
+    chunks x 5 row groups), splats that cover most of an 800 x 800 image (thousands of spans per chunk: the staged span
+    list is refilled several times per unit), a 4000-px-wide strip (250 tile columns, one row per group), three
+    Gaussians, and the depth order coming from the LSD radix variant of the sort."""
+    dbg.set_binning_mode(4)
+    try:
+        if case == "tabletop":
+            rep = _run(scenes.tabletop_scene("xarm6_align", n=400_000, seed=8), scenes.sensor_camera("xarm6_align"))
+            assert rep["R"] > 500_000
+        elif case == "huge_splats_800":
+            raw = scenes.random_scene_camera_frame(6_000, seed=33, near_fraction=0.0)
+            raw.scaling += 2.2  # ~9x larger: a splat covers hundreds of tiles
+            raw.opacity -= 3.0
+            rep = _run(raw, scenes.identity_camera(800, 800, 60.0))
+            assert rep["R"] > 150 * rep["V"]
+        elif case == "wide_strip":
+            rep = _run(scenes.random_scene_camera_frame(40_000, seed=34), scenes.identity_camera(4000, 48, 120.0))
+            assert rep["R"] > rep["V"] > 1000
+        elif case == "tiny":
+            _run(scenes.random_scene_camera_frame(3, seed=35, near_fraction=0.0), scenes.identity_camera(64, 64, 60.0))
+        else:
+            dbg.set_depth_sort(1)
+            try:
+                _run(scenes.tabletop_scene("xarm6_align", n=200_000, seed=9), scenes.sensor_camera("xarm6_align"))
+            finally:
+                dbg.set_depth_sort(0)
+    finally:
+        dbg.set_binning_mode(1)
 
 
 def test_cull_and_rect_on_stress_inputs(cuda_device):
