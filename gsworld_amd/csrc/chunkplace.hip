@@ -26,16 +26,32 @@
 // tiles wide; beyond that the band / older placements run.
 #include "gsr_internal.h"
 
+// -DCP_TIMING=<unit>: cycle stamps of that unit's phases into the state's debug words 48.. (tools/scratch/cp_stamps.py)
+#ifdef CP_TIMING
+#define CP_STAMP(k) do { __syncthreads(); if (unit == (uint32_t)(CP_TIMING) && threadIdx.x == 0) dbg[48 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CP_STAMP(k) do { } while (0)
+#endif
+#ifndef CP_EXP
+#define CP_EXP 0  // tuning experiments (tools/gpu_variants.sh): 2 = no mask atomics, 3 = loads + scan only
+#endif
+
 namespace {
 
 constexpr int kT = GSR_BLOCK;          // 256 threads = 4 waves
 constexpr int kCH = 512;               // depth ranks per chunk: 8 mask words per tile
 constexpr int kNW = kCH / GSR_WAVE;
 constexpr int kPT = kCH / kT;          // ranks per thread
-constexpr int kTG = 256;               // tiles per placement group (whole tile rows)
-constexpr int kSpan = 16;              // columns per span
-constexpr int kPairCap = 2048;         // spans staged in LDS at a time
-constexpr int kMaxGrid = 2048;         // workgroups launched at most (they loop over their units)
+#ifndef CP_TG
+#define CP_TG 128
+#endif
+#ifndef CP_CAP
+#define CP_CAP 1024
+#endif
+constexpr int kTG = CP_TG;             // tiles per placement group (whole tile rows)
+constexpr int kSpan = 8;               // columns per span: a wave takes 64 / kSpan spans at a time, one lane per column
+constexpr int kPairCap = CP_CAP;       // spans staged in LDS at a time
+constexpr int kMaxGrid = 8192;         // workgroups launched at most (they loop over their units)
 
 __device__ __forceinline__ void cp_unpack(uint2 rc, uint32_t &minx, uint32_t &miny, uint32_t &maxx, uint32_t &maxy) {
     minx = rc.x & 0xffffu; miny = rc.x >> 16; maxx = rc.y & 0xffffu; maxy = rc.y >> 16;
@@ -90,40 +106,45 @@ __global__ __launch_bounds__(kT) void cp_count_kernel(const uint2 *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // cp_scan: per tile, exclusive running sum over the chunks (in place) and the total.  Lane = tile, the four waves take
 // contiguous quarters of the chunks: partial sums first, then the running sums on a second sweep (the rows are L2 /
-// L1 resident by then); 16 rows in flight per lane.
+// L1 resident by then).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void cp_scan_kernel(uint32_t *__restrict__ table, const GsrHeader *__restrict__ hdr,
-                                                     int T, uint32_t *__restrict__ totals) {
-    __shared__ uint32_t s_sum[kT / GSR_WAVE][GSR_WAVE];
-    const int lane = gsr_lane(), wave = gsr_wave();
+constexpr int kScanT = 1024;  // 16 waves: the chunks of a 64-tile column are split 16 ways, one or two round trips each
+constexpr int kScanB = 24;    // rows requested together per lane
+
+__global__ __launch_bounds__(kScanT) void cp_scan_kernel(uint32_t *__restrict__ table,
+                                                         const GsrHeader *__restrict__ hdr, int T,
+                                                         uint32_t *__restrict__ totals) {
+    constexpr int NWV = kScanT / GSR_WAVE;
+    __shared__ uint32_t s_sum[NWV][GSR_WAVE];
+    const int lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
     const int t = (int)blockIdx.x * GSR_WAVE + lane;
     const bool ok = t < T;
     const uint32_t V = hdr->V;
     const int nch = (int)((V + (uint32_t)kCH - 1u) / (uint32_t)kCH);
-    const int q = (nch + 3) >> 2, c0 = min(nch, wave * q), c1 = min(nch, c0 + q);
+    const int q = (nch + NWV - 1) / NWV, c0 = min(nch, wave * q), c1 = min(nch, c0 + q);
     uint32_t sum = 0;
-    for (int c = c0; c < c1; c += 16) {
-        uint32_t v[16];
+    for (int c = c0; c < c1; c += kScanB) {
+        uint32_t v[kScanB];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = (ok && c + u < c1) ? table[(size_t)(c + u) * T + t] : 0u;
+        for (int u = 0; u < kScanB; u++) v[u] = (ok && c + u < c1) ? table[(size_t)(c + u) * T + t] : 0u;
 #pragma unroll
-        for (int u = 0; u < 16; u++) sum += v[u];
+        for (int u = 0; u < kScanB; u++) sum += v[u];
     }
     s_sum[wave][lane] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kT / GSR_WAVE; w++) {
+    for (int w = 0; w < NWV; w++) {
         const uint32_t s = s_sum[w][lane];
         if (w < wave) run += s;
         total += s;
     }
-    for (int c = c0; c < c1; c += 16) {
-        uint32_t v[16];
+    for (int c = c0; c < c1; c += kScanB) {
+        uint32_t v[kScanB];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = (ok && c + u < c1) ? table[(size_t)(c + u) * T + t] : 0u;
+        for (int u = 0; u < kScanB; u++) v[u] = (ok && c + u < c1) ? table[(size_t)(c + u) * T + t] : 0u;
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
+        for (int u = 0; u < kScanB; u++) {
             if (ok && c + u < c1) table[(size_t)(c + u) * T + t] = run;
             run += v[u];
         }
@@ -152,41 +173,40 @@ __device__ __forceinline__ CpRect cp_clip(uint2 rc, uint32_t gy0, uint32_t gy1) 
     return r;
 }
 
-// thread-private span generator: writes those of the thread's spans whose global number falls into [w0, w0 + cap)
-__device__ __forceinline__ void cp_emit(const CpRect (&r)[kPT], uint32_t first, int tid, uint32_t gy0, uint32_t w0,
+constexpr int kPlaceT = kCH;                    // one thread per rank of the chunk: 8 waves
+constexpr int kPlaceW = kPlaceT / GSR_WAVE;
+constexpr int kSlots = GSR_WAVE / kSpan;        // spans a wave takes per step, one lane per column
+constexpr int kUnroll = 4;                      // independent steps in flight per wave (the loop is LDS round trips)
+
+// thread-private span generator: writes those of the thread's spans whose number falls into [w0, w0 + kPairCap)
+__device__ __forceinline__ void cp_emit(const CpRect &r, uint32_t first, uint32_t p, uint32_t gy0, uint32_t w0,
                                         uint2 *pairs) {
-    uint32_t q = first;
-#pragma unroll
-    for (int k = 0; k < kPT; k++) {
-        const uint32_t n = r[k].ny * r[k].nsx;
-        if (n == 0u) continue;
-        if (q + n > w0 && q < w0 + (uint32_t)kPairCap) {
-            const uint32_t p = (uint32_t)(k * kT + tid);
-            uint32_t j = q < w0 ? w0 - q : 0u;           // first span of this rect inside the window
-            uint32_t yy = 0u, sx = 0u;
-            if (j != 0u) { yy = j / r[k].nsx; sx = j - yy * r[k].nsx; }
-            for (; j < n && q + j < w0 + (uint32_t)kPairCap; j++) {
-                const uint32_t x0 = r[k].minx + sx * (uint32_t)kSpan, x1 = min(r[k].maxx, x0 + (uint32_t)kSpan);
-                pairs[q + j - w0] = make_uint2(p | ((r[k].y0 + yy - gy0) << 16), x0 | (x1 << 16));
-                if (++sx == r[k].nsx) { sx = 0u; yy++; }
-            }
-        }
-        q += n;
+    const uint32_t n = r.ny * r.nsx;
+    if (n == 0u || first + n <= w0 || first >= w0 + (uint32_t)kPairCap) return;
+    uint32_t j = first < w0 ? w0 - first : 0u;  // first span of this rect inside the window
+    uint32_t yy = 0u, sx = 0u;
+    if (j != 0u) { yy = j / r.nsx; sx = j - yy * r.nsx; }
+    for (; j < n && first + j < w0 + (uint32_t)kPairCap; j++) {
+        const uint32_t x0 = r.minx + sx * (uint32_t)kSpan, x1 = min(r.maxx, x0 + (uint32_t)kSpan);
+        pairs[first + j - w0] = make_uint2(p | ((r.y0 + yy - gy0) << 16), x0 | (x1 << 16));
+        if (++sx == r.nsx) { sx = 0u; yy++; }
     }
 }
 
-__global__ __launch_bounds__(kT) void cp_place_kernel(const uint2 *__restrict__ rect_sorted,
-                                                      const uint32_t *__restrict__ order,
-                                                      const GsrHeader *__restrict__ hdr, int gx, int gy, int rows_per_group,
-                                                      int groups, const uint32_t *__restrict__ table, const uint2 *__restrict__ ranges,
-                                                      uint32_t *__restrict__ point_list) {
+__global__ __launch_bounds__(kPlaceT) void cp_place_kernel(const uint2 *__restrict__ rect_sorted,
+                                                           const uint32_t *__restrict__ order,
+                                                           const GsrHeader *__restrict__ hdr, int gx, int gy,
+                                                           int rows_per_group, int groups,
+                                                           const uint32_t *__restrict__ table,
+                                                           const uint2 *__restrict__ ranges,
+                                                           uint32_t *__restrict__ point_list,
+                                                           uint64_t *__restrict__ dbg) {
     __shared__ unsigned long long s_mask[kNW][kTG];
-    __shared__ uint16_t s_pre[kNW][kTG];
-    __shared__ uint32_t s_cur[kTG];
+    __shared__ uint32_t s_cp[kNW][kTG];  // first slot of the chunk in the tile's list + ranks below the 64-rank word
     __shared__ uint32_t s_g[kCH];
     __shared__ uint2 s_pair[kPairCap];
-    __shared__ uint32_t s_w[4];
-    const int tid = (int)threadIdx.x;
+    __shared__ uint32_t s_w[kPlaceW];
+    const int tid = (int)threadIdx.x, lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
     if (hdr->overflow) return;
     const uint32_t V = hdr->V;
     const uint32_t nch = (V + (uint32_t)kCH - 1u) / (uint32_t)kCH;
@@ -197,82 +217,124 @@ __global__ __launch_bounds__(kT) void cp_place_kernel(const uint2 *__restrict__ 
     const uint32_t base = chunk * (uint32_t)kCH;
     const uint32_t gy0 = grp * (uint32_t)rows_per_group, gy1 = min((uint32_t)gy, gy0 + (uint32_t)rows_per_group);
     const int ntl = (int)(gy1 - gy0) * gx, tile0 = (int)gy0 * gx, T = gx * gy;
-    uint2 rc[kPT];
-    uint32_t gi[kPT];
-#pragma unroll
-    for (int k = 0; k < kPT; k++) {
-        const uint32_t i = base + (uint32_t)(k * kT + tid);
-        rc[k] = i < V ? rect_sorted[i] : make_uint2(0u, 0u);
-        gi[k] = i < V ? order[i] : 0u;
-    }
+    CP_STAMP(0);
+    const uint32_t i = base + (uint32_t)tid;
+    const uint2 rc = i < V ? rect_sorted[i] : make_uint2(0u, 0u);
+    const uint32_t gi = i < V ? order[i] : 0u;
     uint32_t cur0 = 0u;
     if (tid < ntl) cur0 = ranges[tile0 + tid].x + table[(size_t)chunk * T + tile0 + tid];
-    for (int i = tid; i < kNW * kTG; i += kT) (&s_mask[0][0])[i] = 0ull;
-    CpRect r[kPT];
-    uint32_t mine = 0;
+    for (int k = tid; k < kNW * kTG; k += kPlaceT) (&s_mask[0][0])[k] = 0ull;
+    const CpRect r = cp_clip(rc, gy0, gy1);
+    const uint32_t mine = r.ny * r.nsx;
+    s_g[tid] = gi;
+    // spans before mine / spans of the unit (block scan over 8 waves)
+    uint32_t first, Q;
+    {
+        const uint32_t incl = gsr_wave_incl_scan(mine);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t add = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < kPT; k++) {
-        r[k] = cp_clip(rc[k], gy0, gy1);
-        mine += r[k].ny * r[k].nsx;
-        s_g[k * kT + tid] = gi[k];
+        for (int w = 0; w < kPlaceW; w++) {
+            const uint32_t v = s_w[w];
+            if (w < wave) add += v;
+            tot += v;
+        }
+        first = add + incl - mine;
+        Q = tot;
     }
-    if (tid < ntl) s_cur[tid] = cur0;
-    uint32_t Q;
-    const uint32_t first = gsr_block_incl_scan(mine, s_w, Q) - mine;  // (two barriers: the LDS stores above are visible)
-    if (Q == 0u) continue;
-    // ---- sweep 1: the masks
+    if (Q == 0u) { __syncthreads(); continue; }
+    CP_STAMP(1);
+#ifdef CP_TIMING
+    if (unit == (uint32_t)(CP_TIMING) && tid == 0) dbg[48 + 8] = Q;
+#endif
+#if CP_EXP == 3
+    __syncthreads();
+    continue;
+#endif
+    // ---- sweep 1: the masks.  lane = (span slot, column of the span): the kSpan lanes of a slot touch consecutive
+    // tiles; kUnroll independent steps per wave are in flight (a step is a chain of LDS round trips)
     for (uint32_t w0 = 0; w0 < Q; w0 += (uint32_t)kPairCap) {
         if (w0 > 0u) __syncthreads();
-        cp_emit(r, first, tid, gy0, w0, s_pair);
+        cp_emit(r, first, (uint32_t)tid, gy0, w0, s_pair);
         __syncthreads();
+        if (w0 == 0u) CP_STAMP(2);
         const uint32_t nq = min((uint32_t)kPairCap, Q - w0);
-        for (uint32_t j = (uint32_t)tid; j < nq; j += (uint32_t)kT) {
-            const uint2 pr = s_pair[j];
-            const uint32_t p = pr.x & 0xffffu, row = (pr.x >> 16) * (uint32_t)gx;
-            const unsigned long long bit = 1ull << (p & 63u);
-            unsigned long long *m = s_mask[p >> 6];
-            for (uint32_t x = pr.y & 0xffffu, x1 = pr.y >> 16; x < x1; x++) atomicOr(&m[row + x], bit);
+        for (uint32_t j0 = (uint32_t)(wave * kSlots * kUnroll); j0 < nq; j0 += (uint32_t)(kPlaceW * kSlots * kUnroll)) {
+            uint2 pr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t j = j0 + (uint32_t)(u * kSlots + lane / kSpan);
+                pr[u] = j < nq ? s_pair[j] : make_uint2(0u, 0u);
+            }
+#if CP_EXP != 2
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t p = pr[u].x & 0xffffu, x = (pr[u].y & 0xffffu) + (uint32_t)(lane % kSpan);
+                if (x < (pr[u].y >> 16))
+                    atomicOr(&s_mask[p >> 6][(pr[u].x >> 16) * (uint32_t)gx + x], 1ull << (p & 63u));
+            }
+#endif
         }
     }
     __syncthreads();
+    CP_STAMP(3);
     // ---- ranks below every 64-rank word
     if (tid < ntl) {
-        uint32_t run = 0;
+        uint32_t run = cur0;  // first slot of the chunk in this tile's list
 #pragma unroll
         for (int w = 0; w < kNW; w++) {
-            s_pre[w][tid] = (uint16_t)run;
+            s_cp[w][tid] = run;
             run += (uint32_t)__popcll(s_mask[w][tid]);
         }
     }
     __syncthreads();
-    // ---- sweep 2: the slots
+    CP_STAMP(4);
+    // ---- sweep 2: the slots.  (Staging the unit's instances tile-major in LDS and writing them out in runs of
+    // consecutive words was built and measured: 39 us against 33 us for the direct stores below -- a (chunk, tile) run
+    // is ~10 words, too short for the extra pass to pay.)
     for (uint32_t w0 = 0; w0 < Q; w0 += (uint32_t)kPairCap) {
         if (Q > (uint32_t)kPairCap) {  // (a single window is still staged from sweep 1)
             __syncthreads();
-            cp_emit(r, first, tid, gy0, w0, s_pair);
+            cp_emit(r, first, (uint32_t)tid, gy0, w0, s_pair);
             __syncthreads();
         }
         const uint32_t nq = min((uint32_t)kPairCap, Q - w0);
-        for (uint32_t j = (uint32_t)tid; j < nq; j += (uint32_t)kT) {
-            const uint2 pr = s_pair[j];
-            const uint32_t p = pr.x & 0xffffu, row = (pr.x >> 16) * (uint32_t)gx;
-            const unsigned long long below = (1ull << (p & 63u)) - 1ull;
-            const unsigned long long *m = s_mask[p >> 6];
-            const uint16_t *pre = s_pre[p >> 6];
-            const uint32_t g = s_g[p];
-            for (uint32_t x = pr.y & 0xffffu, x1 = pr.y >> 16; x < x1; x++) {
-                const uint32_t tl = row + x;
-                point_list[s_cur[tl] + (uint32_t)pre[tl] + (uint32_t)__popcll(m[tl] & below)] = g;
+        for (uint32_t j0 = (uint32_t)(wave * kSlots * kUnroll); j0 < nq; j0 += (uint32_t)(kPlaceW * kSlots * kUnroll)) {
+            uint2 pr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t j = j0 + (uint32_t)(u * kSlots + lane / kSpan);
+                pr[u] = j < nq ? s_pair[j] : make_uint2(0u, 0u);
+            }
+            uint32_t cp[kUnroll], g[kUnroll];
+            unsigned long long m[kUnroll];
+            bool on[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t p = pr[u].x & 0xffffu, x = (pr[u].y & 0xffffu) + (uint32_t)(lane % kSpan);
+                on[u] = x < (pr[u].y >> 16);
+                const uint32_t tl = on[u] ? (pr[u].x >> 16) * (uint32_t)gx + x : 0u;
+                cp[u] = s_cp[p >> 6][tl];
+                m[u] = s_mask[p >> 6][tl];
+                g[u] = s_g[p];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t p = pr[u].x & 0xffffu;
+                if (on[u]) point_list[cp[u] + (uint32_t)__popcll(m[u] & ((1ull << (p & 63u)) - 1ull))] = g[u];
             }
         }
     }
     __syncthreads();  // (the next unit rewrites the LDS state)
+    CP_STAMP(5);
     }
 }
 
 }  // namespace
 
 bool gsr_chunk_supported(int gx, int gy) { return gx <= kTG && gx * gy <= 4096; }
+
 
 // counts -> per-chunk offsets + tile totals (tile_starts_kernel of binning.hip turns the totals into ranges, R)
 int gsr_launch_chunk_count(const GsrSettings &st, int32_t P, const GeomState &g, bool debug, hipStream_t stream) {
@@ -283,7 +345,7 @@ int gsr_launch_chunk_count(const GsrSettings &st, int32_t P, const GeomState &g,
     hipLaunchKernelGGL(cp_count_kernel, dim3(chunks < kMaxGrid ? chunks : kMaxGrid), dim3(kT), (size_t)gy * (gx + 1) * sizeof(int), stream, g.rect_sorted,
                        g.hdr, gx, gy, g.tile_table);
     if (int e = gsr_check_launch("cp_count", debug, stream)) return e;
-    hipLaunchKernelGGL(cp_scan_kernel, dim3(gsr_div_up(T, GSR_WAVE)), dim3(kT), 0, stream, g.tile_table, g.hdr, T,
+    hipLaunchKernelGGL(cp_scan_kernel, dim3(gsr_div_up(T, GSR_WAVE)), dim3(kScanT), 0, stream, g.tile_table, g.hdr, T,
                        g.tile_totals);
     return gsr_check_launch("cp_scan", debug, stream);
 }
@@ -294,7 +356,7 @@ int gsr_launch_chunk_place(const GsrSettings &st, int32_t P, const GeomState &g,
     const int chunks = gsr_div_up(P > 0 ? P : 1, kCH);
     const int rows = kTG / gx > 0 ? kTG / gx : 1, groups = gsr_div_up(gy, rows);
     const int64_t units = (int64_t)chunks * groups;
-    hipLaunchKernelGGL(cp_place_kernel, dim3((unsigned)(units < kMaxGrid ? units : kMaxGrid)), dim3(kT), 0, stream,
-                       g.rect_sorted, g.order, g.hdr, gx, gy, rows, groups, g.tile_table, img.ranges, b.gidx[0]);
+    hipLaunchKernelGGL(cp_place_kernel, dim3((unsigned)(units < kMaxGrid ? units : kMaxGrid)), dim3(kPlaceT), 0, stream,
+                       g.rect_sorted, g.order, g.hdr, gx, gy, rows, groups, g.tile_table, img.ranges, b.gidx[0], g.ss_dbg);
     return gsr_check_launch("cp_place", debug, stream);
 }

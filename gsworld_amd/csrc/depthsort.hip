@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                                                         const uint32_t *__restrict__ block_counts,
                                                         const uint32_t *__restrict__ block_cand,
                                                         uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
-                                                        uint32_t *__restrict__ splitters,
+                                                        const uint32_t *__restrict__ splitters,
+                                                        uint32_t *__restrict__ splitters_new,
                                                         uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
                                                         uint64_t *__restrict__ dbg, const float *__restrict__ view) {
     extern __shared__ uint32_t smem[];
@@ -445,9 +446,13 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
             const uint32_t sp = (i < B - 1 && q < S) ? sorted[q] : 0xFFFFFFFFu;
             s_split[i] = sp;
-            if (blockIdx.x == 0) splitters[i] = sp;
+            // NOT into the table the other workgroups may still be reading (a workgroup dispatched late would see it
+            // half rewritten and could validate a mixture nobody else classified with): the drawn table goes to its
+            // own array, which only the partition pass reads; `splitters` is written by ss_buckets alone
+            if (blockIdx.x == 0) splitters_new[i] = sp;
         }
     }
+    if (me == 0 && tid == 0) hdr->ss_fresh = (!reuse && !blind) ? 1u : 0u;
     __syncthreads();
     for (int i = tid; i < B; i += kT) s_hist[i] = 0u;
     SS_STAMP(dbg, 3);
@@ -582,6 +587,7 @@ __device__ __forceinline__ void ss_column_sums(const uint32_t *__restrict__ tabl
 __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 *__restrict__ in,
                                                           uint2 *__restrict__ out, const uint32_t *__restrict__ table,
                                                           const uint32_t *__restrict__ splitters,
+                                                          const uint32_t *__restrict__ splitters_new,
                                                           const uint32_t *__restrict__ seg_off,
                                                           uint32_t *__restrict__ bucket_start,
                                                           GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
@@ -600,6 +606,8 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
     const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint32_t V = hdr->V;
+    // the table this frame's compaction classified with: the kept one, or the one it drew (ss_compact_kernel)
+    const uint32_t *__restrict__ split_src = hdr->ss_fresh != 0u ? splitters_new : splitters;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // The imbalance flag of the last frame was read by every compaction workgroup; ss_buckets sets it again.  New
         // samples do not always help -- depth ties (a flat table seen from straight above) cannot be split by ANY
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
             if (k < PER) {
                 const int d = tid * PER + k;
                 s_run[d] = run + M[k];
-                s_split[d] = splitters[d];
+                s_split[d] = split_src[d];
                 if (me == 0) bucket_start[d] = run;
                 run += T[k];
             }
@@ -866,12 +874,13 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
-                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_seg, g.hdr, g.ss_dbg,
-                       viewmatrix);
+                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
+                       g.ss_dbg, viewmatrix);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
-                       g.pair[1], g.ss_table, g.ss_splitters, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work,
+                       g.pair[1], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg, nbc,
+                       quad_work,
                        num_quads, quad_order, gsr_render_cus_per_xcd());
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);

@@ -45,7 +45,8 @@ struct GsrHeader {
     uint32_t br_P;        //   carry an old header over new garbage: both users also check what they read)
     uint32_t ss_wait;     // frames left in which a flagged imbalance does NOT trigger new samples ...
     uint32_t ss_backoff;  // ... and the wait after the next sampling that still ends unbalanced (1, 2, 4 .. 64)
-    uint32_t pad[31];
+    uint32_t ss_fresh;    // this frame's compaction drew new splitters: the partition pass reads ss_splitters_new
+    uint32_t pad[30];
 };
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -82,7 +83,8 @@ struct GeomState {
     uint32_t *vis_key;        // [P]   depth bits of a visible Gaussian, 0 otherwise
     uint32_t *block_cand;     // [ceil(P/256)]  depth bits of the first visible Gaussian of every preprocess block
     uint32_t *ss_table;       // [nbc * bmax]   bucket histogram of every compaction workgroup
-    uint32_t *ss_splitters;   // [bmax]
+    uint32_t *ss_splitters;   // [bmax]  last frame's exact quantiles (written by ss_buckets only: never while it is read)
+    uint32_t *ss_splitters_new; // [bmax] the table a sampling frame draws (written by ss_compact, read by ss_partition)
     uint32_t *ss_bucket_start;// [bmax + 1]
     uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
     uint64_t *ss_dbg;         // [64] cycle stamps of workgroup 0 (builds with -DGSR_SS_TIMING only)
@@ -145,11 +147,14 @@ struct GeomState {
         g.ss_dbg = take<uint64_t>(p, 64);
         g.rect_sorted = take<uint2>(p, n);
         g.band_table = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES + 1);
-        g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));
         g.tile_cum = take<uint32_t>(p, n);
         g.bucket_tiles = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.wave_lo = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         g.wave_lo_base = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
+        g.ss_splitters_new = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
+        // LAST: the only array whose size depends on tiles_x, which the read-only carvers (gsr_backward,
+        // gsr_state_view, gsr_debug_ss_stamps) do not pass -- nothing may follow it
+        g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
