@@ -27,10 +27,11 @@ if _os.environ.get("GSWORLD_AMD_CTYPES", "") != "1":
         _ext = None
 
 
-def _tuning_list():
+def _tuning_list(forward_only: int = 0):
     t = _lib.TUNING
+    fo = int(t["forward_only"]) if int(t["forward_only"]) >= 0 else int(forward_only)
     return [int(t["binning_path"]), int(t["render_variant"]), int(t["render_blocks_per_cu"]), int(t["depth_sort"]),
-            int(t["render_split"])]
+            int(t["render_split"]), fo]
 
 
 # GSWorld's edit of cuda_rasterizer/auxiliary.h (/root/reference/README.md:33).  Module-level so that a stock
@@ -75,13 +76,14 @@ def _require_gpu(t: torch.Tensor, what: str):
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                 imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
-                rgb8_out=None, parts=None):
+                rgb8_out=None, parts=None, forward_only: bool = False):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes.
     ``parts``: optional ``(labels (P,) float32, lut (L,) int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- the
-    per-frame rigid transform of labelled Gaussians applied inside preprocess (GsrInputs.part_*)."""
+    per-frame rigid transform of labelled Gaussians applied inside preprocess (GsrInputs.part_*).
+    ``forward_only``: GsrSettings.forward_only (inference frame; ``radii`` may then be None)."""
     dev = means3D.device
     if _ext is not None:
         st = settings
@@ -92,15 +94,17 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
             colors if colors is not None else e, opacity, scales if scales is not None else e,
             rotations if rotations is not None else e, cov3D_precomp if cov3D_precomp is not None else e, viewmatrix,
             projmatrix, sh if sh is not None else e, sh_rest if sh_rest is not None else e, campos, out_color,
-            out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
+            out_invdepth, radii if radii is not None else torch.empty(0, dtype=torch.int32, device=dev), geomBuffer,
+            binningBuffer, imgBuffer,
             rgb8_out if rgb8_out is not None else torch.empty(0, dtype=torch.uint8, device=dev), int(r_capacity),
-            bool(want_stats), int(param_space), _tuning_list(),
+            bool(want_stats), int(param_space), _tuning_list(int(forward_only)),
             parts[0] if parts is not None else e, parts[1] if parts is not None else torch.empty(0, dtype=torch.int32, device=dev),
             parts[2] if parts is not None else e,
             parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev))
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
+    settings.forward_only = int(forward_only)
     _lib.apply_tuning(settings)
     inp = GsrInputs(
         P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),

@@ -28,6 +28,10 @@ def _bind():
                                    C.POINTER(GsrGrads), C.c_void_p]
         L.gsr_selftest_wave_sum.restype = C.c_int
         L.gsr_selftest_wave_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        sizes = (C.c_int32 * 6)()
+        L.gsr_abi_sizes(sizes)
+        if (sizes[4], sizes[5]) != (C.sizeof(GsrBackwardInputs), C.sizeof(GsrGrads)):
+            raise RuntimeError("libgsr_hip.so was built from a different include/gsr.h (backward structs): rebuild it")
         L._bwd_bound = True
     return L
 

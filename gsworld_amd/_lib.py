@@ -30,12 +30,16 @@ class GsrSettings(C.Structure):
         # A/B and test selectors, 0 = library default (include/gsr.h); they travel with every call
         ("binning_path", C.c_int32), ("render_variant", C.c_int32), ("render_blocks_per_cu", C.c_int32),
         ("depth_sort", C.c_int32), ("render_split", C.c_int32),
+        # 1 = inference frame: nothing a backward would read is written, instances are binned per 2 x 2 super-tile
+        # (bit-identical image; include/gsr.h)
+        ("forward_only", C.c_int32),
     ]
 
 
 # Python-side defaults of the three selectors above (tests, tools/ab_render.py, bench.py --render-bpc): the shared
 # library itself keeps no mutable state, every GsrSettings built by this package copies these in.
-TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0, "depth_sort": 0, "render_split": 0}
+TUNING = {"binning_path": 0, "render_variant": 0, "render_blocks_per_cu": 0, "depth_sort": 0, "render_split": 0,
+          "forward_only": -1}  # forward_only: -1 = each caller's own choice, 0 / 1 = forced (A/B runs)
 # GSWORLD_AMD_TUNING="binning_path=4,depth_sort=1": A/B runs of the tools and bench.py without editing them
 for _kv in filter(None, os.environ.get("GSWORLD_AMD_TUNING", "").split(",")):
     _k, _, _v = _kv.partition("=")
@@ -50,6 +54,8 @@ def apply_tuning(st: "GsrSettings") -> "GsrSettings":
     st.render_blocks_per_cu = int(TUNING["render_blocks_per_cu"])
     st.depth_sort = int(TUNING["depth_sort"])
     st.render_split = int(TUNING["render_split"])
+    if int(TUNING["forward_only"]) >= 0:
+        st.forward_only = int(TUNING["forward_only"])
     return st
 
 
@@ -126,6 +132,16 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     L.gsr_last_error.restype = C.c_char_p
     L.gsr_version.restype = C.c_char_p
+    # ABI handshake: the structs above mirror include/gsr.h by hand; a library built from another header revision
+    # would read garbage selectors and pointers out of them
+    if not hasattr(L, "gsr_abi_sizes"):
+        raise RuntimeError(f"{LIB_PATH} predates the ABI handshake (gsr_abi_sizes): rebuild it (make -C gsworld_amd/csrc)")
+    sizes = (C.c_int32 * 6)()
+    L.gsr_abi_sizes(sizes)
+    mine = (C.sizeof(GsrSettings), C.sizeof(GsrInputs), C.sizeof(GsrOutputs), C.sizeof(GsrBuffers))
+    if tuple(sizes[:4]) != mine:
+        raise RuntimeError(f"{LIB_PATH} was built from a different include/gsr.h (struct sizes {tuple(sizes[:4])} there, "
+                           f"{mine} in gsworld_amd/_lib.py): rebuild the library")
     L.gsr_geom_bytes.restype = C.c_size_t
     L.gsr_geom_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.gsr_binning_bytes.restype = C.c_size_t

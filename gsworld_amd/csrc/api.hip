@@ -54,7 +54,15 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream) {
 extern "C" {
 
 const char *gsr_last_error(void) { return g_err; }
-const char *gsr_version(void) { return "gsworld_amd-gsr 0.1 (gfx950)"; }
+const char *gsr_version(void) { return "gsworld_amd-gsr 0.3 (gfx950)"; }
+void gsr_abi_sizes(int32_t out[6]) {
+    out[0] = (int32_t)sizeof(GsrSettings);
+    out[1] = (int32_t)sizeof(GsrInputs);
+    out[2] = (int32_t)sizeof(GsrOutputs);
+    out[3] = (int32_t)sizeof(GsrBuffers);
+    out[4] = (int32_t)sizeof(GsrBackwardInputs);
+    out[5] = (int32_t)sizeof(GsrGrads);
+}
 
 size_t gsr_geom_bytes(int32_t P, int32_t width, int32_t height) {
     return GeomState::required(P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE), gsr_div_up(width, GSR_TILE));
@@ -84,8 +92,10 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
         return GSR_E_INVALID;
     }
     if (in->P > 0) {
-        if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->campos || !out->radii) {
-            gsr_set_error("gsr_forward: means3D, opacities, viewmatrix, projmatrix, campos and radii are required");
+        if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->campos ||
+            (!out->radii && !st->forward_only)) {
+            gsr_set_error("gsr_forward: means3D, opacities, viewmatrix, projmatrix, campos and radii are required "
+                          "(radii may be NULL for forward_only frames)");
             return GSR_E_INVALID;
         }
         if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
@@ -182,6 +192,17 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const bool band = mode == 1 && (st->binning_path == 0 || (st->binning_path == 4 && !chunk)) &&
                       gsr_band_supported(tiles_x);
     const bool exact = r_capacity <= 0;
+    // inference frames (GsrSettings.forward_only): binned per 2 x 2 super-tile on the default path; the binning kernels
+    // take their grid from a settings copy whose image is the super-tile grid
+    const int tiles_y = tiles / tiles_x;
+    const bool infer = st->forward_only != 0;
+    const bool super = infer && (band || chunk) && st->depth_sort != 1 && st->render_variant == 0 && tiles_x <= 255 &&
+                       tiles_y <= 255;
+    GsrSettings st_bin = *st;
+    if (super) {
+        st_bin.image_width = gsr_div_up(tiles_x, 2) * GSR_TILE;
+        st_bin.image_height = gsr_div_up(tiles_y, 2) * GSR_TILE;
+    }
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
     const bool order_early = (band || chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
@@ -196,7 +217,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         }
     }
     prof_mark(0, stream);
-    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, stream)) return e;
+    // (rec2.w carries the packed tile rect only when the compositor will read it)
+    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, super, stream)) return e;
     if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
     prof_mark(1, stream);
     if (mode != 2) {
@@ -208,7 +230,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         } else {
             if (int e = gsr_launch_sample_depth_sort(in->P, g, in->viewmatrix,
                                                      order_early ? img.quad_work : (const uint32_t *)nullptr,
-                                                     4 * tiles, img.quad_order, debug, stream))
+                                                     4 * tiles, img.quad_order, super ? 1 : 0, debug, stream))
                 return e;
         }
     }
@@ -216,11 +238,11 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     if (mode == 2) {
         if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
     } else if (chunk) {
-        if (int e = gsr_launch_chunk_count(*st, in->P, g, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, order_early, debug, stream)) return e;
+        if (int e = gsr_launch_chunk_count(st_bin, in->P, g, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(st_bin, g, img, cap32, order_early, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_count(*st, in->P, g, st->depth_sort != 1, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(*st, g, img, cap32, order_early, debug, stream)) return e;
+        if (int e = gsr_launch_band_count(st_bin, in->P, g, st->depth_sort != 1, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(st_bin, g, img, cap32, order_early, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
     } else {
@@ -251,9 +273,9 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     if (mode == 2) {
         if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
     } else if (chunk) {
-        if (int e = gsr_launch_chunk_place(*st, in->P, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_chunk_place(st_bin, in->P, g, b, img, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_place(*st, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_band_place(st_bin, g, b, img, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_place(*st, in->P, g, b, img, debug, stream)) return e;
     } else {
@@ -262,7 +284,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     prof_mark(4, stream);
     // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
     if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth,
-                                  out->out_rgb8, mode != 0, mode == 1, stream))
+                                  out->out_rgb8, mode != 0, mode == 1, super, stream))
         return e;
     prof_mark(5, stream);
     prof_end_frame();

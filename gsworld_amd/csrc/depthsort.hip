@@ -57,6 +57,13 @@ __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
 }
 __device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
 
+// tile rect -> rect in 2^s x 2^s super-tile units (min rounds down, the exclusive max rounds up); s = 0: unchanged
+__device__ __forceinline__ uint2 ss_super_rect(uint2 rc, int s) {
+    const uint32_t r = (1u << s) - 1u;
+    return make_uint2(((rc.x & 0xffffu) >> s) | (((rc.x >> 16) >> s) << 16),
+                      (((rc.y & 0xffffu) + r) >> s) | ((((rc.y >> 16) + r) >> s) << 16));
+}
+
 // number of splitters <= tkey among split[0 .. B-2]  (split is ascending; B is a power of two)
 __device__ __forceinline__ uint32_t ss_bucket(const uint32_t *split, int B, uint32_t tkey) {
     uint32_t lo = 0;
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
-                                                        const float *__restrict__ view, int P) {
+                                                        const float *__restrict__ view, int P, int sshift) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
             uint32_t t = 0;
             if (i < n) {
                 const uint32_t gi = (uint32_t)comp[i];
-                const uint2 rc = rects[gi];
+                const uint2 rc = ss_super_rect(rects[gi], sshift);
                 order[s + i] = gi;
                 rect_sorted[s + i] = rc;
                 t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         uint32_t t = 0;
         if (i < n) {
             const uint32_t gi = s_v[src * kBucketCap + i];
-            const uint2 rc = rects[gi];
+            const uint2 rc = ss_super_rect(rects[gi], sshift);
             order[s + i] = gi;
             rect_sorted[s + i] = rc;
             t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
@@ -869,7 +876,7 @@ int gsr_ss_bmax(int32_t P) {
 
 // preprocess left vis_key / block_counts / block_cand; the sorted depth order ends in g.order
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, bool debug, hipStream_t stream) {
+                                 int num_quads, uint32_t *quad_order, int super_shift, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
@@ -886,6 +893,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
                        g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
-                       viewmatrix, P);
+                       viewmatrix, P, super_shift);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

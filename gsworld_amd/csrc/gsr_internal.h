@@ -269,7 +269,7 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
 
 // ---- launchers implemented in the kernel files -----------------------------------------------------------
 int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          bool count_tiles, hipStream_t stream);
+                          bool count_tiles, bool infer, hipStream_t stream);
 // bin-then-sort path (default): unordered binning into tile segments, then a per-tile (depth, index) sort
 int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                           bool debug, hipStream_t stream);
@@ -277,8 +277,9 @@ int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const Geom
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 // (quad_work != nullptr: a spare workgroup of the partition pass also deals the num_quads quadrants -> quad_order)
+// (super_shift: 1 = rect_sorted in 2 x 2 super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, bool debug, hipStream_t stream);
+                                 int num_quads, uint32_t *quad_order, int super_shift, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
@@ -301,7 +302,7 @@ bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
 int gsr_render_cus_per_xcd();  // CUs of one XCD (the quadrant deal of gsr_quad_order_block)
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
                       const ImageState &img, const float *background, float *out_color, float *out_invdepth,
-                      uint8_t *out_rgb8, bool order_ready, bool split_ready, hipStream_t stream);
+                      uint8_t *out_rgb8, bool order_ready, bool split_ready, bool super_tiles, hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

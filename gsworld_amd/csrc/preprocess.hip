@@ -17,6 +17,7 @@ struct PreprocessArgs {
     float tanfovx, tanfovy, fx, fy, scale_modifier, near_plane;
     int antialiasing;
     int param_space;  // GSR_RAW_* flags: activations evaluated here instead of three torch passes per frame
+    int infer;        // GsrSettings.forward_only: nothing a backward would read is written; rec2.w = packed tile rect
     const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;
     // optional rigid transform of labelled Gaussians (GsrInputs.part_*): same arithmetic as transform.hip
@@ -257,17 +258,24 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                 float4 *rec = a.splat + 3 * (size_t)i;
                 rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
                 rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
-                float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
-                cv[0] = make_float2(c0, c1);
-                cv[1] = make_float2(c2, c3);
-                cv[2] = make_float2(c4, c5);
+                if (!a.infer) {  // (the 3D covariance is kept for the backward only)
+                    float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);
+                    cv[0] = make_float2(c0, c1);
+                    cv[1] = make_float2(c2, c3);
+                    cv[2] = make_float2(c4, c5);
+                }
                 my_rect = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
                                      (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 a.rects[i] = my_rect;
                 radius = ir;
                 touched = (uint32_t)area;
                 visible = true;
-                mypos = make_float4(px, py, pz, fr);
+                // fourth word of the colour record: the radius (unused downstream), or -- inference frames -- the tile
+                // rect as four bytes, which the compositor tests its tile against (super-tile binning, render.hip)
+                mypos = make_float4(px, py, pz,
+                                    a.infer ? __uint_as_float((uint32_t)rminx | ((uint32_t)rminy << 8) |
+                                                              ((uint32_t)rmaxx << 16) | ((uint32_t)rmaxy << 24))
+                                            : fr);
             }
         }
     }
@@ -348,7 +356,7 @@ __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g
         cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
     }
     a.splat[3 * (size_t)g + 2] = make_float4(cr, cg, cb, pp.w);
-    a.clamped[g] = clamp_bits;
+    if (!a.infer) a.clamped[g] = clamp_bits;
 }
 
 template <bool FAST_SH16, bool COUNT_TILES>
@@ -368,8 +376,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         mypos = o.pos;
         my_tiles = o.tiles;
         my_rect = o.rect;
-        a.radii[i] = o.radius;
-        a.tiles_touched[i] = o.tiles;
+        if (a.radii != nullptr) a.radii[i] = o.radius;
+        if (!a.infer) a.tiles_touched[i] = o.tiles;
         my_key = o.key;
         a.vis_key[i] = my_key;
     }
@@ -419,8 +427,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 }  // namespace
 
 int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          bool count_tiles, hipStream_t stream) {
+                          bool count_tiles, bool infer, hipStream_t stream) {
     PreprocessArgs a;
+    a.infer = infer ? 1 : 0;
     a.P = in.P;
     a.D = st.sh_degree;
     a.M = st.sh_coeffs;

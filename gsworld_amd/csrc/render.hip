@@ -421,6 +421,12 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
     f[20] = pos;
 }
 
+// SUPER (GsrSettings.forward_only): `ranges` / `point_list` are the lists of 2 x 2 SUPER-TILES (a third of the
+// instances to place and fetch at config 2).  A candidate then passes the reference's own tile test first -- its tile
+// rect (four bytes in the spare word of the colour record, preprocess.hip) must contain this wave's tile -- so the
+// wave composites exactly the depth-ordered list of its 16 x 16 tile and the image is bit-identical.  final_T /
+// n_contrib (read by the backward only) are not written.
+template <bool SUPER>
 __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ point_list,
                                                                   const float4 *__restrict__ splat, int W, int H, int gx,
@@ -505,7 +511,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         const float pfx = (float)px, pfy = (float)py;
         const float qxf = (float)qx0, qyf = (float)qy0;
         const float yext = half == 0 ? 7.0f : 3.0f;
-        const uint2 range = ranges[tile];
+        const uint32_t tx = (uint32_t)(tile % gx), ty = (uint32_t)(tile / gx);
+        const uint2 range = ranges[SUPER ? (int)((ty >> 1) * (uint32_t)((gx + 1) >> 1) + (tx >> 1)) : tile];
         const int n_inst = (int)(range.y - range.x);
         const uint32_t *src = point_list + range.x;
 
@@ -541,7 +548,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
 #pragma unroll
             for (int s = 0; s < kStreamLanesItems; s++) {
                 const int p = rd * kStreamRound + s * GSR_WAVE + lane;
-                const bool keep = p < n_inst && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext);
+                bool keep = p < n_inst;
+                if (SUPER) {  // getRect of upstream: rect_min <= tile < rect_max on both axes
+                    const uint32_t rb = __float_as_uint(f2[s].w);
+                    keep = keep && tx - (rb & 255u) < ((rb >> 16) & 255u) - (rb & 255u) &&
+                           ty - ((rb >> 8) & 255u) < (rb >> 24) - ((rb >> 8) & 255u);
+                }
+                keep = keep && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext);
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
                 unsafe |= __builtin_amdgcn_ballot_w64(keep && !stream_conic_is_safe(f1[s]));
                 const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -602,8 +615,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             const size_t pid = (size_t)py * W + px;
             const size_t plane = (size_t)H * W;
             T = fabsf(T);
-            final_T[pid] = T;
-            n_contrib[pid] = last_contributor;
+            if (!SUPER) {
+                final_T[pid] = T;
+                n_contrib[pid] = last_contributor;
+            }
             const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
             out_color[pid] = r;
             out_color[plane + pid] = g;
@@ -712,7 +727,7 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
 
 int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
                       const float *background, float *out_color, float *out_invdepth, uint8_t *out_rgb8,
-                      bool order_ready, bool split_ready, hipStream_t stream) {
+                      bool order_ready, bool split_ready, bool super_tiles, hipStream_t stream) {
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     // the default kernel writes the uint8 frame itself; the A/B variants get a separate conversion pass
@@ -728,12 +743,20 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
         if (rc.variant == 4) {
             // (the split list is built by tile_starts_kernel: counting placements, grids up to 2048 tiles)
             const int extra = split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
-            hipLaunchKernelGGL(render_stream_kernel, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream, img.ranges,
-                               point_list, g.splat, W, H, gx, T, order, background, out_color, out_invdepth, img.final_T,
-                               img.n_contrib, out_rgb8, img.quad_work, render_num_cus(), blocks,
-                               extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list, img.split_count,
-                               img.quad_work_b,
-                               (split_ready && gsr_render_uses_quad_order(st, T)) ? img.quad_order : (const uint32_t *)nullptr);
+            const uint32_t *qorder =
+                (split_ready && gsr_render_uses_quad_order(st, T)) ? img.quad_order : (const uint32_t *)nullptr;
+            if (super_tiles)
+                hipLaunchKernelGGL(render_stream_kernel<true>, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream,
+                                   img.ranges, point_list, g.splat, W, H, gx, T, order, background, out_color,
+                                   out_invdepth, img.final_T, img.n_contrib, out_rgb8, img.quad_work, render_num_cus(),
+                                   blocks, extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list,
+                                   img.split_count, img.quad_work_b, qorder);
+            else
+                hipLaunchKernelGGL(render_stream_kernel<false>, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream,
+                                   img.ranges, point_list, g.splat, W, H, gx, T, order, background, out_color,
+                                   out_invdepth, img.final_T, img.n_contrib, out_rgb8, img.quad_work, render_num_cus(),
+                                   blocks, extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list,
+                                   img.split_count, img.quad_work_b, qorder);
         }
         else if (rc.variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,

@@ -43,7 +43,8 @@ void require_gpu(const torch::Tensor &t, const char *what) {
 }
 
 struct Tuning {
-    int binning_path = 0, render_variant = 0, render_blocks_per_cu = 0, depth_sort = 0, render_split = 0;
+    int binning_path = 0, render_variant = 0, render_blocks_per_cu = 0, depth_sort = 0, render_split = 0,
+        forward_only = 0;
 };
 
 GsrSettings settings(int H, int W, float tanfovx, float tanfovy, float scale_modifier, int degree, int M,
@@ -65,6 +66,7 @@ GsrSettings settings(int H, int W, float tanfovx, float tanfovy, float scale_mod
     st.render_blocks_per_cu = tn.render_blocks_per_cu;
     st.depth_sort = tn.depth_sort;
     st.render_split = tn.render_split;
+    st.forward_only = tn.forward_only;
     return st;
 }
 
@@ -77,6 +79,7 @@ Tuning tuning_from(const std::vector<int> &v) {
         t.depth_sort = v[3];
         t.render_split = v[4];
     }
+    if (v.size() >= 6) t.forward_only = v[5];
     return t;
 }
 
@@ -120,7 +123,8 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
         in.part_count = (int32_t)part_table.size(0);
         in.part_rescale = part_rescale.numel() ? part_rescale.data_ptr<uint8_t>() : nullptr;
     }
-    GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(), radii.data_ptr<int32_t>(),
+    GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
+                   radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
                    rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
     GsrBuffers buf{resize_cb, &geom, resize_cb, &binning, resize_cb, &image};
     GsrFrameStats stats{};
@@ -285,6 +289,18 @@ torch::Tensor mark_visible(const torch::Tensor &means3D, const torch::Tensor &vi
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled binding of libgsr_hip.so (MI355X 3DGS rasterizer) with upstream's _C signatures";
+    {
+        // ABI handshake: this file was compiled against include/gsr.h; the library it is linked to may have been
+        // rebuilt from another revision since (struct layouts would then disagree silently).  Importing fails instead,
+        // and gsworld_amd/_C.py falls back to the ctypes binding, which performs the same check.
+        int32_t sizes[6] = {0, 0, 0, 0, 0, 0};
+        gsr_abi_sizes(sizes);
+        if (sizes[0] != (int32_t)sizeof(GsrSettings) || sizes[1] != (int32_t)sizeof(GsrInputs) ||
+            sizes[2] != (int32_t)sizeof(GsrOutputs) || sizes[3] != (int32_t)sizeof(GsrBuffers) ||
+            sizes[4] != (int32_t)sizeof(GsrBackwardInputs) || sizes[5] != (int32_t)sizeof(GsrGrads))
+            throw py::import_error("gsworld_amd._C_ext was built against another revision of include/gsr.h than "
+                                   "libgsr_hip.so: run gsworld_amd/build_ext.py again");
+    }
     m.def("rasterize_gaussians", &rasterize_gaussians, py::arg("background"), py::arg("means3D"), py::arg("colors"),
           py::arg("opacity"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"),
           py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"),

@@ -31,8 +31,19 @@ class FrameStats:
 
 
 class FrameRenderer:
-    def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None):
+    def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
+                 forward_only: bool = False, want_radii: bool = True):
+        """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
+        nothing a backward would read is written and the instances are binned per 2 x 2 super-tile -- the state buffers
+        are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
+        (forward_only only): the (P,) radii array is not written either; :meth:`render` returns ``None`` for it."""
         self.device = torch.device(device)
+        if self.device.index is None and self.device.type == "cuda":
+            # an unindexed device never equals a tensor's `cuda:0`: resolve it once (multi-GPU processes: the CURRENT
+            # device at construction is this renderer's device from then on)
+            self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.forward_only = bool(forward_only)
+        self.want_radii = bool(want_radii) or not self.forward_only
         self.growth = growth
         self.near_plane = _C.NEAR_PLANE if near_plane is None else near_plane
         u8 = dict(dtype=torch.uint8, device=self.device)
@@ -104,14 +115,19 @@ class FrameRenderer:
         H, W = view.image_height, view.image_width
         if outputs is not None:
             color, invd, radii = outputs
-            if (color.shape != (3, H, W) or invd.shape != (1, H, W) or radii.shape != (P,) or color.dtype != torch.float32
-                    or invd.dtype != torch.float32 or radii.dtype != torch.int32
-                    or not (color.is_contiguous() and invd.is_contiguous() and radii.is_contiguous())
-                    or color.device != dev or invd.device != dev or radii.device != dev):
+            rad = radii if radii is not None else torch.empty((P,), dtype=torch.int32, device=dev)
+            if radii is None and self.want_radii:
+                raise ValueError("outputs: radii may only be None on a renderer built with want_radii=False")
+            if (color.shape != (3, H, W) or invd.shape != (1, H, W) or rad.shape != (P,) or color.dtype != torch.float32
+                    or invd.dtype != torch.float32 or rad.dtype != torch.int32
+                    or not (color.is_contiguous() and invd.is_contiguous() and rad.is_contiguous())
+                    or color.device != dev or invd.device != dev or rad.device != dev):
                 raise ValueError("outputs must be dense (3,H,W) float32, (1,H,W) float32, (P,) int32 tensors on the "
                                  "renderer's device")
         else:
             color, invd, radii = self._outputs(P, H, W)
+        if not self.want_radii:
+            radii = None
         self._P = P
         if bg is None:
             bg = torch.zeros(3, device=dev)
@@ -130,7 +146,7 @@ class FrameRenderer:
             cov3D_precomp if cov3D_precomp is not None else empty, view_m,
             proj_m, shs if shs is not None else empty, campos, color, invd, radii,
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
-            param_space=param_space, rgb8_out=rgb8_out, parts=parts)
+            param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only)
         if cap == 0:
             self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
         return color, radii, invd

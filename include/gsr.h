@@ -72,6 +72,19 @@ typedef struct GsrSettings {
     /* render_split: 1 = the costliest quadrants of the previous frame are composited as two 8x4 halves on two waves
      *   (image state bit-identical; measured slower than the default 0 = never split, kept for A/B). */
     int32_t render_split;
+    /* forward_only: 1 = inference frame (GSWorld's closed loop never runs a backward: gs_world_wrapper.py:266-270 keeps
+     * ["render"] only).  The image is bit-identical to forward_only = 0; what changes is the work behind it:
+     *   - preprocess writes nothing a backward would read (cov3D, SH clamp flags, tiles_touched) and GsrOutputs.radii
+     *     may be NULL;
+     *   - instances are binned per 2 x 2 SUPER-TILE (32 x 32 px) instead of per tile -- a third of the instances to
+     *     count, place and fetch at config 2 -- and the compositor applies the reference's per-tile membership test
+     *     (getRect) to every candidate itself, so every pixel still composites exactly the depth-ordered list of ITS
+     *     16 x 16 tile;
+     *   - final_T / n_contrib (read by the backward only) are not written.
+     * The state buffers of such a frame are NOT valid inputs of gsr_backward, and gsr_state_view / GsrFrameStats then
+     * describe the super-tile lists (num_rendered = super-tile instances).  Tile grids wider or higher than 255 tiles
+     * ignore the flag. */
+    int32_t forward_only;
 } GsrSettings;
 
 typedef struct GsrInputs {
@@ -144,6 +157,9 @@ typedef struct GsrFrameStats {
 
 const char *gsr_last_error(void);
 const char *gsr_version(void);
+/* ABI handshake for bindings that mirror the structs above (ctypes, the compiled torch extension): sizes of
+ * GsrSettings, GsrInputs, GsrOutputs, GsrBuffers, GsrBackwardInputs, GsrGrads as THIS library was compiled. */
+void gsr_abi_sizes(int32_t out[6]);
 
 /* Bytes needed for each state buffer. */
 size_t gsr_geom_bytes(int32_t P, int32_t width, int32_t height);

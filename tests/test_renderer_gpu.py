@@ -226,3 +226,80 @@ def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
         want = FrameRenderer(dev).render(cam, means, op, shs=shs, scales=sc, rotations=rot, exact=True)
         for a, b, what in zip(got, want, ("color", "radii", "invdepth")):
             assert torch.equal(a, b), f"model of {n2}: {what} differs from a fresh renderer's"
+
+
+@pytest.mark.parametrize("case", ["tabletop_640x480", "odd_grid_70x50", "one_tile_16x16", "huge_splats_400x304",
+                                  "tall_33x257", "chunk_placement", "raw_split_sh"])
+def test_forward_only_frames_are_bit_identical(cuda_device, case):
+    """GsrSettings.forward_only (include/gsr.h): instances binned per 2 x 2 super-tile, the compositor applying the
+    reference's per-tile rect test itself, nothing a backward reads written -- the colour image, inverse depth, uint8
+    frame and radii must be the very bits of the default frame (which the other tests hold against the oracle), on
+    even and odd tile grids, with splats that cover many super-tiles, on the exact AND the no-sync capacity path, and
+    the super-tile lists must be a third of the per-tile ones."""
+    from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    W, H = {"tabletop_640x480": (640, 480), "odd_grid_70x50": (70, 50), "one_tile_16x16": (16, 16),
+            "huge_splats_400x304": (400, 304), "tall_33x257": (33, 257), "chunk_placement": (640, 480),
+            "raw_split_sh": (640, 480)}[case]
+    if case in ("tabletop_640x480", "chunk_placement", "raw_split_sh"):
+        raw, cam = scenes.tabletop_scene("xarm6_align", n=300_000, seed=12), scenes.sensor_camera("xarm6_align")
+    else:
+        raw = scenes.random_scene_camera_frame(30_000, seed=13)
+        cam = scenes.identity_camera(W, H, 70.0)
+        if case == "huge_splats_400x304":
+            raw.scaling += 1.8
+            raw.opacity -= 2.0
+    cam = cam.to(dev)
+    bg = torch.tensor([0.3, 0.1, 0.6], device=dev)
+    if case == "raw_split_sh":
+        r_ = raw.to(dev)
+        args = (r_.xyz, r_.opacity)
+        kw = dict(shs=r_.features_dc, shs_rest=r_.features_rest, scales=r_.scaling, rotations=r_.rotation,
+                  param_space=RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS, bg=bg)
+    else:
+        means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+        args, kw = (means, op), dict(shs=shs, scales=sc, rotations=rot, bg=bg)
+    if case == "chunk_placement":
+        dbg.set_binning_mode(4)
+    try:
+        full, fast, bare = FrameRenderer(dev), FrameRenderer(dev, forward_only=True), \
+            FrameRenderer(dev, forward_only=True, want_radii=False)
+        f8 = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(3)]
+        for it in range(3):  # frame 0 exact (sizes the capacity), frames 1, 2 on the no-sync path
+            want = full.render(cam, *args, rgb8_out=f8[0], **kw)
+            got = fast.render(cam, *args, rgb8_out=f8[1], **kw)
+            got2 = bare.render(cam, *args, rgb8_out=f8[2], **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]), f"{case}: frame {it} differs"
+            assert torch.equal(got[1], want[1]), "radii"
+            assert got2[1] is None and torch.equal(got2[0], want[0]) and torch.equal(got2[2], want[2])
+            assert torch.equal(f8[1], f8[0]) and torch.equal(f8[2], f8[0])
+        sf, ss = full.ensure_valid(lambda: None), fast.ensure_valid(lambda: None)
+        assert not sf.overflow and not ss.overflow and sf.num_visible == ss.num_visible > 0
+        assert ss.num_rendered <= sf.num_rendered
+        if case == "tabletop_640x480":
+            assert ss.num_rendered < 0.45 * sf.num_rendered
+        assert int(f8[0].max()) > 60
+    finally:
+        dbg.set_binning_mode(1)
+
+
+def test_forward_only_capacity_overflow_is_recovered(cuda_device):
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=150_000, seed=14)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    ref = FrameRenderer(dev).render(cam, means, op, **kw)[0].clone()
+    r = FrameRenderer(dev, forward_only=True)
+    r.render(cam, means, op, **kw)
+    r.r_capacity = 1 << 10
+    r.render(cam, means, op, **kw)
+    assert r.stats().overflow
+    s = r.ensure_valid(lambda: r.render(cam, means, op, **kw))
+    assert not s.overflow
+    assert torch.equal(r.render(cam, means, op, **kw)[0], ref)
