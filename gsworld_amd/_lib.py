@@ -30,7 +30,7 @@ class GsrSettings(C.Structure):
         # A/B and test selectors, 0 = library default (include/gsr.h); they travel with every call
         ("binning_path", C.c_int32), ("render_variant", C.c_int32), ("render_blocks_per_cu", C.c_int32),
         ("depth_sort", C.c_int32), ("render_split", C.c_int32),
-        # 1 = inference frame: nothing a backward would read is written, instances are binned per 2 x 2 super-tile
+        # 1 = inference frame: nothing a backward would read is written, instances are binned per 2 x 1 super-tile
         # (bit-identical image; include/gsr.h)
         ("forward_only", C.c_int32),
     ]

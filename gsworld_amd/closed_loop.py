@@ -76,7 +76,8 @@ class ClosedLoopRenderer:
         self.frames = {n: torch.zeros((self.num_envs, c.image_height, c.image_width, 3), dtype=torch.uint8, device=dev)
                        for n, c in zip(self.names, self.cameras)}
         self.bg = torch.zeros(3, device=dev) if background is None else background.to(dev, torch.float32)
-        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev)
+        # the loop never differentiates a frame: inference frames (GsrSettings.forward_only), no radii array
+        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev, forward_only=True, want_radii=False)
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
         self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()

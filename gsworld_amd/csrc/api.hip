@@ -200,8 +200,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
                        tiles_y <= 255;
     GsrSettings st_bin = *st;
     if (super) {
-        st_bin.image_width = gsr_div_up(tiles_x, 2) * GSR_TILE;
-        st_bin.image_height = gsr_div_up(tiles_y, 2) * GSR_TILE;
+        st_bin.image_width = gsr_div_up(tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
+        st_bin.image_height = gsr_div_up(tiles_y, 1 << GSR_SUPER_SY) * GSR_TILE;
     }
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
     const bool order_early = (band || chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);

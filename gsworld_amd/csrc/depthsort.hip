@@ -57,11 +57,12 @@ __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
 }
 __device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
 
-// tile rect -> rect in 2^s x 2^s super-tile units (min rounds down, the exclusive max rounds up); s = 0: unchanged
+// tile rect -> rect in super-tile units (min rounds down, the exclusive max rounds up); s = 0: unchanged
 __device__ __forceinline__ uint2 ss_super_rect(uint2 rc, int s) {
-    const uint32_t r = (1u << s) - 1u;
-    return make_uint2(((rc.x & 0xffffu) >> s) | (((rc.x >> 16) >> s) << 16),
-                      (((rc.y & 0xffffu) + r) >> s) | ((((rc.y >> 16) + r) >> s) << 16));
+    if (s == 0) return rc;
+    constexpr uint32_t sx = GSR_SUPER_SX, sy = GSR_SUPER_SY, rx = (1u << sx) - 1u, ry = (1u << sy) - 1u;
+    return make_uint2(((rc.x & 0xffffu) >> sx) | (((rc.x >> 16) >> sy) << 16),
+                      (((rc.y & 0xffffu) + rx) >> sx) | ((((rc.y >> 16) + ry) >> sy) << 16));
 }
 
 // number of splitters <= tkey among split[0 .. B-2]  (split is ascending; B is a power of two)

@@ -22,6 +22,16 @@
                                        // Measured with 1024: headline +2 %, dense view +12 %, closed loop -8 %: kept at 512
 #endif
 #define GSR_BAND_RANGES 64            // band placement (bandplace.hip): depth-rank ranges per tile row
+// forward_only frames bin per (2^SX x 2^SY)-tile super-tile.  Measured at config 2 (one frame at a time; default
+// per-tile binning 195 us): 2 x 1 tiles (32 x 16 px) 168 us -- 0.58 of the instances, compositor unchanged at 54 us;
+// 2 x 2 179 us -- 0.34 of the instances, but the compositor 70 us (a quadrant then walks every nearer splat of its
+// vertical neighbour before it reaches its own); 1 x 2 175 us; 4 x 1 176 us.
+#ifndef GSR_SUPER_SX
+#define GSR_SUPER_SX 1
+#endif
+#ifndef GSR_SUPER_SY
+#define GSR_SUPER_SY 0
+#endif
 #define GSR_MAX_COUNT_TILES 16384     // counting placement: tile_table is tiles x ceil(P/256) words (bands keep LDS <= 40 KiB)
 
 // Frame header, first 256 bytes of the geometry state.  Lives on the device so that no kernel launch

@@ -421,8 +421,8 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
     f[20] = pos;
 }
 
-// SUPER (GsrSettings.forward_only): `ranges` / `point_list` are the lists of 2 x 2 SUPER-TILES (a third of the
-// instances to place and fetch at config 2).  A candidate then passes the reference's own tile test first -- its tile
+// SUPER (GsrSettings.forward_only): `ranges` / `point_list` are the lists of SUPER-TILES (2 x 1 tiles: 0.58 of the
+// instances to place and fetch at config 2; gsr_internal.h GSR_SUPER_SX / SY).  A candidate then passes the reference's own tile test first -- its tile
 // rect (four bytes in the spare word of the colour record, preprocess.hip) must contain this wave's tile -- so the
 // wave composites exactly the depth-ordered list of its 16 x 16 tile and the image is bit-identical.  final_T /
 // n_contrib (read by the backward only) are not written.
@@ -512,7 +512,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         const float qxf = (float)qx0, qyf = (float)qy0;
         const float yext = half == 0 ? 7.0f : 3.0f;
         const uint32_t tx = (uint32_t)(tile % gx), ty = (uint32_t)(tile / gx);
-        const uint2 range = ranges[SUPER ? (int)((ty >> 1) * (uint32_t)((gx + 1) >> 1) + (tx >> 1)) : tile];
+        constexpr int kSX = GSR_SUPER_SX, kSY = GSR_SUPER_SY;
+        const uint2 range = ranges[SUPER ? (int)((ty >> kSY) * (uint32_t)((gx + (1 << kSX) - 1) >> kSX) + (tx >> kSX)) : tile];
         const int n_inst = (int)(range.y - range.x);
         const uint32_t *src = point_list + range.x;
 

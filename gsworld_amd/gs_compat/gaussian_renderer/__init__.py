@@ -186,7 +186,8 @@ def _frame_renderer(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     r = _RENDERERS.get(key)
     if r is None:
-        r = _RENDERERS[key] = FrameRenderer(torch.device(key[0], key[1]))
+        # frozen parameters = inference: forward_only frames (bit-identical image and radii; nothing kept for a backward)
+        r = _RENDERERS[key] = FrameRenderer(torch.device(key[0], key[1]), forward_only=True)
     return r
 
 

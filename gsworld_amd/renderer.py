@@ -34,7 +34,7 @@ class FrameRenderer:
     def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
                  forward_only: bool = False, want_radii: bool = True):
         """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
-        nothing a backward would read is written and the instances are binned per 2 x 2 super-tile -- the state buffers
+        nothing a backward would read is written and the instances are binned per super-tile of 2 x 1 tiles -- the state buffers
         are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
         (forward_only only): the (P,) radii array is not written either; :meth:`render` returns ``None`` for it."""
         self.device = torch.device(device)

@@ -76,8 +76,8 @@ typedef struct GsrSettings {
      * ["render"] only).  The image is bit-identical to forward_only = 0; what changes is the work behind it:
      *   - preprocess writes nothing a backward would read (cov3D, SH clamp flags, tiles_touched) and GsrOutputs.radii
      *     may be NULL;
-     *   - instances are binned per 2 x 2 SUPER-TILE (32 x 32 px) instead of per tile -- a third of the instances to
-     *     count, place and fetch at config 2 -- and the compositor applies the reference's per-tile membership test
+     *   - instances are binned per SUPER-TILE of 2 x 1 tiles (32 x 16 px) instead of per tile -- 0.58 of the instances
+     *     to count, place and fetch at config 2 -- and the compositor applies the reference's per-tile membership test
      *     (getRect) to every candidate itself, so every pixel still composites exactly the depth-ordered list of ITS
      *     16 x 16 tile;
      *   - final_T / n_contrib (read by the backward only) are not written.

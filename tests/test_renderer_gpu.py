@@ -231,11 +231,11 @@ def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
 @pytest.mark.parametrize("case", ["tabletop_640x480", "odd_grid_70x50", "one_tile_16x16", "huge_splats_400x304",
                                   "tall_33x257", "chunk_placement", "raw_split_sh"])
 def test_forward_only_frames_are_bit_identical(cuda_device, case):
-    """GsrSettings.forward_only (include/gsr.h): instances binned per 2 x 2 super-tile, the compositor applying the
+    """GsrSettings.forward_only (include/gsr.h): instances binned per super-tile of 2 x 1 tiles, the compositor applying the
     reference's per-tile rect test itself, nothing a backward reads written -- the colour image, inverse depth, uint8
     frame and radii must be the very bits of the default frame (which the other tests hold against the oracle), on
     even and odd tile grids, with splats that cover many super-tiles, on the exact AND the no-sync capacity path, and
-    the super-tile lists must be a third of the per-tile ones."""
+    the super-tile lists must be well below the per-tile ones."""
     from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
     from gsworld_amd.renderer import FrameRenderer
 
@@ -280,7 +280,7 @@ def test_forward_only_frames_are_bit_identical(cuda_device, case):
         assert not sf.overflow and not ss.overflow and sf.num_visible == ss.num_visible > 0
         assert ss.num_rendered <= sf.num_rendered
         if case == "tabletop_640x480":
-            assert ss.num_rendered < 0.45 * sf.num_rendered
+            assert ss.num_rendered < 0.7 * sf.num_rendered
         assert int(f8[0].max()) > 60
     finally:
         dbg.set_binning_mode(1)

@@ -21,24 +21,13 @@ from fused_ssim import fused_ssim  # noqa: E402
 from gsworld_amd import debug as dbg, scenes  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--num-gaussians", type=int, default=500_000)
-    ap.add_argument("--size", type=int, default=800)
-    ap.add_argument("--binning-mode", type=int, default=-1, help="A/B: 0 radix, 1 counting placement, 2 bin-then-sort")
-    ap.add_argument("--fused", action="store_true",
-                    help="raw parameters + split SH through the autograd Function (activations and their chain rule "
-                         "inside the kernels) instead of upstream's torch packing")
-    args = ap.parse_args()
-    if args.binning_mode >= 0:
-        dbg.set_binning_mode(args.binning_mode)
-    dev = torch.device("cuda:0")
-    S = args.size
+def run(steps=50, warmup=5, num_gaussians=500_000, size=800, fused=False, device="cuda:0"):
+    """One measurement of the training step; returns the JSON-able record (bench.py quotes it under `train_step`)."""
+    dev = torch.device(device)
+    S = size
     cam = scenes.training_camera(S, S, 60.0).to(dev)
-    raw = scenes.random_scene_camera_frame(args.num_gaussians, seed=5).to(dev)
-    tgt = scenes.random_scene_camera_frame(args.num_gaussians, seed=5).to(dev)
+    raw = scenes.random_scene_camera_frame(num_gaussians, seed=5).to(dev)
+    tgt = scenes.random_scene_camera_frame(num_gaussians, seed=5).to(dev)
     gen = torch.Generator(device="cpu").manual_seed(6)
     tgt.xyz += (0.01 * torch.randn(tgt.xyz.shape, generator=gen)).to(dev)
     tgt.features_dc += (0.1 * torch.randn(tgt.features_dc.shape, generator=gen)).to(dev)
@@ -54,7 +43,7 @@ def main():
                 p.requires_grad_(True)
                 p.grad = None
         means2D = torch.zeros_like(r.xyz, requires_grad=grad)
-        if args.fused:
+        if fused:
             color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=r.features_dc, shs_rest=r.features_rest,
                                       opacities=r.opacity, scales=r.scaling, rotations=r.rotation, param_space=7)
             return color.clamp(0, 1), radii
@@ -74,14 +63,14 @@ def main():
         loss.backward()
         return loss, radii
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss, radii = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss, radii = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     # algorithmic bytes of the step: forward 48 N + 280 V + 64 R + 16 W H; backward: twice the forward's
     # instance traffic (128 R) + the gradient bytes 4 (3+3+1+3+6+48+3+4) V = 284 V + the image gradient read (16 W H)
     from gsworld_amd import _C
@@ -92,23 +81,39 @@ def main():
                                    1.0, torch.empty(0, device=dev), cam.world_view_transform, cam.full_proj_transform,
                                    cam.tanfovx, cam.tanfovy, S, S, shs_.detach(), 3, cam.camera_center, False, False,
                                    False)[0]
-    N, V = args.num_gaussians, int((radii > 0).sum().item())
+    N, V = num_gaussians, int((radii > 0).sum().item())
     b_alg = (48 * N + 280 * V + 64 * R + 16 * S * S) + (128 * R + 284 * V + 16 * S * S)
     finite = all(torch.isfinite(p.grad).all().item() for p in (raw.xyz, raw.features_dc, raw.features_rest,
                                                                raw.opacity, raw.scaling, raw.rotation))
-    print(json.dumps({
+    return {
         "metric": "training iterations/sec (forward + backward, fused-ssim loss)", "value": 1.0 / dt,
-        "unit": "it/s", "ms_per_step": dt * 1e3, "steps": args.steps, "warmup": args.warmup, "dtype": "f32",
+        "unit": "it/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
         "data": "synthetic",
         "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(b_alg), "achieved": b_alg / dt / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": b_alg / dt / 1e9 / 8000.0,
                      "note": "whole step (forward + backward + loss) against the HBM peak; SURVEY.md 8d byte model"},
-        "config": {"workload": f"{args.num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
+        "config": {"workload": f"{num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
                                "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step "
                                "(BASELINE.json configs[4])",
-                   "parameter_packing": "fused (raw parameters, split SH)" if args.fused else "upstream (torch)",
+                   "parameter_packing": "fused (raw parameters, split SH)" if fused else "upstream (torch)",
                    "num_visible": V, "num_rendered": int(R), "loss": float(loss.item()),
-                   "grads_finite": bool(finite)}}))
+                   "grads_finite": bool(finite)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--num-gaussians", type=int, default=500_000)
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--binning-mode", type=int, default=-1, help="A/B: 0 radix, 1 counting placement, 2 bin-then-sort")
+    ap.add_argument("--fused", action="store_true",
+                    help="raw parameters + split SH through the autograd Function (activations and their chain rule "
+                         "inside the kernels) instead of upstream's torch packing")
+    args = ap.parse_args()
+    if args.binning_mode >= 0:
+        dbg.set_binning_mode(args.binning_mode)
+    print(json.dumps(run(args.steps, args.warmup, args.num_gaussians, args.size, args.fused)))
 
 
 if __name__ == "__main__":
