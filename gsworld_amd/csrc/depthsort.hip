@@ -16,8 +16,9 @@
 //   ss_buckets   one workgroup per bucket: stable LSD radix sort in LDS on the bits that actually differ inside the
 //                bucket (typically 2 passes of 8 bits), result = the bare Gaussian indices in `order`
 //
-// Stability (index order on equal keys) is kept end to end: compaction in index order, stable partition, stable LSD
-// passes.  Samples are uniform over the VISIBLE Gaussians: sample s is the first visible key of the preprocess block
+// Index order on equal keys: the compaction is in index order, the partition pass is NOT stable across workgroups (it
+// claims bucket space with global atomics), so ss_buckets checks its sorted keys for misordered ties and re-sorts such
+// a bucket on (depth, index).  Samples are uniform over the VISIBLE Gaussians: sample s is the first visible key of the preprocess block
 // (256 Gaussians) that holds visible Gaussian s V / S -- uniform over the blocks would starve the dense part of an
 // index-coherent model.  Splitters carry the top 24 key bits only, so records with equal depth never straddle a bucket
 // boundary by accident of the sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a
@@ -160,10 +161,10 @@ __device__ __forceinline__ void lds_radix_pass(const uint32_t *kin, const uint32
 // global-memory fallback of ss_buckets sorts.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw, int bmax,
-                                                        const uint32_t *__restrict__ vis_key,
+                                                        const uint2 *__restrict__ block_recs,
                                                         const uint32_t *__restrict__ block_counts,
                                                         const uint32_t *__restrict__ block_cand,
-                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
+                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ ghist,
                                                         const uint32_t *__restrict__ splitters,
                                                         uint32_t *__restrict__ splitters_new,
                                                         uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
@@ -492,36 +493,25 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         __syncthreads();
         SS_STAMP(dbg, 4);
         {
-            constexpr int NW = kT / GSR_WAVE, kWalk = 6;
+            // a wave per block: the block's records sit compacted at the head of its own 256 slots (preprocess), so a
+            // block is one 8-byte load per lane for up to 64 records; kWalk blocks are requested together
+            constexpr int NW = kT / GSR_WAVE, kWalk = 8;
             for (int k0 = wave; k0 < nblk; k0 += NW * kWalk) {
-                uint32_t key[kWalk][4];
+                uint2 rec[kWalk];
+                uint32_t cnt[kWalk], pos[kWalk];
 #pragma unroll
                 for (int w = 0; w < kWalk; w++) {
                     const int k = k0 + w * NW;
-                    const bool live = k < nblk && s_boff[k + 1] != s_boff[k];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int i = (c0 + k) * GSR_BLOCK + r * GSR_WAVE + lane;
-                        key[w][r] = (live && i < P) ? vis_key[i] : 0u;
-                    }
+                    pos[w] = k < nblk ? s_boff[k] : 0u;
+                    cnt[w] = k < nblk ? s_boff[k + 1] - pos[w] : 0u;
+                    rec[w] = (uint32_t)lane < cnt[w] ? block_recs[(size_t)(c0 + k) * GSR_BLOCK + lane] : make_uint2(0u, 0u);
                 }
 #pragma unroll
                 for (int w = 0; w < kWalk; w++) {
-                    const int k = k0 + w * NW;
-                    if (k >= nblk) break;
-                    const int base_i = (c0 + k) * GSR_BLOCK;
-                    uint32_t pos = chunk_before + s_boff[k];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool vis = key[w][r] != 0u;
-                        const uint64_t mask = __builtin_amdgcn_ballot_w64(vis);
-                        if (vis) {
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
-                                (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            pairs[pos + rank] = make_uint2((uint32_t)(base_i + r * GSR_WAVE + lane), key[w][r]);
-                        }
-                        pos += (uint32_t)__popcll(mask);
-                    }
+                    if ((uint32_t)lane < cnt[w]) pairs[chunk_before + pos[w] + (uint32_t)lane] = rec[w];
+                    // (a block with more than 64 visible Gaussians: the rest, 64 at a time)
+                    for (uint32_t j = 64u + (uint32_t)lane; j < cnt[w]; j += 64u)
+                        pairs[chunk_before + pos[w] + j] = block_recs[(size_t)(c0 + k0 + w * NW) * GSR_BLOCK + j];
                 }
             }
         }
@@ -549,7 +539,12 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     }
     SS_STAMP(dbg, 6);
     __syncthreads();
-    for (int i = tid; i < B; i += kT) table[(size_t)blockIdx.x * bmax + i] = s_hist[i];
+    // bucket totals of the frame: one global atomic per non-empty bucket of this workgroup (no per-workgroup histogram
+    // rows any more: summing them was O(workgroups x buckets) in the partition pass -- 87 us at 883 k visible)
+    for (int i = tid; i < B; i += kT) {
+        const uint32_t c = s_hist[i];
+        if (c != 0u) atomicAdd(&ghist[i], c);
+    }
     SS_STAMP(dbg, 7);
 #ifdef GSR_SS_TIMING
     if (tid == 0) {
@@ -561,39 +556,15 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #endif
 }
 
-// Partial column sums of the histogram rows this wave owns (rows wave*RS + [0, RS), + 4 RS, ...): lane l covers the
-// 4 NV buckets [4 NV l, 4 NV (l + 1)) of a row with NV 16-byte loads; 16 loads are in flight per step.
-template <int NV>
-__device__ __forceinline__ void ss_column_sums(const uint32_t *__restrict__ table, int bmax, int nbc, int me, int wave,
-                                               int lane, uint32_t (&tot)[32], uint32_t (&mine)[32]) {
-    constexpr int RS = 16 / NV;
-    for (int r0 = wave * RS; r0 < nbc; r0 += 4 * RS) {
-        uint4 c[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int r = r0 + u / NV;
-            c[u] = r < nbc ? reinterpret_cast<const uint4 *>(table + (size_t)r * bmax)[lane * NV + (u % NV)]
-                           : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const bool m = r0 + u / NV < me;
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int v = u % NV;
-            tot[4 * v + 0] += c[u].x; tot[4 * v + 1] += c[u].y; tot[4 * v + 2] += c[u].z; tot[4 * v + 3] += c[u].w;
-            if (m) {
-                mine[4 * v + 0] += c[u].x; mine[4 * v + 1] += c[u].y; mine[4 * v + 2] += c[u].z; mine[4 * v + 3] += c[u].w;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// ss_partition: bucket starts from the histogram rows, then the stable move of this workgroup's segment.
+// ss_partition: bucket starts from the frame's bucket histogram, then this workgroup's segment moves into the buckets.
+// NOT stable across workgroups: a workgroup claims its share of a bucket with one global atomic per bucket it holds
+// records for, so records of equal depth may arrive in any order -- ss_buckets sorts on (depth, index) where that
+// matters.  (The stable version summed per-workgroup histogram rows: O(workgroups x buckets) loads per workgroup.)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 *__restrict__ in,
-                                                          uint2 *__restrict__ out, const uint32_t *__restrict__ table,
+                                                          uint2 *__restrict__ out, const uint32_t *__restrict__ ghist,
+                                                          uint32_t *__restrict__ gcursor,
                                                           const uint32_t *__restrict__ splitters,
                                                           const uint32_t *__restrict__ splitters_new,
                                                           const uint32_t *__restrict__ seg_off,
@@ -610,9 +581,9 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
     uint32_t *s_split = smem;            // [bmax]
-    uint32_t *s_run = s_split + bmax;    // [bmax]  next free slot of every bucket for this workgroup
-    uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
-    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
+    uint32_t *s_base = s_split + bmax;   // [bmax]  first slot of the bucket; inside a tile: first slot of this tile's share
+    uint32_t *s_cnt = s_base + bmax;     // [bmax]  records of the current tile per bucket
+    const int tid = (int)threadIdx.x;
     const uint32_t V = hdr->V;
     // the table this frame's compaction classified with: the kept one, or the one it drew (ss_compact_kernel)
     const uint32_t *__restrict__ split_src = hdr->ss_fresh != 0u ? splitters_new : splitters;
@@ -635,49 +606,25 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         hdr->ss_bad = 0u;
     }
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
+    const int B = ss_num_buckets(V, bmax), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
     const int me = (int)blockIdx.x;
     {
-        // Column sums of the histogram rows (all rows -> bucket totals, rows before mine -> my first slot per bucket).
-        // The rows sit in other XCDs' L2s / HBM: a round trip is ~2 k cycles, so rows are spread over the waves and a
-        // lane keeps up to 16 wide loads in flight; the four partial sums meet in LDS.
-        const int NV = B / 256;                       // uint4 per lane and row: 1, 2, 4 or 8
-        uint32_t tot[32], mine[32];
+        // bucket starts: exclusive running sum of the bucket totals (every workgroup for itself: B <= 2048 words)
+        uint32_t T[8], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) tot[k] = mine[k] = 0u;
-        switch (NV) {
-            case 1: ss_column_sums<1>(table, bmax, nbc, me, wave, lane, tot, mine); break;
-            case 2: ss_column_sums<2>(table, bmax, nbc, me, wave, lane, tot, mine); break;
-            case 4: ss_column_sums<4>(table, bmax, nbc, me, wave, lane, tot, mine); break;
-            default: ss_column_sums<8>(table, bmax, nbc, me, wave, lane, tot, mine); break;
+        for (int k = 0; k < 8; k++) {
+            T[k] = k < PER ? ghist[tid * PER + k] : 0u;
+            sum += T[k];
         }
-        // lane l holds buckets [4 NV l, 4 NV (l+1)): partial sums of this wave -> LDS, then thread t sums its PER buckets
-        uint32_t sum = 0, T[8], M[8];
-        for (int phase = 0; phase < 2; phase++) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 32; k++)
-                if (k < 4 * NV) s_cnt[wave * bmax + lane * 4 * NV + k] = phase == 0 ? tot[k] : mine[k];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < PER) {
-                    const int d = tid * PER + k;
-                    const uint32_t v = s_cnt[d] + s_cnt[bmax + d] + s_cnt[2 * bmax + d] + s_cnt[3 * bmax + d];
-                    if (phase == 0) T[k] = v; else M[k] = v;
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < PER) sum += T[k];
         uint32_t all;
         uint32_t run = gsr_block_incl_scan(sum, s_w, all) - sum;
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < PER) {
                 const int d = tid * PER + k;
-                s_run[d] = run + M[k];
+                s_base[d] = run;
                 s_split[d] = split_src[d];
+                s_cnt[d] = 0u;
                 if (me == 0) bucket_start[d] = run;
                 run += T[k];
             }
@@ -685,15 +632,13 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     }
     SS_STAMP(dbg, 1);
     const uint32_t s0 = seg_off[me], s1 = seg_off[me + 1];
-    const uint64_t lt = gsr_lanemask_lt();
-    constexpr int kPR = 8;  // rounds per wave and tile: a tile is 4 x kPR x 64 = 2048 records (most segments: one tile)
-    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(4 * kPR * GSR_WAVE)) {
-        for (int i = tid; i < 4 * B; i += kT) s_cnt[(i >> nbits) * bmax + (i & (B - 1))] = 0u;
-        __syncthreads();  // (also: s_run / s_split of the set-up above, cursors of the previous tile)
-        uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR];
+    constexpr int kPR = 8;  // records per thread and tile: a tile is 2048 records (most segments: one tile)
+    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(kPR * kT)) {
+        __syncthreads();  // (s_base / s_split / s_cnt of the set-up above, or the previous tile's scatter)
+        uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR], rank[kPR];
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
+            const uint32_t i = tile + (uint32_t)(r * kT + tid);
             const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
             idx[r] = rec.x;
             key[r] = rec.y;
@@ -702,36 +647,36 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         ss_bucketN<kPR>(s_split, B, tk, dig);
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
-            if (i < s1) atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
+            const uint32_t i = tile + (uint32_t)(r * kT + tid);
+            rank[r] = i < s1 ? atomicAdd(&s_cnt[dig[r]], 1u) : 0u;  // position among this tile's records of the bucket
         }
         __syncthreads();
+        // this tile's share of every bucket it holds records for: one global atomic each
+        uint32_t claim[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < PER) {
                 const int d = tid * PER + k;
-                const uint32_t c0 = s_cnt[d], c1 = s_cnt[bmax + d], c2 = s_cnt[2 * bmax + d], c3 = s_cnt[3 * bmax + d];
-                const uint32_t start = s_run[d];
-                s_cnt[d] = start;
-                s_cnt[bmax + d] = start + c0;
-                s_cnt[2 * bmax + d] = start + c0 + c1;
-                s_cnt[3 * bmax + d] = start + c0 + c1 + c2;
-                s_run[d] = start + c0 + c1 + c2 + c3;
+                const uint32_t c = s_cnt[d];
+                claim[k] = c != 0u ? atomicAdd(&gcursor[d], c) : 0u;
+            }
+        // (s_base keeps the bucket start; the tile's first slot goes through s_cnt, which is no longer needed as a count)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < PER) {
+                const int d = tid * PER + k;
+                s_cnt[d] = s_base[d] + claim[k];
             }
         __syncthreads();
-        uint32_t *cur = s_cnt + wave * bmax;
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
-            const bool valid = i < s1;
-            const uint64_t same = ss_match(dig[r], nbits, valid);
-            const uint32_t rank = (uint32_t)__popcll(same & lt);
-            if (valid) out[cur[dig[r]] + rank] = make_uint2(idx[r], key[r]);
-            __builtin_amdgcn_wave_barrier();
-            if (valid && rank == 0u) cur[dig[r]] += (uint32_t)__popcll(same);
-            __builtin_amdgcn_wave_barrier();
+            const uint32_t i = tile + (uint32_t)(r * kT + tid);
+            if (i < s1) out[s_cnt[dig[r]] + rank[r]] = make_uint2(idx[r], key[r]);
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < PER) s_cnt[tid * PER + k] = 0u;
     }
     SS_STAMP(dbg, 2);
 }
@@ -830,6 +775,38 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                              s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
         src ^= 1;
     }
+    {
+        // Ties.  The partition pass is not stable, so records of EQUAL depth sit in arrival order here, while the
+        // reference's key sort leaves them by ascending index.  Checked on the sorted keys; a bucket that holds a
+        // misordered tie (rare: two Gaussians with the same depth bits) is sorted again on (depth, index) -- stable LSD
+        // passes on the index bits that differ, then on the depth bits.
+        uint32_t bad = 0u, dv = 0u;
+        const uint32_t *ks = s_k + src * kBucketCap, *vs = s_v + src * kBucketCap;
+        const uint32_t v0 = vs[0];
+        for (int i = tid; i < n; i += kT) {
+            dv |= vs[i] ^ v0;
+            if (i + 1 < n && ks[i] == ks[i + 1] && vs[i] > vs[i + 1]) bad = 1u;
+        }
+        if (__syncthreads_or((int)bad) != 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dv |= (uint32_t)__shfl_xor((int)dv, o, 64);
+            if (gsr_lane() == 0) s_w[gsr_wave()] = dv;
+            __syncthreads();
+            dv = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+            __syncthreads();
+            const int vbits = dv == 0u ? 0 : 32 - __builtin_clz(dv);
+            for (int shift = 0; shift < vbits; shift += 8) {  // (roles swapped: the index is the sort key here)
+                lds_radix_pass<true>(s_v + src * kBucketCap, s_k + src * kBucketCap, s_v + (src ^ 1) * kBucketCap,
+                                     s_k + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
+                src ^= 1;
+            }
+            for (int shift = 0; shift < bits; shift += 8) {
+                lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
+                                     s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
+                src ^= 1;
+            }
+        }
+    }
     SS_STAMP(dbg, 3);
     // next frame's splitters: the exact B-quantiles of this frame's depth order (top 24 bits), each written by the
     // bucket that holds its rank
@@ -865,7 +842,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
 int gsr_ss_nbc(int32_t P) {
     const int nb1 = GeomState::prep_blocks(P);
     int nbc = gsr_div_up(nb1, 8);
-    if (nbc > 128) nbc = 128;
+    if (nbc > 256) nbc = 256;  // (one per CU: no per-workgroup table any more whose column sums grew with this)
     const int need = gsr_div_up(nb1, 1024);  // at most 1024 blocks per workgroup (LDS offsets)
     return nbc > need ? nbc : need;
 }
@@ -881,15 +858,15 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.vis_key,
+    hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.pair[1],
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
                        g.ss_dbg, viewmatrix);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
-    const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
+    const size_t lds2 = (size_t)(3 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
-                       g.pair[1], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.ss_bucket_start, g.hdr, g.ss_dbg, nbc,
-                       quad_work,
-                       num_quads, quad_order, gsr_render_cus_per_xcd());
+                       g.pair[1], g.ss_table, g.ss_table + bmax, g.ss_splitters, g.ss_splitters_new, g.ss_seg,
+                       g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work, num_quads, quad_order,
+                       gsr_render_cus_per_xcd());
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,

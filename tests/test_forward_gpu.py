@@ -169,7 +169,7 @@ def test_alternative_binning_paths_match_too(cuda_device, mode):
 
 
 @pytest.mark.parametrize("case", ["lsd_radix_variant", "all_equal_depth", "two_depths", "one_million_visible", "tiny",
-                                  "index_coherent"])
+                                  "index_coherent", "quantised_depths", "a_few_equal_depths"])
 def test_depth_sort_paths(cuda_device, case):
     """The depth order (ascending depth bits, ties by index) from every path of the depth sort: the default sample sort
     with buckets of every size class (LDS radix; a bucket too large for the LDS -> global-memory bitonic fallback;
@@ -198,6 +198,20 @@ def test_depth_sort_paths(cuda_device, case):
         raw.scaling -= 2.0  # small splats: the oracle's compositing stays cheap
         rep = _run(raw, scenes.identity_camera(256, 256, 75.0))
         assert rep["V"] > 900_000
+        return
+    if case in ("quantised_depths", "a_few_equal_depths"):
+        # equal depth bits inside ordinary buckets: the partition pass moves records with global atomics (any arrival
+        # order), so the bucket sort has to restore the index order of ties itself
+        raw = scenes.random_scene_camera_frame(120_000, seed=36, near_fraction=0.0)
+        raw.scaling -= 1.5
+        if case == "quantised_depths":
+            raw.xyz[:, 2] = torch.round(raw.xyz[:, 2] * 200.0) / 200.0  # ~600 distinct depths, ~200 Gaussians each
+        else:
+            src = torch.randperm(raw.num, generator=torch.Generator().manual_seed(1))[:400]
+            raw.xyz[src[:200], 2] = raw.xyz[src[200:], 2]
+        for _ in range(3):  # (arrival order varies from run to run)
+            rep = _run(raw, scenes.identity_camera(192, 192, 60.0))
+        assert rep["V"] > 100_000
         return
     n = {"all_equal_depth": 20_000, "two_depths": 9_000, "tiny": 3}[case]
     raw = scenes.random_scene_camera_frame(n, seed=32, near_fraction=0.0)

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Renders a few frames of the headline scene eagerly (for rocprofv3 --kernel-trace --stats / --pmc runs).
+usage: prof_scene.py [--view sensor|dense] [--frames N] [--default-mode] [--moving]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gsworld_amd import scenes  # noqa: E402
+from gsworld_amd.renderer import FrameRenderer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--view", default="sensor")
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--default-mode", action="store_true", help="forward_only = 0 (the training-capable frame)")
+ap.add_argument("--moving", action="store_true", help="turn the camera a little on every frame")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+raw = scenes.tabletop_scene("xarm6_align")
+cam0 = scenes.dense_view_camera("xarm6_align") if args.view == "dense" else scenes.sensor_camera("xarm6_align")
+cam = cam0.to(dev)
+means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+r = FrameRenderer(dev, forward_only=not args.default_mode, want_radii=args.default_mode)
+rgb8 = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+proj = cam0.world_view_transform.inverse() @ cam0.full_proj_transform
+for k in range(args.frames):
+    if args.moving:
+        a = math.radians(2.0) * math.sin(2.0 * math.pi * k / 97.0)
+        Rz = torch.tensor([[math.cos(a), -math.sin(a), 0, 0], [math.sin(a), math.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+        wvt = Rz @ cam0.world_view_transform
+        cam.world_view_transform.copy_(wvt)
+        cam.full_proj_transform.copy_(wvt @ proj)
+        cam.camera_center.copy_(wvt.inverse()[3, :3])
+    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8)
+    if k == 1:
+        r.ensure_valid(lambda: None)
+torch.cuda.synchronize()
+print("stats", r.stats())
