@@ -16,9 +16,8 @@
 //   ss_buckets   one workgroup per bucket: stable LSD radix sort in LDS on the bits that actually differ inside the
 //                bucket (typically 2 passes of 8 bits), result = the bare Gaussian indices in `order`
 //
-// Index order on equal keys: the compaction is in index order, the partition pass is NOT stable across workgroups (it
-// claims bucket space with global atomics), so ss_buckets checks its sorted keys for misordered ties and re-sorts such
-// a bucket on (depth, index).  Samples are uniform over the VISIBLE Gaussians: sample s is the first visible key of the preprocess block
+// Stability (index order on equal keys) is kept end to end: compaction in index order, stable partition, stable LSD
+// passes.  Samples are uniform over the VISIBLE Gaussians: sample s is the first visible key of the preprocess block
 // (256 Gaussians) that holds visible Gaussian s V / S -- uniform over the blocks would starve the dense part of an
 // index-coherent model.  Splitters carry the top 24 key bits only, so records with equal depth never straddle a bucket
 // boundary by accident of the sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                                                         const uint2 *__restrict__ block_recs,
                                                         const uint32_t *__restrict__ block_counts,
                                                         const uint32_t *__restrict__ block_cand,
-                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ ghist,
+                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
                                                         const uint32_t *__restrict__ splitters,
                                                         uint32_t *__restrict__ splitters_new,
                                                         uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
@@ -539,12 +538,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     }
     SS_STAMP(dbg, 6);
     __syncthreads();
-    // bucket totals of the frame: one global atomic per non-empty bucket of this workgroup (no per-workgroup histogram
-    // rows any more: summing them was O(workgroups x buckets) in the partition pass -- 87 us at 883 k visible)
-    for (int i = tid; i < B; i += kT) {
-        const uint32_t c = s_hist[i];
-        if (c != 0u) atomicAdd(&ghist[i], c);
-    }
+    for (int i = tid; i < B; i += kT) table[(size_t)blockIdx.x * bmax + i] = s_hist[i];
     SS_STAMP(dbg, 7);
 #ifdef GSR_SS_TIMING
     if (tid == 0) {
@@ -557,14 +551,59 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ss_partition: bucket starts from the frame's bucket histogram, then this workgroup's segment moves into the buckets.
-// NOT stable across workgroups: a workgroup claims its share of a bucket with one global atomic per bucket it holds
-// records for, so records of equal depth may arrive in any order -- ss_buckets sorts on (depth, index) where that
-// matters.  (The stable version summed per-workgroup histogram rows: O(workgroups x buckets) loads per workgroup.)
+// ss_colscan: exclusive running sum of every bucket's column of the histogram rows (in place) and the column totals.
+// One workgroup per 64 buckets, lane = bucket, the four waves take contiguous quarters of the rows.  (The partition
+// pass used to sum the rows before its own by itself: O(workgroups x buckets) loads per workgroup -- 17 us of its time
+// at config 2, 87 us at 883 k visible Gaussians.)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void ss_colscan_kernel(int bmax, int nbc, uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ totals,
+                                                        const GsrHeader *__restrict__ hdr) {
+    __shared__ uint32_t s_sum[kT / GSR_WAVE][GSR_WAVE];
+    const int lane = gsr_lane(), wave = gsr_wave();
+    const uint32_t V = hdr->V;
+    if (V == 0u) return;
+    const int B = ss_num_buckets(V, bmax);
+    const int b = (int)blockIdx.x * GSR_WAVE + lane;
+    if ((int)blockIdx.x * GSR_WAVE >= B) return;
+    const int q = (nbc + 3) >> 2, r0 = min(nbc, wave * q), r1 = min(nbc, r0 + q);
+    constexpr int kB = 32;
+    uint32_t sum = 0;
+    for (int r = r0; r < r1; r += kB) {
+        uint32_t v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) v[u] = r + u < r1 ? table[(size_t)(r + u) * bmax + b] : 0u;
+#pragma unroll
+        for (int u = 0; u < kB; u++) sum += v[u];
+    }
+    s_sum[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kT / GSR_WAVE; w++) {
+        const uint32_t x = s_sum[w][lane];
+        if (w < wave) run += x;
+        total += x;
+    }
+    for (int r = r0; r < r1; r += kB) {
+        uint32_t v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) v[u] = r + u < r1 ? table[(size_t)(r + u) * bmax + b] : 0u;
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            if (r + u < r1) table[(size_t)(r + u) * bmax + b] = run;
+            run += v[u];
+        }
+    }
+    if (wave == 0) totals[b] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_partition: bucket starts from the histogram rows, then the stable move of this workgroup's segment.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 *__restrict__ in,
-                                                          uint2 *__restrict__ out, const uint32_t *__restrict__ ghist,
-                                                          uint32_t *__restrict__ gcursor,
+                                                          uint2 *__restrict__ out, const uint32_t *__restrict__ table,
+                                                          const uint32_t *__restrict__ totals,
                                                           const uint32_t *__restrict__ splitters,
                                                           const uint32_t *__restrict__ splitters_new,
                                                           const uint32_t *__restrict__ seg_off,
@@ -581,9 +620,9 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
     uint32_t *s_split = smem;            // [bmax]
-    uint32_t *s_base = s_split + bmax;   // [bmax]  first slot of the bucket; inside a tile: first slot of this tile's share
-    uint32_t *s_cnt = s_base + bmax;     // [bmax]  records of the current tile per bucket
-    const int tid = (int)threadIdx.x;
+    uint32_t *s_run = s_split + bmax;    // [bmax]  next free slot of every bucket for this workgroup
+    uint32_t *s_cnt = s_run + bmax;      // [4][bmax]
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
     const uint32_t V = hdr->V;
     // the table this frame's compaction classified with: the kept one, or the one it drew (ss_compact_kernel)
     const uint32_t *__restrict__ split_src = hdr->ss_fresh != 0u ? splitters_new : splitters;
@@ -606,14 +645,16 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         hdr->ss_bad = 0u;
     }
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
+    const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
     const int me = (int)blockIdx.x;
+    (void)lane;
     {
-        // bucket starts: exclusive running sum of the bucket totals (every workgroup for itself: B <= 2048 words)
-        uint32_t T[8], sum = 0;
+        // bucket starts from the column totals, my first slot per bucket from my (prefixed) histogram row: ss_colscan
+        uint32_t sum = 0, T[8], M[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            T[k] = k < PER ? ghist[tid * PER + k] : 0u;
+            T[k] = k < PER ? totals[tid * PER + k] : 0u;
+            M[k] = k < PER ? table[(size_t)me * bmax + tid * PER + k] : 0u;
             sum += T[k];
         }
         uint32_t all;
@@ -622,9 +663,8 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         for (int k = 0; k < 8; k++)
             if (k < PER) {
                 const int d = tid * PER + k;
-                s_base[d] = run;
+                s_run[d] = run + M[k];
                 s_split[d] = split_src[d];
-                s_cnt[d] = 0u;
                 if (me == 0) bucket_start[d] = run;
                 run += T[k];
             }
@@ -632,13 +672,15 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     }
     SS_STAMP(dbg, 1);
     const uint32_t s0 = seg_off[me], s1 = seg_off[me + 1];
-    constexpr int kPR = 8;  // records per thread and tile: a tile is 2048 records (most segments: one tile)
-    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(kPR * kT)) {
-        __syncthreads();  // (s_base / s_split / s_cnt of the set-up above, or the previous tile's scatter)
-        uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR], rank[kPR];
+    const uint64_t lt = gsr_lanemask_lt();
+    constexpr int kPR = 8;  // rounds per wave and tile: a tile is 4 x kPR x 64 = 2048 records (most segments: one tile)
+    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(4 * kPR * GSR_WAVE)) {
+        for (int i = tid; i < 4 * B; i += kT) s_cnt[(i >> nbits) * bmax + (i & (B - 1))] = 0u;
+        __syncthreads();  // (also: s_run / s_split of the set-up above, cursors of the previous tile)
+        uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR];
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(r * kT + tid);
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
             const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
             idx[r] = rec.x;
             key[r] = rec.y;
@@ -647,36 +689,36 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
         ss_bucketN<kPR>(s_split, B, tk, dig);
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(r * kT + tid);
-            rank[r] = i < s1 ? atomicAdd(&s_cnt[dig[r]], 1u) : 0u;  // position among this tile's records of the bucket
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
+            if (i < s1) atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
         }
         __syncthreads();
-        // this tile's share of every bucket it holds records for: one global atomic each
-        uint32_t claim[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < PER) {
                 const int d = tid * PER + k;
-                const uint32_t c = s_cnt[d];
-                claim[k] = c != 0u ? atomicAdd(&gcursor[d], c) : 0u;
-            }
-        // (s_base keeps the bucket start; the tile's first slot goes through s_cnt, which is no longer needed as a count)
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < PER) {
-                const int d = tid * PER + k;
-                s_cnt[d] = s_base[d] + claim[k];
+                const uint32_t c0 = s_cnt[d], c1 = s_cnt[bmax + d], c2 = s_cnt[2 * bmax + d], c3 = s_cnt[3 * bmax + d];
+                const uint32_t start = s_run[d];
+                s_cnt[d] = start;
+                s_cnt[bmax + d] = start + c0;
+                s_cnt[2 * bmax + d] = start + c0 + c1;
+                s_cnt[3 * bmax + d] = start + c0 + c1 + c2;
+                s_run[d] = start + c0 + c1 + c2 + c3;
             }
         __syncthreads();
+        uint32_t *cur = s_cnt + wave * bmax;
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(r * kT + tid);
-            if (i < s1) out[s_cnt[dig[r]] + rank[r]] = make_uint2(idx[r], key[r]);
+            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
+            const bool valid = i < s1;
+            const uint64_t same = ss_match(dig[r], nbits, valid);
+            const uint32_t rank = (uint32_t)__popcll(same & lt);
+            if (valid) out[cur[dig[r]] + rank] = make_uint2(idx[r], key[r]);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0u) cur[dig[r]] += (uint32_t)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < PER) s_cnt[tid * PER + k] = 0u;
     }
     SS_STAMP(dbg, 2);
 }
@@ -775,38 +817,6 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                              s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
         src ^= 1;
     }
-    {
-        // Ties.  The partition pass is not stable, so records of EQUAL depth sit in arrival order here, while the
-        // reference's key sort leaves them by ascending index.  Checked on the sorted keys; a bucket that holds a
-        // misordered tie (rare: two Gaussians with the same depth bits) is sorted again on (depth, index) -- stable LSD
-        // passes on the index bits that differ, then on the depth bits.
-        uint32_t bad = 0u, dv = 0u;
-        const uint32_t *ks = s_k + src * kBucketCap, *vs = s_v + src * kBucketCap;
-        const uint32_t v0 = vs[0];
-        for (int i = tid; i < n; i += kT) {
-            dv |= vs[i] ^ v0;
-            if (i + 1 < n && ks[i] == ks[i + 1] && vs[i] > vs[i + 1]) bad = 1u;
-        }
-        if (__syncthreads_or((int)bad) != 0) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) dv |= (uint32_t)__shfl_xor((int)dv, o, 64);
-            if (gsr_lane() == 0) s_w[gsr_wave()] = dv;
-            __syncthreads();
-            dv = s_w[0] | s_w[1] | s_w[2] | s_w[3];
-            __syncthreads();
-            const int vbits = dv == 0u ? 0 : 32 - __builtin_clz(dv);
-            for (int shift = 0; shift < vbits; shift += 8) {  // (roles swapped: the index is the sort key here)
-                lds_radix_pass<true>(s_v + src * kBucketCap, s_k + src * kBucketCap, s_v + (src ^ 1) * kBucketCap,
-                                     s_k + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
-                src ^= 1;
-            }
-            for (int shift = 0; shift < bits; shift += 8) {
-                lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
-                                     s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
-                src ^= 1;
-            }
-        }
-    }
     SS_STAMP(dbg, 3);
     // next frame's splitters: the exact B-quantiles of this frame's depth order (top 24 bits), each written by the
     // bucket that holds its rank
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
 int gsr_ss_nbc(int32_t P) {
     const int nb1 = GeomState::prep_blocks(P);
     int nbc = gsr_div_up(nb1, 8);
-    if (nbc > 256) nbc = 256;  // (one per CU: no per-workgroup table any more whose column sums grew with this)
+    if (nbc > 128) nbc = 128;
     const int need = gsr_div_up(nb1, 1024);  // at most 1024 blocks per workgroup (LDS offsets)
     return nbc > need ? nbc : need;
 }
@@ -862,9 +872,12 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
                        g.ss_dbg, viewmatrix);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
-    const size_t lds2 = (size_t)(3 * bmax) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE)), dim3(kT), 0, stream, bmax, nbc, g.ss_table,
+                       g.ss_totals, g.hdr);
+    if (int e = gsr_check_launch("ss_colscan", debug, stream)) return e;
+    const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
-                       g.pair[1], g.ss_table, g.ss_table + bmax, g.ss_splitters, g.ss_splitters_new, g.ss_seg,
+                       g.pair[1], g.ss_table, g.ss_totals, g.ss_splitters, g.ss_splitters_new, g.ss_seg,
                        g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work, num_quads, quad_order,
                        gsr_render_cus_per_xcd());
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;

@@ -94,6 +94,7 @@ struct GeomState {
     uint32_t *block_cand;     // [ceil(P/256)]  depth bits of the first visible Gaussian of every preprocess block
     uint32_t *ss_table;       // [nbc * bmax]   bucket histogram of every compaction workgroup
     uint32_t *ss_splitters;   // [bmax]  last frame's exact quantiles (written by ss_buckets only: never while it is read)
+    uint32_t *ss_totals;      // [bmax]  records per bucket (column totals of ss_table, ss_colscan)
     uint32_t *ss_splitters_new; // [bmax] the table a sampling frame draws (written by ss_compact, read by ss_partition)
     uint32_t *ss_bucket_start;// [bmax + 1]
     uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
@@ -162,6 +163,7 @@ struct GeomState {
         g.wave_lo = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         g.wave_lo_base = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         g.ss_splitters_new = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
+        g.ss_totals = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         // LAST: the only array whose size depends on tiles_x, which the read-only carvers (gsr_backward,
         // gsr_state_view, gsr_debug_ss_stamps) do not pass -- nothing may follow it
         g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));

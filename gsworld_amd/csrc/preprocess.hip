@@ -36,8 +36,7 @@ struct PreprocessArgs {
                            // own 256 slots (depthsort.hip gathers them: 8 B per VISIBLE Gaussian instead of a 4-byte key
                            // written and re-read for all N)
     uint32_t *block_cand;  // depth bits of the block's first visible Gaussian (sort sample)
-    uint32_t *sort_counters;  // [sort_counter_words] bucket histogram + cursors of the depth sort: cleared here
-    int sort_counter_words;
+
     // bin-then-sort path: per-tile instance totals and the visible count are accumulated here
     int num_tiles;
     uint32_t *tile_accum;
@@ -384,10 +383,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         if (!a.infer) a.tiles_touched[i] = o.tiles;
         my_key = o.key;
     }
-    // (the depth sort accumulates its bucket histogram and claims bucket space with global atomics: this kernel is the
-    // one that always runs before it, so its last workgroup leaves the counters at zero)
-    if (blockIdx.x == gridDim.x - 1)
-        for (int k = (int)threadIdx.x; k < a.sort_counter_words; k += GSR_BLOCK) a.sort_counters[k] = 0u;
+
     // ---- phase 2: colour, on the block-compacted list of survivors ------------------------------------------
     // Typically only a fraction of the 256 lanes survive cull + rect; evaluating the SH (48 loads + ~110 VALU per
     // Gaussian) in place would run all 4 waves at that fraction of their lanes.  Dense lanes instead.
@@ -480,8 +476,7 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.block_recs = g.pair[1];  // (the sort's compaction gathers from here into pair[0]; its partition pass then
                                //  overwrites this array with the bucketed records)
     a.block_cand = g.block_cand;
-    a.sort_counters = g.ss_table;
-    a.sort_counter_words = 2 * gsr_ss_bmax(in.P);
+
     a.num_tiles = a.gx * a.gy;
     a.tile_accum = g.tile_accum;
     a.hdr = g.hdr;

@@ -200,8 +200,8 @@ def test_depth_sort_paths(cuda_device, case):
         assert rep["V"] > 900_000
         return
     if case in ("quantised_depths", "a_few_equal_depths"):
-        # equal depth bits inside ordinary buckets: the partition pass moves records with global atomics (any arrival
-        # order), so the bucket sort has to restore the index order of ties itself
+        # equal depth bits inside ordinary buckets (two Gaussians with the same depth bits are common: ~1 300 pairs per
+        # config-2 frame): the reference's key sort leaves them by ascending index
         raw = scenes.random_scene_camera_frame(120_000, seed=36, near_fraction=0.0)
         raw.scaling -= 1.5
         if case == "quantised_depths":
@@ -209,8 +209,7 @@ def test_depth_sort_paths(cuda_device, case):
         else:
             src = torch.randperm(raw.num, generator=torch.Generator().manual_seed(1))[:400]
             raw.xyz[src[:200], 2] = raw.xyz[src[200:], 2]
-        for _ in range(3):  # (arrival order varies from run to run)
-            rep = _run(raw, scenes.identity_camera(192, 192, 60.0))
+        rep = _run(raw, scenes.identity_camera(192, 192, 60.0))
         assert rep["V"] > 100_000
         return
     n = {"all_equal_depth": 20_000, "two_depths": 9_000, "tiny": 3}[case]
