@@ -160,7 +160,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
                 const float q = fma_(r1.z * dy, dy, (r1.x * dx) * dx);
                 const float power = fma_(-(r1.y * dx), dy, -0.5f * q);
                 if (power <= 0.0f) {
-                    const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                    const float G = gsr_exp_power(power);
                     const float alpha = fminf(0.99f, r1.w * G);
                     if (alpha >= 1.0f / 255.0f) {
                         hit = true;

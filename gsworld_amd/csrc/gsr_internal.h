@@ -271,6 +271,26 @@ __device__ __forceinline__ float exp_canonical(float x) {
     return __builtin_ldexpf(y, (int)n);
 }
 
+// exp(power) of the compositors (forward and backward evaluate the same value).  The hardware transcendental works in
+// base 2: t = power * log2(e) is rounded once (relative 2^-24 of |t|, i.e. up to ~3 ulp of the result at |t| ~ 8) before
+// v_exp_f32 adds its own ~1 ulp.  -DGSR_EXP_ACCURATE=1 recovers the rounding of t -- e = fma(power, L, -t) + power * L_lo
+// is the exact residual, exp2(t + e) = exp2(t) (1 + e ln 2) -- which leaves v_exp_f32's own error only.
+#ifndef GSR_EXP_ACCURATE
+#define GSR_EXP_ACCURATE 0
+#endif
+__device__ __forceinline__ float gsr_exp_power(float power) {
+    constexpr float L = 1.4426950408889634f;
+    const float t = power * L;
+#if GSR_EXP_ACCURATE
+    constexpr float L_lo = (float)(1.4426950408889634073599246810019 - (double)1.4426950408889634f);
+    const float e = __builtin_fmaf(power, L_lo, __builtin_fmaf(power, L, -t));
+    const float x = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(x * 0.6931471805599453f, e, x);
+#else
+    return __builtin_amdgcn_exp2f(t);
+#endif
+}
+
 // sigmoid of the raw-parameter path (forward and backward use the same value)
 __device__ __forceinline__ float sigmoid_canonical(float x) { return 1.0f / (1.0f + exp_canonical(-x)); }
 #endif

@@ -259,7 +259,19 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                 if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
                 const float opacity = opacity_in * h_scale;
                 float4 *rec = a.splat + 3 * (size_t)i;
-                rec[0] = make_float4(pix_x, pix_y, vz, 1.0f / vz);
+                float third = vz;
+                if (a.infer) {
+                    // inference frames: the compositor never reads the depth word of the record; it carries what its
+                    // per-quadrant cull would otherwise recompute for every candidate of every quadrant (render.hip
+                    // quadrant_may_hit): tau = -ln(255 opacity), lowered by ~2 ulp (the cull may only err towards
+                    // keeping), with the "conic is comfortably positive definite" flag in its last mantissa bit
+                    const float tau = -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opacity);
+                    const float low = tau - fma_(2e-7f, fabsf(tau), 1e-30f);
+                    const float ac = conic_x * conic_z;
+                    const bool safe = conic_x > 0.0f && conic_z > 0.0f && ac > 1e-20f && conic_y * conic_y <= 0.999f * ac;
+                    third = __uint_as_float((__float_as_uint(low) & ~1u) | (safe ? 1u : 0u));
+                }
+                rec[0] = make_float4(pix_x, pix_y, third, 1.0f / vz);
                 rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
                 if (!a.infer) {  // (the 3D covariance is kept for the backward only)
                     float2 *cv = reinterpret_cast<float2 *>(a.cov3D + 6 * (size_t)i);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_kernel(const uint2 *__restri
             const float q = fma_(r1.z * dy, dy, (r1.x * dx) * dx);
             const float power = fma_(-(r1.y * dx), dy, -0.5f * q);
             if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, r1.w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+            const float alpha = fminf(0.99f, r1.w * gsr_exp_power(power));
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1.0f - alpha);
             if (test_T < 0.0001f) {
@@ -136,13 +136,15 @@ constexpr int kBatch = 4;
 // of the per-pixel evaluation (a few ulps of the largest term), and a conic that is not positive definite in
 // float is never culled.  A culled instance is one every pixel of the quadrant would have skipped (alpha < 1/255),
 // so the image, final_T and n_contrib are bit-identical with and without the test.
+template <bool HAVE_TAU = false>
 __device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float4 q, float x0, float y0,
-                                                 float yext = 7.0f) {
+                                                 float yext = 7.0f, float tau_in = 0.0f) {
     const float A = q.x, B = q.y, C = q.z;
     // the same subtractions the corner pixels perform: every pixel's rounded offset lies in [dxl, dxh] x [dyl, dyh]
     const float dxh = cx - x0, dxl = cx - (x0 + 7.0f);
     const float dyh = cy - y0, dyl = cy - (y0 + yext);  // (yext = rows - 1: 7 for a quadrant, 3 for half of one)
-    const float tau = -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * q.w);  // opacity 0 -> +inf
+    // opacity 0 -> +inf.  HAVE_TAU: computed once per Gaussian by preprocess (inference frames), a hair lower
+    const float tau = HAVE_TAU ? tau_in : -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * q.w);
     const float ex = fminf(fmaxf(0.0f, dxl), dxh);
     const float ey = fminf(fmaxf(0.0f, dyl), dyh);
     const float sy = fminf(fmaxf(-(B * ex) * __builtin_amdgcn_rcpf(C), dyl), dyh);
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
                     const float dx = c0[k].x - pfx, dy = c0[k].y - pfy;
                     const float q = fma_(c1[k].z * dy, dy, (c1[k].x * dx) * dx);
                     const float power = fma_(-(c1[k].y * dx), dy, -0.5f * q);
-                    alpha[k] = fminf(0.99f, c1[k].w * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+                    alpha[k] = fminf(0.99f, c1[k].w * gsr_exp_power(power));
                     valid[k] = power <= 0.0f && alpha[k] >= 1.0f / 255.0f;
                     any |= __builtin_amdgcn_ballot_w64(valid[k]);
                 }
@@ -361,7 +363,7 @@ __device__ __forceinline__ bool stream_conic_is_safe(const float4 conic_op) {
 
 // CHECK_POWER = false: every survivor of the round has a comfortably positive definite conic (stream_conic_is_safe), for
 // which the computed power cannot come out positive -- the `power <= 0` half of the validity test is then dropped.
-template <bool CHECK_POWER>
+template <bool CHECK_POWER, bool TRACK>
 __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int i, v2f pf2x, v2f pf2y) {
     StreamBatch b;
 #pragma unroll
@@ -370,14 +372,23 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
         const float4 qxy = pr[0], qac = pr[1], qbo = pr[2];
         b.col[2 * h] = pr[3];
         b.col[2 * h + 1] = pr[4];
-        const float2 qpos = *reinterpret_cast<const float2 *>(pr + 5);
+        const float2 qpos = TRACK ? *reinterpret_cast<const float2 *>(pr + 5) : make_float2(0.f, 0.f);
         const v2f dx = v2f{qxy.x, qxy.y} - pf2x, dy = v2f{qxy.z, qxy.w} - pf2y;
         const v2f cA = {qac.x, qac.y}, cC = {qac.z, qac.w};
         const v2f cB = {qbo.x, qbo.y}, op = {qbo.z, qbo.w};
         const v2f q = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);   // = -0.5 (A dx^2 + C dy^2): pre-scaled
         const v2f power = __builtin_elementwise_fma(cB * dx, dy, q);             // cB = -B
-        const v2f pe = power * v2f{1.4426950408889634f, 1.4426950408889634f};
+        // (gsr_exp_power of gsr_internal.h, two survivors per packed instruction: the same operations per element)
+        const v2f kL = {1.4426950408889634f, 1.4426950408889634f};
+        const v2f pe = power * kL;
+#if GSR_EXP_ACCURATE
+        constexpr float L_lo = (float)(1.4426950408889634073599246810019 - (double)1.4426950408889634f);
+        const v2f e = __builtin_elementwise_fma(power, v2f{L_lo, L_lo}, __builtin_elementwise_fma(power, kL, -pe));
+        const v2f x = {__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
+        const v2f a = op * __builtin_elementwise_fma(x * v2f{0.6931471805599453f, 0.6931471805599453f}, e, x);
+#else
         const v2f a = op * v2f{__builtin_amdgcn_exp2f(pe.x), __builtin_amdgcn_exp2f(pe.y)};
+#endif
         const float a0 = fminf(0.99f, a.x), a1 = fminf(0.99f, a.y);
         b.valid[2 * h] = (!CHECK_POWER || power.x <= 0.0f) && a0 >= 1.0f / 255.0f;
         b.valid[2 * h + 1] = (!CHECK_POWER || power.y <= 0.0f) && a1 >= 1.0f / 255.0f;
@@ -389,6 +400,8 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
     return b;
 }
 
+// TRACK = false (inference frames): n_contrib is not written, so the last contributor is not tracked either
+template <bool TRACK>
 __device__ __forceinline__ void stream_blend(const StreamBatch &b, float &T, v2f &acc_rg, v2f &acc_bd, uint32_t &last) {
 #pragma unroll
     for (int k = 0; k < kBatch; k++) {
@@ -398,7 +411,7 @@ __device__ __forceinline__ void stream_blend(const StreamBatch &b, float &T, v2f
         const float w = stop ? 0.0f : b.alpha[k] * T;
         acc_rg = __builtin_elementwise_fma(v2f{b.col[k].x, b.col[k].y}, v2f{w, w}, acc_rg);
         acc_bd = __builtin_elementwise_fma(v2f{b.col[k].z, b.col[k].w}, v2f{w, w}, acc_bd);
-        last = (b.valid[k] && !stop) ? __float_as_uint(b.pos[k]) : last;
+        if (TRACK) last = (b.valid[k] && !stop) ? __float_as_uint(b.pos[k]) : last;
         T = stop ? -fabsf(T) : test_T;
     }
 }
@@ -555,9 +568,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                     keep = keep && tx - (rb & 255u) < ((rb >> 16) & 255u) - (rb & 255u) &&
                            ty - ((rb >> 8) & 255u) < (rb >> 24) - ((rb >> 8) & 255u);
                 }
-                keep = keep && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext);
+                if (SUPER) {  // tau and the safe-conic flag come with the record (preprocess.hip)
+                    keep = keep && quadrant_may_hit<true>(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext, f0[s].z);
+                    unsafe |= __builtin_amdgcn_ballot_w64(keep && (__float_as_uint(f0[s].z) & 1u) == 0u);
+                } else {
+                    keep = keep && quadrant_may_hit(f0[s].x, f0[s].y, f1[s], qxf, qyf, yext);
+                    unsafe |= __builtin_amdgcn_ballot_w64(keep && !stream_conic_is_safe(f1[s]));
+                }
                 const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
-                unsafe |= __builtin_amdgcn_ballot_w64(keep && !stream_conic_is_safe(f1[s]));
                 const int rank = n_surv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 if (keep)
@@ -595,16 +613,16 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                 // six v_mov per iteration)
                 int i = 0;
                 if (n_surv > 0) do {
-                    const StreamBatch b = stream_eval<false>(list, i, pf2x, pf2y);
-                    stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                    const StreamBatch b = stream_eval<false, !SUPER>(list, i, pf2x, pf2y);
+                    stream_blend<!SUPER>(b, T, acc_rg, acc_bd, last_contributor);
                     work += (uint32_t)kBatch;  // survivors actually replayed (a saturated quadrant stops early)
                     i += kBatch;
                 } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);
             } else {
                 int i = 0;
                 if (n_surv > 0) do {
-                    const StreamBatch b = stream_eval<true>(list, i, pf2x, pf2y);
-                    stream_blend(b, T, acc_rg, acc_bd, last_contributor);
+                    const StreamBatch b = stream_eval<true, !SUPER>(list, i, pf2x, pf2y);
+                    stream_blend<!SUPER>(b, T, acc_rg, acc_bd, last_contributor);
                     work += (uint32_t)kBatch;
                     i += kBatch;
                 } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""exp() at the compositing thresholds: for the 8 scenes of BASELINE configs[3] at 200 k
+Gaussians and the two headline configurations, how far is the HIP image from the oracle's on EVERY pixel (borderline
+ones included), how many pixels exceed 1e-4, how many pixels does the oracle flag as borderline.  Run once per library
+build (-DGSR_EXP_ACCURATE=0 / 1).  GPU.  usage: exp_parity.py [--json out]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gsworld_amd import scenes  # noqa: E402
+from tests import helpers as hp  # noqa: E402
+
+rows = {}
+cases = [(n, scenes.tabletop_scene(n, n=200_000, seed=1 + i), scenes.sensor_camera(n)) for i, n in enumerate(scenes.SCENE_NAMES)]
+cases.append(("configs[0]", scenes.random_scene_camera_frame(100_000, seed=0), scenes.identity_camera(256, 256, 60.0)))
+if "--full" in sys.argv:
+    cases.append(("configs[1]", scenes.tabletop_scene("xarm6_align"), scenes.sensor_camera("xarm6_align")))
+for name, raw, cam in cases:
+    inp, st = hp.np_inputs(raw, cam), hp.oracle_settings(cam)
+    bg = np.zeros(3, np.float32)
+    o = hp.oracle_forward(inp, st, bg)
+    g = hp.gpu_forward(inp, st, bg)
+    d = np.abs(g["color"] - o["color"]).max(0)
+    border = o["borderline"] != 0
+    rows[name] = dict(all_pixel_max=float(d.max()), pixels_gt_1e4=int((d > 1e-4).sum()), borderline=int(border.sum()),
+                      off_borderline_max=float(d[~border].max()),
+                      n_contrib_differ=int((g["views"]["n_contrib"] != o["n_contrib"]).sum()))
+    print(name, rows[name], flush=True)
+if "--json" in sys.argv:
+    json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
