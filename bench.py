@@ -89,7 +89,7 @@ def main():
     K_g = max(1, args.gather_every)
     K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
     fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1,
-                        collective=args.collective)
+                        collective=args.collective, timing=world > 1)
     n_slots = fg.num_slots
     # inference frames (GsrSettings.forward_only): GSWorld's loop keeps ["render"] only (gs_world_wrapper.py:266-270) --
     # nothing a backward would read is written, instances are binned per 2 x 1 super-tile; the image is bit-identical
@@ -282,6 +282,11 @@ def main():
                 "frame_gather": (f"RCCL {args.collective} of uint8 frames every {K_g} frames "
                                  f"(backend {dist.get_backend()}, {dist.get_world_size()} ranks)") if world > 1 else "none",
                 "world_size": world,
+                # N > 1: which collective library ran, how long a gather of one batch took on its side stream (HIP
+                # events) and whether any render stream depended on a collective younger than two batches
+                "collective_library": gd.rccl_info() if world > 1 else None,
+                "gather_ms_per_batch": fg.gather_time_ms() if world > 1 else None,
+                "render_waited_on_batches_back": sorted({(i // K_g) - b for i, b, _ in fg.waits}) if world > 1 else None,
                 # every rank's own rate over the same K steps: sum ~ value when no rank is a straggler, and rank 0's
                 # figure is directly comparable with the N = 1 run
                 "per_rank_frames_per_s": [args.steps / t for t in per_rank],

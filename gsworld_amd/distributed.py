@@ -8,6 +8,8 @@ that the gather of batch b overlaps the rendering of batch b+1.
 from __future__ import annotations
 
 import os
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import torch.distributed as dist
@@ -33,6 +35,18 @@ def init_from_env(device: torch.device | None = None):
     return rank, world, local_rank
 
 
+def rccl_info() -> dict:
+    """What the N > 1 bench line reports about the collective library (RCCL is torch's "nccl" backend on ROCm)."""
+    info = {"backend": dist.get_backend() if dist.is_initialized() else None,
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1}
+    try:
+        info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as ex:  # noqa: BLE001
+        info["rccl_version"] = f"unavailable ({type(ex).__name__})"
+    info["hip"] = getattr(torch.version, "hip", None)
+    return info
+
+
 def scene_for_rank(rank: int, names) -> tuple[str, int]:
     """rank r renders scene r (mod the number of configured scenes) with seed r + 1."""
     return names[rank % len(names)], 1 + rank
@@ -54,7 +68,13 @@ class FrameGather:
     :attr:`gathered`."""
 
     def __init__(self, height: int, width: int, batch: int = 16, device="cpu", world: int | None = None,
-                 buffers: int = 1, collective: str = "gather", dst: int = 0):
+                 buffers: int = 1, collective: str = "gather", dst: int = 0, background: bool = False,
+                 timing: bool = False):
+        """``background`` (host tensors only): the collective of a full batch runs on a worker thread, the CPU
+        counterpart of the GPU path's side stream -- the caller goes on filling the other half and only
+        :meth:`wait_reusable` / :meth:`wait_gathered` block (what the scheduling tests exercise).  ``timing``: record
+        how long every collective took (:attr:`gather_ms`; HIP events on the side stream, wall clock on the host) and
+        how long callers were held in :meth:`wait_reusable` (:attr:`waits`)."""
         if collective not in ("gather", "all_gather"):
             raise ValueError("collective must be 'gather' or 'all_gather'")
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
@@ -72,8 +92,14 @@ class FrameGather:
         self.gathered = self._gathered[0]  # result of the most recent gather (this rank's own frames if it is not a receiver)
         self.stream = torch.cuda.Stream(self.device) if (self.world > 1 and self.device.type == "cuda") else None
         self._done = [None] * self.buffers  # event after the collective that last read half b
+        self._done_batch = [None] * self.buffers  # ... and which batch that was
         self._last = None  # event of the most recent collective (what `gathered` waits for)
         self.num_gathers = 0
+        self.timing = bool(timing)
+        self.gather_ms = []      # per collective (timing=True)
+        self._timers = []        # (start event, end event) pairs not yet read (GPU)
+        self.waits = []          # (step, batch waited for, seconds blocked) of every wait_reusable that found a collective
+        self._pool = ThreadPoolExecutor(1) if (background and self.device.type != "cuda" and self.world > 1) else None
 
     def _half(self, b: int) -> torch.Tensor:
         return self.frames if self.buffers == 1 else self.frames[b * self.batch:(b + 1) * self.batch]
@@ -86,18 +112,48 @@ class FrameGather:
         """Frame buffer that step ``i`` renders / packs into."""
         return self.frames[i % self.num_slots]
 
-    def wait_reusable(self, i: int, stream=None) -> None:
-        """Makes ``stream`` (default: current) wait until the collective that last read step ``i``'s half has finished."""
-        ev = self._done[(i // self.batch) % self.buffers]
-        if ev is not None:
+    def wait_reusable(self, i: int, stream=None):
+        """Makes ``stream`` (default: current) wait until the collective that last read step ``i``'s half has finished.
+        Returns the index of the batch whose collective it depended on (None: nothing to wait for) -- with ``buffers``
+        halves that is always the batch ``buffers`` batches before step ``i``'s own, never the one just issued."""
+        h = (i // self.batch) % self.buffers
+        ev = self._done[h]
+        if ev is None:
+            return None
+        if hasattr(ev, "result"):  # host path with a worker thread
+            t0 = time.perf_counter()
+            ev.result()
+            self.waits.append((i, self._done_batch[h], time.perf_counter() - t0))
+        else:
             (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(ev)
+            self.waits.append((i, self._done_batch[h], 0.0))  # (a stream dependency: the host is never blocked)
+        return self._done_batch[h]
 
     def wait_gathered(self, stream=None) -> torch.Tensor:
         """Makes ``stream`` (default: current) wait for the most recent collective and returns :attr:`gathered`: the
         collective runs on a side stream, so a consumer must call this before it reads the frames."""
         if self._last is not None:
-            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._last)
+            if hasattr(self._last, "result"):
+                self._last.result()
+            else:
+                (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._last)
         return self.gathered
+
+    def gather_time_ms(self):
+        """Mean / max duration of the collectives issued so far (``timing=True``; synchronises the side stream)."""
+        for e0, e1 in self._timers:
+            e1.synchronize()
+            self.gather_ms.append(e0.elapsed_time(e1))
+        self._timers = []
+        if not self.gather_ms:
+            return None
+        return {"mean": sum(self.gather_ms) / len(self.gather_ms), "max": max(self.gather_ms), "count": len(self.gather_ms)}
+
+    def _timed_collective(self, dst_buf, src):
+        t0 = time.perf_counter()
+        self._collective(dst_buf, src)
+        if self.timing:
+            self.gather_ms.append(1e3 * (time.perf_counter() - t0))
 
     def _collective(self, dst_buf: torch.Tensor, src: torch.Tensor) -> None:
         if self.device.type == "cuda" and dist.get_backend() == "gloo":
@@ -131,15 +187,28 @@ class FrameGather:
                 cur = torch.cuda.current_stream(self.device)
                 self.stream.wait_stream(cur)
                 with torch.cuda.stream(self.stream):
+                    if self.timing:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record(self.stream)
                     self._collective(dst_buf, src)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=self.timing)
                     ev.record(self.stream)
+                    if self.timing:
+                        self._timers.append((e0, ev))
                 self._done[b] = ev
+                self._done_batch[b] = i // self.batch
                 self._last = ev
                 if self.buffers == 1:
                     cur.wait_stream(self.stream)  # the next batch overwrites the same slots
+            elif self._pool is not None:
+                fut = self._pool.submit(self._timed_collective, dst_buf, src)
+                self._done[b] = fut
+                self._done_batch[b] = i // self.batch
+                self._last = fut
+                if self.buffers == 1:
+                    fut.result()
             else:
-                self._collective(dst_buf, src)
+                self._timed_collective(dst_buf, src)
         self.gathered = dst_buf
         self.num_gathers += 1
         return True

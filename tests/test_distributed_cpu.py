@@ -70,3 +70,62 @@ def test_single_process_gather_is_identity():
     fg.slot(1).fill_(2)
     assert fg.step_done(1) and fg.gathered is fg.frames and fg.num_gathers == 1
     assert gd.scene_for_rank(9, scenes.SCENE_NAMES) == ("xarm6_rot_banana", 10)
+
+
+def _sched_worker(rank, world, port, q, collective_s, frame_s):
+    import time
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    gd.init_from_env(torch.device("cpu"))
+    K, B = 4, 6
+    fg = gd.FrameGather(6, 8, batch=K, device="cpu", buffers=2, collective="gather", background=True, timing=True)
+    real = fg._collective
+
+    def slow(dst_buf, src):  # a collective that takes `collective_s` on the wire
+        time.sleep(collective_s)
+        real(dst_buf, src)
+
+    fg._collective = slow
+    deps, t0 = [], time.perf_counter()
+    for i in range(K * B):
+        if i % K == 0:
+            deps.append((i // K, fg.wait_reusable(i)))  # first frame of a batch: its half must be free again
+        time.sleep(frame_s)                              # "render" the frame
+        fg.slot(i).fill_((10 * rank + i) % 256)
+        fg.step_done(i)
+    loop_s = time.perf_counter() - t0
+    last = fg.wait_gathered().clone()
+    torch.distributed.barrier()
+    q.put((rank, deps, loop_s, sum(w for _, _, w in fg.waits), fg.gather_time_ms(), last[:, 0, 0, 0].tolist()))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective_s,frame_s,expect_blocked", [(0.03, 0.012, False), (0.10, 0.012, True)])
+def test_render_loop_only_depends_on_the_collective_two_batches_back(collective_s, frame_s, expect_blocked):
+    """SURVEY.md 8e / DESIGN 6: frames are gathered a batch at a time on a side channel (a HIP stream on the GPU, a worker
+    thread in this host-side test) from double-buffered slots.  With an injected slow collective: the loop that renders
+    batch b only ever depends on the collective of batch b - 2 (never on the one just issued), so a collective that
+    fits inside a batch's render time costs the loop nothing; a slower one holds it back by the excess only."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sched_worker, args=(r, world, port, q, collective_s, frame_s)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    K, B = 4, 6
+    for rank, deps, loop_s, blocked_s, gms, last in out:
+        assert deps[0] == (0, None) and deps[1] == (1, None)          # both halves are fresh
+        assert deps[2:] == [(b, b - 2) for b in range(2, B)]          # always the batch two back
+        assert gms["count"] >= B - 1 and gms["mean"] >= 1e3 * collective_s
+        render_s = K * B * frame_s
+        if not expect_blocked:  # collective (30 ms) < batch (48 ms): the loop never waits for it
+            assert blocked_s < 0.02 and loop_s < render_s + 0.08, (loop_s, blocked_s)
+        else:                   # collective (100 ms) > batch (48 ms): held back by the excess, not by the whole collective
+            assert blocked_s > 0.05
+            assert loop_s < B * collective_s + render_s / B + 0.15, (loop_s, blocked_s)
+    assert out[0][5] == [20, 21, 22, 23, 30, 31, 32, 33]  # root holds both ranks' last batch
