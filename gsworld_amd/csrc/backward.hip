@@ -99,6 +99,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     const int px = tile_x * GSR_TILE + lx, py = tile_y * GSR_TILE + ly;
     const bool inside = px < W && py < H;
     const float pfx = (float)px, pfy = (float)py;
+    const float qxf = (float)(tile_x * GSR_TILE + ((wave & 1) << 3)), qyf = (float)(tile_y * GSR_TILE + ((wave >> 1) << 3));
     const size_t pid = (size_t)py * W + px;
     const size_t plane = (size_t)H * W;
 
@@ -148,7 +149,23 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
         for (int c = 0; c < kGradRec; c++) s_grad[c * GSR_BLOCK + threadIdx.x] = 0.f;
         __syncthreads();
         const int cnt = min(GSR_BLOCK, n_inst - rd * GSR_BLOCK);
-        for (int j = 0; j < cnt; j++) {
+        // The forward's per-quadrant cull applies unchanged: an instance that cannot reach alpha >= 1/255 on any pixel
+        // of this wave's 8 x 8 quadrant is one every lane would skip below, and ~6 of 7 staged instances are of that
+        // kind.  64 of them are tested at a time (one per lane), then only the survivors are walked, in order.
+        for (int j0 = 0; j0 < cnt; j0 += GSR_WAVE) {
+        uint64_t todo;
+        {
+            const int jj = j0 + lane;
+            bool may = jj < cnt;
+            if (may) {
+                const float4 c0 = s_rec0[jj];
+                may = quadrant_may_hit(c0.x, c0.y, s_rec1[jj], qxf, qyf);
+            }
+            todo = __builtin_amdgcn_ballot_w64(may);
+        }
+        while (todo != 0ull) {
+            const int j = j0 + (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
             const uint32_t contributor = (uint32_t)(n_inst - 1 - (rd * GSR_BLOCK + j));  // 0-based position
             float g_mx = 0.f, g_my = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f,
                   g_b = 0.f, g_d = 0.f;
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             const float gv[kGrad] = {g_mx, g_my, g_cxx, g_cxy, g_cyy, g_op, g_r, g_g, g_b, g_d};
             const float total = wave_reduce10(gv);
             if (my_comp >= 0) atomicAdd(&s_grad[j * kGradRec + my_comp], total);  // LDS: at most 4 waves per address
+        }
         }
         __syncthreads();
         // flush: ONE device-scope atomic per (tile, instance, component), issued TRANSPOSED -- twelve consecutive lanes

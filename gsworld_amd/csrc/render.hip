@@ -126,41 +126,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_kernel(const uint2 *__restri
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBatch = 4;
 
-// Can instance (centre, conic|opacity) reach alpha >= 1/255 on ANY pixel of the 8x8 quadrant whose first pixel is
-// (x0, y0)?  alpha >= 1/255 <=> power >= tau = -ln(255 * opacity), and power(d) = -(A dx^2 + C dy^2)/2 - B dx dy is
-// concave in d = centre - pixel, so its maximum over the quadrant's (continuous) rectangle of offsets is at
-// d = 0 when the centre is inside, otherwise on an edge facing the centre; on an edge it is a 1-D concave
-// parabola whose maximiser is the clamped stationary point.  Evaluating both the dx = clamp(0) line and the
-// dy = clamp(0) line covers every case (extra candidates are points of the rectangle, they cannot exceed the
-// true maximum).  The answer must never be a false "no": the slack covers the float rounding of this bound and
-// of the per-pixel evaluation (a few ulps of the largest term), and a conic that is not positive definite in
-// float is never culled.  A culled instance is one every pixel of the quadrant would have skipped (alpha < 1/255),
-// so the image, final_T and n_contrib are bit-identical with and without the test.
-template <bool HAVE_TAU = false>
-__device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float4 q, float x0, float y0,
-                                                 float yext = 7.0f, float tau_in = 0.0f) {
-    const float A = q.x, B = q.y, C = q.z;
-    // the same subtractions the corner pixels perform: every pixel's rounded offset lies in [dxl, dxh] x [dyl, dyh]
-    const float dxh = cx - x0, dxl = cx - (x0 + 7.0f);
-    const float dyh = cy - y0, dyl = cy - (y0 + yext);  // (yext = rows - 1: 7 for a quadrant, 3 for half of one)
-    // opacity 0 -> +inf.  HAVE_TAU: computed once per Gaussian by preprocess (inference frames), a hair lower
-    const float tau = HAVE_TAU ? tau_in : -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * q.w);
-    const float ex = fminf(fmaxf(0.0f, dxl), dxh);
-    const float ey = fminf(fmaxf(0.0f, dyl), dyh);
-    const float sy = fminf(fmaxf(-(B * ex) * __builtin_amdgcn_rcpf(C), dyl), dyh);
-    const float sx = fminf(fmaxf(-(B * ey) * __builtin_amdgcn_rcpf(A), dxl), dxh);
-    const float f1 = fma_(-B * ex, sy, -0.5f * fma_(C * sy, sy, (A * ex) * ex));
-    const float f2 = fma_(-B * sx, ey, -0.5f * fma_(C * ey, ey, (A * sx) * sx));
-    const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
-    const float mag = fma_(A * mx, mx, fma_(C * my, my, 2.0f * fabsf(B) * mx * my));
-    const float slack = fma_(4e-6f, mag, 1e-4f);
-    const bool concave = A > 0.0f && C > 0.0f && A * C > B * B * 1.00001f;
-    const bool miss = fmaxf(f1, f2) < tau - slack;  // false on NaN
-    // opacity < 1/255: alpha = opacity * exp(power <= 0) <= opacity can never pass (a NaN opacity is not culled:
-    // fminf(0.99, NaN) = 0.99 composites, as it does upstream)
-    return !(q.w < 1.0f / 255.0f || (concave && miss));
-}
-
 template <bool CULL>
 __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__restrict__ ranges,
                                                                  const uint32_t *__restrict__ point_list,

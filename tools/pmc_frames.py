@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 raw = scenes.tabletop_scene("xarm6_align")
 cam = scenes.sensor_camera("xarm6_align").to(dev)
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
-r = FrameRenderer(dev)
+r = FrameRenderer(dev, forward_only=True, want_radii=False)  # the frame bench.py times (inference frame)
 L = lib()
 dbg.set_render_variant(variant, bpc)
 for _ in range(frames):
