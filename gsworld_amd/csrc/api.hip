@@ -171,15 +171,6 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     }
 
     const int tiles_x = gsr_div_up(W, GSR_TILE);
-    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles, tiles_x));
-    char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
-    if (!geom_mem || !img_mem) {
-        gsr_set_error("gsr_forward: resize callback returned NULL");
-        return GSR_E_ALLOC;
-    }
-    const GeomState g = GeomState::carve(geom_mem, in->P, tiles, nullptr, tiles_x);
-    const ImageState img = ImageState::carve(img_mem, W, H);
-
     // binning path: 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
     // (tile grids above GSR_MAX_COUNT_TILES, or wider than 2048 tiles -- one band row of counters must fit 64 KiB of
     // LDS -- always take 0)
@@ -192,17 +183,27 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const bool band = mode == 1 && (st->binning_path == 0 || (st->binning_path == 4 && !chunk)) &&
                       gsr_band_supported(tiles_x);
     const bool exact = r_capacity <= 0;
-    // inference frames (GsrSettings.forward_only): binned per 2 x 2 super-tile on the default path; the binning kernels
-    // take their grid from a settings copy whose image is the super-tile grid
+    // inference frames (GsrSettings.forward_only): binned per super-tile on the default path; the binning kernels take
+    // their grid from a settings copy whose image is the super-tile grid
     const int tiles_y = tiles / tiles_x;
     const bool infer = st->forward_only != 0;
     const bool super = infer && (band || chunk) && st->depth_sort != 1 && st->render_variant == 0 && tiles_x <= 255 &&
                        tiles_y <= 255;
+    // (the chunk placement keeps its table in an array the lean layout drops)
+    const bool lean = super && !chunk;
     GsrSettings st_bin = *st;
     if (super) {
         st_bin.image_width = gsr_div_up(tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
         st_bin.image_height = gsr_div_up(tiles_y, 1 << GSR_SUPER_SY) * GSR_TILE;
     }
+    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles, tiles_x, lean));
+    char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
+    if (!geom_mem || !img_mem) {
+        gsr_set_error("gsr_forward: resize callback returned NULL");
+        return GSR_E_ALLOC;
+    }
+    const GeomState g = GeomState::carve(geom_mem, in->P, tiles, nullptr, tiles_x, lean);
+    const ImageState img = ImageState::carve(img_mem, W, H);
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
     const bool order_early = (band || chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
     // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
@@ -264,12 +265,14 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             stats->overflow = 0;
         }
     }
-    char *bin_mem = buf->binning_resize(buf->binning_user, BinningState::required(cap));
+    // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
+    const bool lean_bin = band || chunk;
+    char *bin_mem = buf->binning_resize(buf->binning_user, BinningState::required(cap, lean_bin));
     if (!bin_mem) {
         gsr_set_error("gsr_forward: binning resize callback returned NULL");
         return GSR_E_ALLOC;
     }
-    const BinningState b = BinningState::carve(bin_mem, cap);
+    const BinningState b = BinningState::carve(bin_mem, cap, nullptr, lean_bin);
     if (mode == 2) {
         if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
     } else if (chunk) {

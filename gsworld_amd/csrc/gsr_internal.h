@@ -124,32 +124,35 @@ struct GeomState {
         const int rows = tiles / tiles_x, padded = tiles_x <= 64 ? 64 : (tiles_x <= 128 ? 128 : 256);
         return (size_t)rows * GSR_BAND_RANGES * 4 * padded;
     }
-    static GeomState carve(char *base, int32_t P, int tiles, size_t *bytes = nullptr, int tiles_x = 0) {
+    // lean (inference frames, GsrSettings.forward_only on the default path): the arrays only a backward or a fallback
+    // placement reads are not carved -- 62 % of the state at config 2 (157 of 253 MB; a closed loop keeps one state per
+    // environment x camera).  A lean state is no input for gsr_backward / gsr_state_view.
+    static GeomState carve(char *base, int32_t P, int tiles, size_t *bytes = nullptr, int tiles_x = 0, bool lean = false) {
         GeomState g;
         char *p = base;
-        const size_t n = (size_t)(P > 0 ? P : 1);
+        const size_t n = (size_t)(P > 0 ? P : 1), nf = lean ? 0 : n;
         g.hdr = take<GsrHeader>(p, 1);
         // GSR_BIN_SLOTS copies of each per-tile counter: workgroup b uses copy b % GSR_BIN_SLOTS, which divides the
         // same-address contention of the device-scope atomics (they resolve memory-side, ~100 ns apiece) by 16
         g.tile_accum = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles * GSR_BIN_SLOTS : 0) + 1);
         g.tile_cursor = take<uint32_t>(p, (counting(tiles) ? (size_t)tiles * GSR_BIN_SLOTS : 0) + 1);
         g.splat = take<float4>(p, 3 * n);
-        g.cov3D = take<float>(p, 6 * n);
-        g.clamped = take<uint32_t>(p, n);
-        g.grad_rec = take<float>(p, 12 * n);
-        g.tiles_touched = take<uint32_t>(p, n);
+        g.cov3D = take<float>(p, 6 * nf);
+        g.clamped = take<uint32_t>(p, nf);
+        g.grad_rec = take<float>(p, 12 * nf);
+        g.tiles_touched = take<uint32_t>(p, nf);
         g.rects = take<uint2>(p, n);
         g.block_counts = take<uint32_t>(p, (size_t)prep_blocks(P) + 1);
         g.pair[0] = take<uint2>(p, n);
         g.pair[1] = take<uint2>(p, n);
         g.order = take<uint32_t>(p, n);
-        g.sort_table = take<uint32_t>(p, (size_t)GSR_DEPTH_RADIX_BINS * sort_blocks(P));
+        g.sort_table = take<uint32_t>(p, lean ? 0 : (size_t)GSR_DEPTH_RADIX_BINS * sort_blocks(P));
         g.sort_totals = take<uint32_t>(p, GSR_DEPTH_RADIX_BINS);
         g.tile_bsum = take<uint32_t>(p, (size_t)sort_blocks(P) + 1);
         const size_t tt = counting(tiles) ? (size_t)tiles : 0;
-        g.tile_table = take<uint32_t>(p, tt * prep_blocks(P) + 1);
+        g.tile_table = take<uint32_t>(p, (lean ? 0 : tt * prep_blocks(P)) + 1);
         g.tile_totals = take<uint32_t>(p, tt + 1);
-        g.vis_key = take<uint32_t>(p, n);
+        g.vis_key = take<uint32_t>(p, nf);  // (unused since the block-local records of preprocess)
         g.block_cand = take<uint32_t>(p, (size_t)prep_blocks(P));
         g.ss_table = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) * gsr_ss_bmax(P));
         g.ss_splitters = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
@@ -170,9 +173,9 @@ struct GeomState {
         if (bytes) *bytes = (size_t)(p - base);
         return g;
     }
-    static size_t required(int32_t P, int tiles, int tiles_x = 0) {
+    static size_t required(int32_t P, int tiles, int tiles_x = 0, bool lean = false) {
         size_t bytes = 0;
-        carve(nullptr, P, tiles, &bytes, tiles_x);
+        carve(nullptr, P, tiles, &bytes, tiles_x, lean);
         return bytes;
     }
 };
@@ -186,23 +189,26 @@ struct BinningState {
     uint64_t *keys64;      // [Rcap] (depth bits << 32 | Gaussian index) per instance, grouped by tile, unsorted
 
     static int sort_blocks(int64_t rcap) { return gsr_div_up(rcap > 0 ? rcap : 1, GSR_SORT_CHUNK); }
-    static BinningState carve(char *base, int64_t rcap, size_t *bytes = nullptr) {
+    // gidx[0] -- the point list every path ends in -- comes first, so that a view of the state finds it whatever was
+    // carved behind it.  lean: nothing else (the counting placements write the list in place; the keys, tile ids and
+    // ping-pong sides only serve the radix / bin-then-sort fallbacks): 4 instead of 24 bytes per instance.
+    static BinningState carve(char *base, int64_t rcap, size_t *bytes = nullptr, bool lean = false) {
         BinningState b;
         char *p = base;
-        const size_t n = (size_t)(rcap > 0 ? rcap : 1);
-        b.keys64 = GeomState::take<uint64_t>(p, n);
-        b.tile[0] = GeomState::take<uint32_t>(p, n);
-        b.tile[1] = GeomState::take<uint32_t>(p, n);
+        const size_t n = (size_t)(rcap > 0 ? rcap : 1), nf = lean ? 0 : n;
         b.gidx[0] = GeomState::take<uint32_t>(p, n);
-        b.gidx[1] = GeomState::take<uint32_t>(p, n);
-        b.sort_table = GeomState::take<uint32_t>(p, (size_t)GSR_RADIX_BINS * sort_blocks(rcap));
-        b.sort_totals = GeomState::take<uint32_t>(p, GSR_RADIX_BINS);
+        b.keys64 = GeomState::take<uint64_t>(p, nf);
+        b.tile[0] = GeomState::take<uint32_t>(p, nf);
+        b.tile[1] = GeomState::take<uint32_t>(p, nf);
+        b.gidx[1] = GeomState::take<uint32_t>(p, nf);
+        b.sort_table = GeomState::take<uint32_t>(p, lean ? 0 : (size_t)GSR_RADIX_BINS * sort_blocks(rcap));
+        b.sort_totals = GeomState::take<uint32_t>(p, lean ? 0 : GSR_RADIX_BINS);
         if (bytes) *bytes = (size_t)(p - base);
         return b;
     }
-    static size_t required(int64_t rcap) {
+    static size_t required(int64_t rcap, bool lean = false) {
         size_t bytes = 0;
-        carve(nullptr, rcap, &bytes);
+        carve(nullptr, rcap, &bytes, lean);
         return bytes;
     }
     // number of tile-sort passes and therefore which ping-pong side holds the sorted result
