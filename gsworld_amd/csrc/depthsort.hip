@@ -852,7 +852,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
 int gsr_ss_nbc(int32_t P) {
     const int nb1 = GeomState::prep_blocks(P);
     int nbc = gsr_div_up(nb1, 8);
-    if (nbc > 128) nbc = 128;
+    if (nbc > 256) nbc = 256;  // (one per CU; 128 measured: same at config 2, dense view compaction + partition 103 -> 67 us)
     const int need = gsr_div_up(nb1, 1024);  // at most 1024 blocks per workgroup (LDS offsets)
     return nbc > need ? nbc : need;
 }
