@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
                                                           const uint32_t *__restrict__ bucket_tiles,
                                                           const uint32_t *__restrict__ tile_cum, int waves,
                                                           uint32_t *__restrict__ wave_lo,
-                                                          uint32_t *__restrict__ wave_lo_base, int P) {
+                                                          uint32_t *__restrict__ wave_lo_base, uint32_t sig) {
     __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
     __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
         return;
     }
     const uint32_t base_V = hdr->br_V, age = hdr->br_age;
-    bool keep = hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && hdr->br_P == (uint32_t)P && age < kCutsMaxAge &&
+    bool keep = hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && hdr->br_P == sig && age < kCutsMaxAge &&
                 base_V != 0u;
     if (keep) {
         // (the kept table is checked before it is used -- ascending from 0 to base_V -- see ss_compact_kernel)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
     }
     if (tid == 0) {
         hdr->br_magic = kCutsMagic;
-        hdr->br_P = (uint32_t)P;
+        hdr->br_P = sig;
         hdr->br_V = V;
         hdr->br_age = 0u;
     }
@@ -417,7 +417,9 @@ int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     const dim3 grid(GSR_BAND_RANGES, gy);
     hipLaunchKernelGGL(band_ranges_kernel, dim3(1), dim3(kBT), 0, stream, g.hdr, gsr_ss_bmax(P), g.ss_bucket_start,
                        g.bucket_tiles, balanced ? g.tile_cum : (const uint32_t *)nullptr, GSR_BAND_RANGES * kBW,
-                       g.wave_lo, g.wave_lo_base, P);
+                       g.wave_lo, g.wave_lo_base,
+                       // (model size and state layout the kept cuts belong to: see gsr_launch_sample_depth_sort)
+                       (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.wave_lo_base - (char *)g.hdr));
     if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
         hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                                                         const uint32_t *__restrict__ splitters,
                                                         uint32_t *__restrict__ splitters_new,
                                                         uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
-                                                        uint64_t *__restrict__ dbg, const float *__restrict__ view) {
+                                                        uint64_t *__restrict__ dbg, const float *__restrict__ view,
+                                                        uint32_t sig) {
     extern __shared__ uint32_t smem[];
     const unsigned dbg_wg = 64; (void)dbg_wg;
     SS_STAMP(dbg, 0);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // BALANCE of the buckets, never the order; ss_buckets flags a bucket that came out far above its share (the scene
     // changed under a static camera) and the next frame samples again.
     bool blind = all_staged && same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
-                 (h_bad == 0u || (h_wait != 0u && h_wait <= 64u)) && h_P == (uint32_t)P;
+                 (h_bad == 0u || (h_wait != 0u && h_wait <= 64u)) && h_P == sig;
     if (blind) {
         // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
         // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
     // (the largest of B Poisson(2) sample counts grows with B: 8 passes for 512 buckets 9 times out of 10, 12 for 2048)
     const uint32_t reuse_max = 4u * (S / (uint32_t)B) + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
-    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B;
+    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B && h_P == sig;
     if (blind) {
         // (s_split was filled when the table was checked)
     } else if (reuse) {
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
-                                                        const float *__restrict__ view, int P, int sshift) {
+                                                        const float *__restrict__ view, uint32_t sig, int sshift) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     if (blockIdx.x == 0 && tid == 0) {
         hdr->ss_magic = kSplitMagic;
         hdr->ss_buckets = (uint32_t)B;
-        hdr->ss_P = (uint32_t)P;
+        hdr->ss_P = sig;
     }
     if (blockIdx.x == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
     const uint32_t s = bucket_start[blockIdx.x];
@@ -868,9 +869,13 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
+    // what a kept splitter table is valid for: this model size AND this state layout (a buffer the allocator hands back
+    // can carry a plausible header of another layout over arrays that have moved: a lean inference state after a full
+    // one took a zero-filled "table" blind once, and one bucket of 175 k records went through the global-memory sort)
+    const uint32_t sig = (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.ss_splitters - (char *)g.hdr);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.pair[1],
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
-                       g.ss_dbg, viewmatrix);
+                       g.ss_dbg, viewmatrix, sig);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE)), dim3(kT), 0, stream, bmax, nbc, g.ss_table,
                        g.ss_totals, g.hdr);
@@ -884,6 +889,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
                        g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
-                       viewmatrix, P, super_shift);
+                       viewmatrix, sig, super_shift);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

@@ -303,3 +303,28 @@ def test_forward_only_capacity_overflow_is_recovered(cuda_device):
     s = r.ensure_valid(lambda: r.render(cam, means, op, **kw))
     assert not s.overflow
     assert torch.equal(r.render(cam, means, op, **kw)[0], ref)
+
+
+def test_state_buffers_recycled_between_layouts(cuda_device):
+    """The same byte buffers used first by a default (full-layout) frame, then by inference frames (lean layout) and
+    back: what the first frame left in the header -- kept splitters, placement cuts, static-camera flags -- belongs to
+    arrays that have moved.  The kept tables are tied to the layout they were written under (depthsort.hip `sig`), so
+    such a hand-over costs one sampling frame; every frame must be the reference frame bit for bit either way."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=250_000, seed=15)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    full, lean = FrameRenderer(dev), FrameRenderer(dev, forward_only=True, want_radii=False)
+    want = full.render(cam, means, op, **kw)[0].clone()
+    for _ in range(3):
+        full.render(cam, means, op, **kw)  # static camera: the header now says "take the splitters blind"
+    for a, b in ((full, lean), (lean, full), (full, lean)):
+        b.geom, b.binning, b.image = a.geom, a.binning, a.image  # hand the very same storage over
+        b.r_capacity = 0
+        for _ in range(3):
+            got = b.render(cam, means, op, **kw)[0]
+            assert torch.equal(got, want)
+        assert not b.ensure_valid(lambda: None).overflow
