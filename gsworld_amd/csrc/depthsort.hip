@@ -553,22 +553,25 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 
 // ---------------------------------------------------------------------------------------------------------
 // ss_colscan: exclusive running sum of every bucket's column of the histogram rows (in place) and the column totals.
-// One workgroup per 64 buckets, lane = bucket, the four waves take contiguous quarters of the rows.  (The partition
+// One workgroup of 16 waves per 64 buckets, lane = bucket, every wave a contiguous share of the rows.  (The partition
 // pass used to sum the rows before its own by itself: O(workgroups x buckets) loads per workgroup -- 17 us of its time
 // at config 2, 87 us at 883 k visible Gaussians.)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ss_colscan_kernel(int bmax, int nbc, uint32_t *__restrict__ table,
-                                                        uint32_t *__restrict__ totals,
-                                                        const GsrHeader *__restrict__ hdr) {
-    __shared__ uint32_t s_sum[kT / GSR_WAVE][GSR_WAVE];
-    const int lane = gsr_lane(), wave = gsr_wave();
+constexpr int kColT = 1024;  // 16 waves: 256 rows are one batch of 16 loads per lane and pass
+
+__global__ __launch_bounds__(kColT) void ss_colscan_kernel(int bmax, int nbc, uint32_t *__restrict__ table,
+                                                           uint32_t *__restrict__ totals,
+                                                           const GsrHeader *__restrict__ hdr) {
+    constexpr int NWV = kColT / GSR_WAVE;
+    __shared__ uint32_t s_sum[NWV][GSR_WAVE];
+    const int lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
     const uint32_t V = hdr->V;
     if (V == 0u) return;
     const int B = ss_num_buckets(V, bmax);
     const int b = (int)blockIdx.x * GSR_WAVE + lane;
     if ((int)blockIdx.x * GSR_WAVE >= B) return;
-    const int q = (nbc + 3) >> 2, r0 = min(nbc, wave * q), r1 = min(nbc, r0 + q);
-    constexpr int kB = 32;
+    const int q = (nbc + NWV - 1) / NWV, r0 = min(nbc, wave * q), r1 = min(nbc, r0 + q);
+    constexpr int kB = 16;
     uint32_t sum = 0;
     for (int r = r0; r < r1; r += kB) {
         uint32_t v[kB];
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(kT) void ss_colscan_kernel(int bmax, int nbc, uint3
     __syncthreads();
     uint32_t run = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kT / GSR_WAVE; w++) {
+    for (int w = 0; w < NWV; w++) {
         const uint32_t x = s_sum[w][lane];
         if (w < wave) run += x;
         total += x;
@@ -877,7 +880,7 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
                        g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
                        g.ss_dbg, viewmatrix, sig);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
-    hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE)), dim3(kT), 0, stream, bmax, nbc, g.ss_table,
+    hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE)), dim3(kColT), 0, stream, bmax, nbc, g.ss_table,
                        g.ss_totals, g.hdr);
     if (int e = gsr_check_launch("ss_colscan", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
