@@ -866,7 +866,7 @@ int gsr_ss_bmax(int32_t P) {
     return b;
 }
 
-// preprocess left vis_key / block_counts / block_cand; the sorted depth order ends in g.order
+// preprocess left the block-local records (pair[1]) / block_counts / block_cand; the sorted depth order ends in g.order
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
                                  int num_quads, uint32_t *quad_order, int super_shift, bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);

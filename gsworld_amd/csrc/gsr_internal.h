@@ -90,7 +90,7 @@ struct GeomState {
     uint32_t *tile_table;     // [tiles * prep_blocks]  per-workgroup tile histograms (counting placement)
     uint32_t *tile_totals;    // [tiles]
     // sample sort of the depth keys (depthsort.hip)
-    uint32_t *vis_key;        // [P]   depth bits of a visible Gaussian, 0 otherwise
+    uint32_t *vis_key;        // (round 2: depth bits of a visible Gaussian per index; not carved any more)
     uint32_t *block_cand;     // [ceil(P/256)]  depth bits of the first visible Gaussian of every preprocess block
     uint32_t *ss_table;       // [nbc * bmax]   bucket histogram of every compaction workgroup
     uint32_t *ss_splitters;   // [bmax]  last frame's exact quantiles (written by ss_buckets only: never while it is read)
@@ -152,7 +152,7 @@ struct GeomState {
         const size_t tt = counting(tiles) ? (size_t)tiles : 0;
         g.tile_table = take<uint32_t>(p, (lean ? 0 : tt * prep_blocks(P)) + 1);
         g.tile_totals = take<uint32_t>(p, tt + 1);
-        g.vis_key = take<uint32_t>(p, nf);  // (unused since the block-local records of preprocess)
+        g.vis_key = take<uint32_t>(p, 0);   // (no longer carved: preprocess leaves block-local records in pair[1] instead)
         g.block_cand = take<uint32_t>(p, (size_t)prep_blocks(P));
         g.ss_table = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) * gsr_ss_bmax(P));
         g.ss_splitters = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));

@@ -114,7 +114,7 @@ struct GeomOut {
 };
 
 // The exact per-Gaussian geometry: cull, projection, covariances, conic, radius, rect.
-// Writes rec0 / rec1 / cov3D / rects of a visible Gaussian; the caller writes radii, tiles_touched and vis_key.
+// Writes rec0 / rec1 / cov3D / rects of a visible Gaussian; the caller writes radii, tiles_touched and the block-local sort record.
 __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i) {
     bool visible = false;
     float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);
