@@ -186,11 +186,15 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     // inference frames (GsrSettings.forward_only): binned per super-tile on the default path; the binning kernels take
     // their grid from a settings copy whose image is the super-tile grid
     const int tiles_y = tiles / tiles_x;
-    const bool infer = st->forward_only != 0;
-    const bool super = infer && (band || chunk) && st->depth_sort != 1 && st->render_variant == 0 && tiles_x <= 255 &&
-                       tiles_y <= 255;
+    // infer: preprocess writes nothing a backward would read (the depth / radius words of the record carry tau / the
+    // tile rect instead, which only the super-tile compositor looks at).  super: lists per super-tile -- needs the
+    // compositor that has every quadrant resident and its order computed early (grids up to 1536 tiles on 256 CUs), and
+    // tile coordinates that fit a byte; larger images keep per-tile lists.
+    const bool infer = st->forward_only != 0 && (band || chunk) && st->depth_sort != 1;
+    const bool super = infer && st->render_variant == 0 && tiles_x <= 255 && tiles_y <= 255 &&
+                       gsr_render_uses_quad_order(*st, tiles) && gsr_render_split_blocks(*st, tiles) == 0;
     // (the chunk placement keeps its table in an array the lean layout drops)
-    const bool lean = super && !chunk;
+    const bool lean = infer && !chunk;
     GsrSettings st_bin = *st;
     if (super) {
         st_bin.image_width = gsr_div_up(tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
@@ -218,8 +222,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         }
     }
     prof_mark(0, stream);
-    // (rec2.w carries the packed tile rect only when the compositor will read it)
-    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, super, stream)) return e;
+    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, infer, stream)) return e;
     if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
     prof_mark(1, stream);
     if (mode != 2) {

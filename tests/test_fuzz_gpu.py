@@ -15,3 +15,13 @@ def test_random_parity_slice(cuda_device):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "fuzz ok: 16 cases" in out.stdout
+
+
+def test_random_forward_only_slice(cuda_device):
+    """A slice of tools/fuzz_forward_only.py: inference frames vs default frames, bit for bit, on random sizes / shapes /
+    options (700 cases clean in round 3; the sweep is what found that grids beyond the resident-quadrant compositor
+    must keep per-tile lists)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_forward_only.py"), "40", "321"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "40 cases x 2 frames bit-identical" in out.stdout

@@ -229,20 +229,23 @@ def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
 
 
 @pytest.mark.parametrize("case", ["tabletop_640x480", "odd_grid_70x50", "one_tile_16x16", "huge_splats_400x304",
-                                  "tall_33x257", "chunk_placement", "raw_split_sh"])
+                                  "tall_33x257", "chunk_placement", "raw_split_sh", "beyond_resident_796x648",
+                                  "wide_4100x40"])
 def test_forward_only_frames_are_bit_identical(cuda_device, case):
     """GsrSettings.forward_only (include/gsr.h): instances binned per super-tile of 2 x 1 tiles, the compositor applying the
     reference's per-tile rect test itself, nothing a backward reads written -- the colour image, inverse depth, uint8
     frame and radii must be the very bits of the default frame (which the other tests hold against the oracle), on
     even and odd tile grids, with splats that cover many super-tiles, on the exact AND the no-sync capacity path, and
-    the super-tile lists must be well below the per-tile ones."""
+    the super-tile lists must be well below the per-tile ones.  Grids the super-tile compositor does not take (more
+    tiles than resident quadrant waves -- found by tools/fuzz_forward_only.py --, more than 255 tile columns) keep
+    per-tile lists and must still be the same bits."""
     from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
     from gsworld_amd.renderer import FrameRenderer
 
     dev = cuda_device
     W, H = {"tabletop_640x480": (640, 480), "odd_grid_70x50": (70, 50), "one_tile_16x16": (16, 16),
             "huge_splats_400x304": (400, 304), "tall_33x257": (33, 257), "chunk_placement": (640, 480),
-            "raw_split_sh": (640, 480)}[case]
+            "raw_split_sh": (640, 480), "beyond_resident_796x648": (796, 648), "wide_4100x40": (4100, 40)}[case]
     if case in ("tabletop_640x480", "chunk_placement", "raw_split_sh"):
         raw, cam = scenes.tabletop_scene("xarm6_align", n=300_000, seed=12), scenes.sensor_camera("xarm6_align")
     else:
