@@ -48,6 +48,15 @@ constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'
 constexpr uint32_t kRankCost = 40u;
 // compaction cost of one preprocess block (256 keys fetched and tested), in records
 constexpr uint32_t kBlockCost = 8u;
+#ifndef GSR_SS_KEY_MASK
+#define GSR_SS_KEY_MASK 0xFFFFFFFFu
+#endif
+// key bits the splitters see.  Equal keys always classify alike, whatever the mask; a coarser key only makes the buckets
+// coarser: with the top 24 bits (rounds 1-2) a flat table seen from straight above had ~200 distinct splitter values for
+// 600 k Gaussians, every frame ended "unbalanced" and the compaction kept drawing new samples (dense view: 36 -> 29 us
+// with all 32 bits; config 2 unchanged)
+constexpr uint32_t kKeyMask = GSR_SS_KEY_MASK;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // (never a depth key: those are positive floats)
 constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const uint32_t i = (uint32_t)(tid + u * kT);
-            if (i < S) s_key[i] = k[u] & 0xFFFFFF00u;
+            if (i < S) s_key[i] = k[u] & kKeyMask;
         }
     }
     __syncthreads();
@@ -435,11 +444,11 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         for (uint32_t i0 = (uint32_t)tid; i0 < S; i0 += 4u * kT) {
             uint32_t tk[4], bk[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) tk[u] = i0 + (uint32_t)(u * kT) < S ? s_key[i0 + (uint32_t)(u * kT)] : 0xFFFFFF00u;
+            for (int u = 0; u < 4; u++) tk[u] = i0 + (uint32_t)(u * kT) < S ? s_key[i0 + (uint32_t)(u * kT)] : kNoKey;
             ss_bucketN<4>(s_split, B, tk, bk);
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (tk[u] != 0xFFFFFF00u) atomicAdd(&s_hist[bk[u]], 1u);
+                if (tk[u] != kNoKey) atomicAdd(&s_hist[bk[u]], 1u);
         }
         __syncthreads();
         for (int i = tid; i < B; i += kT)
@@ -447,10 +456,19 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
         reuse = __syncthreads_or((int)bad) == 0;
     }
     if (!reuse && !blind) {
-        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 8, s_cur, s_w);
-        lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 16, s_cur, s_w);
-        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
-        const uint32_t *sorted = s_key + kMaxSamples;
+        const uint32_t *sorted;
+        if ((kKeyMask & 0xFFu) != 0u) {  // (four digits when the low byte takes part)
+            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 0, s_cur, s_w);
+            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 8, s_cur, s_w);
+            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 16, s_cur, s_w);
+            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 24, s_cur, s_w);
+            sorted = s_key;
+        } else {
+            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 8, s_cur, s_w);
+            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 16, s_cur, s_w);
+            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
+            sorted = s_key + kMaxSamples;
+        }
         for (int i = tid; i < B; i += kT) {
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
             const uint32_t sp = (i < B - 1 && q < S) ? sorted[q] : 0xFFFFFFFFu;
@@ -529,7 +547,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t i = i0 + (uint32_t)(u * kT);
-                tk[u] = i < seg1 ? (pairs[i].y & 0xFFFFFF00u) : 0u;
+                tk[u] = i < seg1 ? (pairs[i].y & kKeyMask) : 0u;
             }
             ss_bucketN<8>(s_split, B, tk, bk);
 #pragma unroll
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
             const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
             idx[r] = rec.x;
             key[r] = rec.y;
-            tk[r] = rec.y & 0xFFFFFF00u;
+            tk[r] = rec.y & kKeyMask;
         }
         ss_bucketN<kPR>(s_split, B, tk, dig);
 #pragma unroll
@@ -791,7 +809,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         if (tid == 0) bucket_tiles[blockIdx.x] = carry;
         for (int i = tid; i < B - 1; i += kT) {  // next frame's splitters: exact quantiles (see below)
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
-            if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & 0xFFFFFF00u;
+            if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & kKeyMask;
         }
         return;
     }
@@ -826,7 +844,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     // bucket that holds its rank
     for (int i = tid; i < B - 1; i += kT) {
         const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
-        if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & 0xFFFFFF00u;
+        if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & kKeyMask;
     }
     // depth order, the tile rects in that order (what the placement streams), and the running sum of tiles touched
     // inside the bucket (the placement cuts the depth order into shares of equal INSTANCE count with it)
