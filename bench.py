@@ -423,11 +423,13 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     # ---- closed loop (configs[2] surrogate) -------------------------------------------------------------------
     cams = {"right_cam": scenes.sensor_camera(name, W, H),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
-    parts, actors = cl.xarm6_parts()
+    # robot-link poses: forward kinematics of the reference's xarm6 URDF along a seeded random-action rollout
+    # (tests/golden/xarm6_rollout.npz, tools/make_xarm6_rollout.py); the two tracked objects random-walk
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
     loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
-    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS if name.startswith("xarm") else scenes.SIM2GS_ARM_TRANS)
     ep_len = 200
-    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=ep_len + 1, seed=0))
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0))
     pinned = [(M.pin_memory(), s.pin_memory()) for M, s in poses]
 
     # the wrist camera rides on the arm: the wrapper recomputes its cameras on every render (gs_world_wrapper.py:238),
@@ -458,8 +460,11 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     out["closed_loop"] = {
         "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
+        # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity
+        "overflow_frames": loop.overflow_frames(),
         "workload": f"BASELINE.json configs[2] surrogate: 1 reset + {ep_len} steps x {len(cams)} cameras {W}x{H}, "
-                    f"{raw.num} Gaussians, {len(parts)} moving parts (seeded random walk instead of PhysX), per step: "
+                    f"{raw.num} Gaussians, {len(parts)} moving parts (robot links: FK of the reference's xarm6 URDF along a seeded "
+                    "random-action rollout, kinematic PD stand-in instead of PhysX; objects: seeded random walk), per step: "
                     "pose + wrist-camera upload (the wrist camera moves every step), device-side pose table, rigid transform inside "
                     "preprocess, both frames, one hipGraph replay"}
     del loop

@@ -55,9 +55,15 @@ def _f32(t: torch.Tensor, device, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def _resizer(t: torch.Tensor):
+def _resizer(t: torch.Tensor, header: bool = False):
+    """``header``: the geometry state -- storage the allocator hands out may be a freed state of another renderer, whose
+    frame header still says how many of ITS frames overflowed: new storage starts with a zeroed header (enqueued on the
+    frame's stream, ahead of the frame's first kernel; zeroed kept-splitter / kept-cut fields just mean "sample")."""
     def fn(_user, nbytes):
+        before = t.data_ptr() if t.numel() else 0
         t.resize_(int(nbytes))
+        if header and t.data_ptr() != before and nbytes >= 256:
+            t[:256].zero_()
         return t.data_ptr()
 
     return RESIZE_FN(fn)
@@ -118,7 +124,7 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         inp.part_rescale = _ptr(rescale) if rescale is not None else None
     out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii),
                      _ptr(rgb8_out) if rgb8_out is not None else None)
-    cbs = (_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer))
+    cbs = (_resizer(geomBuffer, header=True), _resizer(binningBuffer), _resizer(imgBuffer))
     buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
     stats = GsrFrameStats()
     with torch.cuda.device(dev):

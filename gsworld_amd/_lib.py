@@ -94,7 +94,8 @@ class GsrBuffers(C.Structure):
 
 
 class GsrFrameStats(C.Structure):
-    _fields_ = [("num_visible", C.c_int64), ("num_rendered", C.c_int64), ("overflow", C.c_int32)]
+    _fields_ = [("num_visible", C.c_int64), ("num_rendered", C.c_int64), ("overflow", C.c_int32),
+                ("overflow_frames", C.c_int32)]
 
 
 class GsrStateView(C.Structure):

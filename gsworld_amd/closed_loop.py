@@ -14,10 +14,12 @@ scene held on one MI355X:
 
 Returns what ``_render_gsworld`` returns: ``{camera name: uint8 (num_envs, H, W, 3)}``.
 
-SAPIEN / PhysX do not run on a headless GPU box, so :func:`random_walk_poses` stands in for the simulator when the loop
-is measured (``bench.py``, ``tools/closed_loop_surrogate.py``): a seeded random walk of the part poses, i.e. the
-random-action rollout of /root/reference/examples/maniskill/gsworld_rand_action_tabletop.py:99-133 reduced to what
-reaches the renderer.
+SAPIEN / PhysX do not run on a headless GPU box, so when the loop is measured (``bench.py``,
+``tools/closed_loop_surrogate.py``) :func:`rollout_poses` stands in for the simulator: the robot-link poses of a seeded
+random-action rollout (/root/reference/examples/maniskill/gsworld_rand_action_tabletop.py:99-133) from forward
+kinematics of the reference's xarm6 URDF, committed as a data fixture (:func:`xarm6_rollout`), pushed through the
+wrapper's own pose arithmetic (:func:`part_poses_from_sim`); the tracked objects, which only contacts would move, take a
+seeded random walk (:func:`random_walk_poses`, which the smaller tests also use for every part).
 """
 from __future__ import annotations
 
@@ -30,7 +32,7 @@ from .renderer import MultiCameraRenderer
 
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
-                 background=None, fuse_transform: bool = True):
+                 background=None, fuse_transform: bool = True, growth: float = 2.0):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -39,7 +41,12 @@ class ClosedLoopRenderer:
         (``GsrInputs.part_*``): every (environment, camera) frame reads the one base model plus that environment's pose
         table, and no transformed copy of the model is written -- per step that saves a 60 B/Gaussian pass per
         environment (88 MB at 1.47 M) and, for ``num_envs`` > 1, the (E,P,.) buffers themselves.  ``False``: one
-        ``gsr_transform_gaussians_batch`` pass per step, frames read its outputs (same bytes out: tests)."""
+        ``gsr_transform_gaussians_batch`` pass per step, frames read its outputs (same bytes out: tests).
+        ``growth``: every lane's binning capacity is ``max(growth x R, 2 N)`` instances, ``R`` the instance count of
+        the frame that sized it (:meth:`reset`, or the re-render after an overflow).  An arm sweeping past a wrist
+        camera changes that count far more than a fixed camera ever sees (0.39 M .. 1.46 M over the xarm6 random-action
+        rollout, against 0.71 M at reset): the margin costs a few tens of MB per lane and keeps that rollout clear of
+        the limit; :meth:`overflow_frames` says, without a per-step sync, whether a rollout stayed clear."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
@@ -77,7 +84,8 @@ class ClosedLoopRenderer:
                        for n, c in zip(self.names, self.cameras)}
         self.bg = torch.zeros(3, device=dev) if background is None else background.to(dev, torch.float32)
         # the loop never differentiates a frame: inference frames (GsrSettings.forward_only), no radii array
-        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev, forward_only=True, want_radii=False)
+        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev, forward_only=True, want_radii=False,
+                                         growth=growth, min_capacity=2 * int(self.xyz.shape[0]))
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
         self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()
@@ -188,6 +196,13 @@ class ClosedLoopRenderer:
             self._gpu_step()
         return self.multi.ensure_valid(again)
 
+    def overflow_frames(self) -> int:
+        """How many frames of this loop exceeded their lane's binning capacity since the lane's state was allocated
+        (such a frame shows the background only).  Counted on the device by the frames themselves, so a rollout that
+        never calls :meth:`ensure_valid` between steps can still tell at its end whether every frame was valid
+        (synchronises)."""
+        return sum(lane.stats().overflow_frames for lane in self.multi.lanes)
+
     def capture(self):
         """Captures the GPU side of a step into one hipGraph (call after :meth:`reset`)."""
         dev = self.device
@@ -289,6 +304,65 @@ def random_walk_poses(sim2gs: torch.Tensor, num_parts: int, num_actors: int, ste
             yield rigid[0].contiguous(), scales[0].contiguous()
         else:
             yield rigid.contiguous(), scales.contiguous()
+
+
+def xarm6_rollout(path: str | None = None) -> dict:
+    """The committed link-pose fixture of a seeded random-action xarm6 rollout (tests/golden/xarm6_rollout.npz, written
+    by tools/make_xarm6_rollout.py from forward kinematics of the reference's URDF; 1 reset + 200 steps): the arrays as
+    torch tensors plus ``parts`` -- link name -> label(s) per ``xarm_gs_semantics`` for the 15 links that move
+    (``world`` carries the background label 0 and never moves: its matrix is the identity by construction)."""
+    import os
+
+    import numpy as np
+
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "xarm6_rollout.npz")
+    z = np.load(path)
+    names = [str(n) for n in z["link_names"]]
+    keep = [i for i, n in enumerate(names) if n != "world"]
+    parts = {}
+    for i in keep:
+        lab = [int(v) for v in z["labels"][i] if v >= 0]
+        parts[names[i]] = lab[0] if len(lab) == 1 else lab
+    return dict(parts=parts, link_now=torch.from_numpy(z["link_now"][:, keep]), link_scan=torch.from_numpy(z["link_scan"][keep]),
+                sim2gs_arm=torch.from_numpy(z["sim2gs_arm"]), link_offset=torch.from_numpy(z["link_offset"]),
+                qpos=torch.from_numpy(z["qpos"]))
+
+
+def rollout_poses(rollout: dict, num_actors: int, steps: int, seed: int = 0, num_envs: int = 1):
+    """Per-step part matrices of the closed loop from the FK rollout: the robot links go through
+    :func:`part_poses_from_sim` (the wrapper's own arithmetic, gs_world_wrapper.py:114-120) at step ``t`` of the
+    fixture; the ``num_actors`` tracked objects, which only the physics could move, keep the seeded small random walk
+    of :func:`random_walk_poses`.  Environment ``e`` plays the same trajectory ``17 e`` steps ahead, reflecting at the
+    ends (no jump), so environments differ the way independently acting robots would.  Yields what
+    :func:`random_walk_poses` yields: ``(matrices (K,4,4) | (E,K,4,4), scales (K,) | (E,K))``, links first."""
+    T = rollout["link_now"].shape[0]
+
+    def at(t):
+        t = t % (2 * (T - 1))
+        return t if t < T else 2 * (T - 1) - t
+
+    actors = random_walk_poses(rollout["sim2gs_arm"], num_actors, num_actors, steps, seed, num_envs) if num_actors else None
+    for t in range(steps):
+        now = torch.stack([rollout["link_now"][at(t + 17 * e)] for e in range(num_envs)])
+        m, s = part_poses_from_sim(rollout["sim2gs_arm"], now, rollout["link_scan"], rollout["link_offset"])
+        if actors is not None:
+            am, asc = next(actors)
+            m = torch.cat((m, am.reshape(num_envs, num_actors, 4, 4)), 1)
+            s = torch.cat((s, asc.reshape(num_envs, num_actors)), 1)
+        if num_envs == 1:
+            yield m[0].contiguous(), s[0].contiguous()
+        else:
+            yield m.contiguous(), s.contiguous()
+
+
+def xarm6_rollout_parts(rollout: dict):
+    """``(parts, actors)`` for :class:`ClosedLoopRenderer` over the synthetic table-top scene: the fixture's 15 moving
+    links under their ``xarm_gs_semantics`` labels (1..16) and the two tracked actors (labels 17, 18)."""
+    parts = dict(rollout["parts"])
+    parts.update({"005_tomato_soup_can": 17, "dtc_green_can": 18})
+    return parts, ("005_tomato_soup_can", "dtc_green_can")
 
 
 def xarm6_parts():

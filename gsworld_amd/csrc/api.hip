@@ -214,9 +214,12 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
 
     if (mode == 2) {
-        // header + per-tile totals are adjacent: one memset; both are accumulated by preprocess
-        const size_t clear = (size_t)((char *)g.tile_cursor - (char *)g.hdr);
-        if (hipMemsetAsync(g.hdr, 0, clear, stream) != hipSuccess) {
+        // header + per-tile totals are adjacent and both accumulated by preprocess; the overflow count at the header's
+        // end outlives the frame
+        const size_t head = offsetof(GsrHeader, of_magic);
+        const size_t clear = (size_t)((char *)g.tile_cursor - (char *)g.tile_accum);
+        if (hipMemsetAsync(g.hdr, 0, head, stream) != hipSuccess ||
+            hipMemsetAsync(g.tile_accum, 0, clear, stream) != hipSuccess) {
             gsr_set_error("gsr_forward: hipMemsetAsync(header) failed");
             return GSR_E_HIP;
         }
@@ -266,6 +269,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             stats->num_visible = h.V;
             stats->num_rendered = h.R_raw;
             stats->overflow = 0;
+            stats->overflow_frames = h.of_magic == GSR_OF_MAGIC ? (int32_t)h.overflow_frames : 0;
         }
     }
     // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
@@ -371,6 +375,7 @@ int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream_) {
     stats->num_visible = h.V;
     stats->num_rendered = h.R_raw;
     stats->overflow = (int32_t)h.overflow;
+    stats->overflow_frames = h.of_magic == GSR_OF_MAGIC ? (int32_t)h.overflow_frames : 0;
     return h.overflow ? GSR_E_OVERFLOW : GSR_OK;
 }
 

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     if (threadIdx.x == 0) {
         hdr->R_raw = grand;
         hdr->r_capacity = r_capacity;
-        hdr->overflow = overflow ? 1u : 0u;
+        gsr_set_overflow(hdr, overflow);
         hdr->R = overflow ? 0u : grand;
     }
     if (tile_order == nullptr || keyed) return;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void bin_starts_kernel(const uint32_t *_
     if (threadIdx.x == 0) {
         hdr->R_raw = grand;
         hdr->r_capacity = r_capacity;
-        hdr->overflow = overflow ? 1u : 0u;
+        gsr_set_overflow(hdr, overflow);
         hdr->R = overflow ? 0u : grand;
     }
     __syncthreads();

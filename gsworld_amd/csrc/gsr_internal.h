@@ -56,8 +56,25 @@ struct GsrHeader {
     uint32_t ss_wait;     // frames left in which a flagged imbalance does NOT trigger new samples ...
     uint32_t ss_backoff;  // ... and the wait after the next sampling that still ends unbalanced (1, 2, 4 .. 64)
     uint32_t ss_fresh;    // this frame's compaction drew new splitters: the partition pass reads ss_splitters_new
-    uint32_t pad[30];
+    uint32_t pad[28];
+    uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
+    uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
+                               //   a no-sync rollout learns at its end whether EVERY frame was valid)
 };
+#define GSR_OF_MAGIC 0x0F10F10Fu
+// The one thread that compared R with the capacity.  Every frame clears hdr->overflow before its first such check, and a
+// path with two checks per frame (bin-then-sort) must count the frame once: only the 0 -> 1 edge counts.
+__device__ inline void gsr_set_overflow(GsrHeader *hdr, bool overflow) {
+    const bool was = hdr->overflow != 0u;
+    hdr->overflow = overflow ? 1u : 0u;
+    if (overflow && !was) {
+        if (hdr->of_magic != GSR_OF_MAGIC) {
+            hdr->of_magic = GSR_OF_MAGIC;
+            hdr->overflow_frames = 0u;
+        }
+        hdr->overflow_frames += 1u;
+    }
+}
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
 static inline size_t gsr_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

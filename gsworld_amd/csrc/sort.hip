@@ -37,13 +37,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void scan_small_kernel(uint32_t *data, i
         if (mode == 1) {
             hdr->R_raw = carry;
             hdr->r_capacity = r_capacity;
-            if (carry > r_capacity) {
-                hdr->overflow = 1u;
-                hdr->R = 0u;
-            } else {
-                hdr->overflow = 0u;
-                hdr->R = carry;
-            }
+            gsr_set_overflow(hdr, carry > r_capacity);
+            hdr->R = carry > r_capacity ? 0u : carry;
         }
     }
 }

@@ -28,6 +28,17 @@ char *resize_cb(void *user, size_t bytes) {
     return reinterpret_cast<char *>(t->data_ptr());
 }
 
+// The geometry state: storage the allocator hands out may be a freed state of another renderer, whose frame header
+// still says how many of ITS frames overflowed -- new storage starts with a zeroed header (enqueued on the frame's
+// stream ahead of the frame's first kernel).
+char *resize_geom_cb(void *user, size_t bytes) {
+    auto *t = static_cast<torch::Tensor *>(user);
+    const void *before = t->numel() ? t->data_ptr() : nullptr;
+    t->resize_({static_cast<long long>(bytes)});
+    if (t->data_ptr() != before && bytes >= 256) t->narrow(0, 0, 256).zero_();
+    return reinterpret_cast<char *>(t->data_ptr());
+}
+
 const float *fptr(const torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
 
 // float32, on `dev`, dense -- what upstream's `.contiguous().data<float>()` implies
@@ -126,7 +137,7 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
     GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
                    radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
                    rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
-    GsrBuffers buf{resize_cb, &geom, resize_cb, &binning, resize_cb, &image};
+    GsrBuffers buf{resize_geom_cb, &geom, resize_cb, &binning, resize_cb, &image};
     GsrFrameStats stats{};
     const int rc = gsr_forward(&st, &in, &out, &buf, r_capacity, want_stats ? &stats : nullptr, current_stream(dev));
     TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());

@@ -24,6 +24,7 @@ class FrameStats:
     num_visible: int
     num_rendered: int
     overflow: bool
+    overflow_frames: int = 0  # frames on this renderer's state that overflowed since its buffers were allocated
 
     def algorithmic_bytes(self, width: int, height: int) -> int:
         """B_alg of SURVEY.md 8d: 48 N + 280 V + 64 R + 16 W H."""
@@ -32,11 +33,13 @@ class FrameStats:
 
 class FrameRenderer:
     def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
-                 forward_only: bool = False, want_radii: bool = True):
+                 forward_only: bool = False, want_radii: bool = True, min_capacity: int = 1 << 16):
         """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
         nothing a backward would read is written and the instances are binned per super-tile of 2 x 1 tiles -- the state buffers
         are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
-        (forward_only only): the (P,) radii array is not written either; :meth:`render` returns ``None`` for it."""
+        (forward_only only): the (P,) radii array is not written either; :meth:`render` returns ``None`` for it.
+        ``growth`` / ``min_capacity``: the binning capacity of the no-sync frames is
+        ``max(growth x R of the frame that sized it, min_capacity)`` instances (8 B each)."""
         self.device = torch.device(device)
         if self.device.index is None and self.device.type == "cuda":
             # an unindexed device never equals a tensor's `cuda:0`: resolve it once (multi-GPU processes: the CURRENT
@@ -45,6 +48,7 @@ class FrameRenderer:
         self.forward_only = bool(forward_only)
         self.want_radii = bool(want_radii) or not self.forward_only
         self.growth = growth
+        self.min_capacity = int(min_capacity)
         self.near_plane = _C.NEAR_PLANE if near_plane is None else near_plane
         u8 = dict(dtype=torch.uint8, device=self.device)
         self.geom = torch.empty(0, **u8)
@@ -53,6 +57,9 @@ class FrameRenderer:
         self.r_capacity = 0
         self._out = None
         self._P = 0
+
+    def _capacity_for(self, num_rendered: int) -> int:
+        return max(int(num_rendered * self.growth), self.min_capacity, 1 << 16)
 
     def _outputs(self, P, H, W):
         if self._out is None or self._out[0].shape != (3, H, W) or self._out[2].shape[0] != P:
@@ -148,7 +155,7 @@ class FrameRenderer:
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
             param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only)
         if cap == 0:
-            self.r_capacity = max(int(stats.num_rendered * self.growth), 1 << 16)
+            self.r_capacity = self._capacity_for(stats.num_rendered)
         return color, radii, invd
 
     def pack_rgb8(self, color: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -170,14 +177,14 @@ class FrameRenderer:
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if code not in (0, -4):
             check(code)
-        return FrameStats(self._P, int(s.num_visible), int(s.num_rendered), bool(s.overflow))
+        return FrameStats(self._P, int(s.num_visible), int(s.num_rendered), bool(s.overflow), int(s.overflow_frames))
 
     def ensure_valid(self, rerender) -> FrameStats:
         """Checks the last frame for capacity overflow; if it overflowed, grows the capacity and calls
         ``rerender()`` (which must call :meth:`render` again with the same arguments)."""
         s = self.stats()
         if s.overflow:
-            self.r_capacity = int(s.num_rendered * self.growth)
+            self.r_capacity = self._capacity_for(s.num_rendered)
             rerender()
             s = self.stats()
         return s
@@ -232,7 +239,7 @@ class MultiCameraRenderer:
         if any(s.overflow for s in stats):
             for lane, s in zip(self.lanes, stats):
                 if s.overflow:
-                    lane.r_capacity = int(s.num_rendered * lane.growth)
+                    lane.r_capacity = lane._capacity_for(s.num_rendered)
             rerender()
             stats = [lane.stats() for lane in self.lanes]
         return stats

@@ -153,6 +153,10 @@ typedef struct GsrFrameStats {
     int64_t num_visible;  /* V: Gaussians with radii > 0 */
     int64_t num_rendered; /* R: sum of tiles touched */
     int32_t overflow;     /* 1 if R exceeded the binning capacity (no-sync mode only) */
+    int32_t overflow_frames; /* how many frames rendered on this geometry state overflowed since the first 256 bytes of
+                              * the buffer were last zeroed (this package's resize callbacks zero them on new storage;
+                              * a header that never held a count reads as 0) -- a rollout that never synchronises reads
+                              * it once at the end to learn whether every frame was valid.  Occupies former padding. */
 } GsrFrameStats;
 
 const char *gsr_last_error(void);

@@ -20,11 +20,11 @@ from oracle import wrapper_glue_ref as ref
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, n, num_envs=1, seed=1, fuse_transform=True):
+def _setup(dev, n, num_envs=1, seed=1, fuse_transform=True, rollout=None):
     raw = scenes.tabletop_scene("xarm6_align", n=n, seed=seed)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
-    parts, actors = cl.xarm6_parts()
+    parts, actors = cl.xarm6_parts() if rollout is None else cl.xarm6_rollout_parts(rollout)
     loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=num_envs, device=dev,
                                  fuse_transform=fuse_transform)
     rawd = raw.to(dev)
@@ -123,23 +123,31 @@ def test_env_batch_matches_the_wrapper_glue(cuda_device):
 
 def test_full_size_rollout_200_steps(cuda_device):
     """configs[2] at size: 1,468,850 Gaussians, 1 reset + 200 steps x 2 cameras = 402 frames, replayed from the captured
-    step graph.  Properties: no capacity overflow anywhere, frames keep changing, and the LAST step equals the wrapper
-    glue on the last poses (<= 1 LSB) -- i.e. nothing drifted over the rollout."""
+    step graph.  The robot links follow forward kinematics of the reference's xarm6 URDF along a seeded random-action
+    rollout (tests/golden/xarm6_rollout.npz; ``link6`` carries two labels, as ``xarm_gs_semantics`` has it), through
+    the wrapper's own pose arithmetic (closed_loop.part_poses_from_sim).  Properties: no capacity overflow anywhere,
+    frames keep changing, and steps 100 and 200 equal the wrapper glue on their poses (<= 1 LSB) -- i.e. nothing
+    drifted over the rollout."""
     dev = cuda_device
-    raw, cams, parts, actors, loop, model = _setup(dev, scenes.XARM6_ALIGN_NUM_GAUSSIANS)
-    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
-    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=201, seed=0))
+    rollout = cl.xarm6_rollout()
+    raw, cams, parts, actors, loop, model = _setup(dev, scenes.XARM6_ALIGN_NUM_GAUSSIANS, rollout=rollout)
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=201, seed=0))
     loop.reset(*poses[0])
     loop.capture()
     sums = []
     for i, (M, s) in enumerate(poses[1:]):
         frames = loop.step(M, s)
         if i % 20 == 0:
-            sums.append(int(frames["wrist_cam"].sum().item()))
+            sums.append((int(frames["wrist_cam"].sum().item()), int(frames["right_cam"].sum().item())))
+        if i == 99:
+            mid = {k: v.clone() for k, v in loop.frames.items()}
     last = {k: v.clone() for k, v in loop.frames.items()}
     stats = loop.ensure_valid()
     assert not any(st.overflow for st in stats), "a lane overflowed its binning capacity during the rollout"
-    assert len(set(sums)) == len(sums), "frames stopped changing"
+    assert loop.overflow_frames() == 0, "some frame of the rollout exceeded its lane's binning capacity"
+    assert len(set(sums)) == len(sums), f"frames stopped changing: {sums}"
+    M, s = poses[100]
+    _compare(mid, ref.render_step(model, parts, cams, M, s, _rasterize, actors), "step 100")
     M, s = poses[-1]
     _compare(last, ref.render_step(model, parts, cams, M, s, _rasterize, actors), "step 200")
 

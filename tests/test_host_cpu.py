@@ -214,3 +214,55 @@ def test_closed_loop_pose_generator_is_seeded_and_shaped():
     E = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=2, seed=3, num_envs=3))
     assert E[0][0].shape == (3, len(parts), 4, 4)
     assert not torch.equal(a[0][0], a[-1][0])  # the poses do walk
+
+
+def test_xarm6_rollout_fixture_is_a_kinematic_chain():
+    """tests/golden/xarm6_rollout.npz (tools/make_xarm6_rollout.py: forward kinematics of the reference's xarm6 URDF
+    along a seeded random-action rollout, 1 reset + 200 steps).  What must hold of ANY valid run of that chain:
+    every link pose is rigid; the base never moves; a fixed joint keeps parent and child together
+    (``gripper_fix`` has a zero origin: xarm_gripper_base_link == link6); joint1 turns about z, so link1's origin stays
+    0.267 m above the base; no joint moves faster than its URDF velocity limit allows per control step; the scan pose is
+    the FK of ``xarm_gs_qpos``, which differs from the reset pose only in joints 3 and 5 (constants.py:75-103)."""
+    import numpy as np
+    import torch
+
+    from gsworld_amd import closed_loop as cl
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "xarm6_rollout.npz"))
+    names = [str(n) for n in z["link_names"]]
+    now, scan, q = z["link_now"].astype(np.float64), z["link_scan"].astype(np.float64), z["qpos"]
+    assert now.shape == (201, 16, 4, 4) and scan.shape == (16, 4, 4) and q.shape == (201, 12)
+    R = now[..., :3, :3]
+    assert np.abs(R @ R.swapaxes(-1, -2) - np.eye(3)).max() < 1e-5 and np.allclose(np.linalg.det(R), 1, atol=1e-5)
+    assert np.allclose(now[..., 3, :], [0, 0, 0, 1])
+    for fixed in ("world", "link_base"):
+        assert np.allclose(now[:, names.index(fixed)], np.eye(4))
+    assert np.allclose(now[:, names.index("xarm_gripper_base_link")], now[:, names.index("link6")])
+    assert np.allclose(now[:, names.index("link1"), :3, 3], [0, 0, 0.267], atol=1e-6)
+    dq = np.abs(np.diff(q, axis=0))
+    assert dq[:, :6].max() <= 3.14 / 20 + 1e-6 and dq[:, 6:].max() <= 2.0 / 20 + 1e-6 and dq[:, :6].max() > 0.1
+    assert np.allclose(q[:, 6:], q[:, 6:7])  # the six finger joints mimic the drive joint
+    changed = np.nonzero(np.abs(z["qpos_scan"] - q[0]) > 1e-6)[0].tolist()
+    assert changed == [2, 4]
+    # joint3 at -pi/3 instead of -pi/4: link3 turns by 15 degrees about its own z relative to link2
+    rel = lambda P, a, b: np.linalg.inv(P[names.index(a)]) @ P[names.index(b)]  # noqa: E731
+    turn = np.linalg.inv(rel(scan, "link2", "link3")) @ rel(now[0], "link2", "link3")
+    assert np.allclose(turn[:3, 3], 0, atol=1e-6) and np.isclose(np.arctan2(turn[1, 0], turn[0, 0]), -np.pi / 12, atol=1e-5)
+
+    # the generator built on it: links through the wrapper's pose arithmetic, actors random-walk; seeded; envs differ
+    r = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(r)
+    assert parts["link6"] == [7, 8] and "world" not in parts and len(parts) == 17
+    assert sorted(v for x in parts.values() for v in (x if isinstance(x, list) else [x])) == list(range(1, 19))
+    a = list(cl.rollout_poses(r, len(actors), steps=201, seed=0))
+    b = list(cl.rollout_poses(r, len(actors), steps=3, seed=0))
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b))
+    M, s = a[200]
+    assert M.shape == (17, 4, 4) and s.shape == (17,) and torch.all(s[:15] == 1)
+    RR = M[:15, :3, :3]
+    assert (RR @ RR.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-5       # sim2gs's scale cancels: links stay rigid
+    want, _ = cl.part_poses_from_sim(r["sim2gs_arm"], r["link_now"][200][None], r["link_scan"], r["link_offset"])
+    assert torch.equal(M[:15], want[0])
+    e3 = list(cl.rollout_poses(r, len(actors), steps=2, seed=0, num_envs=3))
+    assert e3[0][0].shape == (3, 17, 4, 4) and e3[0][1].shape == (3, 17)
+    assert torch.equal(e3[0][0][0, :15], a[0][0][:15]) and torch.equal(e3[0][0][1, :15], a[17][0][:15])

@@ -300,12 +300,30 @@ def test_forward_only_capacity_overflow_is_recovered(cuda_device):
     ref = FrameRenderer(dev).render(cam, means, op, **kw)[0].clone()
     r = FrameRenderer(dev, forward_only=True)
     r.render(cam, means, op, **kw)
+    assert r.stats().overflow_frames == 0  # a fresh buffer's header is garbage: the count must not be
     r.r_capacity = 1 << 10
-    r.render(cam, means, op, **kw)
-    assert r.stats().overflow
+    for _ in range(3):
+        bg_only = r.render(cam, means, op, **kw)[0]
+    assert r.stats().overflow and r.stats().overflow_frames == 3  # counted on the device, frame by frame
+    assert float(bg_only.abs().max()) == 0.0                      # an overflowed frame shows the background only
     s = r.ensure_valid(lambda: r.render(cam, means, op, **kw))
-    assert not s.overflow
+    assert not s.overflow and s.overflow_frames == 3              # ... and valid frames do not clear the count
     assert torch.equal(r.render(cam, means, op, **kw)[0], ref)
+    # the default (training-capable) frames and the alternative binning paths count the same way
+    from gsworld_amd import _lib
+
+    for tune in ({}, {"binning_path": 2}, {"binning_path": 1}, {"binning_path": 3}, {"depth_sort": 1}):
+        saved = dict(_lib.TUNING)
+        _lib.TUNING.update(tune)
+        try:
+            d = FrameRenderer(dev)
+            d.render(cam, means, op, **kw)
+            d.r_capacity = 1 << 10
+            d.render(cam, means, op, **kw)
+            d.render(cam, means, op, **kw)
+            assert d.stats().overflow_frames == 2, tune
+        finally:
+            _lib.TUNING.update(saved)
 
 
 def test_state_buffers_recycled_between_layouts(cuda_device):

@@ -3,8 +3,9 @@
 1 reset + 200 steps x 2 cameras = 402 frames of the xarm6_align-like scene, with the per-step work GSWorldWrapper does
 around the rasterizer (/root/reference/gsworld/mani_skill/utils/wrappers/gs_world_wrapper.py:176-198 step/reset,
 :110-162 per-link transforms, :232-275 per-camera render + uint8 conversion).  SAPIEN / PhysX are not available on
-a headless MI355X box, so the robot motion is a seeded random walk of 16 link poses + 2 tracked actors
-(gsworld_amd.closed_loop.random_walk_poses); what is reproduced is the RENDER-SIDE workload, not the physics.
+a headless MI355X box, so the robot motion is forward kinematics of the reference's xarm6 URDF along a seeded
+random-action trajectory (15 moving links: tests/golden/xarm6_rollout.npz, gsworld_amd.closed_loop.rollout_poses) and the
+2 tracked actors random-walk; what is reproduced is the RENDER-SIDE workload, not the physics.
 
 Two glue variants around the same HIP rasterizer, same pose sequence (their frames agree within 1 LSB:
 tests/test_closed_loop_gpu.py):
@@ -41,10 +42,10 @@ def main():
     raw = scenes.tabletop_scene("xarm6_align", n=args.num_gaussians, seed=1)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
-    parts, actors = cl.xarm6_parts()
-    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
     E = args.num_envs
-    poses = cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=args.steps + 1, seed=0, num_envs=E)
+    poses = cl.rollout_poses(rollout, len(actors), steps=args.steps + 1, seed=0, num_envs=E)
     t_pose = t_gpu = 0.0
 
     if args.glue == "fused":
