@@ -154,6 +154,8 @@ def lib() -> C.CDLL:
                               C.POINTER(GsrBuffers), C.c_int64, C.POINTER(GsrFrameStats), C.c_void_p]
     L.gsr_frame_stats.restype = C.c_int
     L.gsr_frame_stats.argtypes = [C.c_void_p, C.POINTER(GsrFrameStats), C.c_void_p]
+    L.gsr_debug_sort_state.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.gsr_debug_sort_state.restype = C.c_int
     L.gsr_state_view.restype = C.c_int
     L.gsr_state_view.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(GsrStateView)]

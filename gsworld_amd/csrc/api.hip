@@ -360,6 +360,26 @@ int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *ge
     return GSR_OK;
 }
 
+// What the depth sort of the last frame on this state did with the splitters it found there (tests, tools).
+int gsr_debug_sort_state(const void *geom, int32_t out[4], void *stream_) {
+    if (!geom || !out) {
+        gsr_set_error("gsr_debug_sort_state: null argument");
+        return GSR_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    GsrHeader h;
+    if (hipMemcpyAsync(&h, geom, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        gsr_set_error("gsr_debug_sort_state: read-back failed: %s", hipGetErrorString(hipGetLastError()));
+        return GSR_E_HIP;
+    }
+    out[0] = (int32_t)h.ss_blind;
+    out[1] = (int32_t)h.ss_fresh;
+    out[2] = (int32_t)h.ss_bad;
+    out[3] = (int32_t)h.ss_trust;
+    return GSR_OK;
+}
+
 int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream_) {
     if (!geom || !stats) {
         gsr_set_error("gsr_frame_stats: null argument");

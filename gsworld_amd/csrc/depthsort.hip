@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself
     // (up to 8 entries per thread): by the time the counts are summed it has all arrived, instead of costing three
     // dependent round trips (header, view, table) in the middle of the kernel.
-    const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_wait = hdr->ss_wait,
+    const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_trust = hdr->ss_trust,
                    h_P = hdr->ss_P;
     bool same_view = true;
 #pragma unroll
@@ -280,12 +280,16 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
     const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
     const int logS = ss_log2((int)S);  // (S is a power of two)
-    // A fixed sensor camera (GSWorld's right_cam and the like): the view matrix is bit for bit the one the splitters in
-    // the state were built under, so they are taken as they are -- no samples, no check.  Splitters only decide the
-    // BALANCE of the buckets, never the order; ss_buckets flags a bucket that came out far above its share (the scene
-    // changed under a static camera) and the next frame samples again.
+    // A fixed sensor camera (GSWorld's right_cam and the like) over a scene that stands still: the view matrix is bit
+    // for bit the one the splitters in the state were built under and the last frames that classified with the kept
+    // table came out as balanced as exact quantiles of an unchanged scene do (ss_trust, kept by ss_partition /
+    // ss_buckets) -- then they are taken as they are: no samples, no check.  Splitters only decide the BALANCE of the
+    // buckets, never the order; but balance matters: under a fixed camera a MOVING scene (an arm swinging through a
+    // depth range that was empty a frame ago, where the kept buckets are wide) can put ten thousand records into one
+    // bucket, far beyond the LDS, and that bucket's workgroup then sorts in global memory for a millisecond.  Such a
+    // scene never earns the trust; its frames check the kept table against samples below.
     bool blind = all_staged && same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
-                 (h_bad == 0u || (h_wait != 0u && h_wait <= 64u)) && h_P == sig;
+                 h_bad == 0u && h_trust >= 2u && h_trust <= 255u && h_P == sig;
     if (blind) {
         // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
         // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
@@ -649,21 +653,15 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
     // the table this frame's compaction classified with: the kept one, or the one it drew (ss_compact_kernel)
     const uint32_t *__restrict__ split_src = hdr->ss_fresh != 0u ? splitters_new : splitters;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // The imbalance flag of the last frame was read by every compaction workgroup; ss_buckets sets it again.  New
-        // samples do not always help -- depth ties (a flat table seen from straight above) cannot be split by ANY
-        // splitters, and the exact quantiles the state holds are already the best table there is -- so a sampling
-        // frame that still ends unbalanced doubles the number of frames the flag is ignored afterwards (1 .. 64).
-        const uint32_t was_bad = hdr->ss_bad, wait = hdr->ss_wait, backoff = hdr->ss_backoff;
-        if (was_bad == 0u) {
-            hdr->ss_wait = 0u;
-            hdr->ss_backoff = 1u;
-        } else if (hdr->ss_blind != 0u) {
-            hdr->ss_wait = (wait != 0u && wait <= 64u) ? wait - 1u : 0u;
-        } else {
-            const uint32_t b = (backoff == 0u || backoff > 64u) ? 1u : backoff;
-            hdr->ss_wait = b;
-            hdr->ss_backoff = b >= 64u ? 64u : 2u * b;
-        }
+        // The balance flag of the last frame was read by every compaction workgroup (all of them are done: this kernel
+        // follows theirs); ss_buckets sets it again.  Trust in the kept table grows by one with every frame that
+        // classified WITH it and came out balanced, and is gone with the first one that did not (or that drew its own
+        // splitters, which says nothing about the kept ones).
+        const uint32_t was_bad = hdr->ss_bad, trust = hdr->ss_trust;
+        // (a state no frame has sorted on yet holds garbage here: no kept table, no trust)
+        hdr->ss_trust = (hdr->ss_magic == kSplitMagic && was_bad == 0u && hdr->ss_prev_fresh == 0u)
+                            ? (trust < 255u ? trust + 1u : 255u) : 0u;
+        hdr->ss_prev_fresh = hdr->ss_fresh;
         hdr->ss_bad = 0u;
     }
     if (V == 0u) return;
@@ -775,8 +773,9 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     if (blockIdx.x == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
     const uint32_t s = bucket_start[blockIdx.x];
     const int n = (int)(bucket_start[blockIdx.x + 1] - s);
-    // far above the bucket's share (V / B): whatever splitters the compaction used, the next frame draws new ones
-    if (tid == 0 && (uint32_t)n > 4u * (V / (uint32_t)B) + 64u) hdr->ss_bad = 1u;
+    // above what the exact quantiles of the last frame give when nothing moved (share V / B, plus depth ties): the scene
+    // is changing under the camera, the next frames check the kept table against samples (ss_compact_kernel)
+    if (tid == 0 && (uint32_t)n > (V / (uint32_t)B) + (V / (uint32_t)B) / 4u + 64u) hdr->ss_bad = 1u;
     if (n == 0) {
         if (tid == 0) bucket_tiles[blockIdx.x] = 0u;
         return;

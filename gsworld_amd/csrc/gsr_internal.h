@@ -45,7 +45,7 @@ struct GsrHeader {
     uint32_t tile_queue;  // ticket counter of the compositing kernel's tile queue (zeroed with the header)
     uint32_t ss_magic;    // depth sort: the splitters in the state are the exact quantiles of the last frame ...
     uint32_t ss_buckets;  // ... for this bucket count (both survive from frame to frame; garbage on a fresh state)
-    uint32_t ss_bad;      // a bucket of the last frame came out far above its share: sample again
+    uint32_t ss_bad;      // a bucket of the last frame came out above what exact quantiles of an UNCHANGED scene give
     uint32_t ss_view[16]; // bits of the view matrix the splitters were built under
     uint32_t ss_blind;    // this frame's compaction took the splitters unchecked (static camera)
     uint32_t br_magic;    // band placement: wave_lo_base holds exact equal-cost cuts of a depth order of ...
@@ -53,8 +53,8 @@ struct GsrHeader {
     uint32_t br_age;      // ... this many frames ago
     uint32_t ss_P;        // model size the splitters / cuts belong to (the arrays move with P; a recycled buffer may
     uint32_t br_P;        //   carry an old header over new garbage: both users also check what they read)
-    uint32_t ss_wait;     // frames left in which a flagged imbalance does NOT trigger new samples ...
-    uint32_t ss_backoff;  // ... and the wait after the next sampling that still ends unbalanced (1, 2, 4 .. 64)
+    uint32_t ss_trust;    // consecutive frames that classified with the KEPT table and came out balanced (blind needs 2)
+    uint32_t ss_prev_fresh;  // the previous frame drew its own splitters (says nothing about the kept table)
     uint32_t ss_fresh;    // this frame's compaction drew new splitters: the partition pass reads ss_splitters_new
     uint32_t pad[28];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)

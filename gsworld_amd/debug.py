@@ -89,3 +89,15 @@ def state_view(P: int, width: int, height: int, num_rendered: int, num_visible: 
         out["final_T"] = _view(imgBuffer, v.final_T, width * height, torch.float32).view(height, width)
         out["n_contrib"] = _view(imgBuffer, v.n_contrib, width * height, torch.int32).view(height, width)
     return out
+
+
+def sort_state(geomBuffer: torch.Tensor) -> dict:
+    """What the sample sort of the last frame on this geometry state did with the splitters it found there
+    (``gsr_debug_sort_state``; synchronises the current stream): ``blind`` -- taken unchecked, ``fresh`` -- drawn anew from
+    samples, neither -- the kept ones checked against samples and kept; ``bad`` -- some depth bucket came out above what
+    quantiles of an unchanged scene give; ``trust`` -- consecutive balanced frames on kept splitters before this one."""
+    out = (C.c_int32 * 4)()
+    with torch.cuda.device(geomBuffer.device):
+        check(lib().gsr_debug_sort_state(C.c_void_p(geomBuffer.data_ptr()), out,
+                                         C.c_void_p(torch.cuda.current_stream(geomBuffer.device).cuda_stream)))
+    return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]))

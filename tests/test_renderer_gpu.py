@@ -349,3 +349,39 @@ def test_state_buffers_recycled_between_layouts(cuda_device):
             got = b.render(cam, means, op, **kw)[0]
             assert torch.equal(got, want)
         assert not b.ensure_valid(lambda: None).overflow
+
+
+def test_fixed_camera_takes_kept_splitters_blind_only_while_the_scene_stands_still(cuda_device):
+    """Depth-sort splitters kept from frame to frame (depthsort.hip).  Under a fixed camera a scene that stands still
+    earns the right to skip the sample check ("blind") after a few balanced frames; a scene that MOVES under the same
+    camera must lose it at once and not get it back while it moves -- an arm swinging into a depth range that was empty a
+    frame ago lands in one wide kept bucket, and a bucket beyond the LDS is sorted in global memory for a millisecond
+    (found with the forward-kinematics rollout: a quarter of its frames did).  Every frame is the exact-mode frame bit
+    for bit whatever the policy does."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=400_000, seed=21)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    arm = (raw.semantics.reshape(-1) > 0).to(dev)
+    r = FrameRenderer(dev, forward_only=True, want_radii=False)
+    for _ in range(6):
+        r.render(cam, means, op, **kw)
+    assert dbg.sort_state(r.geom)["blind"], "a static scene under a fixed camera should reuse its splitters unchecked"
+    toward_camera = (cam.camera_center - means[arm].mean(0))
+    toward_camera = toward_camera / toward_camera.norm()
+    states = []
+    for k in range(1, 7):
+        moved = means.clone()
+        moved[arm] += 0.12 * k * toward_camera  # the robot's clusters travel 12 cm in depth per frame
+        got = r.render(cam, moved, op, **kw)[0].clone()
+        states.append(dbg.sort_state(r.geom))
+        want = FrameRenderer(dev).render(cam, moved, op, exact=True, **kw)[0]
+        assert torch.equal(got, want), f"frame {k} of the moving scene"
+    assert states[0]["blind"] and states[0]["bad"], states[0]      # the first moved frame could not know
+    assert not any(s["blind"] for s in states[1:]), states         # ... the following ones sample
+    for _ in range(6):                                             # the scene stops: trust comes back
+        r.render(cam, moved, op, **kw)
+    assert dbg.sort_state(r.geom)["blind"]
