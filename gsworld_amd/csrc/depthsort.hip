@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
 // ---------------------------------------------------------------------------------------------------------
 // ss_buckets: one workgroup per bucket.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs,
+__global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs, uint2 *__restrict__ scratch,
                                                         const uint32_t *__restrict__ bucket_start,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     uint32_t *s_k = smem;                      // [2][kBucketCap]
     uint32_t *s_v = s_k + 2 * kBucketCap;      // [2][kBucketCap]
     uint32_t *s_cur = s_v + 2 * kBucketCap;    // [4][256]
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[4], s_d[4];
     const int tid = (int)threadIdx.x;
     const uint32_t V = hdr->V;
     if (V == 0u) return;
@@ -781,88 +781,152 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         return;
     }
     uint2 *seg = recs + s;
-    if (n > kBucketCap) {
-        // does not fit the LDS: bitonic network over the (key << 32 | index) composites in global memory (one
-        // workgroup, barriers order the stages); unique composites, so the result is the stable order
-        int N = 2;
-        while (N < n) N <<= 1;
-        uint64_t *comp = reinterpret_cast<uint64_t *>(seg);
-        __syncthreads();
-        bitonic_sort_block(comp, n, N);
-        uint32_t carry = 0;
-        for (int i0 = 0; i0 < n; i0 += kT) {
+    // ---- what leaves the kernel for records [abs, abs + cnt) of the depth order, `at(i)` = (index, key) of the i-th
+    // of them: depth order, the tile rects in that order (what the placement streams), the running sum of tiles touched
+    // inside the bucket (the placement cuts the depth order into shares of equal INSTANCE count with it), and next
+    // frame's splitters -- the exact B-quantiles of this frame's depth order, each written by whoever holds its rank
+    auto emit = [&](auto at, uint32_t abs, int cnt, uint32_t carry) -> uint32_t {
+        for (int i = tid; i < B - 1; i += kT) {
+            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
+            if (q >= abs && q < abs + (uint32_t)cnt) splitters[i] = at((int)(q - abs)).y & kKeyMask;
+        }
+        for (int i0 = 0; i0 < cnt; i0 += kT) {
             const int i = i0 + tid;
             uint32_t t = 0;
-            if (i < n) {
-                const uint32_t gi = (uint32_t)comp[i];
+            if (i < cnt) {
+                const uint32_t gi = at(i).x;
                 const uint2 rc = ss_super_rect(rects[gi], sshift);
-                order[s + i] = gi;
-                rect_sorted[s + i] = rc;
+                order[abs + i] = gi;
+                rect_sorted[abs + i] = rc;
                 t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
             }
             uint32_t tot;
             const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
-            if (i < n) tile_cum[s + i] = carry + incl;
+            if (i < cnt) tile_cum[abs + i] = carry + incl;
             carry += tot;
         }
-        if (tid == 0) bucket_tiles[blockIdx.x] = carry;
-        for (int i = tid; i < B - 1; i += kT) {  // next frame's splitters: exact quantiles (see below)
-            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
-            if (q >= s && q < s + (uint32_t)n) splitters[i] = (uint32_t)(comp[q - s] >> 32) & kKeyMask;
+        return carry;
+    };
+    // ---- cnt <= kBucketCap records from global memory into the LDS, sorted there by key (stable: LSD passes over the
+    // bits in which the keys differ); `by_index` first sorts them by index the same way, for records that did not
+    // arrive in index order.  -> which half of s_k / s_v holds the result
+    auto sort_in_lds = [&](const uint2 *from, int cnt, bool by_index) -> int {
+        const uint2 r0 = from[0];
+        uint32_t kdiff = 0, vdiff = 0;
+        for (int i = tid; i < cnt; i += kT) {
+            const uint2 r = from[i];
+            s_v[i] = r.x;
+            s_k[i] = r.y;
+            kdiff |= r.y ^ r0.y;
+            vdiff |= r.x ^ r0.x;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kdiff |= (uint32_t)__shfl_xor((int)kdiff, o, 64);
+            vdiff |= (uint32_t)__shfl_xor((int)vdiff, o, 64);
+        }
+        __syncthreads();  // (s_w may still be read by the scan of an earlier emit)
+        if (gsr_lane() == 0) {
+            s_w[gsr_wave()] = kdiff;
+            s_d[gsr_wave()] = vdiff;
+        }
+        __syncthreads();
+        kdiff = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+        vdiff = s_d[0] | s_d[1] | s_d[2] | s_d[3];
+        __syncthreads();
+        int src = 0;
+        if (by_index) {
+            const int vbits = vdiff == 0u ? 0 : 32 - __builtin_clz(vdiff);
+            for (int shift = 0; shift < vbits; shift += 8) {
+                lds_radix_pass<true>(s_v + src * kBucketCap, s_k + src * kBucketCap, s_v + (src ^ 1) * kBucketCap,
+                                     s_k + (src ^ 1) * kBucketCap, cnt, shift, s_cur, s_w);
+                src ^= 1;
+            }
+        }
+        const int bits = kdiff == 0u ? 0 : 32 - __builtin_clz(kdiff);
+#ifdef GSR_SS_TIMING
+        if (blockIdx.x == dbg_wg && tid == 0) { dbg[8] = (uint64_t)bits; dbg[9] = (uint64_t)cnt; }
+#endif
+        for (int shift = 0; shift < bits; shift += 8) {
+            lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
+                                 s_v + (src ^ 1) * kBucketCap, cnt, shift, s_cur, s_w);
+            src ^= 1;
+        }
+        return src;
+    };
+    if (n > kBucketCap) {
+        // Does not fit the LDS (the kept splitters were taken unchecked and the scene had moved; a sample check that
+        // missed; depth ties).  The bucket is cut once more, by this workgroup alone: sub-splitters from 1024 of its own
+        // keys, an unordered scatter into the record buffer the partition pass has finished with (`scratch`, same
+        // offsets), then every piece is sorted in the LDS -- by index first, since the scatter lost the index order
+        // the stable sort by key relies on.  A piece that still does not fit (more than kBucketCap records between two
+        // sub-splitters: ties) goes through a bitonic network over its (key << 32 | index) composites in global memory.
+        constexpr int kSub = 64, kSubSamples = 1024;
+        __shared__ uint32_t s_sub[kSub], s_cnt[kSub], s_off[kSub + 1], s_fill[kSub];
+        uint2 *tmp = scratch + s;
+        const int m = min(kSub, (n + kBucketCap / 2 - 1) / (kBucketCap / 2));
+        for (int i = tid; i < kSubSamples; i += kT) s_k[i] = seg[(int)(((int64_t)i * n) / kSubSamples)].y;
+        if (tid < kSub) s_cnt[tid] = 0u;
+        __syncthreads();
+        lds_radix_pass<false>(s_k, nullptr, s_k + kBucketCap, nullptr, kSubSamples, 0, s_cur, s_w);
+        lds_radix_pass<false>(s_k + kBucketCap, nullptr, s_k, nullptr, kSubSamples, 8, s_cur, s_w);
+        lds_radix_pass<false>(s_k, nullptr, s_k + kBucketCap, nullptr, kSubSamples, 16, s_cur, s_w);
+        lds_radix_pass<false>(s_k + kBucketCap, nullptr, s_k, nullptr, kSubSamples, 24, s_cur, s_w);
+        if (tid < m - 1) s_sub[tid] = s_k[((tid + 1) * kSubSamples) / m];
+        __syncthreads();
+        // piece of a key = number of sub-splitters <= key: equal keys stay together
+        auto piece = [&](uint32_t key) -> int {
+            int lo = 0, hi = m - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_sub[mid] <= key) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        for (int i = tid; i < n; i += kT) atomicAdd(&s_cnt[piece(seg[i].y)], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int j = 0; j < m; j++) {
+                s_off[j] = run;
+                s_fill[j] = run;
+                run += s_cnt[j];
+            }
+            s_off[m] = run;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kT) {
+            const uint2 r = seg[i];
+            tmp[atomicAdd(&s_fill[piece(r.y)], 1u)] = r;
+        }
+        __syncthreads();  // (this workgroup's stores to `tmp` are complete and visible to all of its waves)
+        uint32_t carry = 0;
+        for (int j = 0; j < m; j++) {
+            const uint32_t o = s_off[j];
+            const int nj = (int)(s_off[j + 1] - o);
+            if (nj == 0) continue;
+            if (nj <= kBucketCap) {
+                const int src = sort_in_lds(tmp + o, nj, true);
+                const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
+                carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s + o, nj, carry);
+            } else {
+                int N = 2;
+                while (N < nj) N <<= 1;
+                uint64_t *comp = reinterpret_cast<uint64_t *>(tmp + o);
+                bitonic_sort_block(comp, nj, N);
+                carry = emit([&](int i) { const uint64_t c = comp[i]; return make_uint2((uint32_t)c, (uint32_t)(c >> 32)); },
+                             s + o, nj, carry);
+            }
+            __syncthreads();  // the LDS halves are free for the next piece
+        }
+        if (tid == 0) bucket_tiles[blockIdx.x] = carry;
         return;
     }
     SS_STAMP(dbg, 1);
-    const uint32_t key0 = seg[0].y;
-    uint32_t diff = 0;
-    for (int i = tid; i < n; i += kT) {
-        const uint2 r = seg[i];
-        s_v[i] = r.x;
-        s_k[i] = r.y;
-        diff |= r.y ^ key0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o, 64);
-    if (gsr_lane() == 0) s_w[gsr_wave()] = diff;
-    __syncthreads();
-    diff = s_w[0] | s_w[1] | s_w[2] | s_w[3];
-    __syncthreads();
-    SS_STAMP(dbg, 2);
-    const int bits = diff == 0u ? 0 : 32 - __builtin_clz(diff);
-#ifdef GSR_SS_TIMING
-    if (blockIdx.x == dbg_wg && tid == 0) { dbg[8] = (uint64_t)bits; dbg[9] = (uint64_t)n; }
-#endif
-    int src = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
-        lds_radix_pass<true>(s_k + src * kBucketCap, s_v + src * kBucketCap, s_k + (src ^ 1) * kBucketCap,
-                             s_v + (src ^ 1) * kBucketCap, n, shift, s_cur, s_w);
-        src ^= 1;
-    }
+    const int src = sort_in_lds(seg, n, false);
     SS_STAMP(dbg, 3);
-    // next frame's splitters: the exact B-quantiles of this frame's depth order (top 24 bits), each written by the
-    // bucket that holds its rank
-    for (int i = tid; i < B - 1; i += kT) {
-        const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
-        if (q >= s && q < s + (uint32_t)n) splitters[i] = s_k[src * kBucketCap + (int)(q - s)] & kKeyMask;
-    }
-    // depth order, the tile rects in that order (what the placement streams), and the running sum of tiles touched
-    // inside the bucket (the placement cuts the depth order into shares of equal INSTANCE count with it)
-    uint32_t carry = 0;
-    for (int i0 = 0; i0 < n; i0 += kT) {
-        const int i = i0 + tid;
-        uint32_t t = 0;
-        if (i < n) {
-            const uint32_t gi = s_v[src * kBucketCap + i];
-            const uint2 rc = ss_super_rect(rects[gi], sshift);
-            order[s + i] = gi;
-            rect_sorted[s + i] = rc;
-            t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
-        }
-        uint32_t tot;
-        const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
-        if (i < n) tile_cum[s + i] = carry + incl;
-        carry += tot;
-    }
+    const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
+    const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s, n, 0u);
     if (tid == 0) bucket_tiles[blockIdx.x] = carry;
     SS_STAMP(dbg, 4);
 }
@@ -907,7 +971,7 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
                        gsr_render_cus_per_xcd());
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.ss_bucket_start,
+    hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.pair[0], g.ss_bucket_start,
                        g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
                        viewmatrix, sig, super_shift);
     return gsr_check_launch("ss_buckets", debug, stream);

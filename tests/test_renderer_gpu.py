@@ -385,3 +385,49 @@ def test_fixed_camera_takes_kept_splitters_blind_only_while_the_scene_stands_sti
     for _ in range(6):                                             # the scene stops: trust comes back
         r.render(cam, moved, op, **kw)
     assert dbg.sort_state(r.geom)["blind"]
+
+
+@pytest.mark.parametrize("case", ["ten_thousand_into_one_bucket", "forty_thousand_into_one_bucket", "five_thousand_equal_depths"])
+def test_depth_bucket_beyond_the_lds_is_still_sorted_exactly(cuda_device, case):
+    """A depth bucket of the sample sort that outgrows the LDS (kBucketCap = 3584 records): the kept splitters were
+    taken unchecked under a fixed camera and the scene jumped.  The bucket's workgroup cuts it once more by
+    sub-splitters drawn from its own keys and sorts the pieces in the LDS (by index, then by key); a piece that still
+    does not fit -- thousands of EQUAL depths -- goes through the global-memory network.  Whatever route, the frame is the
+    exact-mode frame of a fresh renderer bit for bit, and so is the next one (the splitters that frame left behind)."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=400_000, seed=22)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    arm = torch.nonzero((raw.semantics.reshape(-1) > 0).to(dev)).reshape(-1)
+    # (binning capacity for whatever lands in front of the camera: this test is about the depth sort)
+    r = FrameRenderer(dev, forward_only=True, want_radii=False, min_capacity=1 << 26)
+    for _ in range(6):
+        r.render(cam, means, op, **kw)
+    assert dbg.sort_state(r.geom)["blind"]
+    gen = torch.Generator().manual_seed(5)
+    # a spot in the middle of what the camera sees, a tenth of the way towards it (depths nothing else has)
+    seen = FrameRenderer(dev).render(cam, means, op, **kw)[1] > 0
+    spot = means[seen].mean(0)
+    spot = spot + 0.1 * (cam.camera_center - spot)
+    moved = means.clone()
+    if case == "ten_thousand_into_one_bucket":
+        pick = arm[torch.randperm(arm.numel(), generator=gen)[:10_000].to(dev)]
+        moved[pick] = spot + 0.002 * torch.randn(pick.numel(), 3, generator=gen).to(dev)
+    elif case == "forty_thousand_into_one_bucket":  # (V stays below the next bucket count: the kept table is taken)
+        pick = arm[torch.randperm(arm.numel(), generator=gen)[:40_000].to(dev)]
+        moved[pick] = spot + 0.002 * torch.randn(pick.numel(), 3, generator=gen).to(dev)
+    else:
+        pick = arm[torch.randperm(arm.numel(), generator=gen)[:5_000].to(dev)]
+        moved[pick] = spot  # one position: 5 000 identical depth keys, ordered by index alone
+    for k in range(2):
+        got = r.render(cam, moved, op, **kw)[0].clone()
+        st = dbg.sort_state(r.geom)
+        want = FrameRenderer(dev).render(cam, moved, op, exact=True, **kw)[0]
+        assert not r.stats().overflow
+        assert torch.equal(got, want), f"{case}: frame {k} after the jump"
+        if k == 0:
+            assert st["blind"] and st["bad"], (st, r.stats())
+            assert r.stats().num_visible > 40_000 + (4_000 if case != "forty_thousand_into_one_bucket" else 30_000)
