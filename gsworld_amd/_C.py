@@ -57,13 +57,15 @@ def _f32(t: torch.Tensor, device, what: str) -> torch.Tensor:
 
 def _resizer(t: torch.Tensor, header: bool = False):
     """``header``: the geometry state -- storage the allocator hands out may be a freed state of another renderer, whose
-    frame header still says how many of ITS frames overflowed: new storage starts with a zeroed header (enqueued on the
-    frame's stream, ahead of the frame's first kernel; zeroed kept-splitter / kept-cut fields just mean "sample")."""
+    frame header still says how many of ITS frames overflowed: on new storage the count (the header's last two words)
+    is zeroed, enqueued on the frame's stream ahead of the frame's first kernel.  The rest of a recycled header is left
+    alone on purpose: kept splitters / cuts are tied to model size and layout and checked before use (depthsort.hip),
+    and a training loop, which gets the block it freed a step ago back every step, keeps its splitters that way."""
     def fn(_user, nbytes):
         before = t.data_ptr() if t.numel() else 0
         t.resize_(int(nbytes))
         if header and t.data_ptr() != before and nbytes >= 256:
-            t[:256].zero_()
+            t[248:256].zero_()
         return t.data_ptr()
 
     return RESIZE_FN(fn)
@@ -157,9 +159,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P = means3D.size(0)
     H, W = int(image_height), int(image_width)
     f32 = dict(dtype=torch.float32, device=dev)
-    out_color = torch.zeros((3, H, W), **f32)
-    out_invdepth = torch.zeros((1, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # (a frame writes every pixel and every radius itself; upstream's zero fill is what P == 0 returns)
+    alloc = torch.empty if P != 0 else torch.zeros
+    out_color = alloc((3, H, W), **f32)
+    out_invdepth = alloc((1, H, W), **f32)
+    radii = alloc((P,), dtype=torch.int32, device=dev)
     geomBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
     binningBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
     imgBuffer = torch.empty(0, dtype=torch.uint8, device=dev)

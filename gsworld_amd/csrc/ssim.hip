@@ -21,13 +21,18 @@ __device__ __forceinline__ float load_px(const float *__restrict__ img, int x, i
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.f;
 }
 
+// LOSS (gsr_photometric_loss): img1 is read through clamp(., 0, 1) when `clamp01`; no ssim map is written -- the
+// workgroup's sums of the ssim values and of |img1 - img2| over its 16 x 16 pixels go to partials[2 b], [2 b + 1]
+// (b = the workgroup's linear index; summed in a fixed order: the loss is reproducible bit for bit).
+template <bool LOSS>
 __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, float C1, float C2, Gauss11 g,
                                                                  const float *__restrict__ img1,
                                                                  const float *__restrict__ img2, int train,
                                                                  float *__restrict__ ssim_map,
                                                                  float *__restrict__ dm_dmu1,
                                                                  float *__restrict__ dm_dsigma1_sq,
-                                                                 float *__restrict__ dm_dsigma12) {
+                                                                 float *__restrict__ dm_dsigma12, int clamp01,
+                                                                 float *__restrict__ partials) {
     __shared__ float s1[kH][kH + 1];
     __shared__ float s2[kH][kH + 1];
     __shared__ float sh[5][kH][kT + 1];
@@ -37,7 +42,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < kH * kH; i += GSR_BLOCK) {
         const int ly = i / kH, lx = i - ly * kH;
-        s1[ly][lx] = load_px(p1, x0 + lx - kR, y0 + ly - kR, W, H);
+        float a = load_px(p1, x0 + lx - kR, y0 + ly - kR, W, H);
+        if (LOSS && clamp01) a = a != a ? a : fminf(fmaxf(a, 0.f), 1.f);  // (torch.clamp keeps a NaN; max / min drop it)
+        s1[ly][lx] = a;
         s2[ly][lx] = load_px(p2, x0 + lx - kR, y0 + ly - kR, W, H);
     }
     __syncthreads();
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
     const int lx = tid & (kT - 1), ly = tid >> 4;
     const int x = x0 + lx, y = y0 + ly;
     float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    float v_ssim = 0.f, v_l1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const float w = g.w[k];
@@ -75,7 +83,12 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
         const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
         const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
         const size_t o = plane + (size_t)y * W + x;
-        ssim_map[o] = (Cc * D) / (A * B);
+        if (LOSS) {
+            v_ssim = (Cc * D) / (A * B);
+            v_l1 = fabsf(s1[ly + kR][lx + kR] - s2[ly + kR][lx + kR]);
+        } else {
+            ssim_map[o] = (Cc * D) / (A * B);
+        }
         if (train) {
             dm_dmu1[o] = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * Cc) / (A * B) - (mu1 * 2.f * Cc * D) / (A * A * B) +
                          (mu1 * 2.f * Cc * D) / (A * B * B);
@@ -83,8 +96,55 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
             dm_dsigma12[o] = (2.f * Cc) / (A * B);
         }
     }
+    if (LOSS) {
+        __shared__ float s_red[2][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v_ssim += __shfl_xor(v_ssim, o, 64);
+            v_l1 += __shfl_xor(v_l1, o, 64);
+        }
+        if (gsr_lane() == 0) {
+            s_red[0][gsr_wave()] = v_ssim;
+            s_red[1][gsr_wave()] = v_l1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partials[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            partials[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+        }
+    }
 }
 
+// one workgroup: loss = (1 - lambda) sum|.| / n + lambda (1 - sum ssim / n) from the per-workgroup partial sums
+__global__ __launch_bounds__(GSR_BLOCK) void loss_finish_kernel(const float *__restrict__ partials, int nb, double n,
+                                                                float lambda, float *__restrict__ loss) {
+    __shared__ double s_a[GSR_BLOCK], s_b[GSR_BLOCK];
+    double a = 0.0, b = 0.0;
+    for (int i = (int)threadIdx.x; i < nb; i += GSR_BLOCK) {
+        a += (double)partials[2 * i];
+        b += (double)partials[2 * i + 1];
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = GSR_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_a[threadIdx.x] += s_a[threadIdx.x + o];
+            s_b[threadIdx.x] += s_b[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double l1 = s_b[0] / n, ssim = s_a[0] / n;
+        loss[0] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ssim));
+    }
+}
+
+// LOSS (gsr_photometric_loss): dL/dmap is the constant w_ssim (= -lambda / n); the L1 term w_l1 sign(x - y) is added
+// (sign(0) = 0, torch's abs backward) and the whole gradient passes through clamp(., 0, 1)'s backward when `clamp01`
+// (kept where 0 <= img1 <= 1, bounds included, as torch.clamp).
+template <bool LOSS>
 __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, Gauss11 g,
                                                                   const float *__restrict__ img1,
                                                                   const float *__restrict__ img2,
@@ -92,7 +152,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
                                                                   const float *__restrict__ dm_dmu1,
                                                                   const float *__restrict__ dm_dsigma1_sq,
                                                                   const float *__restrict__ dm_dsigma12,
-                                                                  float *__restrict__ dL_dimg1) {
+                                                                  float *__restrict__ dL_dimg1, float w_ssim,
+                                                                  float w_l1, int clamp01) {
     __shared__ float s[3][kH][kH + 1];
     __shared__ float sh[3][kH][kT + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -104,7 +165,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
         float a = 0.f, b = 0.f, c = 0.f;
         if (x >= 0 && x < W && y >= 0 && y < H) {
             const size_t o = plane + (size_t)y * W + x;
-            const float dl = dL_dmap[o];
+            const float dl = LOSS ? w_ssim : dL_dmap[o];
             a = dl * dm_dmu1[o];
             b = dl * dm_dsigma1_sq[o];
             c = dl * dm_dsigma12[o];
@@ -137,7 +198,16 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
     }
     if (x < W && y < H) {
         const size_t o = plane + (size_t)y * W + x;
-        dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+        if (LOSS) {
+            const float raw = img1[o], yv = img2[o];
+            const float xv = (clamp01 && raw == raw) ? fminf(fmaxf(raw, 0.f), 1.f) : raw;
+            const float d = xv - yv;
+            float gsum = a + 2.f * xv * b + yv * c;
+            gsum += w_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            dL_dimg1[o] = (!clamp01 || (raw >= 0.f && raw <= 1.f)) ? gsum : 0.f;
+        } else {
+            dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+        }
     }
 }
 
@@ -171,8 +241,9 @@ extern "C" int gsr_ssim_forward(int32_t B, int32_t CH, int32_t H, int32_t W, flo
         return GSR_E_INVALID;
     }
     const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), B * CH);
-    hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, C1, C2, make_window(),
-                       img1, img2, train, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+    hipLaunchKernelGGL(ssim_forward_kernel<false>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, C1, C2,
+                       make_window(), img1, img2, train, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, 0,
+                       (float *)nullptr);
     return gsr_check_launch("ssim_forward", false, (hipStream_t)stream);
 }
 
@@ -195,7 +266,49 @@ extern "C" int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, fl
         return GSR_E_INVALID;
     }
     const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), B * CH);
-    hipLaunchKernelGGL(ssim_backward_kernel, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, make_window(), img1,
-                       img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+    hipLaunchKernelGGL(ssim_backward_kernel<false>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, make_window(),
+                       img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, 0.f, 0.f, 0);
     return gsr_check_launch("ssim_backward", false, (hipStream_t)stream);
+}
+
+// ---- the photometric loss of the 3DGS training step in two passes --------------------------------------------------
+extern "C" size_t gsr_photometric_loss_scratch_floats(int32_t planes, int32_t H, int32_t W) {
+    if (planes <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t nb = (size_t)gsr_div_up(W, kT) * gsr_div_up(H, kT) * planes;
+    return 3 * (size_t)planes * H * W + 2 * nb;
+}
+
+extern "C" int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const float *img, const float *target,
+                                    float lambda_dssim, int32_t clamp01, float *scratch, float *loss, float *dL_dimg,
+                                    void *stream_) {
+    if (planes <= 0 || H <= 0 || W <= 0 || planes > 65535) {
+        gsr_set_error("gsr_photometric_loss: planes must be in 1 .. 65535, H and W positive");
+        return GSR_E_INVALID;
+    }
+    if (!img || !target || !scratch || !loss) {
+        gsr_set_error("gsr_photometric_loss: null pointer");
+        return GSR_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n = (size_t)planes * H * W;
+    const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), planes);
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    float *dm_dmu1 = scratch, *dm_dsigma1_sq = scratch + n, *dm_dsigma12 = scratch + 2 * n, *partials = scratch + 3 * n;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const Gauss11 g = make_window();
+    hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, C1, C2, g, img, target,
+                       dL_dimg != nullptr ? 1 : 0, (float *)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, clamp01, partials);
+    if (int e = gsr_check_launch("photometric_loss (forward)", false, stream)) return e;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, (const float *)partials, nb, (double)n,
+                       lambda_dssim, loss);
+    if (int e = gsr_check_launch("photometric_loss (sum)", false, stream)) return e;
+    if (dL_dimg != nullptr) {
+        const float w_ssim = (float)(-(double)lambda_dssim / (double)n);
+        const float w_l1 = (float)((1.0 - (double)lambda_dssim) / (double)n);
+        hipLaunchKernelGGL(ssim_backward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, g, img, target,
+                           (const float *)nullptr, (const float *)dm_dmu1, (const float *)dm_dsigma1_sq,
+                           (const float *)dm_dsigma12, dL_dimg, w_ssim, w_l1, clamp01);
+        if (int e = gsr_check_launch("photometric_loss (gradient)", false, stream)) return e;
+    }
+    return GSR_OK;
 }

@@ -29,13 +29,14 @@ char *resize_cb(void *user, size_t bytes) {
 }
 
 // The geometry state: storage the allocator hands out may be a freed state of another renderer, whose frame header
-// still says how many of ITS frames overflowed -- new storage starts with a zeroed header (enqueued on the frame's
-// stream ahead of the frame's first kernel).
+// still says how many of ITS frames overflowed -- on new storage that count (the header's last two words) is zeroed,
+// enqueued on the frame's stream ahead of the frame's first kernel; the kept splitters / cuts of a recycled header
+// are checked before use and stay (a training loop gets the block it freed a step ago back every step).
 char *resize_geom_cb(void *user, size_t bytes) {
     auto *t = static_cast<torch::Tensor *>(user);
     const void *before = t->numel() ? t->data_ptr() : nullptr;
     t->resize_({static_cast<long long>(bytes)});
-    if (t->data_ptr() != before && bytes >= 256) t->narrow(0, 0, 256).zero_();
+    if (t->data_ptr() != before && bytes >= 256) t->narrow(0, 248, 8).zero_();
     return reinterpret_cast<char *>(t->data_ptr());
 }
 
@@ -168,8 +169,11 @@ rasterize_gaussians(const torch::Tensor &background, const torch::Tensor &means3
     const int P = (int)means3D.size(0), H = image_height, W = image_width;
     auto fopt = means3D.options().dtype(torch::kFloat32);
     auto bopt = means3D.options().dtype(torch::kByte);
-    torch::Tensor out_color = torch::zeros({3, H, W}, fopt), out_invdepth = torch::zeros({1, H, W}, fopt);
-    torch::Tensor radii = torch::zeros({P}, means3D.options().dtype(torch::kInt32));
+    // (a frame writes every pixel and every radius itself; upstream's zero fill is what P == 0 returns)
+    auto iopt = means3D.options().dtype(torch::kInt32);
+    torch::Tensor out_color = P != 0 ? torch::empty({3, H, W}, fopt) : torch::zeros({3, H, W}, fopt);
+    torch::Tensor out_invdepth = P != 0 ? torch::empty({1, H, W}, fopt) : torch::zeros({1, H, W}, fopt);
+    torch::Tensor radii = P != 0 ? torch::empty({P}, iopt) : torch::zeros({P}, iopt);
     torch::Tensor geom = torch::empty({0}, bopt), binning = torch::empty({0}, bopt), img = torch::empty({0}, bopt);
     int rendered = 0;
     if (P != 0) {

@@ -21,6 +21,10 @@ def _bind():
             [C.c_void_p] * 5
         L.gsr_ssim_backward.restype = C.c_int
         L.gsr_ssim_backward.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_float] + [C.c_void_p] * 8
+        L.gsr_photometric_loss_scratch_floats.restype = C.c_size_t
+        L.gsr_photometric_loss_scratch_floats.argtypes = [C.c_int32] * 3
+        L.gsr_photometric_loss.restype = C.c_int
+        L.gsr_photometric_loss.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 2 + [C.c_float, C.c_int32] + [C.c_void_p] * 4
         L._ssim_bound = True
     return L
 
@@ -98,3 +102,41 @@ def fused_ssim(img1, img2, padding="same", train=True):
     assert padding in allowed_padding
     ssim_map = FusedSSIMMap.apply(C1, C2, img1, img2, padding, train)
     return ssim_map.mean()
+
+
+class _PhotometricLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, target, lambda_dssim, clamp01):
+        L = _bind()
+        if not (img.is_cuda and target.is_cuda):
+            raise RuntimeError("photometric_loss: images must live on a HIP device (no CPU path)")
+        if img.shape != target.shape or img.ndim < 2:
+            raise RuntimeError("photometric_loss: img and target must have the same (..., H, W) shape")
+        x = img.detach().to(torch.float32).contiguous()
+        t = target.detach().to(torch.float32).contiguous()
+        H, W = x.shape[-2:]
+        planes = x.numel() // (H * W) if H * W else 0
+        need_grad = ctx.needs_input_grad[0]
+        scratch = torch.empty(int(L.gsr_photometric_loss_scratch_floats(planes, H, W)), dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if need_grad else None
+        with torch.cuda.device(x.device):
+            check(L.gsr_photometric_loss(planes, H, W, _p(x), _p(t), float(lambda_dssim), int(bool(clamp01)), _p(scratch),
+                                         _p(loss), _p(grad) if need_grad else None,
+                                         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, ctx.grad = ctx.grad, None
+        return (grad * g if grad is not None else None), None, None, None
+
+
+def photometric_loss(img, target, lambda_dssim: float = 0.2, clamp01: bool = False):
+    """``(1 - lambda) * l1_loss(x, target) + lambda * (1 - fused_ssim(x[None], target[None]))`` with
+    ``x = img.clamp(0, 1)`` when ``clamp01`` -- the loss of the 3DGS training step (gs_utils.py:96 ``lambda_dssim``;
+    upstream train.py) as ONE autograd node over three kernels (``gsr_photometric_loss``) instead of ~25 elementwise /
+    reduction launches: the value is summed in a fixed order, the gradient w.r.t. ``img`` (through the clamp) is written
+    in the forward and scaled by the incoming gradient in the backward.  An extension: ``fused_ssim`` stays the drop-in."""
+    return _PhotometricLoss.apply(img, target, lambda_dssim, clamp01)

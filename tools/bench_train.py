@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "gsworld_amd", "dropin"))
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 from fused_ssim import fused_ssim  # noqa: E402
+from gsworld_amd.ssim import photometric_loss  # noqa: E402
 from gsworld_amd import debug as dbg, scenes  # noqa: E402
 
 
@@ -32,11 +33,20 @@ def run(steps=50, warmup=5, num_gaussians=500_000, size=800, fused=False, device
     tgt.xyz += (0.01 * torch.randn(tgt.xyz.shape, generator=gen)).to(dev)
     tgt.features_dc += (0.1 * torch.randn(tgt.features_dc.shape, generator=gen)).to(dev)
     bg = torch.zeros(3, device=dev)
-    rs = GaussianRasterizationSettings(S, S, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.world_view_transform,
-                                       cam.full_proj_transform, 3, cam.camera_center, False, False, False)
-    rast = GaussianRasterizer(rs)
+    # A training loop draws another view every iteration: the step cycles through 8 cameras (view 0 = configs[4]'s
+    # identity view, the others 3 cm off the axis looking at the same point), so that nothing the forward keeps from one
+    # frame to the next on a recycled state buffer -- depth-sort splitters, placement cuts -- carries over.
+    import math
 
-    def render(r, grad):
+    from gsworld_amd.camera import look_at_view
+    cams = [cam] + [look_at_view([0.03 * math.cos(k * math.pi / 3.5), 0.03 * math.sin(k * math.pi / 3.5), 0.0],
+                                 [0.0, 0.0, 3.0], [0.0, -1.0, 0.0], cam.FoVx, cam.FoVy, S, S).to(dev) for k in range(1, 8)]
+    rasts = [GaussianRasterizer(GaussianRasterizationSettings(S, S, c.tanfovx, c.tanfovy, bg, 1.0, c.world_view_transform,
+                                                              c.full_proj_transform, 3, c.camera_center, False, False,
+                                                              False)) for c in cams]
+
+    def render(r, grad, view=0):
+        rast = rasts[view]
         params = [r.xyz, r.features_dc, r.features_rest, r.opacity, r.scaling, r.rotation]
         if grad:
             for p in params:
@@ -46,31 +56,35 @@ def run(steps=50, warmup=5, num_gaussians=500_000, size=800, fused=False, device
         if fused:
             color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=r.features_dc, shs_rest=r.features_rest,
                                       opacities=r.opacity, scales=r.scaling, rotations=r.rotation, param_space=7)
-            return color.clamp(0, 1), radii
+            return (color if grad else color.clamp(0, 1)), radii  # (the fused loss clamps on load)
         shs = torch.cat((r.features_dc, r.features_rest), dim=1)
         color, radii, invd = rast(means3D=r.xyz, means2D=means2D, shs=shs, opacities=torch.sigmoid(r.opacity),
                                   scales=torch.exp(r.scaling), rotations=torch.nn.functional.normalize(r.rotation))
         return color.clamp(0, 1), radii
 
     with torch.no_grad():
-        gt, _ = render(tgt, False)
-    gt = gt.detach()
+        gts = [render(tgt, False, v)[0].detach() for v in range(len(cams))]
 
-    def step():
-        img, radii = render(raw, True)
-        l1 = (img - gt).abs().mean()
-        loss = 0.8 * l1 + 0.2 * (1.0 - fused_ssim(img[None], gt[None]))
+    def step(view=0):
+        img, radii = render(raw, True, view)
+        gt = gts[view]
+        if fused:  # clamp, L1, fused-ssim, their weights and the autograd of all of it: one node, three kernels
+            loss = photometric_loss(img, gt, 0.2, clamp01=True)
+        else:
+            l1 = (img - gt).abs().mean()
+            loss = 0.8 * l1 + 0.2 * (1.0 - fused_ssim(img[None], gt[None]))
         loss.backward()
         return loss, radii
 
-    for _ in range(warmup):
-        loss, radii = step()
+    for k in range(warmup):
+        loss, radii = step(k % len(cams))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss, radii = step()
+    for k in range(steps):
+        loss, radii = step(k % len(cams))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    loss, radii = step(0)  # (view 0: the numbers below are configs[4]'s own view)
     # algorithmic bytes of the step: forward 48 N + 280 V + 64 R + 16 W H; backward: twice the forward's
     # instance traffic (128 R) + the gradient bytes 4 (3+3+1+3+6+48+3+4) V = 284 V + the image gradient read (16 W H)
     from gsworld_amd import _C
@@ -93,9 +107,10 @@ def run(steps=50, warmup=5, num_gaussians=500_000, size=800, fused=False, device
                      "peak": 8000.0, "unit": "GB/s", "frac": b_alg / dt / 1e9 / 8000.0,
                      "note": "whole step (forward + backward + loss) against the HBM peak; SURVEY.md 8d byte model"},
         "config": {"workload": f"{num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
-                               "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step "
+                               "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step, another of 8 nearby views every "
+                               "step as a training loop would draw them "
                                "(BASELINE.json configs[4])",
-                   "parameter_packing": "fused (raw parameters, split SH)" if fused else "upstream (torch)",
+                   "parameter_packing": "fused (raw parameters, split SH; photometric_loss)" if fused else "upstream (torch)",
                    "num_visible": V, "num_rendered": int(R), "loss": float(loss.item()),
                    "grads_finite": bool(finite)}}
 
