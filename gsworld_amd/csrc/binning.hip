@@ -248,7 +248,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ quad_order, int cus_per_xcd) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
-    const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 8 * GSR_BLOCK;
+    const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 32 * GSR_BLOCK;
     // workgroup #2: which quadrants the compositor cuts in two this frame -- the costliest ones of the previous frame
     // on this state, as many as spare waves exist (split_cap), and only those clearly above the average.  A quadrant
     // that WAS split reports its two halves separately; together they did about 1.5x the work of the whole (two cull
@@ -315,13 +315,24 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
             gsr_quad_order_block(quad_work, 4 * T, quad_order, s_w, cus_per_xcd);
             return;  // (the tile-level order below is what the compositor uses when it has no quadrant order)
         }
-        uint32_t key[8];
+        if (T <= 8 * GSR_BLOCK) {
+            uint32_t key[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int t = (int)threadIdx.x + i * GSR_BLOCK;
-            key[i] = t < T ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+            for (int i = 0; i < 8; i++) {
+                const int t = (int)threadIdx.x + i * GSR_BLOCK;
+                key[i] = t < T ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+            }
+            gsr_tile_order_block_keys<8>(key, T, tile_order, s_bins, s_w);
+        } else {  // (up to 8192 tiles -- 800 x 800 training frames, 1920 x 1080 -- in this workgroup too, instead of
+                  //  three sweeps over global memory behind the ranges in workgroup #0)
+            uint32_t key[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int t = (int)threadIdx.x + i * GSR_BLOCK;
+                key[i] = t < T ? gsr_tile_order_key(nullptr, quad_work, t) : 0u;
+            }
+            gsr_tile_order_block_keys<32>(key, T, tile_order, s_bins, s_w);
         }
-        gsr_tile_order_block_keys(key, T, tile_order, s_bins, s_w);
         return;
     }
     uint32_t sum = 0;

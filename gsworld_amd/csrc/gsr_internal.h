@@ -594,13 +594,14 @@ __device__ __forceinline__ void gsr_tile_order_block(const uint2 *ranges, int nu
         order[pos] = (uint32_t)t;
     }
 }
-// The same for up to 8 x GSR_BLOCK tiles with the keys already in registers (key[i] belongs to tile
+// The same for up to NK x GSR_BLOCK tiles with the keys already in registers (key[i] belongs to tile
 // threadIdx.x + i * GSR_BLOCK): the caller loads them at the top of its kernel, so no global read sits between the passes.
-__device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[8], int num_tiles, uint32_t *order,
+template <int NK>
+__device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[NK], int num_tiles, uint32_t *order,
                                                           uint32_t *s_bins, uint32_t *s_red) {
     uint32_t mx = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < NK; i++)
         if ((int)threadIdx.x + i * GSR_BLOCK < num_tiles) mx = max(mx, key[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
@@ -610,7 +611,7 @@ __device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[
     mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     const float scale = mx > 0u ? 63.999f / (float)mx : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < NK; i++)
         if ((int)threadIdx.x + i * GSR_BLOCK < num_tiles) atomicAdd(&s_bins[63 - (int)((float)key[i] * scale)], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -625,7 +626,7 @@ __device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NK; i++) {
         const int t = (int)threadIdx.x + i * GSR_BLOCK;
         if (t < num_tiles) order[atomicAdd(&s_bins[63 - (int)((float)key[i] * scale)], 1u)] = (uint32_t)t;
     }

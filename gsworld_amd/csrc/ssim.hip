@@ -117,18 +117,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
 }
 
 // one workgroup: loss = (1 - lambda) sum|.| / n + lambda (1 - sum ssim / n) from the per-workgroup partial sums
-__global__ __launch_bounds__(GSR_BLOCK) void loss_finish_kernel(const float *__restrict__ partials, int nb, double n,
-                                                                float lambda, float *__restrict__ loss) {
-    __shared__ double s_a[GSR_BLOCK], s_b[GSR_BLOCK];
+constexpr int kFinT = 1024;
+__global__ __launch_bounds__(kFinT) void loss_finish_kernel(const float *__restrict__ partials, int nb, double n,
+                                                            float lambda, float *__restrict__ loss) {
+    __shared__ double s_a[kFinT], s_b[kFinT];
     double a = 0.0, b = 0.0;
-    for (int i = (int)threadIdx.x; i < nb; i += GSR_BLOCK) {
-        a += (double)partials[2 * i];
-        b += (double)partials[2 * i + 1];
+    const float2 *pp = reinterpret_cast<const float2 *>(partials);
+    for (int i0 = (int)threadIdx.x; i0 < nb; i0 += 4 * kFinT) {  // (four loads in flight per thread and round)
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = i0 + u * kFinT < nb ? pp[i0 + u * kFinT] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a += (double)v[u].x;
+            b += (double)v[u].y;
+        }
     }
     s_a[threadIdx.x] = a;
     s_b[threadIdx.x] = b;
     __syncthreads();
-    for (int o = GSR_BLOCK / 2; o > 0; o >>= 1) {
+    for (int o = kFinT / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             s_a[threadIdx.x] += s_a[threadIdx.x + o];
             s_b[threadIdx.x] += s_b[threadIdx.x + o];
@@ -293,13 +301,14 @@ extern "C" int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const 
     const size_t n = (size_t)planes * H * W;
     const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), planes);
     const int nb = (int)(grid.x * grid.y * grid.z);
-    float *dm_dmu1 = scratch, *dm_dsigma1_sq = scratch + n, *dm_dsigma12 = scratch + 2 * n, *partials = scratch + 3 * n;
+    float *partials = scratch, *maps = scratch + 2 * (size_t)nb;  // (the pairs first: read as float2)
+    float *dm_dmu1 = maps, *dm_dsigma1_sq = maps + n, *dm_dsigma12 = maps + 2 * n;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const Gauss11 g = make_window();
     hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, C1, C2, g, img, target,
                        dL_dimg != nullptr ? 1 : 0, (float *)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, clamp01, partials);
     if (int e = gsr_check_launch("photometric_loss (forward)", false, stream)) return e;
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, (const float *)partials, nb, (double)n,
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kFinT), 0, stream, (const float *)partials, nb, (double)n,
                        lambda_dssim, loss);
     if (int e = gsr_check_launch("photometric_loss (sum)", false, stream)) return e;
     if (dL_dimg != nullptr) {

@@ -67,6 +67,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _C.rasterize_gaussians(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # (an output the loss does not use arrives as None in backward, not as a zero image autograd had to fill:
+        #  GSWorld's losses never touch invdepths)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, radii, invdepths
@@ -77,6 +80,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color,
                 grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer,
@@ -112,6 +117,7 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos, rs.prefiltered,
             rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
         ctx.raster_settings, ctx.num_rendered, ctx.param_space = rs, num_rendered, param_space
+        ctx.set_materialize_grads(False)  # (see _RasterizeGaussians.forward)
         ctx.save_for_backward(means3D, scales, rotations, radii, sh_dc, sh_rest, opacities, geomBuffer, binningBuffer,
                               imgBuffer)
         return color, radii, invdepths
@@ -122,6 +128,8 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
         (means3D, scales, rotations, radii, sh_dc, sh_rest, opacities, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
         empty = torch.empty(0, device=means3D.device)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
         (grad_means2D, _gc, grad_opacities, grad_means3D, _gcov, grad_dc, grad_scales, grad_rotations,
          grad_rest) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix,
