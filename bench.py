@@ -568,7 +568,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
                 "ms_per_step": rec["ms_per_step"], "it_per_s": rec["value"],
                 "algorithmic_bytes_per_step": rec["roofline"]["algorithmic_bytes_per_step"],
                 "frac_of_8TBs": rec["roofline"]["frac"], "num_visible": rec["config"]["num_visible"],
-                "num_rendered": rec["config"]["num_rendered"], "grads_finite": rec["config"]["grads_finite"]}
+                "num_rendered": rec["config"]["num_rendered"], "grads_finite": rec["config"]["grads_finite"],
+                "variant": rec["config"]["parameter_packing"], "loss": rec["config"]["loss"]}
         out["train_step"]["workload"] = rec["config"]["workload"]
     except Exception as ex:  # noqa: BLE001
         out["train_step"] = {"error": f"{type(ex).__name__}: {ex}"}
