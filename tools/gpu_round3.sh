@@ -17,6 +17,7 @@ stats default_mode_frame tools/prof_scene.py --view sensor --default-mode
 stats dense_view tools/prof_scene.py --view dense
 stats moving_camera tools/prof_scene.py --view sensor --moving
 stats train_step_fused tools/bench_train.py --fused --steps 30
+stats closed_loop tools/closed_loop_surrogate.py --graph
 echo "== pmc (inference frame)"; bash tools/gpu_pmc.sh round3/pmc_raw 4 > $OUT/pmc/frame_config2.txt 2>&1; python tools/pmc_summary.py gpurun_out/round3/pmc_raw --json $OUT/pmc_render.json | tail -1
 grep -E "render_stream|preprocess|band_place" $OUT/pmc/frame_config2.txt | cut -c1-400
 rm -rf gpurun_out/round3/pmc_raw/p*/
