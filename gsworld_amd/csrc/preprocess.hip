@@ -9,6 +9,10 @@
 // +192 B of SH and 88 B of state written only for Gaussians that survive to a non-empty tile rect.
 #include "gsr_internal.h"
 
+#ifndef GSR_TIGHT_RECT
+#define GSR_TIGHT_RECT 1
+#endif
+
 namespace {
 
 struct PreprocessArgs {
@@ -253,13 +257,13 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
             rminy = min(a.gy, max(0, rminy));
             rmaxx = min(a.gx, max(0, rmaxx));
             rmaxy = min(a.gy, max(0, rmaxy));
-            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) radius = ir;  // (what the caller sees as radii: the reference's, whatever the lists keep)
+            float opacity = 0.f, third = vz;
             if (area != 0) {
                 float opacity_in = opacity_raw;
                 if (a.param_space & GSR_RAW_OPACITY) opacity_in = sigmoid_canonical(opacity_in);
-                const float opacity = opacity_in * h_scale;
-                float4 *rec = a.splat + 3 * (size_t)i;
-                float third = vz;
+                opacity = opacity_in * h_scale;
                 if (a.infer) {
                     // inference frames: the compositor never reads the depth word of the record; it carries what its
                     // per-quadrant cull would otherwise recompute for every candidate of every quadrant (render.hip
@@ -270,7 +274,37 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                     const float ac = conic_x * conic_z;
                     const bool safe = conic_x > 0.0f && conic_z > 0.0f && ac > 1e-20f && conic_y * conic_y <= 0.999f * ac;
                     third = __uint_as_float((__float_as_uint(low) & ~1u) | (safe ? 1u : 0u));
+#if GSR_TIGHT_RECT
+                    // ... and the tile rect shrinks to the tiles the splat can COLOUR.  The reference bins by the
+                    // square of ceil(3 sqrt(lambda_max)) around the centre; a pixel is composited only where
+                    // alpha >= 1/255, i.e. inside the ellipse  A dx^2 + 2 B dx dy + C dy^2 <= -2 tau, whose bounding box
+                    // has the half-widths sqrt(-2 tau C / det), sqrt(-2 tau A / det).  For the flat, tilted splats of a
+                    // scanned table that box is a fraction of the square, and every instance outside it is one the
+                    // compositor would fetch, test and skip.  Only for a comfortably positive definite conic (the
+                    // computed power is then <= 0 everywhere: stream_conic_is_safe), with 1e-4 relative + a quarter
+                    // pixel to spare (the compositor's own float error on the power is ~4e-6 of its terms); never
+                    // beyond the reference's rect, which cuts opaque splats at 3 sigma.  Inference frames only: no
+                    // backward reads these lists, the image is the same bit for bit (tests, tools/fuzz_forward_only.py).
+                    if (safe) {
+                        const float k = -2.0f * low;  // (<= 0: opacity below 1/255, alpha never passes)
+                        const float detc = fma_(-conic_y, conic_y, ac);
+                        const float hx = fma_(sqrtf(k * conic_z / detc), 1.0001f, 0.25f);
+                        const float hy = fma_(sqrtf(k * conic_x / detc), 1.0001f, 0.25f);
+                        if (!(k > 0.0f)) {
+                            area = 0;
+                        } else if (hx < 1e6f && hy < 1e6f) {  // (false for NaN / inf: the reference's rect stays)
+                            rminx = max(rminx, (int)floorf((pix_x - hx) * (1.0f / GSR_TILE)));
+                            rminy = max(rminy, (int)floorf((pix_y - hy) * (1.0f / GSR_TILE)));
+                            rmaxx = min(rmaxx, (int)floorf((pix_x + hx) * (1.0f / GSR_TILE)) + 1);
+                            rmaxy = min(rmaxy, (int)floorf((pix_y + hy) * (1.0f / GSR_TILE)) + 1);
+                            area = max(rmaxx - rminx, 0) * max(rmaxy - rminy, 0);
+                        }
+                    }
+#endif
                 }
+            }
+            if (area != 0) {
+                float4 *rec = a.splat + 3 * (size_t)i;
                 rec[0] = make_float4(pix_x, pix_y, third, 1.0f / vz);
                 rec[1] = make_float4(conic_x, conic_y, conic_z, opacity);
                 if (!a.infer) {  // (the 3D covariance is kept for the backward only)
@@ -282,7 +316,6 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                 my_rect = make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16),
                                      (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
                 a.rects[i] = my_rect;
-                radius = ir;
                 touched = (uint32_t)area;
                 visible = true;
                 // fourth word of the colour record: the radius (unused downstream), or -- inference frames -- the tile

@@ -280,7 +280,9 @@ def test_forward_only_frames_are_bit_identical(cuda_device, case):
             assert got2[1] is None and torch.equal(got2[0], want[0]) and torch.equal(got2[2], want[2])
             assert torch.equal(f8[1], f8[0]) and torch.equal(f8[2], f8[0])
         sf, ss = full.ensure_valid(lambda: None), fast.ensure_valid(lambda: None)
-        assert not sf.overflow and not ss.overflow and sf.num_visible == ss.num_visible > 0
+        # (inference frames list a Gaussian only in the tiles it can colour -- alpha >= 1/255 somewhere inside: fewer
+        #  instances, and a Gaussian that colours nothing is not counted visible)
+        assert not sf.overflow and not ss.overflow and 0 < ss.num_visible <= sf.num_visible
         assert ss.num_rendered <= sf.num_rendered
         if case == "tabletop_640x480":
             assert ss.num_rendered < 0.7 * sf.num_rendered

@@ -61,7 +61,7 @@ def main():
                 print(f"MISMATCH at iteration {it} frame {k}: n={n} {w}x{h} kw={ {x: kw[x] for x in ('sh_degree', 'antialiasing', 'scale_modifier')} }")
                 sys.exit(1)
         sa, sb = full.ensure_valid(lambda: None), fast.ensure_valid(lambda: None)
-        assert not sa.overflow and not sb.overflow and sa.num_visible == sb.num_visible
+        assert not sa.overflow and not sb.overflow and sb.num_visible <= sa.num_visible
         if sa.num_rendered:
             inst_ratio.append(sb.num_rendered / sa.num_rendered)
     print(f"forward_only fuzz: {iters} cases x 2 frames bit-identical (seed {seed}), super-tile instances / tile instances: "
