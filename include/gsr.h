@@ -76,14 +76,16 @@ typedef struct GsrSettings {
      * ["render"] only).  The image is bit-identical to forward_only = 0; what changes is the work behind it:
      *   - preprocess writes nothing a backward would read (cov3D, SH clamp flags, tiles_touched) and GsrOutputs.radii
      *     may be NULL;
-     *   - instances are binned per SUPER-TILE of 2 x 1 tiles (32 x 16 px) instead of per tile -- 0.58 of the instances
-     *     to count, place and fetch at config 2 -- and the compositor applies the reference's per-tile membership test
-     *     (getRect) to every candidate itself, so every pixel still composites exactly the depth-ordered list of ITS
-     *     16 x 16 tile;
+     *   - instances are binned per SUPER-TILE of 2 x 1 tiles (32 x 16 px) instead of per tile, and a Gaussian is listed
+     *     only where it can colour a pixel: its tile rect is the reference's (getRect) cut down to the bounding box of
+     *     the ellipse alpha >= 1/255 (a Gaussian below 1/255 everywhere is listed nowhere) -- 0.47 of the reference's
+     *     instances to count, place and fetch at config 2.  The compositor applies that per-tile membership test to
+     *     every candidate itself, so every pixel composites the depth-ordered list of ITS 16 x 16 tile minus entries
+     *     every one of its pixels would have skipped: the same image bit for bit;
      *   - final_T / n_contrib (read by the backward only) are not written.
      * The state buffers of such a frame are NOT valid inputs of gsr_backward, and gsr_state_view / GsrFrameStats then
-     * describe the super-tile lists (num_rendered = super-tile instances).  Tile grids wider or higher than 255 tiles
-     * ignore the flag. */
+     * describe those lists (num_rendered = super-tile instances, num_visible = Gaussians listed somewhere).  Tile grids
+     * wider or higher than 255 tiles keep per-tile lists. */
     int32_t forward_only;
 } GsrSettings;
 
