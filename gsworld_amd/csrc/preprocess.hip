@@ -288,8 +288,10 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                     if (safe) {
                         const float k = -2.0f * low;  // (<= 0: opacity below 1/255, alpha never passes)
                         const float detc = fma_(-conic_y, conic_y, ac);
-                        const float hx = fma_(sqrtf(k * conic_z / detc), 1.0001f, 0.25f);
-                        const float hy = fma_(sqrtf(k * conic_x / detc), 1.0001f, 0.25f);
+                        // (hardware reciprocal / square root, ~1 ulp each: the margins are a hundred times that)
+                        const float kd = k * __builtin_amdgcn_rcpf(detc);
+                        const float hx = fma_(__builtin_amdgcn_sqrtf(kd * conic_z), 1.0001f, 0.25f);
+                        const float hy = fma_(__builtin_amdgcn_sqrtf(kd * conic_x), 1.0001f, 0.25f);
                         if (!(k > 0.0f)) {
                             area = 0;
                         } else if (hx < 1e6f && hy < 1e6f) {  // (false for NaN / inf: the reference's rect stays)
