@@ -40,7 +40,10 @@ namespace {
 #endif
 
 constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
-constexpr int kSamplesPerBucket = 2;
+#ifndef GSR_SS_SPB
+#define GSR_SS_SPB 2
+#endif
+constexpr int kSamplesPerBucket = GSR_SS_SPB;
 constexpr int kMinSamples = 2048;
 constexpr int kMaxSamples = 4096;
 constexpr uint32_t kSplitMagic = 0x53504c54u;  // 'SPLT'

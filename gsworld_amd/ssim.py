@@ -124,13 +124,13 @@ class _PhotometricLoss(torch.autograd.Function):
             check(L.gsr_photometric_loss(planes, H, W, _p(x), _p(t), float(lambda_dssim), int(bool(clamp01)), _p(scratch),
                                          _p(loss), _p(grad) if need_grad else None,
                                          C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        ctx.grad = grad
+        ctx.grad, ctx.in_dtype = grad, img.dtype
         return loss
 
     @staticmethod
     def backward(ctx, g):
         grad, ctx.grad = ctx.grad, None
-        return (grad * g if grad is not None else None), None, None, None
+        return ((grad * g).to(ctx.in_dtype) if grad is not None else None), None, None, None
 
 
 def photometric_loss(img, target, lambda_dssim: float = 0.2, clamp01: bool = False):
