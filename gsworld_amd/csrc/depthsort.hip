@@ -23,12 +23,12 @@
 // boundary by accident of the sample order.  Bucket count B = 256..2048 follows V (read on the device) so that a
 // bucket averages <= 512 records.  ss_buckets leaves the exact quantiles of the frame in the state; the next frame on
 // that state only validates them against its samples and skips the sample sort (any splitters give the same order);
-// under a bit-identical view matrix (a fixed sensor camera) it takes them without drawing samples at all, and a
-// bucket that comes out far above its share makes the following frame sample again.
+// under a bit-identical view matrix (a fixed sensor camera) over a scene that has stood still for two frames (ss_trust)
+// it takes them without drawing samples at all, and a bucket above its share makes the following frames sample again.
 // Compaction workgroups share the blocks by COST (records + kBlockCost per block), not by count: see ss_compact_kernel.
-// A bucket that does not fit the LDS (bad luck or adversarial depths: > 3584 records) is sorted by the same workgroup
-// in global memory with a bitonic network over the (key << 32 | index) composites -- slow, correct, never seen on
-// the BASELINE scenes.
+// A bucket that does not fit the LDS (> kBucketCap records: a sampled table's unlucky bucket, a scene that jumped under
+// kept splitters, depth ties) is cut once more by the same workgroup and sorted in LDS pieces; only a piece of equal
+// keys goes through a bitonic network over the (key << 32 | index) composites in global memory (ss_buckets_kernel).
 #include "gsr_internal.h"
 
 namespace {
@@ -60,7 +60,14 @@ constexpr uint32_t kBlockCost = 8u;
 // with all 32 bits; config 2 unchanged)
 constexpr uint32_t kKeyMask = GSR_SS_KEY_MASK;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // (never a depth key: those are positive floats)
-constexpr int kBucketCap = 3584;     // records per bucket sorted in LDS (4 x 14 KiB + cursors < 64 KiB)
+// Records per bucket sorted in LDS: 4 arrays of this many words + cursors = 36 KiB, four workgroups per CU.  3584 (60 KiB,
+// two per CU) was the value while a bucket beyond it went through a global-memory bitonic network; now that such a bucket
+// is cut once more and sorted in LDS pieces, a smaller cap with twice the residency wins wherever the sort samples
+// (moving camera 8.4 -> 8.9 k frames/s, dense view +3 %, train step -0.01 ms; static headline unchanged; 1536: the same).
+#ifndef GSR_SS_BUCKET_CAP
+#define GSR_SS_BUCKET_CAP 2048
+#endif
+constexpr int kBucketCap = GSR_SS_BUCKET_CAP;
 
 __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
     int B = 256;

@@ -391,7 +391,7 @@ def test_fixed_camera_takes_kept_splitters_blind_only_while_the_scene_stands_sti
 
 @pytest.mark.parametrize("case", ["ten_thousand_into_one_bucket", "forty_thousand_into_one_bucket", "five_thousand_equal_depths"])
 def test_depth_bucket_beyond_the_lds_is_still_sorted_exactly(cuda_device, case):
-    """A depth bucket of the sample sort that outgrows the LDS (kBucketCap = 3584 records): the kept splitters were
+    """A depth bucket of the sample sort that outgrows the LDS (kBucketCap = 2048 records): the kept splitters were
     taken unchecked under a fixed camera and the scene jumped.  The bucket's workgroup cuts it once more by
     sub-splitters drawn from its own keys and sorts the pieces in the LDS (by index, then by key); a piece that still
     does not fit -- thousands of EQUAL depths -- goes through the global-memory network.  Whatever route, the frame is the
