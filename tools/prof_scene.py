@@ -18,6 +18,7 @@ ap.add_argument("--view", default="sensor")
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--default-mode", action="store_true", help="forward_only = 0 (the training-capable frame)")
 ap.add_argument("--moving", action="store_true", help="turn the camera a little on every frame")
+ap.add_argument("--sh-degree", type=int, default=3, help="ablation: evaluate fewer SH bands (0: the DC term only)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 raw = scenes.tabletop_scene("xarm6_align")
@@ -35,7 +36,7 @@ for k in range(args.frames):
         cam.world_view_transform.copy_(wvt)
         cam.full_proj_transform.copy_(wvt @ proj)
         cam.camera_center.copy_(wvt.inverse()[3, :3])
-    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8)
+    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8, sh_degree=args.sh_degree)
     if k == 1:
         r.ensure_valid(lambda: None)
 torch.cuda.synchronize()
