@@ -185,6 +185,52 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
 
 
+# Largest instance list the no-sync training forward may allocate (bytes; 4 per instance).  288 GB of HBM make the TRUE
+# bound affordable for training-sized problems: a Gaussian touches at most every tile, so num_rendered <= P x tiles.
+NOSYNC_LIST_BYTES = 8 << 30
+
+
+def nosync_capacity(P: int, image_height: int, image_width: int):
+    """Instance capacity with which a frame can never overflow (P x tiles), or None when that list would not fit
+    ``NOSYNC_LIST_BYTES`` (or the grid is wider than the counting placement takes): the caller keeps the exact mode."""
+    gx, gy = (int(image_width) + 15) // 16, (int(image_height) + 15) // 16
+    cap = int(P) * gx * gy
+    if P <= 0 or gx > 256 or cap >= (1 << 31) or 4 * cap > NOSYNC_LIST_BYTES:
+        return None
+    if _lib.TUNING["binning_path"] != 0 or _lib.TUNING["depth_sort"] != 0:
+        return None  # (A/B paths keep keys / ping-pong sides per instance: their lists are sized exactly)
+    return cap
+
+
+def rasterize_gaussians_nosync(capacity, background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix,
+                               projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                               antialiasing, debug, sh_rest=None, param_space: int = 0):
+    """The training forward WITHOUT upstream's host read of num_rendered in the middle of the frame (a ~40 us hole in
+    the GPU's timeline per step: D2H copy, host wake-up, allocation, launch): the instance list is sized by ``capacity``
+    = :func:`nosync_capacity`, a bound no frame can exceed, so nothing has to be read back.  Same kernels, same image
+    and state as :func:`rasterize_gaussians`; returns ``capacity`` where that returns num_rendered (it is what the
+    backward carves the binning buffer with)."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(image_height), int(image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out_color, out_invdepth = torch.empty((3, H, W), **f32), torch.empty((1, H, W), **f32)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geomBuffer, binningBuffer, imgBuffer = (torch.empty(0, dtype=torch.uint8, device=dev) for _ in range(3))
+    M = (1 + sh_rest.size(1)) if sh_rest is not None else (sh.size(1) if sh.numel() != 0 else 0)
+    st = GsrSettings(H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M), 0,
+                     int(bool(antialiasing)), int(bool(debug)), float(NEAR_PLANE))
+    e = torch.empty(0, device=dev)
+    forward_raw(st, _f32(background, dev, "background"), _f32(means3D, dev, "means3D"), e,
+                _f32(opacity, dev, "opacity"), _f32(scales, dev, "scales"), _f32(rotations, dev, "rotations"), e,
+                _f32(viewmatrix, dev, "viewmatrix"), _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"),
+                _f32(campos, dev, "campos"), out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
+                r_capacity=int(capacity), want_stats=False,
+                sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space)
+    return int(capacity), out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_invdepth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,

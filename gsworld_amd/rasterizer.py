@@ -112,10 +112,18 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, raster_settings, param_space):
         rs = raster_settings
         empty = torch.empty(0, device=means3D.device)
-        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians(
-            rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix, rs.projmatrix,
-            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos, rs.prefiltered,
-            rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
+        cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width)
+        if cap is not None and not rs.prefiltered:
+            # no host read of num_rendered in mid-frame: the instance list is sized by a bound no frame can exceed
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians_nosync(
+                cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos,
+                rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians(
+                rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
         ctx.raster_settings, ctx.num_rendered, ctx.param_space = rs, num_rendered, param_space
         ctx.set_materialize_grads(False)  # (see _RasterizeGaussians.forward)
         ctx.save_for_backward(means3D, scales, rotations, radii, sh_dc, sh_rest, opacities, geomBuffer, binningBuffer,

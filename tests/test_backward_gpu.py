@@ -235,3 +235,48 @@ def test_config5_full_size_training_step(cuda_device, near_fraction):
     for n, a, b in zip(names, ps1, psf):
         scale = float(a.grad.abs().max()) + 1e-12
         assert float((a.grad - b.grad).abs().max()) / scale <= 5e-3, n
+
+
+def test_training_forward_without_the_mid_frame_host_read(cuda_device):
+    """The fused autograd path sizes its instance list by a bound no frame can exceed (P x tiles: _C.nosync_capacity)
+    instead of reading num_rendered back in the middle of the frame.  Same kernels: the image, radii and inverse depth
+    are the exact-mode frame's bits, the gradients agree to the order of the atomic sums; with the budget too small
+    for the bound the same call takes the exact mode again."""
+    from gsworld_amd import _C, scenes
+    from gsworld_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = cuda_device
+    S = 160
+    cam = scenes.training_camera(S, S, 60.0).to(dev)
+    raw = scenes.random_scene_camera_frame(20_000, seed=43).to(dev)
+    raw.scaling += 0.7
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(S, S, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.world_view_transform,
+                                                            cam.full_proj_transform, 3, cam.camera_center, False, False, False))
+    w_img = torch.randn((3, S, S), generator=torch.Generator().manual_seed(6)).to(dev)
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+
+    def run():
+        ps = [getattr(raw, n).detach().clone().requires_grad_(True) for n in names]
+        xyz, dc, rest, op, sc, rot = ps
+        m2d = torch.zeros_like(xyz, requires_grad=True)
+        color, radii, invd = rast(means3D=xyz, means2D=m2d, shs=dc, shs_rest=rest, opacities=op, scales=sc,
+                                  rotations=rot, param_space=7)
+        (color * w_img).sum().backward()
+        return color.detach(), radii, invd.detach(), [p.grad for p in ps] + [m2d.grad]
+
+    assert _C.nosync_capacity(20_000, S, S) == 20_000 * 100
+    fast = run()
+    budget, _C.NOSYNC_LIST_BYTES = _C.NOSYNC_LIST_BYTES, 1 << 10
+    try:
+        assert _C.nosync_capacity(20_000, S, S) is None
+        exact = run()
+    finally:
+        _C.NOSYNC_LIST_BYTES = budget
+    for a, b, what in zip(fast[:3], exact[:3], ("color", "radii", "invdepth")):
+        assert torch.equal(a, b), what
+    for n, a, b in zip(names + ("means2D",), fast[3], exact[3]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / scale <= 1e-5, n
+    assert _C.nosync_capacity(2_000_000, 1920, 1080) is None       # 65 G instances: not this way
+    assert _C.nosync_capacity(100, 16, 16 * 300) is None           # wider than the counting placement takes
