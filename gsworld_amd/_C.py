@@ -190,12 +190,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 NOSYNC_LIST_BYTES = 8 << 30
 
 
-def nosync_capacity(P: int, image_height: int, image_width: int):
+def nosync_capacity(P: int, image_height: int, image_width: int, device=None):
     """Instance capacity with which a frame can never overflow (P x tiles), or None when that list would not fit
-    ``NOSYNC_LIST_BYTES`` (or the grid is wider than the counting placement takes): the caller keeps the exact mode."""
+    ``NOSYNC_LIST_BYTES`` -- or, with ``device``, a quarter of what is free there -- or the grid is wider than the
+    counting placement takes: the caller keeps sizing the list from a read-back."""
     gx, gy = (int(image_width) + 15) // 16, (int(image_height) + 15) // 16
     cap = int(P) * gx * gy
     if P <= 0 or gx > 256 or cap >= (1 << 31) or 4 * cap > NOSYNC_LIST_BYTES:
+        return None
+    if device is not None and 4 * cap > torch.cuda.mem_get_info(device)[0] // 4:
         return None
     if _lib.TUNING["binning_path"] != 0 or _lib.TUNING["depth_sort"] != 0:
         return None  # (A/B paths keep keys / ping-pong sides per instance: their lists are sized exactly)

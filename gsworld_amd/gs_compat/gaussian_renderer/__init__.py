@@ -115,8 +115,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         # ... and the frame goes through a renderer that is kept per device: its state buffers and the instance
         # capacity of the previous frame are reused, so nothing is allocated and the host is not consulted in the
         # middle of the frame (upstream's contract -- fresh byte tensors sized from a D2H read of num_rendered --
-        # is only needed when a backward will follow).  The capacity flag is checked once the frame is enqueued;
-        # an overflow (the scene grew by more than the head-room) re-renders exactly.
+        # is only needed when a backward will follow).  The instance list is sized by the bound no frame can exceed
+        # (P x tiles) when that fits the memory budget -- then the call returns without ever synchronising with the
+        # device --; otherwise by the previous frame's count with head-room, the capacity flag is checked once the frame
+        # is enqueued, and an overflow (the scene grew by more than the head-room) re-renders exactly.
         rs = raster_settings
         renderer = _frame_renderer(means3D.device)
         view = _View(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.viewmatrix, rs.projmatrix, rs.campos)
@@ -142,7 +144,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                 depth_image = torch.zeros((1, rs.image_height, rs.image_width), device=means3D.device)
             else:
                 rendered_image, radii, depth_image = enqueue()
-                renderer.ensure_valid(enqueue)
+                if not renderer.bounded:  # (a list sized by P x tiles cannot overflow: nothing to read back)
+                    renderer.ensure_valid(enqueue)
         return _finish(rendered_image, radii, depth_image, make_screenspace_points, viewpoint_camera, pc,
                        use_trained_exp, lazy=True)
 
@@ -187,7 +190,7 @@ def _frame_renderer(device):
     r = _RENDERERS.get(key)
     if r is None:
         # frozen parameters = inference: forward_only frames (bit-identical image and radii; nothing kept for a backward)
-        r = _RENDERERS[key] = FrameRenderer(torch.device(key[0], key[1]), forward_only=True)
+        r = _RENDERERS[key] = FrameRenderer(torch.device(key[0], key[1]), forward_only=True, bound_capacity=True)
     return r
 
 

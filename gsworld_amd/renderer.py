@@ -33,13 +33,19 @@ class FrameStats:
 
 class FrameRenderer:
     def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
-                 forward_only: bool = False, want_radii: bool = True, min_capacity: int = 1 << 16):
+                 forward_only: bool = False, want_radii: bool = True, min_capacity: int = 1 << 16,
+                 bound_capacity: bool = False):
         """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
         nothing a backward would read is written and the instances are binned per super-tile of 2 x 1 tiles -- the state buffers
         are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
         (forward_only only): the (P,) radii array is not written either; :meth:`render` returns ``None`` for it.
         ``growth`` / ``min_capacity``: the binning capacity of the no-sync frames is
-        ``max(growth x R of the frame that sized it, min_capacity)`` instances (8 B each)."""
+        ``max(growth x R of the frame that sized it, min_capacity)`` instances (4 B each).
+        ``bound_capacity``: size the instance list by the bound NO frame can exceed -- P x tiles -- whenever that fits
+        the budget of :func:`gsworld_amd._C.nosync_capacity` (8 GiB and a quarter of the free memory; 7 GB at 1.47 M
+        Gaussians, 640 x 480): no exact-mode first frame, no overflow, hence no flag to read back --
+        :attr:`bounded` then says that :meth:`ensure_valid` (a host synchronisation) is not needed.  For a single
+        renderer that serves call after call (the drop-in ``render()``); not for dozens of lanes."""
         self.device = torch.device(device)
         if self.device.index is None and self.device.type == "cuda":
             # an unindexed device never equals a tensor's `cuda:0`: resolve it once (multi-GPU processes: the CURRENT
@@ -49,6 +55,9 @@ class FrameRenderer:
         self.want_radii = bool(want_radii) or not self.forward_only
         self.growth = growth
         self.min_capacity = int(min_capacity)
+        self.bound_capacity = bool(bound_capacity)
+        self.bounded = False   # the current capacity is P x tiles: the last frame cannot have overflowed
+        self._bound_for = None
         self.near_plane = _C.NEAR_PLANE if near_plane is None else near_plane
         u8 = dict(dtype=torch.uint8, device=self.device)
         self.geom = torch.empty(0, **u8)
@@ -146,7 +155,11 @@ class FrameRenderer:
             M = 1 + shs_rest.shape[1]
         st = GsrSettings(H, W, view.tanfovx, view.tanfovy, float(scale_modifier), int(sh_degree), int(M), 0,
                          int(antialiasing), int(debug), float(self.near_plane))
-        cap = 0 if (exact or self.r_capacity == 0) else self.r_capacity
+        if self.bound_capacity and self._bound_for != (P, H, W):
+            bound = _C.nosync_capacity(P, H, W, device=dev)
+            self._bound_for, self.bounded = (P, H, W), bound is not None
+            self.r_capacity = bound if bound is not None else 0
+        cap = self.r_capacity if self.bounded else (0 if (exact or self.r_capacity == 0) else self.r_capacity)
         stats = _C.forward_raw(
             st, bg, means3D, colors_precomp if colors_precomp is not None else empty, opacities,
             scales if scales is not None else empty, rotations if rotations is not None else empty,

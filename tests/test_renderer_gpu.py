@@ -433,3 +433,34 @@ def test_depth_bucket_beyond_the_lds_is_still_sorted_exactly(cuda_device, case):
         if k == 0:
             assert st["blind"] and st["bad"], (st, r.stats())
             assert r.stats().num_visible > 40_000 + (4_000 if case != "forty_thousand_into_one_bucket" else 30_000)
+
+
+def test_bounded_capacity_renderer_never_reads_back(cuda_device):
+    """FrameRenderer(bound_capacity=True): the instance list is sized by P x tiles (no frame can exceed it), so there is
+    no exact-mode first frame and no overflow flag worth reading -- the drop-in render() uses it to return without a host
+    synchronisation.  Frames are the default renderer's bits from the first call on, also after the model or the image
+    size changes; a bound beyond the budget falls back to the read-back protocol."""
+    from gsworld_amd import _C
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    r = FrameRenderer(dev, forward_only=True, want_radii=False, bound_capacity=True)
+    for n, (w, h) in ((60_000, (320, 240)), (60_000, (200, 120)), (25_000, (200, 120))):
+        raw = scenes.random_scene_camera_frame(n, seed=n + w)
+        means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+        cam = scenes.identity_camera(w, h, 60.0).to(dev)
+        kw = dict(shs=shs, scales=sc, rotations=rot)
+        want = FrameRenderer(dev).render(cam, means, op, exact=True, **kw)
+        for _ in range(2):
+            got = r.render(cam, means, op, **kw)
+            assert r.bounded and r.r_capacity == n * ((w + 15) // 16) * ((h + 15) // 16)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
+        assert not r.stats().overflow and r.stats().overflow_frames == 0
+    budget, _C.NOSYNC_LIST_BYTES = _C.NOSYNC_LIST_BYTES, 1 << 12
+    try:
+        r2 = FrameRenderer(dev, forward_only=True, want_radii=False, bound_capacity=True)
+        got = r2.render(cam, means, op, **kw)
+        assert not r2.bounded and torch.equal(got[0], want[0])
+        assert not r2.ensure_valid(lambda: r2.render(cam, means, op, **kw)).overflow
+    finally:
+        _C.NOSYNC_LIST_BYTES = budget
