@@ -32,7 +32,7 @@ from .renderer import MultiCameraRenderer
 
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
-                 background=None, fuse_transform: bool = True, growth: float = 2.0):
+                 background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto"):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -46,7 +46,11 @@ class ClosedLoopRenderer:
         the frame that sized it (:meth:`reset`, or the re-render after an overflow).  An arm sweeping past a wrist
         camera changes that count far more than a fixed camera ever sees (0.39 M .. 1.46 M over the xarm6 random-action
         rollout, against 0.71 M at reset): the margin costs a few tens of MB per lane and keeps that rollout clear of
-        the limit; :meth:`overflow_frames` says, without a per-step sync, whether a rollout stayed clear."""
+        the limit; :meth:`overflow_frames` says, without a per-step sync, whether a rollout stayed clear.
+        ``bound_capacity`` (``"auto"`` / True / False): size every lane's list by the bound no frame can exceed, N x
+        tiles (7 GB per lane at 1.47 M Gaussians, 640 x 480), so that a frame CANNOT overflow whatever the arm does.
+        ``"auto"``: when all lanes together stay below a quarter of the device's free memory and 64 GiB -- one
+        environment with two or three cameras on a 288 GB MI355X; larger batches keep the ``growth`` rule."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
@@ -84,8 +88,14 @@ class ClosedLoopRenderer:
                        for n, c in zip(self.names, self.cameras)}
         self.bg = torch.zeros(3, device=dev) if background is None else background.to(dev, torch.float32)
         # the loop never differentiates a frame: inference frames (GsrSettings.forward_only), no radii array
-        self.multi = MultiCameraRenderer(self.num_envs * len(self.cameras), dev, forward_only=True, want_radii=False,
-                                         growth=growth, min_capacity=2 * int(self.xyz.shape[0]))
+        lanes = self.num_envs * len(self.cameras)
+        if bound_capacity == "auto":
+            per_lane = max(4 * int(self.xyz.shape[0]) * ((c.image_width + 15) // 16) * ((c.image_height + 15) // 16)
+                           for c in self.cameras)
+            free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" and torch.cuda.is_available() else 0
+            bound_capacity = lanes * per_lane <= min(free // 4, 64 << 30)
+        self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, growth=growth,
+                                         min_capacity=2 * int(self.xyz.shape[0]), bound_capacity=bool(bound_capacity))
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
         self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()
