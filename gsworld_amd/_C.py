@@ -207,7 +207,7 @@ def nosync_capacity(P: int, image_height: int, image_width: int, device=None):
 
 def rasterize_gaussians_nosync(capacity, background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix,
                                projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                               antialiasing, debug, sh_rest=None, param_space: int = 0):
+                               antialiasing, debug, sh_rest=None, param_space: int = 0, colors=None, cov3D_precomp=None):
     """The training forward WITHOUT upstream's host read of num_rendered in the middle of the frame (a ~40 us hole in
     the GPU's timeline per step: D2H copy, host wake-up, allocation, launch): the instance list is sized by ``capacity``
     = :func:`nosync_capacity`, a bound no frame can exceed, so nothing has to be read back.  Same kernels, same image
@@ -225,8 +225,10 @@ def rasterize_gaussians_nosync(capacity, background, means3D, opacity, scales, r
     st = GsrSettings(H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M), 0,
                      int(bool(antialiasing)), int(bool(debug)), float(NEAR_PLANE))
     e = torch.empty(0, device=dev)
-    forward_raw(st, _f32(background, dev, "background"), _f32(means3D, dev, "means3D"), e,
-                _f32(opacity, dev, "opacity"), _f32(scales, dev, "scales"), _f32(rotations, dev, "rotations"), e,
+    forward_raw(st, _f32(background, dev, "background"), _f32(means3D, dev, "means3D"),
+                _f32(colors, dev, "colors") if colors is not None else e,
+                _f32(opacity, dev, "opacity"), _f32(scales, dev, "scales"), _f32(rotations, dev, "rotations"),
+                _f32(cov3D_precomp, dev, "cov3D_precomp") if cov3D_precomp is not None else e,
                 _f32(viewmatrix, dev, "viewmatrix"), _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"),
                 _f32(campos, dev, "campos"), out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
                 r_capacity=int(capacity), want_stats=False,

@@ -63,8 +63,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
-                _C.rasterize_gaussians(*args)
+            cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width)
+            if cap is not None and not rs.prefiltered and means3D.dim() == 2 and means3D.size(1) == 3:
+                # (the Function keeps num_rendered to itself: it need not be read back in mid-frame when the instance
+                #  list is sized by the bound P x tiles -- _C.rasterize_gaussians_nosync; same kernels, same state)
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
+                    _C.rasterize_gaussians_nosync(
+                        cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix,
+                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+                        rs.campos, rs.antialiasing, rs.debug, colors=colors_precomp, cov3D_precomp=cov3Ds_precomp)
+            else:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
+                    _C.rasterize_gaussians(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # (an output the loss does not use arrives as None in backward, not as a zero image autograd had to fill:
