@@ -28,6 +28,10 @@
 // wider grids use the older paths.
 #include "gsr_internal.h"
 
+#ifndef GSR_BAND_EXACT_CUTS
+#define GSR_BAND_EXACT_CUTS 0
+#endif
+
 namespace {
 
 constexpr int kBT = GSR_BLOCK;              // 256 threads = 4 waves
@@ -103,13 +107,21 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict_
         int b = 0;
         for (int step = B >> 1; step > 0; step >>= 1)
             if (s_pre[b + step] <= target) b += step;
-        // ranks of that bucket whose inclusive running sum is <= target - exclusive sum
+        // inside that bucket the cut is placed by proportion (the bucket's records are ~V / B consecutive depth ranks of
+        // similar size): any ascending cut gives the same point list, and the exact one -- a binary search over the
+        // bucket's running sums -- was ten dependent global round trips on the critical path of every frame whose
+        // camera or scene moves (band_ranges 10 -> 5 us there)
         const uint32_t s0 = bucket_start[b], n = bucket_start[b + 1] - s0, rest = target - s_pre[b];
+        const uint32_t tb = s_pre[b + 1] - s_pre[b];
+#if GSR_BAND_EXACT_CUTS
         uint32_t lo = 0, hi = n;  // count of entries <= rest: first index with tile_cum > rest
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             if (tile_cum[s0 + mid] <= rest) lo = mid + 1u; else hi = mid;
         }
+#else
+        const uint32_t lo = tb != 0u ? (uint32_t)min((uint64_t)n, ((uint64_t)n * rest) / tb) : 0u;
+#endif
         const uint32_t cut = j == waves ? V : s0 + lo;
         wave_lo[j] = cut;
         wave_lo_base[j] = cut;

@@ -40,6 +40,12 @@ namespace {
 #endif
 
 constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
+#ifndef GSR_SS_TRUST_MIN
+#define GSR_SS_TRUST_MIN 2     // A/B: 0 = a fixed camera takes the kept splitters whatever the last frames looked like
+#endif
+#ifndef GSR_SS_IGNORE_BAD
+#define GSR_SS_IGNORE_BAD 0
+#endif
 #ifndef GSR_SS_SPB
 #define GSR_SS_SPB 2
 #endif
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     // bucket, far beyond the LDS, and that bucket's workgroup then sorts in global memory for a millisecond.  Such a
     // scene never earns the trust; its frames check the kept table against samples below.
     bool blind = all_staged && same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
-                 h_bad == 0u && h_trust >= 2u && h_trust <= 255u && h_P == sig;
+                 (GSR_SS_IGNORE_BAD || h_bad == 0u) && h_trust >= (uint32_t)GSR_SS_TRUST_MIN && h_trust <= 255u &&
+                 h_P == sig;
     if (blind) {
         // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
         // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
