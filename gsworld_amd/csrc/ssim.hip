@@ -17,6 +17,10 @@ struct Gauss11 {
     float w[11];
 };
 
+// (the file is compiled without contraction like the rest of the library; the window sums are spelled as fused
+//  multiply-adds -- one rounding per tap, as nvcc contracts upstream's -- which also halves their instruction count)
+__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 __device__ __forceinline__ float load_px(const float *__restrict__ img, int x, int y, int W, int H) {
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.f;
 }
@@ -55,11 +59,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float a = s1[ly][lx + k], b = s2[ly][lx + k], w = g.w[k];
-            m1 += w * a;
-            m2 += w * b;
-            e11 += w * (a * a);
-            e22 += w * (b * b);
-            e12 += w * (a * b);
+            m1 = fmaf_(w, a, m1);
+            m2 = fmaf_(w, b, m2);
+            e11 = fmaf_(w, a * a, e11);
+            e22 = fmaf_(w, b * b, e22);
+            e12 = fmaf_(w, a * b, e12);
         }
         sh[0][ly][lx] = m1; sh[1][ly][lx] = m2; sh[2][ly][lx] = e11; sh[3][ly][lx] = e22; sh[4][ly][lx] = e12;
     }
@@ -71,11 +75,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const float w = g.w[k];
-        mu1 += w * sh[0][ly + k][lx];
-        mu2 += w * sh[1][ly + k][lx];
-        e11 += w * sh[2][ly + k][lx];
-        e22 += w * sh[3][ly + k][lx];
-        e12 += w * sh[4][ly + k][lx];
+        mu1 = fmaf_(w, sh[0][ly + k][lx], mu1);
+        mu2 = fmaf_(w, sh[1][ly + k][lx], mu2);
+        e11 = fmaf_(w, sh[2][ly + k][lx], e11);
+        e22 = fmaf_(w, sh[3][ly + k][lx], e22);
+        e12 = fmaf_(w, sh[4][ly + k][lx], e12);
     }
     if (x < W && y < H) {
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -187,9 +191,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float w = g.w[k];
-            a += w * s[0][ly][lx + k];
-            b += w * s[1][ly][lx + k];
-            c += w * s[2][ly][lx + k];
+            a = fmaf_(w, s[0][ly][lx + k], a);
+            b = fmaf_(w, s[1][ly][lx + k], b);
+            c = fmaf_(w, s[2][ly][lx + k], c);
         }
         sh[0][ly][lx] = a; sh[1][ly][lx] = b; sh[2][ly][lx] = c;
     }
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const float w = g.w[k];
-        a += w * sh[0][ly + k][lx];
-        b += w * sh[1][ly + k][lx];
-        c += w * sh[2][ly + k][lx];
+        a = fmaf_(w, sh[0][ly + k][lx], a);
+        b = fmaf_(w, sh[1][ly + k][lx], b);
+        c = fmaf_(w, sh[2][ly + k][lx], c);
     }
     if (x < W && y < H) {
         const size_t o = plane + (size_t)y * W + x;
