@@ -266,3 +266,23 @@ def test_xarm6_rollout_fixture_is_a_kinematic_chain():
     e3 = list(cl.rollout_poses(r, len(actors), steps=2, seed=0, num_envs=3))
     assert e3[0][0].shape == (3, 17, 4, 4) and e3[0][1].shape == (3, 17)
     assert torch.equal(e3[0][0][0, :15], a[0][0][:15]) and torch.equal(e3[0][0][1, :15], a[17][0][:15])
+
+
+def test_instance_bound_that_replaces_the_read_back():
+    """_C.nosync_capacity: P x tiles -- a Gaussian touches at most every tile, so no frame exceeds it -- while the list
+    (4 B per instance) fits the budget, the offsets stay 31-bit and the grid is one the counting placement takes;
+    None otherwise (the caller then reads num_rendered back as upstream does)."""
+    from gsworld_amd import _C, _lib
+
+    assert _C.nosync_capacity(500_000, 800, 800) == 500_000 * 50 * 50             # configs[4]: 5 GB
+    assert _C.nosync_capacity(1_468_850, 480, 640) == 1_468_850 * 40 * 30         # configs[1]: 7 GB
+    assert _C.nosync_capacity(1_468_850, 1080, 1920) is None                      # 12 G instances
+    assert _C.nosync_capacity(0, 480, 640) is None
+    assert _C.nosync_capacity(10, 16, 16 * 257) is None                           # 257 tile columns
+    assert _C.nosync_capacity(10, 17, 33) == 10 * 3 * 2                           # partial tiles count
+    saved = dict(_lib.TUNING)
+    try:
+        _lib.TUNING["binning_path"] = 2
+        assert _C.nosync_capacity(1000, 64, 64) is None                           # A/B paths size their lists exactly
+    finally:
+        _lib.TUNING.update(saved)
