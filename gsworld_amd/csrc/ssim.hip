@@ -1,17 +1,17 @@
 // ssim.hip -- fused SSIM map and its analytic backward (upstream fused-ssim/ssim.cu fusedssimCUDA /
 // fusedssim_backwardCUDA).
 //
-// 11x11 Gaussian window (sigma 1.5) applied separably with zero "same" padding.  One 16x16 output tile per
-// 256-thread workgroup, one (batch, channel) plane per blockIdx.z: the 26x26 halo of both images is staged in
-// LDS once, the horizontal pass writes 5 running moments (26 rows x 16 columns) back to LDS, the vertical pass
+// 11x11 Gaussian window (sigma 1.5) applied separably with zero "same" padding.  One 32x16 output tile per
+// 256-thread workgroup, one (batch, channel) plane per blockIdx.z: the 42x26 halo of both images is staged in
+// LDS once, the horizontal pass writes 5 running moments (26 rows x 32 columns) back to LDS, the vertical pass
 // finishes them per pixel.  HBM traffic is one read of each image plus one write of each output map.
 #include "gsr_internal.h"
 
 namespace {
 
-constexpr int kT = 16;        // tile edge
-constexpr int kR = 5;         // window radius
-constexpr int kH = kT + 2 * kR;  // 26
+constexpr int kTX = 32, kTY = 16;  // output tile of a workgroup
+constexpr int kR = 5;              // window radius
+constexpr int kHX = kTX + 2 * kR, kHY = kTY + 2 * kR;  // 42 x 26 halo
 
 struct Gauss11 {
     float w[11];
@@ -26,10 +26,15 @@ __device__ __forceinline__ float load_px(const float *__restrict__ img, int x, i
 }
 
 // LOSS (gsr_photometric_loss): img1 is read through clamp(., 0, 1) when `clamp01`; no ssim map is written -- the
-// workgroup's sums of the ssim values and of |img1 - img2| over its 16 x 16 pixels go to partials[2 b], [2 b + 1]
+// workgroup's sums of the ssim values and of |img1 - img2| over its 32 x 16 pixels go to partials[2 b], [2 b + 1]
 // (b = the workgroup's linear index; summed in a fixed order: the loss is reproducible bit for bit).
+//
+// Tile of 32 x 16 pixels per 256-thread workgroup.  Both passes are bound by their LDS reads, so each thread makes
+// several outputs from one window of loaded values: the horizontal pass 4 adjacent columns from 14 values of a row
+// (instead of 4 x 11), the vertical pass 2 adjacent rows from 12 values of a column.  Every output still sums its 11
+// taps in the same order, one fused multiply-add per tap: the maps are the same bits whatever the tiling.
 template <bool LOSS>
-__global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, float C1, float C2, Gauss11 g,
+__global__ __launch_bounds__(GSR_BLOCK, 5) void ssim_forward_kernel(int H, int W, float C1, float C2, Gauss11 g,
                                                                  const float *__restrict__ img1,
                                                                  const float *__restrict__ img2, int train,
                                                                  float *__restrict__ ssim_map,
@@ -37,67 +42,87 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_forward_kernel(int H, int W, f
                                                                  float *__restrict__ dm_dsigma1_sq,
                                                                  float *__restrict__ dm_dsigma12, int clamp01,
                                                                  float *__restrict__ partials) {
-    __shared__ float s1[kH][kH + 1];
-    __shared__ float s2[kH][kH + 1];
-    __shared__ float sh[5][kH][kT + 1];
+    __shared__ float s1[kHY][kHX + 1];
+    __shared__ float s2[kHY][kHX + 1];
+    __shared__ float sh[5][kHY][kTX + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const float *p1 = img1 + plane, *p2 = img2 + plane;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < kH * kH; i += GSR_BLOCK) {
-        const int ly = i / kH, lx = i - ly * kH;
+    for (int i = tid; i < kHY * kHX; i += GSR_BLOCK) {
+        const int ly = i / kHX, lx = i - ly * kHX;
         float a = load_px(p1, x0 + lx - kR, y0 + ly - kR, W, H);
         if (LOSS && clamp01) a = a != a ? a : fminf(fmaxf(a, 0.f), 1.f);  // (torch.clamp keeps a NaN; max / min drop it)
         s1[ly][lx] = a;
         s2[ly][lx] = load_px(p2, x0 + lx - kR, y0 + ly - kR, W, H);
     }
     __syncthreads();
-    // horizontal pass: 26 rows x 16 columns
-    for (int i = tid; i < kH * kT; i += GSR_BLOCK) {
-        const int ly = i / kT, lx = i - ly * kT;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: 26 rows x 8 groups of 4 columns
+    if (tid < kHY * (kTX / 4)) {
+        const int ly = tid / (kTX / 4), c0 = (tid - ly * (kTX / 4)) * 4;
+        float a[14], b[14];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float a = s1[ly][lx + k], b = s2[ly][lx + k], w = g.w[k];
-            m1 = fmaf_(w, a, m1);
-            m2 = fmaf_(w, b, m2);
-            e11 = fmaf_(w, a * a, e11);
-            e22 = fmaf_(w, b * b, e22);
-            e12 = fmaf_(w, a * b, e12);
+        for (int j = 0; j < 14; j++) {
+            a[j] = s1[ly][c0 + j];
+            b[j] = s2[ly][c0 + j];
         }
-        sh[0][ly][lx] = m1; sh[1][ly][lx] = m2; sh[2][ly][lx] = e11; sh[3][ly][lx] = e22; sh[4][ly][lx] = e12;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float av = a[c + k], bv = b[c + k], w = g.w[k];
+                m1 = fmaf_(w, av, m1);
+                m2 = fmaf_(w, bv, m2);
+                e11 = fmaf_(w, av * av, e11);
+                e22 = fmaf_(w, bv * bv, e22);
+                e12 = fmaf_(w, av * bv, e12);
+            }
+            sh[0][ly][c0 + c] = m1; sh[1][ly][c0 + c] = m2; sh[2][ly][c0 + c] = e11; sh[3][ly][c0 + c] = e22;
+            sh[4][ly][c0 + c] = e12;
+        }
     }
     __syncthreads();
-    const int lx = tid & (kT - 1), ly = tid >> 4;
-    const int x = x0 + lx, y = y0 + ly;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-    float v_ssim = 0.f, v_l1 = 0.f;
+    // vertical pass: column lx, rows 2 rp and 2 rp + 1
+    const int lx = tid & (kTX - 1), rp = tid >> 5;
+    float acc[2][5];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = g.w[k];
-        mu1 = fmaf_(w, sh[0][ly + k][lx], mu1);
-        mu2 = fmaf_(w, sh[1][ly + k][lx], mu2);
-        e11 = fmaf_(w, sh[2][ly + k][lx], e11);
-        e22 = fmaf_(w, sh[3][ly + k][lx], e22);
-        e12 = fmaf_(w, sh[4][ly + k][lx], e12);
-    }
-    if (x < W && y < H) {
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
-        const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
-        const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
-        const size_t o = plane + (size_t)y * W + x;
-        if (LOSS) {
-            v_ssim = (Cc * D) / (A * B);
-            v_l1 = fabsf(s1[ly + kR][lx + kR] - s2[ly + kR][lx + kR]);
-        } else {
-            ssim_map[o] = (Cc * D) / (A * B);
+    for (int m = 0; m < 5; m++) {  // (one moment at a time: 12 live values, not 60)
+        float v[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = sh[m][2 * rp + j][lx];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) t = fmaf_(g.w[k], v[r + k], t);
+            acc[r][m] = t;
         }
-        if (train) {
-            dm_dmu1[o] = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * Cc) / (A * B) - (mu1 * 2.f * Cc * D) / (A * A * B) +
-                         (mu1 * 2.f * Cc * D) / (A * B * B);
-            dm_dsigma1_sq[o] = (-Cc * D) / (A * B * B);
-            dm_dsigma12[o] = (2.f * Cc) / (A * B);
+    }
+    float v_ssim = 0.f, v_l1 = 0.f;
+    const int x = x0 + lx;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int ly = 2 * rp + r, y = y0 + ly;
+        if (x < W && y < H) {
+            const float mu1 = acc[r][0], mu2 = acc[r][1], e11 = acc[r][2], e22 = acc[r][3], e12 = acc[r][4];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
+            const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
+            const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
+            const size_t o = plane + (size_t)y * W + x;
+            if (LOSS) {
+                v_ssim += (Cc * D) / (A * B);
+                v_l1 += fabsf(s1[ly + kR][lx + kR] - s2[ly + kR][lx + kR]);
+            } else {
+                ssim_map[o] = (Cc * D) / (A * B);
+            }
+            if (train) {
+                dm_dmu1[o] = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * Cc) / (A * B) - (mu1 * 2.f * Cc * D) / (A * A * B) +
+                             (mu1 * 2.f * Cc * D) / (A * B * B);
+                dm_dsigma1_sq[o] = (-Cc * D) / (A * B * B);
+                dm_dsigma12[o] = (2.f * Cc) / (A * B);
+            }
         }
     }
     if (LOSS) {
@@ -155,9 +180,9 @@ __global__ __launch_bounds__(kFinT) void loss_finish_kernel(const float *__restr
 
 // LOSS (gsr_photometric_loss): dL/dmap is the constant w_ssim (= -lambda / n); the L1 term w_l1 sign(x - y) is added
 // (sign(0) = 0, torch's abs backward) and the whole gradient passes through clamp(., 0, 1)'s backward when `clamp01`
-// (kept where 0 <= img1 <= 1, bounds included, as torch.clamp).
+// (kept where 0 <= img1 <= 1, bounds included, as torch.clamp).  Same 32 x 16 tiling as the forward.
 template <bool LOSS>
-__global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, Gauss11 g,
+__global__ __launch_bounds__(GSR_BLOCK, 6) void ssim_backward_kernel(int H, int W, Gauss11 g,
                                                                   const float *__restrict__ img1,
                                                                   const float *__restrict__ img2,
                                                                   const float *__restrict__ dL_dmap,
@@ -166,13 +191,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
                                                                   const float *__restrict__ dm_dsigma12,
                                                                   float *__restrict__ dL_dimg1, float w_ssim,
                                                                   float w_l1, int clamp01) {
-    __shared__ float s[3][kH][kH + 1];
-    __shared__ float sh[3][kH][kT + 1];
+    __shared__ float s[3][kHY][kHX + 1];
+    __shared__ float sh[3][kHY][kTX + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < kH * kH; i += GSR_BLOCK) {
-        const int ly = i / kH, lx = i - ly * kH;
+    for (int i = tid; i < kHY * kHX; i += GSR_BLOCK) {
+        const int ly = i / kHX, lx = i - ly * kHX;
         const int x = x0 + lx - kR, y = y0 + ly - kR;
         float a = 0.f, b = 0.f, c = 0.f;
         if (x >= 0 && x < W && y >= 0 && y < H) {
@@ -185,40 +210,55 @@ __global__ __launch_bounds__(GSR_BLOCK) void ssim_backward_kernel(int H, int W, 
         s[0][ly][lx] = a; s[1][ly][lx] = b; s[2][ly][lx] = c;
     }
     __syncthreads();
-    for (int i = tid; i < kH * kT; i += GSR_BLOCK) {
-        const int ly = i / kT, lx = i - ly * kT;
-        float a = 0.f, b = 0.f, c = 0.f;
+    if (tid < kHY * (kTX / 4)) {
+        const int ly = tid / (kTX / 4), c0 = (tid - ly * (kTX / 4)) * 4;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = g.w[k];
-            a = fmaf_(w, s[0][ly][lx + k], a);
-            b = fmaf_(w, s[1][ly][lx + k], b);
-            c = fmaf_(w, s[2][ly][lx + k], c);
+        for (int m = 0; m < 3; m++) {
+            float v[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) v[j] = s[m][ly][c0 + j];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) t = fmaf_(g.w[k], v[c + k], t);
+                sh[m][ly][c0 + c] = t;
+            }
         }
-        sh[0][ly][lx] = a; sh[1][ly][lx] = b; sh[2][ly][lx] = c;
     }
     __syncthreads();
-    const int lx = tid & (kT - 1), ly = tid >> 4;
-    const int x = x0 + lx, y = y0 + ly;
-    float a = 0.f, b = 0.f, c = 0.f;
+    const int lx = tid & (kTX - 1), rp = tid >> 5;
+    float acc[2][3];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = g.w[k];
-        a = fmaf_(w, sh[0][ly + k][lx], a);
-        b = fmaf_(w, sh[1][ly + k][lx], b);
-        c = fmaf_(w, sh[2][ly + k][lx], c);
+    for (int m = 0; m < 3; m++) {
+        float v[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = sh[m][2 * rp + j][lx];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) t = fmaf_(g.w[k], v[r + k], t);
+            acc[r][m] = t;
+        }
     }
-    if (x < W && y < H) {
-        const size_t o = plane + (size_t)y * W + x;
-        if (LOSS) {
-            const float raw = img1[o], yv = img2[o];
-            const float xv = (clamp01 && raw == raw) ? fminf(fmaxf(raw, 0.f), 1.f) : raw;
-            const float d = xv - yv;
-            float gsum = a + 2.f * xv * b + yv * c;
-            gsum += w_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-            dL_dimg1[o] = (!clamp01 || (raw >= 0.f && raw <= 1.f)) ? gsum : 0.f;
-        } else {
-            dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+    const int x = x0 + lx;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = y0 + 2 * rp + r;
+        if (x < W && y < H) {
+            const float a = acc[r][0], b = acc[r][1], c = acc[r][2];
+            const size_t o = plane + (size_t)y * W + x;
+            if (LOSS) {
+                const float raw = img1[o], yv = img2[o];
+                const float xv = (clamp01 && raw == raw) ? fminf(fmaxf(raw, 0.f), 1.f) : raw;
+                const float d = xv - yv;
+                float gsum = a + 2.f * xv * b + yv * c;
+                gsum += w_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                dL_dimg1[o] = (!clamp01 || (raw >= 0.f && raw <= 1.f)) ? gsum : 0.f;
+            } else {
+                dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+            }
         }
     }
 }
@@ -252,7 +292,7 @@ extern "C" int gsr_ssim_forward(int32_t B, int32_t CH, int32_t H, int32_t W, flo
         gsr_set_error("gsr_ssim_forward: batch*channels exceeds the grid's z extent");
         return GSR_E_INVALID;
     }
-    const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), B * CH);
+    const dim3 grid(gsr_div_up(W, kTX), gsr_div_up(H, kTY), B * CH);
     hipLaunchKernelGGL(ssim_forward_kernel<false>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, C1, C2,
                        make_window(), img1, img2, train, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, 0,
                        (float *)nullptr);
@@ -277,7 +317,7 @@ extern "C" int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, fl
         gsr_set_error("gsr_ssim_backward: batch*channels exceeds the grid's z extent");
         return GSR_E_INVALID;
     }
-    const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), B * CH);
+    const dim3 grid(gsr_div_up(W, kTX), gsr_div_up(H, kTY), B * CH);
     hipLaunchKernelGGL(ssim_backward_kernel<false>, grid, dim3(GSR_BLOCK), 0, (hipStream_t)stream, H, W, make_window(),
                        img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, 0.f, 0.f, 0);
     return gsr_check_launch("ssim_backward", false, (hipStream_t)stream);
@@ -286,7 +326,7 @@ extern "C" int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, fl
 // ---- the photometric loss of the 3DGS training step in two passes --------------------------------------------------
 extern "C" size_t gsr_photometric_loss_scratch_floats(int32_t planes, int32_t H, int32_t W) {
     if (planes <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t nb = (size_t)gsr_div_up(W, kT) * gsr_div_up(H, kT) * planes;
+    const size_t nb = (size_t)gsr_div_up(W, kTX) * gsr_div_up(H, kTY) * planes;
     return 3 * (size_t)planes * H * W + 2 * nb;
 }
 
@@ -303,7 +343,7 @@ extern "C" int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const 
     }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t n = (size_t)planes * H * W;
-    const dim3 grid(gsr_div_up(W, kT), gsr_div_up(H, kT), planes);
+    const dim3 grid(gsr_div_up(W, kTX), gsr_div_up(H, kTY), planes);
     const int nb = (int)(grid.x * grid.y * grid.z);
     float *partials = scratch, *maps = scratch + 2 * (size_t)nb;  // (the pairs first: read as float2)
     float *dm_dmu1 = maps, *dm_dsigma1_sq = maps + n, *dm_dsigma12 = maps + 2 * n;
