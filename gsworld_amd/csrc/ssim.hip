@@ -196,6 +196,11 @@ __global__ __launch_bounds__(GSR_BLOCK, 6) void ssim_backward_kernel(int H, int 
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
     const int tid = (int)threadIdx.x;
+    if (LOSS) {  // the scalar loss's incoming gradient scales both terms
+        const float gl = dL_dmap != nullptr ? dL_dmap[0] : 1.0f;
+        w_ssim *= gl;
+        w_l1 *= gl;
+    }
     for (int i = tid; i < kHY * kHX; i += GSR_BLOCK) {
         const int ly = i / kHX, lx = i - ly * kHX;
         const int x = x0 + lx - kR, y = y0 + ly - kR;
@@ -331,8 +336,8 @@ extern "C" size_t gsr_photometric_loss_scratch_floats(int32_t planes, int32_t H,
 }
 
 extern "C" int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const float *img, const float *target,
-                                    float lambda_dssim, int32_t clamp01, float *scratch, float *loss, float *dL_dimg,
-                                    void *stream_) {
+                                    float lambda_dssim, int32_t clamp01, float *scratch, float *loss,
+                                    int32_t keep_for_backward, void *stream_) {
     if (planes <= 0 || H <= 0 || W <= 0 || planes > 65535) {
         gsr_set_error("gsr_photometric_loss: planes must be in 1 .. 65535, H and W positive");
         return GSR_E_INVALID;
@@ -350,18 +355,33 @@ extern "C" int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const 
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const Gauss11 g = make_window();
     hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, C1, C2, g, img, target,
-                       dL_dimg != nullptr ? 1 : 0, (float *)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, clamp01, partials);
+                       keep_for_backward ? 1 : 0, (float *)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, clamp01, partials);
     if (int e = gsr_check_launch("photometric_loss (forward)", false, stream)) return e;
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kFinT), 0, stream, (const float *)partials, nb, (double)n,
                        lambda_dssim, loss);
-    if (int e = gsr_check_launch("photometric_loss (sum)", false, stream)) return e;
-    if (dL_dimg != nullptr) {
-        const float w_ssim = (float)(-(double)lambda_dssim / (double)n);
-        const float w_l1 = (float)((1.0 - (double)lambda_dssim) / (double)n);
-        hipLaunchKernelGGL(ssim_backward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, g, img, target,
-                           (const float *)nullptr, (const float *)dm_dmu1, (const float *)dm_dsigma1_sq,
-                           (const float *)dm_dsigma12, dL_dimg, w_ssim, w_l1, clamp01);
-        if (int e = gsr_check_launch("photometric_loss (gradient)", false, stream)) return e;
+    return gsr_check_launch("photometric_loss (sum)", false, stream);
+}
+
+extern "C" int gsr_photometric_loss_backward(int32_t planes, int32_t H, int32_t W, const float *img, const float *target,
+                                             float lambda_dssim, int32_t clamp01, const float *scratch,
+                                             const float *grad_loss, float *dL_dimg, void *stream_) {
+    if (planes <= 0 || H <= 0 || W <= 0 || planes > 65535) {
+        gsr_set_error("gsr_photometric_loss_backward: planes must be in 1 .. 65535, H and W positive");
+        return GSR_E_INVALID;
     }
-    return GSR_OK;
+    if (!img || !target || !scratch || !dL_dimg) {
+        gsr_set_error("gsr_photometric_loss_backward: null pointer");
+        return GSR_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n = (size_t)planes * H * W;
+    const dim3 grid(gsr_div_up(W, kTX), gsr_div_up(H, kTY), planes);
+    const size_t nb = (size_t)grid.x * grid.y * grid.z;
+    const float *maps = scratch + 2 * nb;
+    const float w_ssim = (float)(-(double)lambda_dssim / (double)n);
+    const float w_l1 = (float)((1.0 - (double)lambda_dssim) / (double)n);
+    // (LOSS mode: the dL_dmap slot carries the incoming gradient of the scalar loss, one float on the device, or NULL = 1)
+    hipLaunchKernelGGL(ssim_backward_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, H, W, make_window(), img, target,
+                       grad_loss, maps, maps + n, maps + 2 * n, dL_dimg, w_ssim, w_l1, clamp01);
+    return gsr_check_launch("photometric_loss (gradient)", false, stream);
 }

@@ -24,7 +24,11 @@ def _bind():
         L.gsr_photometric_loss_scratch_floats.restype = C.c_size_t
         L.gsr_photometric_loss_scratch_floats.argtypes = [C.c_int32] * 3
         L.gsr_photometric_loss.restype = C.c_int
-        L.gsr_photometric_loss.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 2 + [C.c_float, C.c_int32] + [C.c_void_p] * 4
+        L.gsr_photometric_loss.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 2 + [C.c_float, C.c_int32] + \
+            [C.c_void_p] * 2 + [C.c_int32, C.c_void_p]
+        L.gsr_photometric_loss_backward.restype = C.c_int
+        L.gsr_photometric_loss_backward.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 2 + [C.c_float, C.c_int32] + \
+            [C.c_void_p] * 4
         L._ssim_bound = True
     return L
 
@@ -119,24 +123,30 @@ class _PhotometricLoss(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         scratch = torch.empty(int(L.gsr_photometric_loss_scratch_floats(planes, H, W)), dtype=torch.float32, device=x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
-        grad = torch.empty_like(x) if need_grad else None
         with torch.cuda.device(x.device):
             check(L.gsr_photometric_loss(planes, H, W, _p(x), _p(t), float(lambda_dssim), int(bool(clamp01)), _p(scratch),
-                                         _p(loss), _p(grad) if need_grad else None,
-                                         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        ctx.grad, ctx.in_dtype = grad, img.dtype
+                                         _p(loss), int(need_grad), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        if need_grad:
+            ctx.save_for_backward(x, t, scratch)
+            ctx.args = (planes, H, W, float(lambda_dssim), int(bool(clamp01)), img.dtype)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        grad, ctx.grad = ctx.grad, None
-        return ((grad * g).to(ctx.in_dtype) if grad is not None else None), None, None, None
+        x, t, scratch = ctx.saved_tensors
+        planes, H, W, lam, clamp01, in_dtype = ctx.args
+        g = g.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):  # (the incoming gradient is read by the kernel: no multiply pass afterwards)
+            check(_bind().gsr_photometric_loss_backward(planes, H, W, _p(x), _p(t), lam, clamp01, _p(scratch), _p(g),
+                                                        _p(grad), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return grad.to(in_dtype), None, None, None
 
 
 def photometric_loss(img, target, lambda_dssim: float = 0.2, clamp01: bool = False):
     """``(1 - lambda) * l1_loss(x, target) + lambda * (1 - fused_ssim(x[None], target[None]))`` with
     ``x = img.clamp(0, 1)`` when ``clamp01`` -- the loss of the 3DGS training step (gs_utils.py:96 ``lambda_dssim``;
-    upstream train.py) as ONE autograd node over three kernels (``gsr_photometric_loss``) instead of ~25 elementwise /
-    reduction launches: the value is summed in a fixed order, the gradient w.r.t. ``img`` (through the clamp) is written
-    in the forward and scaled by the incoming gradient in the backward.  An extension: ``fused_ssim`` stays the drop-in."""
+    upstream train.py) as ONE autograd node over three kernels (``gsr_photometric_loss`` + ``_backward``) instead of ~25
+    elementwise / reduction launches: the value is summed in a fixed order; the backward pass writes the gradient
+    w.r.t. ``img`` (through the clamp), already scaled by the incoming gradient.  An extension: ``fused_ssim`` stays the drop-in."""
     return _PhotometricLoss.apply(img, target, lambda_dssim, clamp01)

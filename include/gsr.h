@@ -284,14 +284,20 @@ int gsr_ssim_backward(int32_t B, int32_t CH, int32_t H, int32_t W, float C1, flo
  * The photometric loss of the 3DGS training step, (1 - lambda) mean|x - t| + lambda (1 - mean ssim(x, t)) with
  * x = clamp(img, 0, 1) when clamp01 (what train.py builds from l1_loss, fused_ssim and render()'s clamp out of ~25
  * elementwise / reduction launches and their autograd), in three launches: the ssim forward pass with the sums folded
- * in, a one-workgroup sum in a fixed order (binary64), and -- when dL_dimg is given -- the ssim backward pass with the L1
- * sign term and the clamp mask folded in.  img / target / dL_dimg: (planes, H, W) float32; loss: one float on the
- * device; dL_dimg = d loss / d img.  scratch: gsr_photometric_loss_scratch_floats(planes, H, W) floats.
+ * in, a one-workgroup sum in a fixed order (binary64), and -- gsr_photometric_loss_backward, after a forward with
+ * keep_for_backward != 0 on the same scratch -- the ssim backward pass with the L1 sign term, the clamp mask and the
+ * incoming gradient of the loss (grad_loss: one float on the device, NULL = 1) folded in.  img / target / dL_dimg:
+ * (planes, H, W) float32; loss: one float on the device; dL_dimg = grad_loss x d loss / d img.  scratch:
+ * gsr_photometric_loss_scratch_floats(planes, H, W) floats.
  * An extension (no upstream entry point); gsr_ssim_* above remain the drop-in for fused_ssim_cuda.
  */
 size_t gsr_photometric_loss_scratch_floats(int32_t planes, int32_t H, int32_t W);
 int gsr_photometric_loss(int32_t planes, int32_t H, int32_t W, const float *img, const float *target,
-                         float lambda_dssim, int32_t clamp01, float *scratch, float *loss, float *dL_dimg, void *stream);
+                         float lambda_dssim, int32_t clamp01, float *scratch, float *loss, int32_t keep_for_backward,
+                         void *stream);
+int gsr_photometric_loss_backward(int32_t planes, int32_t H, int32_t W, const float *img, const float *target,
+                                  float lambda_dssim, int32_t clamp01, const float *scratch, const float *grad_loss,
+                                  float *dL_dimg, void *stream);
 
 /*
  * Fused per-step rigid transform of labelled Gaussians -- replaces GSWorld's per-link isin() mask / gather /
