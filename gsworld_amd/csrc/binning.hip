@@ -335,9 +335,42 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
         }
         return;
     }
+    uint32_t grand;
+    constexpr int kOwn = 32;  // tiles per thread held in registers: grids up to 8192 tiles in ONE workgroup scan
+    if (T <= kOwn * GSR_BLOCK) {
+        // a thread owns `per` consecutive tiles: their sum goes through one block scan, the ranges follow from the
+        // thread's exclusive base (the loop below costs a scan -- two barriers -- per 256 tiles: 10 of them at 800 x 800)
+        const int per = (T + GSR_BLOCK - 1) / GSR_BLOCK, t0 = (int)threadIdx.x * per;
+        uint32_t v[kOwn], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kOwn; k++) {
+            v[k] = (k < per && t0 + k < T) ? totals[t0 + k] : 0u;
+            sum += v[k];
+        }
+        uint32_t run = gsr_block_incl_scan(sum, s_w, grand) - sum;
+        const bool overflow = grand > r_capacity;
+#pragma unroll
+        for (int k = 0; k < kOwn; k++) {
+            const int t = t0 + k;
+            if (k < per && t < T) {
+                ranges[t] = (v[k] == 0u || overflow) ? make_uint2(0u, 0u) : make_uint2(run, run + v[k]);
+                if (cursor_to_zero) cursor_to_zero[t] = 0u;
+            }
+            run += v[k];
+        }
+        if (threadIdx.x == 0) {
+            hdr->R_raw = grand;
+            hdr->r_capacity = r_capacity;
+            gsr_set_overflow(hdr, overflow);
+            hdr->R = overflow ? 0u : grand;
+        }
+        if (tile_order == nullptr || keyed) return;
+        __syncthreads();  // this workgroup's range stores are visible to all of its threads
+        gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
+        return;
+    }
     uint32_t sum = 0;
     for (int t = (int)threadIdx.x; t < T; t += GSR_BLOCK) sum += totals[t];
-    uint32_t grand;
     gsr_block_incl_scan(sum, s_w, grand);
     const bool overflow = grand > r_capacity;
     uint32_t carry = 0;
