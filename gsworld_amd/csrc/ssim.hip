@@ -112,12 +112,22 @@ __global__ __launch_bounds__(GSR_BLOCK, 5) void ssim_forward_kernel(int H, int W
             const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
             const size_t o = plane + (size_t)y * W + x;
             if (LOSS) {
-                v_ssim += (Cc * D) / (A * B);
+                // (the loss is compared at 1e-6 and summed over a million pixels: the hardware reciprocals of A and B --
+                //  1 ulp each -- replace the seven correctly rounded divisions of upstream's expressions, which the
+                //  drop-in maps below keep)
+                const float iA = __builtin_amdgcn_rcpf(A), iB = __builtin_amdgcn_rcpf(B), iAB = iA * iB;
+                v_ssim += (Cc * D) * iAB;
                 v_l1 += fabsf(s1[ly + kR][lx + kR] - s2[ly + kR][lx + kR]);
+                if (train) {
+                    const float t = 2.f * Cc * D;
+                    dm_dmu1[o] = 2.f * mu2 * (D - Cc) * iAB + mu1 * t * iAB * (iB - iA);
+                    dm_dsigma1_sq[o] = -(Cc * D) * iAB * iB;
+                    dm_dsigma12[o] = (2.f * Cc) * iAB;
+                }
             } else {
                 ssim_map[o] = (Cc * D) / (A * B);
             }
-            if (train) {
+            if (!LOSS && train) {
                 dm_dmu1[o] = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * Cc) / (A * B) - (mu1 * 2.f * Cc * D) / (A * A * B) +
                              (mu1 * 2.f * Cc * D) / (A * B * B);
                 dm_dsigma1_sq[o] = (-Cc * D) / (A * B * B);
