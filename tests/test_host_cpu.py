@@ -286,3 +286,23 @@ def test_instance_bound_that_replaces_the_read_back():
         assert _C.nosync_capacity(1000, 64, 64) is None                           # A/B paths size their lists exactly
     finally:
         _lib.TUNING.update(saved)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gsworld"), reason="the reference tree is only present in the authoring container")
+def test_xarm6_rollout_fixture_is_what_its_script_writes(tmp_path):
+    """tests/golden/xarm6_rollout.npz against a fresh run of tools/make_xarm6_rollout.py on the reference's URDF and
+    constants (authoring container only): the committed fixture is that script's output, array for array."""
+    import importlib.util
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_xarm6_rollout", os.path.join(root, "tools", "make_xarm6_rollout.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "rollout.npz")
+    mod.main(out)
+    a, b = np.load(out), np.load(os.path.join(root, "tests", "golden", "xarm6_rollout.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

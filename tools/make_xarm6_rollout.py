@@ -100,7 +100,7 @@ def forward_kinematics(links, joints, q):
     return np.stack([of(n) for n in links])
 
 
-def main():
+def main(out=None):
     spec = importlib.util.spec_from_file_location("ref_constants", f"{REF}/gsworld/constants.py")
     consts = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(consts)
@@ -135,7 +135,7 @@ def main():
     for i, n in enumerate(links):
         v = np.atleast_1d(sem[n])
         labels[i, :len(v)] = v
-    out = os.path.join(ROOT, "tests", "golden", "xarm6_rollout.npz")
+    out = out or os.path.join(ROOT, "tests", "golden", "xarm6_rollout.npz")
     np.savez_compressed(
         out, link_names=np.array(links), labels=labels, joint_names=np.array(names), arm_joints=np.array(arm),
         qpos=np.array(qs, dtype=np.float32), qpos_scan=np.asarray(consts.xarm_gs_qpos, dtype=np.float32),
