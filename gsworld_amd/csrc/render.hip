@@ -310,6 +310,10 @@ constexpr int kStreamList = kStreamRound + kBatch;                // survivors +
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef GSR_STREAM_STAMPS
+#define GSR_STREAM_STAMPS 0   // 1: tuning build that leaves per-quadrant cycle stamps in the image state
+#endif
+
 // one batch of survivors, evaluated for this lane's pixel (alpha: 0 for an instance that does not touch it)
 struct StreamBatch {
     float alpha[kBatch], pos[kBatch];
@@ -368,10 +372,18 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
 // TRACK = false (inference frames): n_contrib is not written, so the last contributor is not tracked either
 template <bool TRACK>
 __device__ __forceinline__ void stream_blend(const StreamBatch &b, float &T, v2f &acc_rg, v2f &acc_bd, uint32_t &last) {
+    // (1 - alpha) of two survivors per packed subtraction: the same IEEE operation per element
+    float oma[kBatch];
+#pragma unroll
+    for (int h = 0; h < kBatch / 2; h++) {
+        const v2f d = v2f{1.0f, 1.0f} - v2f{b.alpha[2 * h], b.alpha[2 * h + 1]};
+        oma[2 * h] = d.x;
+        oma[2 * h + 1] = d.y;
+    }
 #pragma unroll
     for (int k = 0; k < kBatch; k++) {
         // alpha 0: T * 1 = T (>= 1e-4 by construction) and weight 0; T < 0 (finished): stop again
-        const float test_T = T * (1.0f - b.alpha[k]);
+        const float test_T = T * oma[k];
         const bool stop = test_T < 0.0001f;
         const float w = stop ? 0.0f : b.alpha[k] * T;
         acc_rg = __builtin_elementwise_fma(v2f{b.col[k].x, b.col[k].y}, v2f{w, w}, acc_rg);
@@ -495,6 +507,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
         const int n_inst = (int)(range.y - range.x);
         const uint32_t *src = point_list + range.x;
 
+#if GSR_STREAM_STAMPS
+        const uint64_t stamp0 = __builtin_readcyclecounter();
+#endif
         const v2f pf2x = {pfx, pfx}, pf2y = {pfy, pfy};
         // A pixel that is finished (saturated, or outside the image) carries its transmittance NEGATED: T * (1 - a) is
         // then negative, so the saturation test below fires for it again by itself and no separate done flag has to
@@ -595,6 +610,18 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             __builtin_amdgcn_wave_barrier();  // the next round overwrites the list
         }
         if (quad_work != nullptr && lane == 0) (half == 2 ? quad_work_b : quad_work)[4 * tile + quad] = work;
+#if GSR_STREAM_STAMPS
+        // tuning build (tools/stream_stamps.py, tools/stamps_report.py): per quadrant, shader-clock stamps of its start
+        // and end (the clock is per CU), where it ran (HW_ID | XCC_ID << 28) and what it cost -- left in final_T, which
+        // inference frames do not write
+        if (SUPER && lane == 0) {
+            const uint64_t stamp1 = __builtin_readcyclecounter();
+            const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0x0fffffffu;
+            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+            reinterpret_cast<uint4 *>(final_T)[4 * tile + quad] =
+                make_uint4((uint32_t)stamp0, (uint32_t)stamp1, hw | (xcc << 28), work);
+        }
+#endif
         if (inside) {
             const size_t pid = (size_t)py * W + px;
             const size_t plane = (size_t)H * W;

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""What the stream compositor's waves spend their lanes on at configs[1] (CPU only, through the oracle's lists).
+
+For every 8x8 quadrant of the headline frame: candidates of its tile list walked before the quadrant saturates (rounds
+of 64), survivors of the per-quadrant cull (an instance some pixel of the quadrant composites), and of the
+(survivor x 64 lane) evaluations the share that hits (alpha >= 1/255 on a live pixel), misses, or falls on a pixel
+that is already finished.  Decides which restructuring of render.hip can pay."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+np.seterr(all="ignore")
+from gsworld_amd import scenes  # noqa: E402
+from oracle import gs_oracle as go  # noqa: E402
+
+
+def main():
+    view = sys.argv[1] if len(sys.argv) > 1 else "sensor"
+    raw = scenes.tabletop_scene("xarm6_align", seed=1)
+    cam = scenes.sensor_camera("xarm6_align") if view == "sensor" else scenes.dense_view_camera("xarm6_align", 640, 480)
+    means, shs, op, sc, rot = (t.numpy() for t in raw.activated())
+    st = go.Settings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy)
+    f = go.forward(st, np.zeros(3, np.float32), means, shs, None, op.reshape(-1), sc, rot, None,
+                   cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), cam.camera_center.numpy())
+    g, b = f["geom"], f["binning"]
+    gx, gy = st.grid
+    W, H = st.image_width, st.image_height
+    xy, co = g["means2D"], g["conic_opacity"]
+    pl, ranges = b["point_list"], b["ranges"]
+    tot = dict(quadrants=0, cand=0, rounds=0, surv=0, evals=0, hit=0, miss=0, dead=0, list_len=0, batches=0,
+               hit_inst_pix=0)
+    per_q_surv = []
+    per_q_rounds = []
+    for t in range(gx * gy):
+        lo, hi = int(ranges[t, 0]), int(ranges[t, 1])
+        L = hi - lo
+        tx, ty = t % gx, t // gx
+        idx = pl[lo:hi]
+        cx, cy = xy[idx, 0], xy[idx, 1]
+        A, B, C_, o = co[idx, 0], co[idx, 1], co[idx, 2], co[idx, 3]
+        for q in range(4):
+            x0 = tx * 16 + (q & 1) * 8
+            y0 = ty * 16 + (q >> 1) * 8
+            px = (x0 + np.arange(8, dtype=np.float32))[None, :].repeat(8, 0).reshape(-1)
+            py = (y0 + np.arange(8, dtype=np.float32))[:, None].repeat(8, 1).reshape(-1)
+            inside = (px < W) & (py < H)
+            tot["quadrants"] += 1
+            tot["list_len"] += L
+            if L == 0:
+                per_q_surv.append(0); per_q_rounds.append(0)
+                continue
+            dx = cx[:, None] - px[None, :]
+            dy = cy[:, None] - py[None, :]
+            power = -0.5 * (A[:, None] * dx * dx + C_[:, None] * dy * dy) - B[:, None] * dx * dy
+            alpha = np.minimum(0.99, o[:, None] * np.exp(power))
+            valid = (power <= 0) & (alpha >= 1.0 / 255.0)
+            a_eff = np.where(valid, alpha, 0.0)
+            # transmittance before each instance; a pixel is finished at the first instance whose test_T < 1e-4
+            logT = np.cumsum(np.log1p(-a_eff.astype(np.float64)), axis=0)
+            test_T = np.exp(logT)
+            stop = (test_T < 1e-4)
+            first_stop = np.where(stop.any(0), stop.argmax(0), L)   # instance index at which the pixel finishes
+            first_stop = np.where(inside, first_stop, 0)
+            alive = np.arange(L)[:, None] < first_stop[None, :]      # pixel still live when instance j is examined
+            last_needed = int(first_stop.max())                      # the wave walks candidates up to here (then round end)
+            rounds = min((last_needed + 64) // 64, (L + 63) // 64) if last_needed > 0 else (1 if L > 0 else 0)
+            walked = min(rounds * 64, L)
+            surv_mask = valid[:walked].any(1)                        # ideal per-quadrant cull (exact)
+            ns = int(surv_mask.sum())
+            # the replay stops after the batch in which the last pixel finishes
+            sv = np.nonzero(surv_mask)[0]
+            if ns:
+                upto = np.searchsorted(sv, last_needed, side="right")
+                upto = min(ns, (upto + 3) // 4 * 4)
+                sv = sv[:upto]
+            ev = len(sv) * 64
+            h = int((valid[sv] & alive[sv]).sum())
+            d = int((~alive[sv]).sum())
+            tot["cand"] += walked; tot["rounds"] += rounds; tot["surv"] += len(sv); tot["evals"] += ev
+            tot["hit"] += h; tot["dead"] += d; tot["miss"] += ev - h - d
+            tot["batches"] += (len(sv) + 3) // 4
+            per_q_surv.append(len(sv)); per_q_rounds.append(rounds)
+    s = np.array(per_q_surv); r = np.array(per_q_rounds)
+    out = dict(view=view, **{k: int(v) for k, v in tot.items()},
+               surv_per_quadrant_mean=float(s.mean()), surv_per_quadrant_p99=float(np.percentile(s, 99)),
+               surv_per_quadrant_max=int(s.max()), rounds_per_quadrant_mean=float(r.mean()),
+               hit_frac=tot["hit"] / max(tot["evals"], 1), miss_frac=tot["miss"] / max(tot["evals"], 1),
+               dead_frac=tot["dead"] / max(tot["evals"], 1),
+               tile_list_mean=tot["list_len"] / max(tot["quadrants"], 1),
+               walked_frac_of_list=tot["cand"] / max(tot["list_len"], 1))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
