@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage event timing table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the frame in a hipGraph")
     ap.add_argument("--render-bpc", type=int, default=0, help="persistent compositing workgroups per CU (0 = library default)")
+    ap.add_argument("--no-layout", action="store_true",
+                    help="render the model in the order it was given, without block culling (gsworld_amd/layout.py)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; value = their median")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent frames in flight, each on its own HIP stream with its own renderer state "
                          "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time)")
@@ -74,6 +77,22 @@ def main():
     raw = scenes.tabletop_scene(name, n=n, seed=seed)
     cam_cpu = scenes.sensor_camera(name, args.width, args.height)
     means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    # Load-time layout (gsworld_amd/layout.py): a copy of the model in Morton order per size class + bounds of every block
+    # of 256 Gaussians, built ONCE per scene -- a GSWorld scene is loaded once and rendered for whole episodes.  Frames
+    # then skip the blocks no tile can see (71 % of them from right_cam); same bits out (checked below against a frame
+    # of the model as given).  Not part of the timed region, like the scene load itself; its cost is in the line.
+    lay, layout_s = None, None
+    m_means, m_shs, m_op, m_sc, m_rot = means, shs, op, sc, rot
+    if not args.no_layout:
+        from gsworld_amd.layout import SceneLayout
+
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
+        L = SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+        torch.cuda.synchronize()
+        layout_s = time.perf_counter() - t_l
+        a = L.arrays
+        m_means, m_shs, m_op, m_sc, m_rot, lay = a["means3D"], a["shs"], a["opacities"], a["scales"], a["rotations"], L.layout
     cam = cam_cpu.to(dev)
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
@@ -107,7 +126,7 @@ def main():
     def frame(slot, lane=None):
         rr = rs_[slot % S if lane is None else lane]
         # the uint8 HWC frame GSWorld consumes is written by the compositor itself (GsrOutputs.out_rgb8)
-        rr.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=fg.frames[slot])
+        rr.render(cam, m_means, m_op, shs=m_shs, scales=m_sc, rotations=m_rot, bg=bg, rgb8_out=fg.frames[slot], layout=lay)
 
     # exact-mode frame sizes the binning capacity from the real R; then check the no-sync path is valid
     for l in range(S):
@@ -177,12 +196,16 @@ def main():
     # (events are recorded inside libgsr_hip.so on the stream the kernels run on; not available under graph replay)
     profile_mode = 1 if graph is None else 0
     check(lib().gsr_profile_enable(profile_mode))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    # exactly K steps between barriers, `--blocks` times over: at ~0.1 ms a frame one block of the driver's K is a few
+    # milliseconds, so the line carries the median block and the spread
+    block_s = []
+    for b in range(max(1, args.blocks)):
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(b * args.steps + i)
+        barrier()
+        block_s.append(time.perf_counter() - t0)
+    elapsed = sorted(block_s)[len(block_s) // 2]
     prof = GsrProfile()
     check(lib().gsr_profile_collect(prof))
     check(lib().gsr_profile_enable(0))
@@ -233,7 +256,13 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg)
+        extras = secondary_measurements(args, dev, raw, name, (means, shs, op, sc, rot),
+                                        (m_means, m_shs, m_op, m_sc, m_rot, lay), bg)
+    # strictly one frame at a time (hipGraph replay of one lane), for the line's config: the figure a caller sees who
+    # needs frame k before it can ask for frame k + 1
+    one_fps = None
+    if rank == 0 and world == 1 and graph is not None:
+        one_fps = _time_frames(torch, graph[0].replay, min(args.steps, 300))
 
     if rank == 0:
         binned = stats.num_rendered  # instances actually placed (super-tile lists)
@@ -265,6 +294,18 @@ def main():
                     valu_frac = insts * 4.0 / (256 * 4 * 2.4e9 * render_ms * 1e-3)
             except Exception:  # noqa: BLE001
                 traffic = valu_frac = None
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command (profiles/)
+        rocprof_ms = None
+        try:
+            import csv
+            import glob
+
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "kernel_stats_bench_one_frame_in_flight.csv"))):
+                for row in csv.DictReader(open(path)):
+                    if "render_stream_kernel<true>" in row["Name"]:
+                        rocprof_ms = {"file": os.path.relpath(path, ROOT), "avg_ms": float(row["AverageNs"]) * 1e-6}
+        except Exception:  # noqa: BLE001
+            rocprof_ms = None
         out = {
             "metric": "rendered frames/sec @640x480, 1.5M Gaussians",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -279,6 +320,16 @@ def main():
                               "to the default frame, checked in this run)",
                 "sh_degree": 3, "launch": "hipGraph replay" if graph is not None else "eager",
                 "frames_in_flight": S,
+                # the same frame, strictly one at a time / under a camera that turns on every frame (extras below)
+                "one_frame_in_flight_frames_per_s": one_fps,
+                "moving_camera_frames_per_s": extras.get("moving_camera", {}).get("frames_per_s"),
+                "model_layout": ("Morton order per size class + block bounds built once per scene "
+                                 f"(gsworld_amd/layout.py, {layout_s:.3f} s on this box, outside the timed region): "
+                                 "preprocess skips the blocks of 256 Gaussians no tile can see; image, radii and tie "
+                                 "order unchanged") if lay is not None else "model as given (--no-layout)",
+                "timed_blocks": {"blocks": len(block_s), "steps_each": args.steps,
+                                 "frames_per_s": [world * args.steps / t for t in block_s],
+                                 "value_is": "median block"},
                 "frame_gather": (f"RCCL {args.collective} of uint8 frames every {K_g} frames "
                                  f"(backend {dist.get_backend()}, {dist.get_world_size()} ranks)") if world > 1 else "none",
                 "world_size": world,
@@ -297,6 +348,7 @@ def main():
                 "bound": "valu", "kernel": "render_stream_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
+                "kernel_ms_rocprof_committed": rocprof_ms,
                 "valu_issue_frac": valu_frac,
                 "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
                         "recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not HBM-bound: "
@@ -336,7 +388,7 @@ def _time_frames(torch, enqueue, steps, warmup=10):
     return steps / (time.perf_counter() - t0)
 
 
-def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
+def secondary_measurements(args, dev, raw, name, model, laid, bg):
     """SURVEY.md 8d's second numbers, N = 1 only, outside the headline's timed region, each a few hundred frames:
     * dense_view: the same scene and N from a camera that sees V = 0.6 N of it (8d's worked example; right_cam sees 0.12 N);
     * upstream_packing: the rasterizer figure INCLUDING what upstream render() does per frame before it
@@ -352,6 +404,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     from gsworld_amd.renderer import FrameRenderer
 
     out = {}
+    means, shs, op, sc, rot = model                        # the model as given (what a drop-in call hands over)
+    l_means, l_shs, l_op, l_sc, l_rot, lay = laid          # the headline's layout (== model with --no-layout)
     W, H = args.width, args.height
     steps = min(args.steps, 200)
     rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
@@ -370,7 +424,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     # ---- dense view ---------------------------------------------------------------------------------------------
     cam_d = scenes.dense_view_camera(name, W, H).to(dev)
     rd = FrameRenderer(dev, forward_only=True, want_radii=False)
-    fr = lambda: rd.render(cam_d, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=rgb8)  # noqa: E731
+    fr = lambda: rd.render(cam_d, l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg, rgb8_out=rgb8,  # noqa: E731
+                           layout=lay)
     for _ in range(2):
         fr()
         st = rd.ensure_valid(fr)
@@ -418,7 +473,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
         res[label] = _time_frames(torch, g.replay, steps)
         del g
     out["upstream_packing"] = {"frames_per_s": res, "frames_in_flight": 1,
-                               "workload": "headline scene and camera, one frame at a time, hipGraph replay"}
+                               "workload": "headline scene and camera, the model AS GIVEN (no load-time layout: a drop-in "
+                                           "call gets fresh tensors), one frame at a time, hipGraph replay"}
     del rp
     # ---- closed loop (configs[2] surrogate) -------------------------------------------------------------------
     cams = {"right_cam": scenes.sensor_camera(name, W, H),
@@ -457,7 +513,43 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     overflow = any(x.overflow for x in loop.ensure_valid())
+    # the same steps through the wrapper's OWN glue (baseline leg, like cpu_baseline: oracle/wrapper_glue_ref.py restates
+    # gs_world_wrapper.py:110-162, 232-275 op for op in torch -- deep copies, isin masks, masked write-backs, upstream
+    # render()'s activations and SH concat) around this package's drop-in rasterizer in exact mode: what the loop costs
+    # when only `diff_gaussian_rasterization` is swapped and the wrapper is left as it is
+    ref_glue = None
+    try:
+        import types
+
+        from gsworld_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+        from oracle import wrapper_glue_ref as wg
+
+        rawd2 = raw.to(dev)
+        model = types.SimpleNamespace(_xyz=rawd2.xyz, _scaling=rawd2.scaling, _rotation=rawd2.rotation,
+                                      _opacity=rawd2.opacity.reshape(-1, 1, 1), _semantics=rawd2.semantics,
+                                      _features_dc=rawd2.features_dc, _features_rest=rawd2.features_rest)
+        cams_d = {k: v.to(dev) for k, v in cams.items()}
+
+        def rasterize(view, means3D, shs_, opacities, scales, rotations, bg_):
+            rs = GaussianRasterizationSettings(view.image_height, view.image_width, view.tanfovx, view.tanfovy, bg_, 1.0,
+                                               view.world_view_transform, view.full_proj_transform, 3,
+                                               view.camera_center, False, False, False)
+            return GaussianRasterizer(rs)(means3D=means3D, means2D=torch.zeros_like(means3D), shs=shs_,
+                                          opacities=opacities, scales=scales, rotations=rotations)[0]
+
+        n_ref = 12
+        wg.render_step(model, parts, cams_d, *poses[0], rasterize, actors)
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        for M, s_ in poses[1:1 + n_ref]:
+            wg.render_step(model, parts, cams_d, M, s_, rasterize, actors)
+        torch.cuda.synchronize()
+        ref_glue = n_ref * len(cams) / (time.perf_counter() - t0r)
+        del model, rawd2
+    except Exception as ex:  # noqa: BLE001
+        ref_glue = f"{type(ex).__name__}: {ex}"
     out["closed_loop"] = {
+        "reference_glue_frames_per_s": ref_glue,
         "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity
@@ -487,8 +579,8 @@ def secondary_measurements(args, dev, raw, name, means, shs, op, sc, rot, bg):
             wvt.inverse()[3, :3].contiguous().pin_memory()
 
     poses_mv = [orbit(k) for k in range(steps + 16)]
-    mv_fn = [(lambda l=l: mv_r[l].render(mv_cam[l], means, op, shs=shs, scales=sc, rotations=rot, bg=bg,
-                                        rgb8_out=mv_out[l])) for l in range(S_mv)]
+    mv_fn = [(lambda l=l: mv_r[l].render(mv_cam[l], l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg,
+                                        rgb8_out=mv_out[l], layout=lay)) for l in range(S_mv)]
     mv_g = []
     for l in range(S_mv):
         for _ in range(2):

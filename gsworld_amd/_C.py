@@ -84,14 +84,17 @@ def _require_gpu(t: torch.Tensor, what: str):
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                 imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
-                rgb8_out=None, parts=None, forward_only: bool = False):
+                rgb8_out=None, parts=None, forward_only: bool = False, layout=None):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes.
     ``parts``: optional ``(labels (P,) float32, lut (L,) int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- the
     per-frame rigid transform of labelled Gaussians applied inside preprocess (GsrInputs.part_*).
-    ``forward_only``: GsrSettings.forward_only (inference frame; ``radii`` may then be None)."""
+    ``forward_only``: GsrSettings.forward_only (inference frame; ``radii`` may then be None).
+    ``layout``: optional ``(cull_blocks (ceil(P/256),8) float32, orig_index (P,) int32 | None)`` -- block bounds for
+    view-frustum culling and the original numbering of a permuted model (GsrInputs.cull_blocks / orig_index;
+    :mod:`gsworld_amd.layout` builds them)."""
     dev = means3D.device
     if _ext is not None:
         st = settings
@@ -108,7 +111,9 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
             bool(want_stats), int(param_space), _tuning_list(int(forward_only)),
             parts[0] if parts is not None else e, parts[1] if parts is not None else torch.empty(0, dtype=torch.int32, device=dev),
             parts[2] if parts is not None else e,
-            parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev))
+            parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev),
+            layout[0] if layout is not None else e,
+            layout[1] if (layout is not None and layout[1] is not None) else torch.empty(0, dtype=torch.int32, device=dev))
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
@@ -124,6 +129,14 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         inp.part_labels, inp.part_lut, inp.part_lut_size = _ptr(labels), _ptr(lut), int(lut.numel())
         inp.part_transforms, inp.part_count = _ptr(table), int(table.shape[0])
         inp.part_rescale = _ptr(rescale) if rescale is not None else None
+    if layout is not None:
+        blocks, orig = layout
+        if blocks.numel() != 8 * ((means3D.size(0) + 255) // 256) or blocks.dtype != torch.float32:
+            raise ValueError("layout: cull_blocks must be a float32 tensor of shape (ceil(P / 256), 8)")
+        if orig is not None and (orig.numel() != means3D.size(0) or orig.dtype != torch.int32):
+            raise ValueError("layout: orig_index must be an int32 tensor of shape (P,)")
+        inp.cull_blocks = _ptr(blocks)
+        inp.orig_index = _ptr(orig) if orig is not None else None
     out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii),
                      _ptr(rgb8_out) if rgb8_out is not None else None)
     cbs = (_resizer(geomBuffer, header=True), _resizer(binningBuffer), _resizer(imgBuffer))

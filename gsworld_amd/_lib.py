@@ -71,6 +71,8 @@ class GsrInputs(C.Structure):
         # optional per-frame rigid transform of labelled Gaussians inside preprocess (forward only)
         ("part_labels", C.c_void_p), ("part_lut", C.c_void_p), ("part_lut_size", C.c_int32),
         ("part_transforms", C.c_void_p), ("part_count", C.c_int32), ("part_rescale", C.c_void_p),
+        # optional block bounds for view-frustum culling + original numbering of a permuted model (gsworld_amd/layout.py)
+        ("cull_blocks", C.c_void_p), ("orig_index", C.c_void_p),
     ]
 
 

@@ -32,7 +32,8 @@ from .renderer import MultiCameraRenderer
 
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
-                 background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto"):
+                 background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
+                 layout: bool = True):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -50,7 +51,11 @@ class ClosedLoopRenderer:
         ``bound_capacity`` (``"auto"`` / True / False): size every lane's list by the bound no frame can exceed, N x
         tiles (7 GB per lane at 1.47 M Gaussians, 640 x 480), so that a frame CANNOT overflow whatever the arm does.
         ``"auto"``: when all lanes together stay below a quarter of the device's free memory and 64 GiB -- one
-        environment with two or three cameras on a 288 GB MI355X; larger batches keep the ``growth`` rule."""
+        environment with two or three cameras on a 288 GB MI355X; larger batches keep the ``growth`` rule.
+        ``layout`` (with ``fuse_transform``): the loop keeps its OWN copy of the model in Morton order per part and size
+        class, with block bounds (:mod:`gsworld_amd.layout`): every frame's per-Gaussian pass skips the blocks of the
+        model that the step's poses put outside the camera's frustum (two thirds of them from a sensor camera).  Same
+        frames, bit for bit (tests/test_layout_gpu.py, tests/test_closed_loop_gpu.py)."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
@@ -65,6 +70,20 @@ class ClosedLoopRenderer:
         # opacity is never moved (new_opacity=None at both call sites of the wrapper): activate it once
         self.opacity = torch.sigmoid(g("opacity", "_opacity").detach().to(dev, torch.float32).reshape(-1, 1)).contiguous()
         semantics = g("semantics", "_semantics")
+        self.layout = None
+        if layout and fuse_transform:
+            from .layout import SceneLayout
+
+            L = SceneLayout.build(self.xyz, self.scaling, self.rotation,
+                                  labels=semantics.detach().to(dev, torch.float32).reshape(-1),
+                                  param_space=RAW_SCALES | RAW_ROTATIONS, features_dc=self.features_dc,
+                                  features_rest=self.features_rest, opacity=self.opacity)
+            a = L.arrays
+            self.xyz, self.scaling, self.rotation = a["means3D"], a["scales"], a["rotations"]
+            self.features_dc, self.features_rest, self.opacity = a["features_dc"], a["features_rest"], a["opacity"]
+            semantics = a["labels"]
+            self.layout = L.layout
+            self.perm = L.perm  # (position in the loop's arrays -> number in the caller's model)
         self.op = tf.FusedPartTransform(part_labels, semantics.to(dev), scaled_parts=scaled_parts)
         self.rescaled = len(tuple(scaled_parts)) > 0
         if self.num_envs > 1:
@@ -126,7 +145,7 @@ class ClosedLoopRenderer:
                     per_lane.append(dict(parts=parts if E == 1 else parts[e]))
             self.multi.render(views, self.xyz, self.opacity, rgb8_out=outs, shs=self.features_dc,
                               shs_rest=self.features_rest, scales=self.scaling, rotations=self.rotation,
-                              param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg, per_lane=per_lane)
+                              param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg, per_lane=per_lane, layout=self.layout)
             return
         if self.rescaled:
             xyz, rot, scaling = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales, scaling=self.scaling)

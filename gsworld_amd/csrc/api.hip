@@ -200,6 +200,11 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         st_bin.image_width = gsr_div_up(tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
         st_bin.image_height = gsr_div_up(tiles_y, 1 << GSR_SUPER_SY) * GSR_TILE;
     }
+    if (in->orig_index != nullptr && !(infer && mode == 1)) {
+        gsr_set_error("gsr_forward: orig_index (a permuted model) needs a forward_only frame on the default sort / "
+                      "placement path");
+        return GSR_E_INVALID;
+    }
     char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles, tiles_x, lean));
     char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
     if (!geom_mem || !img_mem) {
@@ -237,7 +242,8 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         } else {
             if (int e = gsr_launch_sample_depth_sort(in->P, g, in->viewmatrix,
                                                      order_early ? img.quad_work : (const uint32_t *)nullptr,
-                                                     4 * tiles, img.quad_order, super ? 1 : 0, debug, stream))
+                                                     4 * tiles, img.quad_order, super ? 1 : 0,
+                                                     in->orig_index, debug, stream))
                 return e;
         }
     }

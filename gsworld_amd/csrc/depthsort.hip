@@ -322,9 +322,13 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
     }
     if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
     if (all_staged) {
-        // Sample s is the first visible key of the block that holds visible Gaussian floor(s V / S): uniform over the
-        // VISIBLE Gaussians.  Two binary searches per sample -- the thread slice (s_pex), then the block inside it
-        // (the slice's running sums) -- four samples side by side; walking the slices instead was 15 k cycles.
+        // Sample s is the key of visible Gaussian floor(s V / S) in index order: uniform over the VISIBLE Gaussians.
+        // Two binary searches per sample -- the thread slice (s_pex), then the block inside it (the slice's running
+        // sums) -- four samples side by side (walking the slices instead was 15 k cycles); the sample is then record
+        // (rank - records before the block) of the block's compacted records.  (Until round 4 the sample was the FIRST
+        // visible key of that block: the same thing for a model in random order, but in a spatially sorted model --
+        // gsworld_amd/layout.py -- the visible Gaussians sit in a fifth of the blocks, several samples drew the same
+        // key, the splitters came out uneven every frame and the buckets outgrew the LDS: ss_buckets 12 -> 72 us.)
 #pragma unroll 1
         for (int q0 = 0; q0 < 16; q0 += 4) {
             if (blind || (uint32_t)(q0 * kT) >= S) break;
@@ -359,7 +363,11 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
-                if (smp < S) s_key[smp] = base[q] + min(pos[q], n[q] - 1u);  // the block that lends its key
+                const uint32_t pb = min(pos[q], n[q] - 1u), blk = base[q] + pb;
+                const uint32_t before_b = pb > 0u ? (uint32_t)s_cnt16[blk - 1u] : 0u;
+                const uint32_t cnt_b = (uint32_t)s_cnt16[blk] - before_b;
+                const uint32_t off = cnt_b > 0u ? min(lt[q] - min(lt[q], before_b), cnt_b - 1u) : 0u;
+                if (smp < S) s_key[smp] = blk * (uint32_t)GSR_BLOCK + off;  // the record that lends its key
             }
         }
         // the two ends of my run of blocks: one lane each
@@ -413,7 +421,9 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
                 if (c == 0u) continue;
                 const bool last_live = run + c == p_incl;  // the slice's last block with records takes the rest
                 while (smp < s_hi && ((uint32_t)(acc >> 32) < run + c || last_live)) {
-                    s_key[smp] = (uint32_t)j;  // the block that lends its key; the keys are fetched together below
+                    const uint32_t r = (uint32_t)(acc >> 32);
+                    // the record that lends its key; the keys are fetched together below
+                    s_key[smp] = (uint32_t)j * (uint32_t)GSR_BLOCK + min(r - min(r, run), c - 1u);
                     smp++;
                     acc += step;
                 }
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const uint32_t i = (uint32_t)(tid + u * kT);
-            k[u] = i < S ? block_cand[s_key[i]] : 0u;
+            k[u] = i < S ? block_recs[s_key[i]].y : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -769,7 +779,8 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
-                                                        const float *__restrict__ view, uint32_t sig, int sshift) {
+                                                        const float *__restrict__ view, uint32_t sig, int sshift,
+                                                        const int32_t *__restrict__ orig) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -871,6 +882,47 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         }
         return src;
     };
+    // ---- a permuted model (GsrInputs.orig_index): the records carry positions in the permuted arrays and the stable sort
+    // left equal keys in that order; the reference breaks depth ties by the ORIGINAL number.  Ties are rare (~1 300 pairs
+    // among the 175 k visible Gaussians of configs[1], but most buckets hold one), so instead of sorting every bucket by
+    // original number first, the members of every run of equal keys are ranked among themselves: their original numbers
+    // go to the free half of the LDS, every member counts the smaller ones of its run and moves to that place.
+    auto fix_ties = [&](int src, int cnt) {
+        if (orig == nullptr) return;
+        uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap, *oo = s_v + (src ^ 1) * kBucketCap;
+        constexpr int kPer = kBucketCap / kT;
+        uint32_t tgt[kPer], val[kPer];
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int i = tid + e * kT;
+            tgt[e] = 0xFFFFFFFFu;
+            if (i < cnt) {
+                const uint32_t k = kk[i];
+                if ((i > 0 && kk[i - 1] == k) || (i + 1 < cnt && kk[i + 1] == k)) {
+                    val[e] = vv[i];
+                    oo[i] = (uint32_t)orig[val[e]];
+                    tgt[e] = 0u;  // (in a run: ranked below)
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int i = tid + e * kT;
+            if (tgt[e] == 0u) {
+                const uint32_t k = kk[i], o = oo[i];
+                int a = i, rank = 0;
+                while (a > 0 && kk[a - 1] == k) rank += oo[--a] < o ? 1 : 0;
+                for (int j = i + 1; j < cnt && kk[j] == k; j++) rank += oo[j] < o ? 1 : 0;
+                tgt[e] = (uint32_t)(a + rank);
+            }
+        }
+        __syncthreads();  // every read of vv / oo is done
+#pragma unroll
+        for (int e = 0; e < kPer; e++)
+            if (tgt[e] != 0xFFFFFFFFu) vv[tgt[e]] = val[e];
+        __syncthreads();
+    };
     if (n > kBucketCap) {
         // Does not fit the LDS (the kept splitters were taken unchecked and the scene had moved; a sample check that
         // missed; depth ties).  The bucket is cut once more, by this workgroup alone: sub-splitters from 1024 of its own
@@ -924,15 +976,30 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
             if (nj == 0) continue;
             if (nj <= kBucketCap) {
                 const int src = sort_in_lds(tmp + o, nj, true);
+                fix_ties(src, nj);
                 const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
                 carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s + o, nj, carry);
             } else {
                 int N = 2;
                 while (N < nj) N <<= 1;
                 uint64_t *comp = reinterpret_cast<uint64_t *>(tmp + o);
-                bitonic_sort_block(comp, nj, N);
-                carry = emit([&](int i) { const uint64_t c = comp[i]; return make_uint2((uint32_t)c, (uint32_t)(c >> 32)); },
-                             s + o, nj, carry);
+                if (orig != nullptr) {
+                    // (permuted model: order by (key, original number); the positions travel as payload in the
+                    // records' first home, which the scatter above has finished with)
+                    uint32_t *pos = reinterpret_cast<uint32_t *>(seg + o);
+                    for (int i = tid; i < nj; i += kT) {
+                        const uint2 r = tmp[o + i];
+                        pos[i] = r.x;
+                        tmp[o + i] = make_uint2((uint32_t)orig[r.x], r.y);
+                    }
+                    __syncthreads();
+                    bitonic_sort_block(comp, nj, N, pos);
+                    carry = emit([&](int i) { return make_uint2(pos[i], (uint32_t)(comp[i] >> 32)); }, s + o, nj, carry);
+                } else {
+                    bitonic_sort_block(comp, nj, N);
+                    carry = emit([&](int i) { const uint64_t c = comp[i]; return make_uint2((uint32_t)c, (uint32_t)(c >> 32)); },
+                                 s + o, nj, carry);
+                }
             }
             __syncthreads();  // the LDS halves are free for the next piece
         }
@@ -942,6 +1009,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     SS_STAMP(dbg, 1);
     const int src = sort_in_lds(seg, n, false);
     SS_STAMP(dbg, 3);
+    fix_ties(src, n);
     const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
     const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s, n, 0u);
     if (tid == 0) bucket_tiles[blockIdx.x] = carry;
@@ -966,7 +1034,8 @@ int gsr_ss_bmax(int32_t P) {
 
 // preprocess left the block-local records (pair[1]) / block_counts / block_cand; the sorted depth order ends in g.order
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, int super_shift, bool debug, hipStream_t stream) {
+                                 int num_quads, uint32_t *quad_order, int super_shift, const int32_t *orig_index,
+                                 bool debug, hipStream_t stream) {
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
@@ -990,6 +1059,6 @@ int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *vie
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.pair[0], g.ss_bucket_start,
                        g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
-                       viewmatrix, sig, super_shift);
+                       viewmatrix, sig, super_shift, orig_index);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

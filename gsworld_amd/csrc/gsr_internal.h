@@ -369,7 +369,8 @@ int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug,
 // (quad_work != nullptr: a spare workgroup of the partition pass also deals the num_quads quadrants -> quad_order)
 // (super_shift: 1 = rect_sorted in 2 x 2 super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, int super_shift, bool debug, hipStream_t stream);
+                                 int num_quads, uint32_t *quad_order, int super_shift, const int32_t *orig_index,
+                                 bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
@@ -633,8 +634,9 @@ __device__ __forceinline__ void gsr_tile_order_block_keys(const uint32_t (&key)[
 }
 // Ascending-only bitonic network over `n` keys padded (virtually) to N = 2^k with +inf: every comparator puts the
 // minimum at the lower index, so padding slots never move and need not exist.  256 threads, barrier per stage.
-template <typename Ptr>
-__device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
+// (pay: optional array of the same length whose elements travel with their keys)
+template <typename Ptr, typename Pay = uint32_t *>
+__device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N, Pay pay = nullptr) {
     // all sizes are powers of two: index arithmetic with shifts and masks only
     for (int lk = 1; (1 << lk) <= N; lk++) {
         const int k = 1 << lk, hk = k >> 1;
@@ -645,7 +647,10 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
             const int i = blk0 + off, j = blk0 + k - 1 - off;
             if (j < n) {
                 const uint64_t x = a[i], y = a[j];
-                if (x > y) { a[i] = y; a[j] = x; }
+                if (x > y) {
+                    a[i] = y; a[j] = x;
+                    if (pay != nullptr) { const auto t = pay[i]; pay[i] = pay[j]; pay[j] = t; }
+                }
             }
         }
         __syncthreads();
@@ -655,7 +660,10 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr a, int n, int N) {
                 const int i = ((p >> ld) << (ld + 1)) | (p & (d - 1)), j = i + d;
                 if (j < n) {
                     const uint64_t x = a[i], y = a[j];
-                    if (x > y) { a[i] = y; a[j] = x; }
+                    if (x > y) {
+                        a[i] = y; a[j] = x;
+                        if (pay != nullptr) { const auto t = pay[i]; pay[i] = pay[j]; pay[j] = t; }
+                    }
                 }
             }
             __syncthreads();

@@ -29,6 +29,12 @@ struct PreprocessArgs {
     const int32_t *part_lut;
     const uint8_t *part_rescale;
     int part_lut_size, part_count;
+    // optional block bounds (GsrInputs.cull_blocks) and the original numbering of a permuted model (GsrInputs.orig_index):
+    // the state stays in the numbering of the ARRAYS (a block's records are neighbours in memory, and so are the records a
+    // tile's list gathers); only `radii` -- the caller's array -- is written by original number, and the depth sort
+    // breaks ties by it (depthsort.hip)
+    const float *cull_blocks;
+    const int32_t *orig_index;
     int32_t *radii;
     float4 *splat;
     float *cov3D;
@@ -39,7 +45,6 @@ struct PreprocessArgs {
     uint2 *block_recs;     // [P] (index, depth bits) of the block's visible Gaussians, compacted to the head of the block's
                            // own 256 slots (depthsort.hip gathers them: 8 B per VISIBLE Gaussian instead of a 4-byte key
                            // written and re-read for all N)
-    uint32_t *block_cand;  // depth bits of the block's first visible Gaussian (sort sample)
 
     // bin-then-sort path: per-tile instance totals and the visible count are accumulated here
     int num_tiles;
@@ -409,6 +414,91 @@ __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g
     if (!a.infer) a.clamped[g] = clamp_bits;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// View-frustum test of one block of GSR_BLOCK consecutive Gaussians (GsrInputs.cull_blocks).  true = NO Gaussian of
+// the block can have a non-empty tile rect in this frame (or pass the near test), so the reference writes radii = 0 for
+// every one of them and the block's workgroup has nothing to do.  Has to err towards false only.
+//
+// The block's record: box of the centres (lo, hi), rho >= sqrt(lambda_max(Sigma)) of every member (scale modifier 1),
+// the common part label.  Lane c < 8 of the calling wave takes corner c through the part pose (affine), the view
+// matrix (affine) and the projection; the members' centres lie in the convex hull of the corners all the way:
+//   * view depth in [min, max] of the corners' -> all behind the near plane: done;
+//   * with every corner in front (w > 0) the pixel coordinates are linear-fractional with a positive denominator on the
+//     hull, so they lie between the corners' minima and maxima;
+//   * radius: my_radius = ceil(3 sqrt(lambda_1)), lambda_1 = mid + sqrt(max(0.1, mid^2 - det)) <= (largest eigenvalue of
+//     the dilated 2D covariance) + sqrt(0.1) = lambda_max(A Sigma A^T) + 0.3 + 0.3163 with A = J W, and
+//     lambda_max(A Sigma A^T) <= |J|_2^2 |W|_2^2 lambda_max(Sigma); |W|_2^2 <= 1 + |W^T W - I|_F;
+//     J J^T = [[a^2 + b^2, b d], [b d, c^2 + d^2]] with a = fx / vz, |b| <= fx limx / vz, c = fy / vz, |d| <= fy limy / vz
+//     (|tx / vz| is clamped to limx = 1.3 tan(fov / 2)), so |J|_2^2 <= (max(fx^2 (1 + limx^2), fy^2 (1 + limy^2)) +
+//     fx fy limx limy) / vz^2 (Gershgorin);
+//   * the rect of a Gaussian is empty when pix + r < 1 or pix - r >= 16 x tiles on an axis (getRect's clamping).
+// Margins: 1e-3 relative on the squared radius, 2 px on the radius, 1 px on the box -- the float error of the corner
+// chain is ~1e-6 of its terms.  A corner that is not finite (NaN / infinite box or pose): not culled.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool prep_block_culled(const PreprocessArgs &a, int block) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(a.cull_blocks + 8 * (size_t)block);
+    const float4 b1 = *reinterpret_cast<const float4 *>(a.cull_blocks + 8 * (size_t)block + 4);
+    const int lane = gsr_lane();
+    float px = (lane & 1) ? b0.w : b0.x, py = (lane & 2) ? b1.x : b0.y, pz = (lane & 4) ? b1.y : b0.z;
+    float rho = b1.z;
+    if (a.part_labels != nullptr) {
+        const float lf = b1.w;
+        if (!(lf == lf)) return false;  // members carry different labels: no common pose
+        const int label = (int)lf;
+        const int part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
+        if (part >= 0 && part < a.part_count) {
+            if (a.part_rescale != nullptr && a.part_rescale[part]) return false;  // (rewritten scales: rho does not hold)
+            const float *xf = a.part_transforms + (size_t)part * 17;
+            const float s = xf[12];
+            px *= s; py *= s; pz *= s;
+            const float rx = xf[0] * px + xf[1] * py + xf[2] * pz + xf[9];
+            const float ry = xf[3] * px + xf[4] * py + xf[5] * pz + xf[10];
+            const float rz = xf[6] * px + xf[7] * py + xf[8] * pz + xf[11];
+            px = rx; py = ry; pz = rz;
+            // R(q) = (1 - n) I + n R(q / |q|), n = |q|^2: the pose quaternion multiplies every member's, so the rotation's
+            // norm grows by at most max(1, 2 n - 1)
+            const float n = xf[13] * xf[13] + xf[14] * xf[14] + xf[15] * xf[15] + xf[16] * xf[16];
+            rho *= fmaxf(1.0f, 2.0f * n - 1.0f) * 1.0001f;
+        }
+    }
+    const float *m = a.view, *q = a.proj;
+    const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
+    const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
+    const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
+    const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15] + 0.0000001f;
+    const float inv = 1.0f / hw;
+    const float cx = fma_(hx * inv + 1.0f, (float)a.W, -1.0f) * 0.5f;
+    const float cy = fma_(hy * inv + 1.0f, (float)a.H, -1.0f) * 0.5f;
+    // (fminf / fmaxf below drop a NaN operand: a corner that is not finite -- a NaN or infinite box, a pose with one -- has
+    // to be seen before the reduction; every group of eight lanes holds the same eight corners)
+    const bool finite = fabsf(vz) < 1e30f && fabsf(hw) < 1e30f && fabsf(cx) < 1e30f && fabsf(cy) < 1e30f && rho == rho;
+    if (__builtin_amdgcn_ballot_w64(!finite) != 0ull) return false;
+    float zlo = vz, zhi = vz, wlo = hw, xlo = cx, xhi = cx, ylo = cy, yhi = cy;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, o, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64));
+        wlo = fminf(wlo, __shfl_xor(wlo, o, 64));
+        xlo = fminf(xlo, __shfl_xor(xlo, o, 64)); xhi = fmaxf(xhi, __shfl_xor(xhi, o, 64));
+        ylo = fminf(ylo, __shfl_xor(ylo, o, 64)); yhi = fmaxf(yhi, __shfl_xor(yhi, o, 64));
+    }
+    const float zmargin = 1e-5f * (fabsf(zlo) + fabsf(zhi) + 1.0f);
+    if (zhi < a.near_plane - zmargin) return true;  // every member fails `vz > near_plane`
+    if (!(zlo > zmargin && wlo > 1e-6f)) return false;
+    // |W|_2^2 <= 1 + |W^T W - I|_F for the view matrix' 3 x 3 block (W[i][j] = m[j * 4 + i])
+    const float g00 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] - 1.0f, g11 = m[4] * m[4] + m[5] * m[5] + m[6] * m[6] - 1.0f;
+    const float g22 = m[8] * m[8] + m[9] * m[9] + m[10] * m[10] - 1.0f;
+    const float g01 = m[0] * m[4] + m[1] * m[5] + m[2] * m[6], g02 = m[0] * m[8] + m[1] * m[9] + m[2] * m[10];
+    const float g12 = m[4] * m[8] + m[5] * m[9] + m[6] * m[10];
+    const float wn2 = 1.0f + sqrtf(g00 * g00 + g11 * g11 + g22 * g22 + 2.0f * (g01 * g01 + g02 * g02 + g12 * g12));
+    const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+    const float j22 = (fmaxf(a.fx * a.fx * (1.0f + limx * limx), a.fy * a.fy * (1.0f + limy * limy)) +
+                       a.fx * a.fy * limx * limy) / ((zlo - zmargin) * (zlo - zmargin));
+    const float sr = rho * fabsf(a.scale_modifier);
+    const float rb = 3.0f * sqrtf(sr * sr * wn2 * j22 * 1.001f + 0.6163f) * 1.0001f + 2.0f;
+    const float xend = (float)(GSR_TILE * a.gx) + 1.0f, yend = (float)(GSR_TILE * a.gy) + 1.0f;
+    return xhi + rb < -1.0f || xlo - rb > xend || yhi + rb < -1.0f || ylo - rb > yend;
+}
+
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
@@ -420,13 +510,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
     if (COUNT_TILES) {
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
     }
+    // the Gaussian's number in the caller's arrays (radii)
+    const int oi = (a.orig_index != nullptr && a.radii != nullptr && i < a.P) ? a.orig_index[i] : i;
+    if (a.cull_blocks != nullptr) {
+        // (every wave evaluates the block's test itself: ~100 instructions, no barrier, no LDS)
+        if (prep_block_culled(a, (int)blockIdx.x)) {
+            if (i < a.P) {
+                if (a.radii != nullptr) a.radii[oi] = 0;
+                if (!a.infer) a.tiles_touched[i] = 0u;
+            }
+            if (threadIdx.x == 0) a.block_counts[blockIdx.x] = 0u;
+            return;
+        }
+    }
     if (i < a.P) {
         const GeomOut o = prep_geometry(a, i);
         visible = o.visible;
         mypos = o.pos;
         my_tiles = o.tiles;
         my_rect = o.rect;
-        if (a.radii != nullptr) a.radii[i] = o.radius;
+        if (a.radii != nullptr) a.radii[oi] = o.radius;
         if (!a.infer) a.tiles_touched[i] = o.tiles;
         my_key = o.key;
     }
@@ -443,7 +546,6 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
         s_pos[incl - 1u] = mypos;
         s_idx[incl - 1u] = i;
         a.block_recs[(size_t)blockIdx.x * GSR_BLOCK + (incl - 1u)] = make_uint2((uint32_t)i, my_key);
-        if (incl == 1u) a.block_cand[blockIdx.x] = my_key;
     }
     if (threadIdx.x == 0) {
         a.block_counts[blockIdx.x] = cnt;  // consumed by the index-ordered compaction (depth-sorted paths)
@@ -513,6 +615,8 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.part_transforms = in.part_transforms;
     a.part_count = in.part_count;
     a.part_rescale = in.part_rescale;
+    a.cull_blocks = in.cull_blocks;
+    a.orig_index = in.orig_index;
     a.radii = radii;
     a.splat = g.splat;
     a.cov3D = g.cov3D;
@@ -522,7 +626,6 @@ int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *r
     a.block_counts = g.block_counts;
     a.block_recs = g.pair[1];  // (the sort's compaction gathers from here into pair[0]; its partition pass then
                                //  overwrites this array with the bucketed records)
-    a.block_cand = g.block_cand;
 
     a.num_tiles = a.gx * a.gy;
     a.tile_accum = g.tile_accum;

@@ -107,7 +107,7 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
     torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
     const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning,
     const torch::Tensor &part_labels, const torch::Tensor &part_lut, const torch::Tensor &part_table,
-    const torch::Tensor &part_rescale) {
+    const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks, const torch::Tensor &orig_index) {
     const auto dev = means3D.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     GsrSettings st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false,
@@ -134,6 +134,14 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
         in.part_transforms = fptr(part_table);
         in.part_count = (int32_t)part_table.size(0);
         in.part_rescale = part_rescale.numel() ? part_rescale.data_ptr<uint8_t>() : nullptr;
+    }
+    if (cull_blocks.numel() != 0) {  // block bounds for view-frustum culling (GsrInputs.cull_blocks)
+        TORCH_CHECK(cull_blocks.numel() == 8 * ((means3D.size(0) + 255) / 256), "cull_blocks must be (ceil(P / 256), 8)");
+        in.cull_blocks = fptr(cull_blocks);
+    }
+    if (orig_index.numel() != 0) {  // the model arrays are a permuted copy (GsrInputs.orig_index)
+        TORCH_CHECK(orig_index.numel() == means3D.size(0), "orig_index must be (P,)");
+        in.orig_index = orig_index.data_ptr<int32_t>();
     }
     GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
                    radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
@@ -198,7 +206,8 @@ rasterize_gaussians(const torch::Tensor &background, const torch::Tensor &means3
                                    out_invdepth, radii, geom, binning, img, torch::empty({0}, bopt), 0, true,
                                    param_space, tuning, torch::empty({0}, fopt),
                                    torch::empty({0}, means3D.options().dtype(torch::kInt32)), torch::empty({0}, fopt),
-                                   torch::empty({0}, bopt));
+                                   torch::empty({0}, bopt), torch::empty({0}, fopt),
+                                   torch::empty({0}, means3D.options().dtype(torch::kInt32)));
         (void)prefiltered;
         rendered = (int)std::get<1>(stats);
     }

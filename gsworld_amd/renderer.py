@@ -80,7 +80,7 @@ class FrameRenderer:
     def render(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
                antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
-               param_space: int = 0, rgb8_out=None, parts=None, outputs=None):
+               param_space: int = 0, rgb8_out=None, parts=None, outputs=None, layout=None):
         """Enqueue one frame; returns (color (3,H,W), radii (P,), invdepth (1,H,W)) -- tensors owned by the
         renderer and overwritten by the next call.  ``view`` is a :class:`gsworld_amd.camera.ViewParams` on device.
         ``shs_rest``: pass the model's two SH parameters as they are stored, ``shs=features_dc`` (P,1,3) and
@@ -94,6 +94,9 @@ class FrameRenderer:
         rigid transform of the labelled Gaussians, applied inside preprocess: ``means3D`` / ``rotations`` / ``scales``
         are then the BASE model and no transformed copy is ever written (:class:`gsworld_amd.transform.FusedPartTransform`
         builds the tuple; bit-identical to transforming first).
+        ``layout``: ``(cull_blocks, orig_index | None)`` of :class:`gsworld_amd.layout.SceneLayout` -- block bounds by
+        which preprocess skips the blocks of the model no tile can see, and, for a model stored in the layout's Morton
+        order, the original numbering (radii, lists and depth ties stay those of the original model; bit-identical frames).
         ``outputs``: optional caller-owned ``(color (3,H,W) f32, invdepth (1,H,W) f32, radii (P,) i32)`` on this device,
         written instead of the renderer's own buffers (every element is written)."""
         dev = self.device
@@ -166,7 +169,7 @@ class FrameRenderer:
             cov3D_precomp if cov3D_precomp is not None else empty, view_m,
             proj_m, shs if shs is not None else empty, campos, color, invd, radii,
             self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
-            param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only)
+            param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout)
         if cap == 0:
             self.r_capacity = self._capacity_for(stats.num_rendered)
         return color, radii, invd

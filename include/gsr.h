@@ -125,6 +125,24 @@ typedef struct GsrInputs {
     const float *part_transforms;  /* (part_count, 17) */
     int32_t part_count;
     const uint8_t *part_rescale;   /* (part_count) or NULL */
+    /* Optional view-frustum culling by blocks of 256 consecutive Gaussians (gsworld_amd/layout.py builds both arrays
+     * once per model).  The reference projects every Gaussian in front of the near plane and only then finds that its
+     * tile rect is empty (forward.cu preprocessCUDA / getRect): at configs[1] that is 88 % of the model.  cull_blocks
+     * holds, per block b of Gaussians [256 b, 256 b + 256), eight floats: the axis-aligned box of their centres
+     * (lo.xyz, hi.xyz), rho >= sqrt(largest eigenvalue of every 3D covariance in the block, at scale_modifier 1) and
+     * the block's common part label (NaN: labels differ -- such a block is never culled while part_labels is given).
+     * A block is skipped only when the box, moved by its part's pose and grown by a rigorous bound of the projected
+     * 3-sigma radius, lies wholly behind the near plane or beside the tile grid -- every Gaussian in it then has
+     * radii == 0 in the reference as well, so images, radii and lists are bit-identical (preprocess.hip
+     * prep_block_culled).  The bounds are the caller's promise: a box that does not contain its Gaussians drops them.
+     * Correct for ANY order of the model; tight when neighbours in the model are neighbours in space, hence:
+     * orig_index ((P) or NULL): the model arrays are a PERMUTED copy of the caller's model (Morton order per part) and
+     * Gaussian i of them is number orig_index[i] of the original.  `radii` is written in ORIGINAL numbering and depth
+     * ties resolve by original number, exactly as without the permutation, so the image is the same bit for bit; the
+     * opaque state (and the point list in it) stays in the numbering of the permuted arrays.  forward_only frames on the
+     * default sort / placement path only. */
+    const float *cull_blocks;      /* (ceil(P / 256), 8) or NULL */
+    const int32_t *orig_index;     /* (P) or NULL */
 } GsrInputs;
 
 #define GSR_RAW_OPACITY 1   /* opacities are logits:        opacity  = 1 / (1 + exp(-x)) */

@@ -1,0 +1,182 @@
+"""View-frustum culling by blocks and a Morton-ordered copy of the model (gsworld_amd/layout.py, GsrInputs.cull_blocks /
+orig_index): nothing that is rendered may change -- a block is only skipped when the reference gives every Gaussian in it
+radii == 0, and a permuted model keeps the original numbering where the caller sees it and in the order of depth ties."""
+import numpy as np
+import pytest
+import torch
+
+from gsworld_amd import layout as gl, scenes
+from gsworld_amd.camera import look_at_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _cams(dev, W=640, H=480):
+    out = [scenes.sensor_camera("xarm6_align", W, H), scenes.dense_view_camera("xarm6_align", W, H),
+           look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H),
+           # inside the scene looking outwards: most of the model behind the camera or beside the frustum
+           look_at_view([0.4, 0.0, 0.3], [2.0, 1.5, 0.2], [0, 0, 1], 0.9715089, 0.7551448, W, H)]
+    return [c.to(dev) for c in out]
+
+
+@pytest.mark.parametrize("case", ["tabletop", "random_odd_grid", "huge_splats", "raw_split_sh"])
+def test_frames_with_a_layout_are_bit_identical(cuda_device, case):
+    """Inference frames of the Morton-ordered copy (blocks culled, ties by original number) against frames of the model
+    as given: colour, inverse depth, uint8 frame and radii (original numbering) equal bit for bit, on the exact and the
+    no-sync path; and the layout really culls."""
+    from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    if case in ("tabletop", "raw_split_sh"):
+        raw, cams, (W, H) = scenes.tabletop_scene("xarm6_align", n=300_000, seed=21), _cams(dev), (640, 480)
+    else:
+        raw = scenes.random_scene_camera_frame(60_000, seed=22)
+        W, H = (70, 50) if case == "random_odd_grid" else (400, 304)
+        cams = [scenes.identity_camera(W, H, 70.0).to(dev)]
+        if case == "huge_splats":
+            raw.scaling += 1.8
+            raw.opacity -= 2.0
+    bg = torch.tensor([0.3, 0.1, 0.6], device=dev)
+    if case == "raw_split_sh":
+        r_ = raw.to(dev)
+        ps = RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS
+        L = gl.SceneLayout.build(r_.xyz, r_.scaling, r_.rotation, param_space=ps, opacity=r_.opacity,
+                                 features_dc=r_.features_dc, features_rest=r_.features_rest)
+        a = L.arrays
+        plain = ((r_.xyz, r_.opacity), dict(shs=r_.features_dc, shs_rest=r_.features_rest, scales=r_.scaling,
+                                             rotations=r_.rotation, param_space=ps, bg=bg))
+        laid = ((a["means3D"], a["opacity"]), dict(shs=a["features_dc"], shs_rest=a["features_rest"], scales=a["scales"],
+                                                    rotations=a["rotations"], param_space=ps, bg=bg, layout=L.layout))
+    else:
+        means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+        L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+        a = L.arrays
+        plain = ((means, op), dict(shs=shs, scales=sc, rotations=rot, bg=bg))
+        laid = ((a["means3D"], a["opacities"]), dict(shs=a["shs"], scales=a["scales"], rotations=a["rotations"], bg=bg,
+                                                     layout=L.layout))
+    assert torch.equal(torch.sort(L.perm).values, torch.arange(raw.num, device=dev))
+    for cam in cams:
+        ref, lay = FrameRenderer(dev, forward_only=True), FrameRenderer(dev, forward_only=True)
+        f8 = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        for it in range(3):
+            want = ref.render(cam, *plain[0], rgb8_out=f8[0], **plain[1])
+            got = lay.render(cam, *laid[0], rgb8_out=f8[1], **laid[1])
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]), f"{case}: frame {it} differs"
+            assert torch.equal(got[1], want[1]), "radii (original numbering)"
+            assert torch.equal(f8[0], f8[1])
+        s0, s1 = ref.ensure_valid(lambda: None), lay.ensure_valid(lambda: None)
+        assert (s0.num_visible, s0.num_rendered, s0.overflow) == (s1.num_visible, s1.num_rendered, s1.overflow)
+
+
+def test_block_bounds_alone_leave_the_reference_state_untouched(cuda_device):
+    """cull_blocks without a permutation on a DEFAULT (training-capable) frame: the model is put in Morton order first and
+    then rendered as 'the model' with and without its block bounds -- image, radii and the opaque state (point list,
+    ranges, rects, tiles touched) must not change by a bit, while most blocks are skipped."""
+    from gsworld_amd import _C, debug as dbg
+    from gsworld_amd._lib import GsrSettings
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=23)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+    a = L.arrays
+    blocks = gl.build_cull_blocks(a["means3D"], a["scales"], a["rotations"])
+    assert torch.equal(blocks, L.cull_blocks)
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    P, W, H = raw.num, 640, 480
+    outs = []
+    for lay in (None, (blocks, None)):
+        st = GsrSettings(H, W, cam.tanfovx, cam.tanfovy, 1.0, 3, 16, 0, 0, 0, _C.NEAR_PLANE)
+        color = torch.empty((3, H, W), device=dev)
+        invd = torch.empty((1, H, W), device=dev)
+        radii = torch.full((P,), -7, dtype=torch.int32, device=dev)
+        geom, binning, image = (torch.empty(0, dtype=torch.uint8, device=dev) for _ in range(3))
+        e = torch.empty(0, device=dev)
+        stats = _C.forward_raw(st, torch.zeros(3, device=dev), a["means3D"], e, a["opacities"], a["scales"], a["rotations"], e,
+                               cam.world_view_transform, cam.full_proj_transform, a["shs"], cam.camera_center, color, invd,
+                               radii, geom, binning, image, r_capacity=0, layout=lay)
+        torch.cuda.synchronize()
+        V = int((radii > 0).sum())
+        v = dbg.state_view(P, W, H, int(stats.num_rendered), V, geom, binning, image)
+        outs.append((color, invd, radii, {k: v[k].clone() for k in ("point_list", "ranges", "final_T", "n_contrib")},
+                     v["rects"][radii > 0].clone(), v["tiles_touched"].clone(), int(stats.num_rendered)))
+    (c0, i0, r0, v0, rc0, t0, R0), (c1, i1, r1, v1, rc1, t1, R1) = outs
+    assert R0 == R1 and R0 > 0 and torch.equal(c0, c1) and torch.equal(i0, i1) and torch.equal(r0, r1)
+    assert torch.equal(rc0, rc1) and torch.equal(t0, t1)
+    for k in v0:
+        assert torch.equal(v0[k], v1[k]), k
+
+
+def test_depth_ties_resolve_by_original_number(cuda_device):
+    """Thousands of Gaussians with bit-equal depth (a plane facing the camera) plus pairs of coincident splats of
+    different colour: the order inside a tie decides the pixel, and the permuted model must give the reference's."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    gen = torch.Generator().manual_seed(5)
+    for n, spread in ((6000, 0.0), (3000, 1e-6), (40_000, 0.0)):
+        raw = scenes.random_scene_camera_frame(n, seed=31)
+        xyz = raw.xyz.clone()
+        xyz[:, 2] = 3.0 + spread * torch.randn(n, generator=gen)  # identity camera: view depth = z
+        xyz[1::2, :2] = xyz[0::2, :2][: xyz[1::2].shape[0]]      # coincident pairs
+        raw.xyz = xyz
+        raw.opacity += 1.5
+        means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+        cam = scenes.identity_camera(256, 256, 60.0).to(dev)
+        L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+        a = L.arrays
+        ref, lay = FrameRenderer(dev, forward_only=True), FrameRenderer(dev, forward_only=True)
+        for _ in range(2):
+            want = ref.render(cam, means, op, shs=shs, scales=sc, rotations=rot)
+            got = lay.render(cam, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"],
+                             layout=L.layout)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (n, spread)
+        # (the test bites: reversing the numbering changes the picture)
+        rev = torch.arange(n - 1, -1, -1, device=dev, dtype=torch.int32)
+        bad = FrameRenderer(dev, forward_only=True).render(
+            cam, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"],
+            layout=(L.cull_blocks, rev[L.perm].contiguous()))
+        torch.cuda.synchronize()
+        assert not torch.equal(bad[0], want[0])
+
+
+def test_moving_parts_are_culled_by_their_pose(cuda_device):
+    """Blocks carry their part label: the box is moved by the step's pose before the test.  Frames of the closed loop's
+    fused transform with and without a layout are the same bits over a rollout in which parts leave and enter the view."""
+    from gsworld_amd import closed_loop as cl
+    from gsworld_amd.renderer import FrameRenderer
+    from gsworld_amd.transform import FusedPartTransform
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=250_000, seed=24)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    r_ = raw.to(dev)
+    from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+
+    ps = RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS
+    sem = r_.semantics.to(torch.float32)
+    op = FusedPartTransform(parts, r_.semantics, scaled_parts=actors)
+    L = gl.SceneLayout.build(r_.xyz, r_.scaling, r_.rotation, labels=sem, param_space=ps, opacity=r_.opacity,
+                             features_dc=r_.features_dc, features_rest=r_.features_rest)
+    a = L.arrays
+    op_l = FusedPartTransform(parts, a["labels"], scaled_parts=actors)
+    cams = _cams(dev)[:3]
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=12, seed=3))
+    ref, lay = FrameRenderer(dev, forward_only=True, want_radii=False), FrameRenderer(dev, forward_only=True, want_radii=False)
+    for k, (M, s) in enumerate(poses):
+        Md, sd = M.to(dev).contiguous(), s.to(dev).contiguous()
+        p_ref, p_lay = op.parts(Md, sd), op_l.parts(Md, sd)
+        for cam in cams:
+            want = ref.render(cam, r_.xyz, r_.opacity, shs=r_.features_dc, shs_rest=r_.features_rest, scales=r_.scaling,
+                              rotations=r_.rotation, param_space=ps, parts=p_ref)
+            w = [t.clone() for t in (want[0], want[2])]
+            got = lay.render(cam, a["means3D"], a["opacity"], shs=a["features_dc"], shs_rest=a["features_rest"],
+                             scales=a["scales"], rotations=a["rotations"], param_space=ps, parts=p_lay,
+                             layout=L.layout)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], w[0]) and torch.equal(got[2], w[1]), f"step {k}"
+    assert float(torch.isnan(L.cull_blocks[:, 7]).float().mean()) < 0.05  # blocks are label-pure but for the seams

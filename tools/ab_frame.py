@@ -24,6 +24,8 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--in-flight", default="1,3")
 ap.add_argument("--tag", default="")
+ap.add_argument("--layouts", default="0", help="comma list: 0 = model as given, 1 = SceneLayout (Morton order + block culling), "
+                "2 = block bounds on the unsorted model")
 ap.add_argument("--pre-alloc", type=int, default=0, help="MiB of device memory allocated (and kept) before anything else")
 ap.add_argument("--pre-streams", type=int, default=0, help="streams taken from torch's pool before the lanes'")
 args = ap.parse_args()
@@ -38,17 +40,34 @@ cam = (scenes.sensor_camera("xarm6_align", W, H) if args.view == "sensor"
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
 bg = torch.zeros(3, device=dev)
 configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in args.configs.split()]
+from gsworld_amd import layout as gl  # noqa: E402
+
+models = {}
+for lay in sorted({int(x) for x in args.layouts.split(",")}):
+    if lay == 0:
+        models[0] = (means, shs, op, sc, rot, None)
+        continue
+    t0 = time.perf_counter()
+    L = gl.SceneLayout.build(means, sc, rot, reorder=(lay == 1), shs=shs, opacities=op)
+    torch.cuda.synchronize()
+    print(f"layout {lay}: built in {time.perf_counter() - t0:.3f} s", file=sys.stderr)
+    a = L.arrays
+    models[lay] = (a["means3D"], a["shs"], a["opacities"], a["scales"], a["rotations"], L.layout)
+configs = [dict(c, layout=lay) for c in configs for lay in sorted(models)]
 flights = [int(x) for x in args.in_flight.split(",")]
 base = dict(_lib.TUNING)
 
 
 def build(cfg, S):
+    cfg = dict(cfg)
+    means, shs, op, sc, rot, lay = models[cfg.pop("layout")]
     _lib.TUNING.update(base)
     _lib.TUNING.update(cfg)
     rs = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
     outs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    fns = [(lambda l=l: rs[l].render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=outs[l]))
+    fns = [(lambda l=l: rs[l].render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=outs[l],
+                                     layout=lay))
            for l in range(S)]
     graphs = []
     for l in range(S):
