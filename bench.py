@@ -665,7 +665,38 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg):
         out["train_step"]["workload"] = rec["config"]["workload"]
     except Exception as ex:  # noqa: BLE001
         out["train_step"] = {"error": f"{type(ex).__name__}: {ex}"}
+    out["parity"] = parity_record(dev)
     return out
+
+
+def parity_record(dev):
+    """The checker's verdict on THIS build, in the line: the 8 scenes of BASELINE.json configs[3] at 200 k Gaussians
+    through the drop-in rasterizer against the CPU oracle (oracle/gs_oracle.c; checker use, like cpu_baseline) -- the
+    worst pixel INCLUDING the ones the oracle flags as borderline (an alpha >= 1/255 or T >= 1e-4 decision within an
+    exp() ulp of its threshold), the worst off them, how many are flagged.  north_star's bar is 1e-4."""
+    try:
+        import numpy as np
+
+        from gsworld_amd import scenes
+        from tests import helpers as hp
+
+        worst_all, worst_off, border, per = 0.0, 0.0, 0, {}
+        for i, n in enumerate(scenes.SCENE_NAMES):
+            raw, cam = scenes.tabletop_scene(n, n=200_000, seed=1 + i), scenes.sensor_camera(n)
+            inp, st = hp.np_inputs(raw, cam), hp.oracle_settings(cam)
+            bg = np.zeros(3, np.float32)
+            o = hp.oracle_forward(inp, st, bg)
+            g = hp.gpu_forward(inp, st, bg, device=str(dev))
+            d = np.abs(g["color"] - o["color"]).max(0)
+            b = o["borderline"] != 0
+            per[n] = float(d.max())
+            worst_all, worst_off, border = max(worst_all, float(d.max())), max(worst_off, float(d[~b].max())), border + int(b.sum())
+        return {"worst_pixel_all_scenes": worst_all, "worst_pixel_off_borderline": worst_off,
+                "borderline_pixels": border, "pixels": 8 * 640 * 480, "per_scene_worst": per,
+                "against": "oracle/gs_oracle.c (CPU restatement; UNPINNED against the CUDA reference, DESIGN.md section 2)",
+                "workload": "8 scenes of configs[3], 200 k Gaussians each, 640x480 sensor camera, default frames"}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def cpu_baseline_config0():

@@ -27,9 +27,16 @@ if _os.environ.get("GSWORLD_AMD_CTYPES", "") != "1":
         _ext = None
 
 
-def _tuning_list(forward_only: int = 0):
+def _tuning_list(forward_only=None):
+    """The A/B selectors of this call.  ``forward_only`` None: a frame whose state a backward will read (the
+    ``rasterize_gaussians*`` paths) -- a forced ``TUNING["forward_only"]`` (GSWORLD_AMD_TUNING, an A/B aid for the frame
+    renderers) must never turn such a frame into an inference frame: gsr_backward would carve the full state layout
+    over a lean buffer."""
     t = _lib.TUNING
-    fo = int(t["forward_only"]) if int(t["forward_only"]) >= 0 else int(forward_only)
+    if forward_only is None:
+        fo = 0
+    else:
+        fo = int(t["forward_only"]) if int(t["forward_only"]) >= 0 else int(forward_only)
     return [int(t["binning_path"]), int(t["render_variant"]), int(t["render_blocks_per_cu"]), int(t["depth_sort"]),
             int(t["render_split"]), fo]
 
@@ -84,14 +91,15 @@ def _require_gpu(t: torch.Tensor, what: str):
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                 imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
-                rgb8_out=None, parts=None, forward_only: bool = False, layout=None):
+                rgb8_out=None, parts=None, forward_only: bool | None = False, layout=None):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes.
     ``parts``: optional ``(labels (P,) float32, lut (L,) int32, table (K,17) float32, rescale (K,) uint8 | None)`` -- the
     per-frame rigid transform of labelled Gaussians applied inside preprocess (GsrInputs.part_*).
-    ``forward_only``: GsrSettings.forward_only (inference frame; ``radii`` may then be None).
+    ``forward_only``: GsrSettings.forward_only (inference frame; ``radii`` may then be None); None = a training frame
+    (never an inference frame, whatever ``TUNING["forward_only"]`` forces for A/B runs).
     ``layout``: optional ``(cull_blocks (ceil(P/256),8) float32, orig_index (P,) int32 | None)`` -- block bounds for
     view-frustum culling and the original numbering of a permuted model (GsrInputs.cull_blocks / orig_index;
     :mod:`gsworld_amd.layout` builds them)."""
@@ -108,7 +116,7 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
             out_invdepth, radii if radii is not None else torch.empty(0, dtype=torch.int32, device=dev), geomBuffer,
             binningBuffer, imgBuffer,
             rgb8_out if rgb8_out is not None else torch.empty(0, dtype=torch.uint8, device=dev), int(r_capacity),
-            bool(want_stats), int(param_space), _tuning_list(int(forward_only)),
+            bool(want_stats), int(param_space), _tuning_list(forward_only),
             parts[0] if parts is not None else e, parts[1] if parts is not None else torch.empty(0, dtype=torch.int32, device=dev),
             parts[2] if parts is not None else e,
             parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev),
@@ -117,8 +125,8 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
-    settings.forward_only = int(forward_only)
-    _lib.apply_tuning(settings)
+    settings.forward_only = int(bool(forward_only))
+    _lib.apply_tuning(settings, allow_forward_only=forward_only is not None)
     inp = GsrInputs(
         P=means3D.size(0), background=_ptr(background), means3D=_ptr(means3D), shs=_ptr(sh),
         colors_precomp=_ptr(colors), opacities=_ptr(opacity), scales=_ptr(scales), rotations=_ptr(rotations),
@@ -162,7 +170,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                         cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
                                         int(image_height), int(image_width), sh, int(degree), campos,
                                         bool(prefiltered), bool(antialiasing), bool(debug), sh_rest, int(param_space),
-                                        float(NEAR_PLANE), _tuning_list())
+                                        float(NEAR_PLANE), _tuning_list(None))
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if sh_rest is not None and (sh.ndim != 3 or sh.size(1) != 1 or sh_rest.ndim != 3 or sh_rest.size(0) != sh.size(0)):
@@ -193,7 +201,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             _f32(cov3D_precomp, dev, "cov3D_precomp"), _f32(viewmatrix, dev, "viewmatrix"),
             _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"), _f32(campos, dev, "campos"),
             out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer, r_capacity=0,
-            sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space)
+            sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space,
+            forward_only=None)
         rendered = int(stats.num_rendered)
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
 
@@ -201,6 +210,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 # Largest instance list the no-sync training forward may allocate (bytes; 4 per instance).  288 GB of HBM make the TRUE
 # bound affordable for training-sized problems: a Gaussian touches at most every tile, so num_rendered <= P x tiles.
 NOSYNC_LIST_BYTES = 8 << 30
+_FREE_CACHE = {}
 
 
 def nosync_capacity(P: int, image_height: int, image_width: int, device=None):
@@ -209,10 +219,19 @@ def nosync_capacity(P: int, image_height: int, image_width: int, device=None):
     counting placement takes: the caller keeps sizing the list from a read-back."""
     gx, gy = (int(image_width) + 15) // 16, (int(image_height) + 15) // 16
     cap = int(P) * gx * gy
-    if P <= 0 or gx > 256 or cap >= (1 << 31) or 4 * cap > NOSYNC_LIST_BYTES:
+    # (gx * gy > 16384 = GSR_MAX_COUNT_TILES: such grids take the radix placement, whose binning state is 24 B per
+    # instance plus sort tables, not 4 -- the byte budget below would be off by 6x)
+    if P <= 0 or gx > 256 or gx * gy > 16384 or cap >= (1 << 31) or 4 * cap > NOSYNC_LIST_BYTES:
         return None
-    if device is not None and 4 * cap > torch.cuda.mem_get_info(device)[0] // 4:
-        return None
+    if device is not None:
+        # a quarter of what is free, looked up at most every 32nd call per (size, device): hipMemGetInfo is a driver call
+        key = (int(P), gx, gy, str(device))
+        n, free = _FREE_CACHE.get(key, (0, None))
+        if free is None or n % 32 == 0:
+            free = torch.cuda.mem_get_info(device)[0]
+        _FREE_CACHE[key] = (n + 1, free)
+        if 4 * cap > free // 4:
+            return None
     if _lib.TUNING["binning_path"] != 0 or _lib.TUNING["depth_sort"] != 0:
         return None  # (A/B paths keep keys / ping-pong sides per instance: their lists are sized exactly)
     return cap
@@ -245,7 +264,8 @@ def rasterize_gaussians_nosync(capacity, background, means3D, opacity, scales, r
                 _f32(viewmatrix, dev, "viewmatrix"), _f32(projmatrix, dev, "projmatrix"), _f32(sh, dev, "sh"),
                 _f32(campos, dev, "campos"), out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer,
                 r_capacity=int(capacity), want_stats=False,
-                sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space)
+                sh_rest=_f32(sh_rest, dev, "sh_rest") if sh_rest is not None else None, param_space=param_space,
+                forward_only=None)
     return int(capacity), out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth
 
 

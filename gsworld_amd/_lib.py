@@ -48,13 +48,15 @@ for _kv in filter(None, os.environ.get("GSWORLD_AMD_TUNING", "").split(",")):
     TUNING[_k.strip()] = int(_v)
 
 
-def apply_tuning(st: "GsrSettings") -> "GsrSettings":
+def apply_tuning(st: "GsrSettings", allow_forward_only: bool = True) -> "GsrSettings":
     st.binning_path = int(TUNING["binning_path"])
     st.render_variant = int(TUNING["render_variant"])
     st.render_blocks_per_cu = int(TUNING["render_blocks_per_cu"])
     st.depth_sort = int(TUNING["depth_sort"])
     st.render_split = int(TUNING["render_split"])
-    if int(TUNING["forward_only"]) >= 0:
+    # (allow_forward_only False: a frame whose state a backward reads -- a forced inference frame there would leave a
+    #  lean state that gsr_backward carves as a full one)
+    if allow_forward_only and int(TUNING["forward_only"]) >= 0:
         st.forward_only = int(TUNING["forward_only"])
     return st
 

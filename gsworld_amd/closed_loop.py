@@ -33,7 +33,7 @@ from .renderer import MultiCameraRenderer
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
-                 layout: bool = True):
+                 layout: bool = True, min_capacity: int | None = None):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -114,7 +114,10 @@ class ClosedLoopRenderer:
             free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" and torch.cuda.is_available() else 0
             bound_capacity = lanes * per_lane <= min(free // 4, 64 << 30)
         self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, growth=growth,
-                                         min_capacity=2 * int(self.xyz.shape[0]), bound_capacity=bool(bound_capacity))
+                                         min_capacity=(2 * int(self.xyz.shape[0]) if min_capacity is None else int(min_capacity)),
+                                         bound_capacity=bool(bound_capacity), overflow_mirror=True)
+        self.recovered_steps = 0      # steps re-rendered because a lane had overflowed (see step())
+        self.late_overflow_frames = 0  # overflowed frames that were only noticed after their step had been returned
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
         self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()
@@ -197,8 +200,22 @@ class ClosedLoopRenderer:
             mine.camera_center.copy_(cam.camera_center.to(torch.float32), non_blocking=True)
 
     def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None,
-             cameras: dict | None = None) -> dict:
-        """-> {camera name: uint8 (num_envs, H, W, 3)} -- renderer-owned tensors, overwritten by the next step."""
+             cameras: dict | None = None, ensure: bool = False) -> dict:
+        """-> {camera name: uint8 (num_envs, H, W, 3)} -- renderer-owned tensors, overwritten by the next step.
+
+        A lane whose instance list is sized from earlier frames (no ``bound_capacity``) can be outgrown by a later frame
+        -- an arm swinging past a wrist camera triples the count -- and such a frame shows the background only.  That is
+        never silent here: every frame copies its state's overflow count to pinned host memory
+        (``FrameRenderer(overflow_mirror=True)``, 8 bytes, also under graph replay), and this method compares the counts
+        it can see with the ones it has handled, WITHOUT synchronising:
+
+        * ``ensure=True`` -- what a closed loop does anyway, since the policy reads the frames before it acts: wait for
+          this step's frames, and if a lane overflowed, grow it, re-render the step and re-capture the graph.  The
+          frames returned are always valid.
+        * ``ensure=False`` (throughput mode): no wait.  An overflow of an EARLIER step shows up here as soon as its
+          mirror copy has landed (normally within a step or two); the loop then recovers as above -- the current step
+          is rendered correctly -- and :attr:`late_overflow_frames` counts the frames that had already been handed out
+          invalid."""
         if matrices is not None:
             self.set_poses(matrices, scales)
         if cameras:
@@ -207,7 +224,42 @@ class ClosedLoopRenderer:
             self._graph.replay()
         else:
             self._gpu_step()
+        if ensure:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._check_overflow(late=not ensure)
         return self.frames
+
+    def _check_overflow(self, late: bool):
+        pending = 0
+        for lane in self.multi.lanes:
+            if lane._mirror is not None and not lane.bounded:
+                pending += lane.overflows_seen() - lane.overflows_handled
+        if pending <= 0:
+            return
+        recapture = self._graph is not None
+        torch.cuda.synchronize(self.device)
+        for lane in self.multi.lanes:
+            if lane._mirror is not None and not lane.bounded:
+                lane.overflows_handled = lane.overflows_seen()
+        # frames of the CURRENT step are re-rendered below; with late=True the earlier ones had been returned already
+        seen_now = sum(1 for lane in self.multi.lanes if lane.stats().overflow)
+        if late:
+            self.late_overflow_frames += max(pending - seen_now, 0)
+        self._graph = None
+        for lane in self.multi.lanes:
+            st = lane.stats()
+            if st.overflow:
+                lane.r_capacity = lane._capacity_for(st.num_rendered)
+        # exact-mode safety net for whatever the grown capacities still do not hold
+        self._gpu_step()
+        self.multi.ensure_valid(self._gpu_step)
+        torch.cuda.synchronize(self.device)
+        for lane in self.multi.lanes:
+            if lane._mirror is not None and not lane.bounded:
+                lane.overflows_handled = lane.overflows_seen()
+        self.recovered_steps += 1
+        if recapture:
+            self.capture()
 
     def reset(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None) -> dict:
         """First frame(s): exact-mode render that sizes every lane's binning capacity, then the validity check."""
@@ -215,7 +267,15 @@ class ClosedLoopRenderer:
             self.set_poses(matrices, scales)
         self._gpu_step()
         self.multi.ensure_valid(self._gpu_step)
+        self._overflows_acknowledged()
         return self.frames
+
+    def _overflows_acknowledged(self):
+        """(after a synchronising validity check: what the mirrors show from now on is news)"""
+        torch.cuda.synchronize(self.device)
+        for lane in self.multi.lanes:
+            if lane._mirror is not None and not lane.bounded:
+                lane.overflows_handled = lane.overflows_seen()
 
     def ensure_valid(self):
         """Overflow check of the last step (synchronises); re-renders exactly if a lane's capacity was exceeded.  A
@@ -247,7 +307,7 @@ class ClosedLoopRenderer:
         with torch.cuda.graph(g, stream=side):
             self._gpu_step()
         self._graph = g
-        torch.cuda.synchronize(dev)
+        self._overflows_acknowledged()
         return g
 
 
@@ -270,26 +330,30 @@ def part_poses_from_sim(sim2gs_arm: torch.Tensor, link_now: torch.Tensor, link_s
     from .camera import extract_rigid_transform
 
     f32 = torch.float32
-    sim2gs_arm = sim2gs_arm.to(f32)
+    dev = link_now.device  # (a GPU simulator hands over device tensors: everything is computed where the poses live)
+    on = lambda t: torch.as_tensor(t, dtype=f32, device=dev)  # noqa: E731
+    sim2gs_arm = on(sim2gs_arm)
     inv_arm = torch.linalg.inv(sim2gs_arm)
     link_mat = link_now.to(f32).clone()
+    link_scan = on(link_scan)
     E, L = link_mat.shape[:2]
     if link_offset is not None:
-        link_mat[:, :, :3, 3] += torch.as_tensor(link_offset, dtype=f32)
+        link_mat[:, :, :3, 3] += on(link_offset)
     mats, scales = [], []
     for k in range(L):  # (:120) sim2gs @ link_now @ inv(link_scan) @ inv(sim2gs), left to right
-        mats.append(sim2gs_arm @ link_mat[:, k] @ torch.linalg.inv(link_scan[k].to(f32)) @ inv_arm)
-        scales.append(torch.ones(E))
+        mats.append(sim2gs_arm @ link_mat[:, k] @ torch.linalg.inv(link_scan[k]) @ inv_arm)
+        scales.append(torch.ones(E, dtype=f32, device=dev))
     if actor_now is not None:
         A = actor_now.shape[1]
+        sim2gs_obj = on(sim2gs_obj)
         for a in range(A):
-            mat = actor_now[:, a].to(f32).clone()
+            mat = on(actor_now[:, a]).clone()
             if actor_offset is not None:
-                mat[:, :3, 3] += actor_offset[a].to(f32)
-            full = sim2gs_arm @ mat @ torch.linalg.inv(sim2gs_obj[a].to(f32))  # (:147)
-            rigid, scale, _, _ = extract_rigid_transform(full)                  # (:150)
+                mat[:, :3, 3] += on(actor_offset[a])
+            full = sim2gs_arm @ mat @ torch.linalg.inv(sim2gs_obj[a])  # (:147)
+            rigid, scale, _, _ = extract_rigid_transform(full)          # (:150)
             mats.append(rigid)
-            scales.append(scale * (1.0 if actor_scale is None else actor_scale[a]))
+            scales.append(on(scale) * (1.0 if actor_scale is None else on(actor_scale[a])))
     return torch.stack(mats, 1).contiguous(), torch.stack(scales, 1).to(f32).contiguous()
 
 

@@ -891,37 +891,41 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         if (orig == nullptr) return;
         uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap, *oo = s_v + (src ^ 1) * kBucketCap;
         constexpr int kPer = kBucketCap / kT;
-        uint32_t tgt[kPer], val[kPer];
+        // pair (i, i + 1) holds equal keys: fixed for the whole fix-up (keys do not move); its members' original numbers
+        // are staged once
+        bool eq[kPer];
+        int any = 0;
 #pragma unroll
         for (int e = 0; e < kPer; e++) {
             const int i = tid + e * kT;
-            tgt[e] = 0xFFFFFFFFu;
-            if (i < cnt) {
-                const uint32_t k = kk[i];
-                if ((i > 0 && kk[i - 1] == k) || (i + 1 < cnt && kk[i + 1] == k)) {
-                    val[e] = vv[i];
-                    oo[i] = (uint32_t)orig[val[e]];
-                    tgt[e] = 0u;  // (in a run: ranked below)
+            eq[e] = i + 1 < cnt && kk[i] == kk[i + 1];
+            const bool tied = eq[e] || (i > 0 && i < cnt && kk[i - 1] == kk[i]);
+            if (tied) oo[i] = (uint32_t)orig[vv[i]];
+            any |= tied ? 1 : 0;
+        }
+        if (__syncthreads_or(any) == 0) return;  // (no tie in this bucket)
+        // Odd-even transposition restricted to the tied pairs: in a round the pairs that start at even (odd) positions
+        // are disjoint, each is put in order by one thread, a barrier ends the round; done when an even and an odd round
+        // in a row moved nothing.  A run of L equal keys takes at most L rounds -- two or three almost always; thousands
+        // of equal depths (a plane facing the camera) cost a barrier each and stay exact.
+        int quiet = 0;
+        for (int round = 0; quiet < 2; round++) {
+            int moved = 0;
+#pragma unroll
+            for (int e = 0; e < kPer; e++) {
+                const int i = tid + e * kT;
+                if (eq[e] && ((i ^ round) & 1) == 0) {
+                    const uint32_t o0 = oo[i], o1 = oo[i + 1];
+                    if (o0 > o1) {
+                        const uint32_t v0 = vv[i], v1 = vv[i + 1];
+                        oo[i] = o1; oo[i + 1] = o0;
+                        vv[i] = v1; vv[i + 1] = v0;
+                        moved = 1;
+                    }
                 }
             }
+            quiet = __syncthreads_or(moved) != 0 ? 0 : quiet + 1;
         }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < kPer; e++) {
-            const int i = tid + e * kT;
-            if (tgt[e] == 0u) {
-                const uint32_t k = kk[i], o = oo[i];
-                int a = i, rank = 0;
-                while (a > 0 && kk[a - 1] == k) rank += oo[--a] < o ? 1 : 0;
-                for (int j = i + 1; j < cnt && kk[j] == k; j++) rank += oo[j] < o ? 1 : 0;
-                tgt[e] = (uint32_t)(a + rank);
-            }
-        }
-        __syncthreads();  // every read of vv / oo is done
-#pragma unroll
-        for (int e = 0; e < kPer; e++)
-            if (tgt[e] != 0xFFFFFFFFu) vv[tgt[e]] = val[e];
-        __syncthreads();
     };
     if (n > kBucketCap) {
         // Does not fit the LDS (the kept splitters were taken unchecked and the scene had moved; a sample check that

@@ -294,9 +294,19 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
                         const float k = -2.0f * low;  // (<= 0: opacity below 1/255, alpha never passes)
                         const float detc = fma_(-conic_y, conic_y, ac);
                         // (hardware reciprocal / square root, ~1 ulp each: the margins are a hundred times that)
-                        const float kd = k * __builtin_amdgcn_rcpf(detc);
-                        const float hx = fma_(__builtin_amdgcn_sqrtf(kd * conic_z), 1.0001f, 0.25f);
-                        const float hy = fma_(__builtin_amdgcn_sqrtf(kd * conic_x), 1.0001f, 0.25f);
+                        const float rdet = __builtin_amdgcn_rcpf(detc);
+                        const float kd = k * rdet;
+                        // The margin follows the conic's conditioning.  The compositor's power is a sum of terms that
+                        // cancel when B^2 approaches A C: its float error is ~4e-6 of sum |terms| (the slack of
+                        // quadrant_may_hit), and on the ellipse's boundary sum |terms| <= ~2 k A C / det.  A pixel just
+                        // outside the exact ellipse can therefore still compute alpha >= 1/255 when the exact power is
+                        // within 8e-6 k A C / det of tau: the ellipse grows by the factor sqrt(1 + 1.6e-5 A C / det) at
+                        // most.  2e-5 A C / det (2.5 x that, up to 2 % at the `safe` limit B^2 = 0.999 A C) + 1e-4
+                        // relative + a quarter pixel.  (Round 3 used 1e-4 + 0.25 px whatever the conditioning: short by
+                        // up to 0.4 % of the half-width for needle-shaped splats near the limit -- ADVICE round 3.)
+                        const float rel = fma_(2e-5f, ac * rdet, 1.0001f);
+                        const float hx = fma_(__builtin_amdgcn_sqrtf(kd * conic_z), rel, 0.25f);
+                        const float hy = fma_(__builtin_amdgcn_sqrtf(kd * conic_x), rel, 0.25f);
                         if (!(k > 0.0f)) {
                             area = 0;
                         } else if (hx < 1e6f && hy < 1e6f) {  // (false for NaN / inf: the reference's rect stays)
@@ -513,8 +523,16 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessA
     // the Gaussian's number in the caller's arrays (radii)
     const int oi = (a.orig_index != nullptr && a.radii != nullptr && i < a.P) ? a.orig_index[i] : i;
     if (a.cull_blocks != nullptr) {
-        // (every wave evaluates the block's test itself: ~100 instructions, no barrier, no LDS)
-        if (prep_block_culled(a, (int)blockIdx.x)) {
+        // (the first wave evaluates the block's test, ~100 instructions; the other three wait for its verdict at a
+        // barrier instead of repeating it: a skipped workgroup costs ~150 wave-instructions instead of ~400, and seven
+        // in ten are skipped)
+        __shared__ int s_culled;
+        if (threadIdx.x < GSR_WAVE) {
+            const bool c = prep_block_culled(a, (int)blockIdx.x);
+            if (threadIdx.x == 0) s_culled = c ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_culled != 0) {
             if (i < a.P) {
                 if (a.radii != nullptr) a.radii[oi] = 0;
                 if (!a.infer) a.tiles_touched[i] = 0u;

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import os
 import time
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -98,7 +99,9 @@ class FrameGather:
         self.timing = bool(timing)
         self.gather_ms = []      # per collective (timing=True)
         self._timers = []        # (start event, end event) pairs not yet read (GPU)
-        self.waits = []          # (step, batch waited for, seconds blocked) of every wait_reusable that found a collective
+        # (step, batch waited for, seconds blocked) of the last wait_reusable calls that found a collective -- kept only
+        # with timing=True, and bounded: a render loop runs for hours
+        self.waits = deque(maxlen=4096)
         self._pool = ThreadPoolExecutor(1) if (background and self.device.type != "cuda" and self.world > 1) else None
 
     def _half(self, b: int) -> torch.Tensor:
@@ -123,10 +126,12 @@ class FrameGather:
         if hasattr(ev, "result"):  # host path with a worker thread
             t0 = time.perf_counter()
             ev.result()
-            self.waits.append((i, self._done_batch[h], time.perf_counter() - t0))
+            if self.timing:
+                self.waits.append((i, self._done_batch[h], time.perf_counter() - t0))
         else:
             (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(ev)
-            self.waits.append((i, self._done_batch[h], 0.0))  # (a stream dependency: the host is never blocked)
+            if self.timing:
+                self.waits.append((i, self._done_batch[h], 0.0))  # (a stream dependency: the host is never blocked)
         return self._done_batch[h]
 
     def wait_gathered(self, stream=None) -> torch.Tensor:
@@ -139,12 +144,20 @@ class FrameGather:
                 (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._last)
         return self.gathered
 
-    def gather_time_ms(self):
-        """Mean / max duration of the collectives issued so far (``timing=True``; synchronises the side stream)."""
-        for e0, e1 in self._timers:
+    def _drain_timers(self, keep: int = 0):
+        """Reads the finished event pairs into ``gather_ms`` (all but the ``keep`` youngest: no wait for collectives
+        still in flight) and bounds the history."""
+        done = self._timers[:len(self._timers) - keep] if keep else self._timers
+        for e0, e1 in done:
             e1.synchronize()
             self.gather_ms.append(e0.elapsed_time(e1))
-        self._timers = []
+        self._timers = self._timers[len(done):]
+        if len(self.gather_ms) > 8192:
+            self.gather_ms = self.gather_ms[-4096:]
+
+    def gather_time_ms(self):
+        """Mean / max duration of the collectives issued so far (``timing=True``; synchronises the side stream)."""
+        self._drain_timers()
         if not self.gather_ms:
             return None
         return {"mean": sum(self.gather_ms) / len(self.gather_ms), "max": max(self.gather_ms), "count": len(self.gather_ms)}
@@ -195,6 +208,8 @@ class FrameGather:
                     ev.record(self.stream)
                     if self.timing:
                         self._timers.append((e0, ev))
+                        if len(self._timers) >= 256:  # (drained here as well: nobody may ever call gather_time_ms)
+                            self._drain_timers(keep=64)
                 self._done[b] = ev
                 self._done_batch[b] = i // self.batch
                 self._last = ev

@@ -63,16 +63,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width)
+            cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width,
+                                     device=means3D.device if means3D.is_cuda else None)
+            done = False
             if cap is not None and not rs.prefiltered and means3D.dim() == 2 and means3D.size(1) == 3:
                 # (the Function keeps num_rendered to itself: it need not be read back in mid-frame when the instance
-                #  list is sized by the bound P x tiles -- _C.rasterize_gaussians_nosync; same kernels, same state)
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
-                    _C.rasterize_gaussians_nosync(
-                        cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix,
-                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-                        rs.campos, rs.antialiasing, rs.debug, colors=colors_precomp, cov3D_precomp=cov3Ds_precomp)
-            else:
+                #  list is sized by the bound P x tiles -- _C.rasterize_gaussians_nosync; same kernels, same state.
+                #  The list is held until the backward: several forwards kept alive at once, or a shared device, may
+                #  not have the room -- then upstream's exact sizing is what runs)
+                try:
+                    num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
+                        _C.rasterize_gaussians_nosync(
+                            cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix,
+                            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+                            rs.campos, rs.antialiasing, rs.debug, colors=colors_precomp, cov3D_precomp=cov3Ds_precomp)
+                    done = True
+                except torch.cuda.OutOfMemoryError:
+                    torch.cuda.empty_cache()
+            if not done:
                 num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = \
                     _C.rasterize_gaussians(*args)
         ctx.raster_settings = rs
@@ -122,14 +130,21 @@ class _RasterizeGaussiansFused(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, raster_settings, param_space):
         rs = raster_settings
         empty = torch.empty(0, device=means3D.device)
-        cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width)
+        cap = _C.nosync_capacity(means3D.size(0), rs.image_height, rs.image_width,
+                                 device=means3D.device if means3D.is_cuda else None)
+        done = False
         if cap is not None and not rs.prefiltered:
             # no host read of num_rendered in mid-frame: the instance list is sized by a bound no frame can exceed
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians_nosync(
-                cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
-                rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos,
-                rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
-        else:
+            # (room permitting -- see _RasterizeGaussians.forward)
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians_nosync(
+                    cap, rs.bg, means3D, opacities, scales, rotations, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+                    rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos,
+                    rs.antialiasing, rs.debug, sh_rest=sh_rest, param_space=param_space)
+                done = True
+            except torch.cuda.OutOfMemoryError:
+                torch.cuda.empty_cache()
+        if not done:
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths = _C.rasterize_gaussians(
                 rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, empty, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh_dc, rs.sh_degree, rs.campos,

@@ -34,7 +34,7 @@ class FrameStats:
 class FrameRenderer:
     def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
                  forward_only: bool = False, want_radii: bool = True, min_capacity: int = 1 << 16,
-                 bound_capacity: bool = False):
+                 bound_capacity: bool = False, overflow_mirror: bool = False):
         """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
         nothing a backward would read is written and the instances are binned per super-tile of 2 x 1 tiles -- the state buffers
         are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
@@ -45,7 +45,11 @@ class FrameRenderer:
         the budget of :func:`gsworld_amd._C.nosync_capacity` (8 GiB and a quarter of the free memory; 7 GB at 1.47 M
         Gaussians, 640 x 480): no exact-mode first frame, no overflow, hence no flag to read back --
         :attr:`bounded` then says that :meth:`ensure_valid` (a host synchronisation) is not needed.  For a single
-        renderer that serves call after call (the drop-in ``render()``); not for dozens of lanes."""
+        renderer that serves call after call (the drop-in ``render()``); not for dozens of lanes.
+        ``overflow_mirror``: after every frame the header's overflow count is copied (8 bytes, asynchronously, also
+        inside a captured graph) into pinned host memory: :meth:`overflows_seen` then tells WITHOUT a synchronisation
+        how many frames on this state have exceeded their capacity so far, as of the last copy that has landed --
+        what lets a loop that never synchronises notice an overflowed frame a few steps later instead of at its end."""
         self.device = torch.device(device)
         if self.device.index is None and self.device.type == "cuda":
             # an unindexed device never equals a tensor's `cuda:0`: resolve it once (multi-GPU processes: the CURRENT
@@ -66,6 +70,8 @@ class FrameRenderer:
         self.r_capacity = 0
         self._out = None
         self._P = 0
+        self._mirror = torch.zeros(2, dtype=torch.int32).pin_memory() if overflow_mirror and torch.cuda.is_available() else None
+        self.overflows_handled = 0  # (callers that re-render on overflow keep their own tally against overflows_seen)
 
     def _capacity_for(self, num_rendered: int) -> int:
         return max(int(num_rendered * self.growth), self.min_capacity, 1 << 16)
@@ -172,7 +178,19 @@ class FrameRenderer:
             param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout)
         if cap == 0:
             self.r_capacity = self._capacity_for(stats.num_rendered)
+        if self._mirror is not None and not self.bounded and self.geom.numel() >= 256:
+            # (of_magic, overflow_frames): the last two words of the 256-byte frame header (csrc/gsr_internal.h GsrHeader)
+            self._mirror.copy_(self.geom[248:256].view(torch.int32), non_blocking=True)
         return color, radii, invd
+
+    def overflows_seen(self) -> int:
+        """Frames on this state whose instance count exceeded the capacity, as far as the host has been told (no
+        synchronisation; needs ``overflow_mirror=True``): the count the device had written when the most recent
+        mirror copy that has COMPLETED was taken."""
+        if self._mirror is None:
+            raise RuntimeError("FrameRenderer was built without overflow_mirror=True")
+        magic, count = int(self._mirror[0]), int(self._mirror[1])
+        return count if (magic & 0xFFFFFFFF) == 0x0F10F10F else 0
 
     def pack_rgb8(self, color: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """(3,H,W) float image -> (H,W,3) uint8 exactly as GSWorld converts frames

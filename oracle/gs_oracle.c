@@ -423,11 +423,22 @@ void gso_render(const GsoSettings *st, const uint32_t *ranges, const uint32_t *p
                 const float test_T = T * (1.0f - alpha);
                 if (borderline && fabsf(test_T - 0.0001f) <= border_eps_T * 0.0001f) nborder++;
                 if (test_T < 0.0001f) break; /* done: this instance is NOT added */
+#ifdef GSO_ASSOC_UPSTREAM
+                /* exposure build (tools/fma_exposure.py, never a checker): upstream writes `C[ch] += features * alpha * T`,
+                 * which parses as ((features * alpha) * T) + C -- the canonical order below forms the weight alpha * T
+                 * first (one multiply instead of four per contribution in the kernels).  A reassociation of roundings,
+                 * up to 1 ulp per contribution; what it moves is counted in profiles/fma_exposure.json. */
+                C[0] = fmaf(rgb[3 * (size_t)g + 0] * alpha, T, C[0]);
+                C[1] = fmaf(rgb[3 * (size_t)g + 1] * alpha, T, C[1]);
+                C[2] = fmaf(rgb[3 * (size_t)g + 2] * alpha, T, C[2]);
+                Dacc = fmaf((1.0f / depths[g]) * alpha, T, Dacc);
+#else
                 const float w = alpha * T;
                 C[0] = fmaf(rgb[3 * (size_t)g + 0], w, C[0]);
                 C[1] = fmaf(rgb[3 * (size_t)g + 1], w, C[1]);
                 C[2] = fmaf(rgb[3 * (size_t)g + 2], w, C[2]);
                 Dacc = fmaf(1.0f / depths[g], w, Dacc);
+#endif
                 T = test_T;
                 last = contributor;
             }

@@ -244,3 +244,71 @@ def test_frames_match_what_the_reference_glue_itself_handed_to_render(cuda_devic
         assert int(d.max()) <= 1, f"{c}: {int(d.max())} LSB"
         assert float((d > 0).float().mean()) < 0.01
     assert int(want["right_cam"].max()) > 100 and int((want["right_cam"].sum(-1) > 0).sum()) > 2000
+
+
+def test_part_poses_from_sim_takes_device_tensors(cuda_device):
+    """A GPU simulator hands over device tensors (ManiSkill link / actor poses live on the GPU): the pose arithmetic runs
+    where they live and gives what the host path gives (the offsets and scales used to be created on
+    the CPU)."""
+    from gsworld_amd import closed_loop as cl
+
+    dev = cuda_device
+    ro = cl.xarm6_rollout()
+    E, L = 2, ro["link_scan"].shape[0]
+    now = torch.stack([ro["link_now"][3], ro["link_now"][40]])
+    g = torch.Generator().manual_seed(0)
+    actor_now = torch.eye(4).repeat(E, 2, 1, 1)
+    actor_now[:, :, :3, 3] = torch.randn(E, 2, 3, generator=g) * 0.1
+    sim2gs_obj = torch.eye(4).repeat(2, 1, 1) * 1.0
+    sim2gs_obj[:, :3, :3] *= 0.5
+    off, sc = torch.randn(2, 3, generator=g) * 0.01, torch.tensor([1.0, 0.7])
+    want = cl.part_poses_from_sim(ro["sim2gs_arm"], now, ro["link_scan"], ro["link_offset"], actor_now, sim2gs_obj, off, sc)
+    got = cl.part_poses_from_sim(ro["sim2gs_arm"].to(dev), now.to(dev), ro["link_scan"].to(dev), ro["link_offset"],
+                                 actor_now.to(dev), sim2gs_obj.to(dev), off.to(dev), sc.to(dev))
+    assert got[0].device.type == "cuda" and got[1].device.type == "cuda" and got[0].shape == (E, L + 2, 4, 4)
+    assert float((got[0].cpu() - want[0]).abs().max()) < 1e-5 and float((got[1].cpu() - want[1]).abs().max()) < 1e-5
+
+
+def test_overflow_under_graph_replay_is_never_returned(cuda_device):
+    """Six lanes (3 environments x 2 cameras) replayed as one hipGraph, their instance lists sized with NO margin from
+    the reset frame, while the arm swings through the wrist camera's view: with ``step(ensure=True)`` -- the closed
+    loop's natural sync point, the policy reads the frames -- every frame handed out equals the frame of a loop whose
+    lists cannot overflow (bound capacity), the overflows are noticed through the pinned mirrors and the graph is
+    re-captured; in throughput mode (``ensure=False``) the same rollout notices them late but never stays wrong."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=150_000, seed=9)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    E, steps = 3, 60
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=steps, seed=1, num_envs=E))
+    safe = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=E, device=dev, bound_capacity=True)
+    tight = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=E, device=dev, bound_capacity=False,
+                                  growth=1.0, min_capacity=1 << 16)
+    safe.reset(*poses[0])
+    tight.reset(*poses[0])
+    assert all(l.bounded for l in safe.multi.lanes) and not any(l.bounded for l in tight.multi.lanes)
+    safe.capture()
+    tight.capture()
+    for k in range(1, steps):
+        want = {n: f.clone() for n, f in safe.step(*poses[k]).items()}
+        got = tight.step(*poses[k], ensure=True)
+        torch.cuda.synchronize()
+        for n in want:
+            assert torch.equal(got[n], want[n]), f"step {k}, {n}: an overflowed frame was returned"
+    assert tight.recovered_steps > 0, "the rollout never outgrew a list: the test proves nothing"
+    assert tight.late_overflow_frames == 0 and tight._graph is not None
+    # throughput mode: no wait per step; whatever overflowed is noticed (late) and the loop ends valid
+    loose = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=E, device=dev, bound_capacity=False,
+                                  growth=1.0, min_capacity=1 << 16)
+    loose.reset(*poses[0])
+    loose.capture()
+    for k in range(1, steps):
+        loose.step(*poses[k])
+    torch.cuda.synchronize()
+    got = loose.step(*poses[steps - 1], ensure=True)
+    want = safe.step(*poses[steps - 1])
+    torch.cuda.synchronize()
+    assert all(torch.equal(got[n], want[n]) for n in want)
+    assert loose.recovered_steps > 0 and loose.overflow_frames() >= loose.late_overflow_frames

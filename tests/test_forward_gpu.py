@@ -112,9 +112,10 @@ def test_all_eight_scenes_of_config4(cuda_device, name):
     seed = 1 + scenes.SCENE_NAMES.index(name)  # gsworld_amd.distributed.scene_for_rank
     cam = scenes.sensor_camera(name)
     # off the borderline pixels 1e-4 as everywhere; a pixel whose alpha >= 1/255 (or T >= 1e-4) decision sits within an
-    # exp() ulp of the threshold may gain or lose one contribution of at most T / 255: bounded by 1e-3 here (observed
-    # 1.4e-4 on fr3_pour; the two BASELINE headline configurations are held to 1e-4 on every pixel above)
-    rep = _run(scenes.tabletop_scene(name, n=200_000, seed=seed), cam, all_pixel_tol=1e-3)
+    # exp() ulp of the threshold may gain or lose one contribution of at most T / 255: bounded by 2e-4 here (observed
+    # worst 1.4e-4, on fr3_pour; bench.py prints the figure of every run as parity.worst_pixel_all_scenes; the two
+    # BASELINE headline configurations are held to 1e-4 on every pixel above)
+    rep = _run(scenes.tabletop_scene(name, n=200_000, seed=seed), cam, all_pixel_tol=2e-4)
     assert rep["V"] > 5_000 and rep["R"] > rep["V"]
     _full_size_properties(scenes.tabletop_scene(name, seed=seed), cam)
 

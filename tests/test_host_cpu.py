@@ -280,12 +280,49 @@ def test_instance_bound_that_replaces_the_read_back():
     assert _C.nosync_capacity(0, 480, 640) is None
     assert _C.nosync_capacity(10, 16, 16 * 257) is None                           # 257 tile columns
     assert _C.nosync_capacity(10, 17, 33) == 10 * 3 * 2                           # partial tiles count
+    assert _C.nosync_capacity(10, 16 * 129, 16 * 128) is None                     # 16 512 tiles > GSR_MAX_COUNT_TILES:
+    assert _C.nosync_capacity(10, 16 * 128, 16 * 128) == 10 * 16384               #   the radix placement is 24 B / instance
     saved = dict(_lib.TUNING)
     try:
         _lib.TUNING["binning_path"] = 2
         assert _C.nosync_capacity(1000, 64, 64) is None                           # A/B paths size their lists exactly
     finally:
         _lib.TUNING.update(saved)
+
+
+def test_a_forced_inference_frame_never_reaches_the_training_paths():
+    """GSWORLD_AMD_TUNING / TUNING["forward_only"] = 1 is an A/B aid for the frame renderers.  The rasterize_gaussians*
+    paths keep their state for gsr_backward, which carves the FULL layout: they must stay training frames whatever is
+    forced."""
+    from gsworld_amd import _C, _lib
+
+    saved = dict(_lib.TUNING)
+    try:
+        _lib.TUNING["forward_only"] = 1
+        assert _C._tuning_list(None)[5] == 0          # training paths
+        assert _C._tuning_list(False)[5] == 1         # a frame renderer's choice IS overridden (that is the A/B)
+        st = _lib.GsrSettings(16, 16, 1.0, 1.0, 1.0, 3, 16, 0, 0, 0, 0.05)
+        _lib.apply_tuning(st, allow_forward_only=False)
+        assert st.forward_only == 0
+        _lib.apply_tuning(st)
+        assert st.forward_only == 1
+        _lib.TUNING["forward_only"] = -1
+        assert _C._tuning_list(True)[5] == 1 and _C._tuning_list(None)[5] == 0
+    finally:
+        _lib.TUNING.update(saved)
+
+
+def test_frame_gather_logs_are_bounded():
+    """FrameGather.waits only records with timing=True and never grows without bound."""
+    import torch
+
+    from gsworld_amd.distributed import FrameGather
+
+    fg = FrameGather(4, 4, batch=2, device=torch.device("cpu"), world=1, buffers=1, timing=False)
+    for i in range(10_000):
+        fg.wait_reusable(i)
+        fg.step_done(i)
+    assert len(fg.waits) == 0 and fg.waits.maxlen == 4096
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gsworld"), reason="the reference tree is only present in the authoring container")

@@ -8,6 +8,7 @@ against).  This tool renders BASELINE.json configs[0] and configs[1] with three 
   canonical   explicit fmaf() where a left-to-right contraction of the published expressions would fuse, -ffp-contract=off
   nofma       no fused operation anywhere (nvcc -fmad=false)
   contract    every a * b + c written plainly and left to gcc under -ffp-contract=fast
+  assoc_upstream  canonical, but the blend in upstream's association ((rgb * alpha) * T) + C instead of rgb * (alpha * T) + C
 
 -- and counts what changes against the canonical build: radii, tile rects, num_rendered, point_list entries,
 pixels beyond north_star's 1e-4.  The spread between the builds is the exposure of "bit-exact tile / key indices
@@ -24,7 +25,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {"canonical": "", "nofma": "oracle/_variants/libgs_oracle_nofma.so",
-            "contract": "oracle/_variants/libgs_oracle_contract.so"}
+            "contract": "oracle/_variants/libgs_oracle_contract.so",
+            # the blend in upstream's association, ((rgb * alpha) * T) + C, instead of the canonical rgb * (alpha * T) + C
+            "assoc_upstream": "oracle/_variants/libgs_oracle_assoc.so"}
 
 
 def worker(config: int, out_path: str):
@@ -98,7 +101,7 @@ def main():
                 env["GS_ORACLE_LIB"] = os.path.join(ROOT, lib)
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", str(c), path], env=env)
             outs[name] = dict(np.load(path))
-        report[f"configs[{c}]"] = {n: compare(outs["canonical"], outs[n]) for n in ("nofma", "contract")}
+        report[f"configs[{c}]"] = {n: compare(outs["canonical"], outs[n]) for n in VARIANTS if n != "canonical"}
         print(json.dumps({f"configs[{c}]": report[f"configs[{c}]"]}, indent=1))
     if args.json:
         with open(args.json, "w") as f:
