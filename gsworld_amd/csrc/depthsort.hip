@@ -907,7 +907,10 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
         // Odd-even transposition restricted to the tied pairs: in a round the pairs that start at even (odd) positions
         // are disjoint, each is put in order by one thread, a barrier ends the round; done when an even and an odd round
         // in a row moved nothing.  A run of L equal keys takes at most L rounds -- two or three almost always; thousands
-        // of equal depths (a plane facing the camera) cost a barrier each and stay exact.
+        // of equal depths (a plane facing the camera) cost a barrier each and stay exact.  (Measured against it: ranking
+        // every member inside a +-6 window with straight-line code and falling back to the rounds for longer runs --
+        // slower on both views, ss_buckets 13.6 -> 14.5 us and 40.5 -> 58 us: the window is probed whether or not a run
+        // is long.)
         int quiet = 0;
         for (int round = 0; quiet < 2; round++) {
             int moved = 0;

@@ -310,6 +310,9 @@ constexpr int kStreamList = kStreamRound + kBatch;                // survivors +
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef GSR_STREAM_MASKED_BLEND
+#define GSR_STREAM_MASKED_BLEND 1   // 0: the select-based blend everywhere (A/B)
+#endif
 #ifndef GSR_STREAM_STAMPS
 #define GSR_STREAM_STAMPS 0   // 1: tuning build that leaves per-quadrant cycle stamps in the image state
 #endif
@@ -319,6 +322,7 @@ struct StreamBatch {
     float alpha[kBatch], pos[kBatch];
     bool valid[kBatch];
     float4 col[kBatch];
+    float araw[kBatch];  // min(0.99, opacity * exp(power)) before the alpha >= 1/255 test (stream_blend_masked)
 };
 
 // same operations in the same order as the scalar kernels, two survivors per packed instruction
@@ -363,6 +367,8 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
         b.valid[2 * h + 1] = (!CHECK_POWER || power.y <= 0.0f) && a1 >= 1.0f / 255.0f;
         b.alpha[2 * h] = b.valid[2 * h] ? a0 : 0.0f;
         b.alpha[2 * h + 1] = b.valid[2 * h + 1] ? a1 : 0.0f;
+        b.araw[2 * h] = a0;
+        b.araw[2 * h + 1] = a1;
         b.pos[2 * h] = qpos.x;
         b.pos[2 * h + 1] = qpos.y;
     }
@@ -390,6 +396,42 @@ __device__ __forceinline__ void stream_blend(const StreamBatch &b, float &T, v2f
         acc_bd = __builtin_elementwise_fma(v2f{b.col[k].z, b.col[k].w}, v2f{w, w}, acc_bd);
         if (TRACK) last = (b.valid[k] && !stop) ? __float_as_uint(b.pos[k]) : last;
         T = stop ? -fabsf(T) : test_T;
+    }
+}
+
+// The same blend with the alpha >= 1/255 test as an EXEC mask instead of a select (inference frames, safe conics: the
+// test is the only condition).  stream_blend zeroes the alpha of a lane the instance does not touch (v_cmp + v_cndmask)
+// and then runs the whole update on it with weight 0; here v_cmpx narrows EXEC to the lanes it touches, the update runs on
+// those only, and EXEC is restored: one VALU instruction less per survivor (8 instead of 9 + the shared 1 - alpha) in a
+// kernel that is bound by exactly that (17.75 per survivor).  Same operations on the same operands
+// in the lanes that matter: bit-identical (tests: compositing variants, forward_only frames).  Hand-placed wait states:
+// gfx950 wants two between a VALU write of VCC and its use as a lane mask; v94 / v95 are scratch (w | test_T).
+__device__ __forceinline__ void stream_blend_masked(const StreamBatch &b, float &T, v2f &acc_rg, v2f &acc_bd) {
+    float oma[kBatch];
+#pragma unroll
+    for (int h = 0; h < kBatch / 2; h++) {
+        const v2f d = v2f{1.0f, 1.0f} - v2f{b.araw[2 * h], b.araw[2 * h + 1]};
+        oma[2 * h] = d.x;
+        oma[2 * h + 1] = d.y;
+    }
+    const uint64_t saved = __builtin_amdgcn_read_exec();  // (the lanes this batch runs on: restored after every survivor)
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+        const v2f crg = {b.col[k].x, b.col[k].y}, cbd = {b.col[k].z, b.col[k].w};
+        asm volatile(
+            "v_cmpx_le_f32 0x3b808081, %[a]\n\t"          // EXEC &= 1/255 <= alpha
+            "v_mul_f32 v95, %[T], %[oma]\n\t"              // test_T = T (1 - alpha)
+            "v_cmp_gt_f32 vcc, 0x38d1b717, v95\n\t"        // stop = test_T < 1e-4
+            "v_mul_f32 v94, %[a], %[T]\n\t"                // w = alpha T
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 v94, v94, 0, vcc\n\t"       // stop: weight 0
+            "v_cndmask_b32_e64 %[T], v95, -|%[T]|, vcc\n\t"  // stop: T = -|T| (finished), else test_T
+            "v_pk_fma_f32 %[rg], %[crg], v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %[bd], %[cbd], v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [T] "+v"(T), [rg] "+v"(acc_rg), [bd] "+v"(acc_bd)
+            : [a] "v"(b.araw[k]), [oma] "v"(oma[k]), [crg] "v"(crg), [cbd] "v"(cbd), [sv] "s"(saved)
+            : "vcc", "v94", "v95");
     }
 }
 
@@ -594,6 +636,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
                 int i = 0;
                 if (n_surv > 0) do {
                     const StreamBatch b = stream_eval<false, !SUPER>(list, i, pf2x, pf2y);
+#if GSR_STREAM_MASKED_BLEND
+                    if (SUPER)
+                        stream_blend_masked(b, T, acc_rg, acc_bd);
+                    else
+#endif
                     stream_blend<!SUPER>(b, T, acc_rg, acc_bd, last_contributor);
                     work += (uint32_t)kBatch;  // survivors actually replayed (a saturated quadrant stops early)
                     i += kBatch;

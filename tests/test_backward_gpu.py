@@ -155,6 +155,21 @@ def test_config5_resolution_800x800_against_the_oracle(cuda_device):
     assert set(rep) >= {"dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"}
 
 
+def test_config5_full_size_gradients_against_the_oracle(cuda_device, capsys):
+    """BASELINE.json configs[4] at FULL size -- 500 k Gaussians, 800x800 -- all eight gradients against the backward
+    oracle (float64 sums; ~20 s of host time).  render_backward_kernel takes one hardware reciprocal of (1 - alpha) per
+    hit instead of two correctly rounded divisions (backward.hip, round 3): this is the assertion of what that costs at
+    the size the step is benchmarked at -- the suite's bounds (99.95 % of the elements within 2e-3 relative, worst
+    normalised error 5e-3) must hold here too, and the worst figure is printed for the record."""
+    raw = scenes.random_scene_camera_frame(500_000, seed=5, near_fraction=0.0)
+    rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw, **hb.SUITE_TOLERANCES)
+    worst = max(v["max_norm_err"] for v in rep.values())
+    with capsys.disabled():
+        print(f"\n[configs[4] full size] worst normalised gradient error {worst:.3e}; per output: " +
+              ", ".join(f"{k} {v['max_norm_err']:.1e} ({100 * v['frac_within']:.3f} % within 2e-3)" for k, v in rep.items()))
+    assert set(rep) >= {"dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"}
+
+
 @pytest.mark.parametrize("near_fraction", [0.01, 0.0])
 def test_config5_full_size_training_step(cuda_device, near_fraction):
     """BASELINE.json configs[4] at full size: 500 k Gaussians, 800x800, loss = 0.8 L1 + 0.2 (1 - fused_ssim) through the

@@ -18,10 +18,15 @@ dev = torch.device("cuda:0")
 raw = scenes.tabletop_scene("xarm6_align")
 cam = scenes.sensor_camera("xarm6_align").to(dev)
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+from gsworld_amd.layout import SceneLayout  # noqa: E402
+
+L_ = SceneLayout.build(means, sc, rot, shs=shs, opacities=op)  # the layout bench.py's headline renders with
+a_ = L_.arrays
+means, shs, op, sc, rot, lay = a_["means3D"], a_["shs"], a_["opacities"], a_["scales"], a_["rotations"], L_.layout
 r = FrameRenderer(dev, forward_only=True, want_radii=False)  # the frame bench.py times (inference frame)
 L = lib()
 dbg.set_render_variant(variant, bpc)
 for _ in range(frames):
-    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot)
+    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, layout=lay)
 torch.cuda.synchronize()
 print("stats", r.stats())

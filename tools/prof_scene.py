@@ -19,12 +19,20 @@ ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--default-mode", action="store_true", help="forward_only = 0 (the training-capable frame)")
 ap.add_argument("--moving", action="store_true", help="turn the camera a little on every frame")
 ap.add_argument("--sh-degree", type=int, default=3, help="ablation: evaluate fewer SH bands (0: the DC term only)")
+ap.add_argument("--no-layout", action="store_true", help="the model as given (no Morton order / block culling)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 raw = scenes.tabletop_scene("xarm6_align")
 cam0 = scenes.dense_view_camera("xarm6_align") if args.view == "dense" else scenes.sensor_camera("xarm6_align")
 cam = cam0.to(dev)
 means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+lay = None
+if not args.no_layout and not args.default_mode:  # (a permuted model needs inference frames; bench.py's headline has both)
+    from gsworld_amd.layout import SceneLayout
+
+    L_ = SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+    a_ = L_.arrays
+    means, shs, op, sc, rot, lay = a_["means3D"], a_["shs"], a_["opacities"], a_["scales"], a_["rotations"], L_.layout
 r = FrameRenderer(dev, forward_only=not args.default_mode, want_radii=args.default_mode)
 rgb8 = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
 proj = cam0.world_view_transform.inverse() @ cam0.full_proj_transform
@@ -36,7 +44,7 @@ for k in range(args.frames):
         cam.world_view_transform.copy_(wvt)
         cam.full_proj_transform.copy_(wvt @ proj)
         cam.camera_center.copy_(wvt.inverse()[3, :3])
-    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8, sh_degree=args.sh_degree)
+    r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8, sh_degree=args.sh_degree, layout=lay)
     if k == 1:
         r.ensure_valid(lambda: None)
 torch.cuda.synchronize()
