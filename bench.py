@@ -45,9 +45,10 @@ def parse():
     ap.add_argument("--no-layout", action="store_true",
                     help="render the model in the order it was given, without block culling (gsworld_amd/layout.py)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; value = their median")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=0,
                     help="independent frames in flight, each on its own HIP stream with its own renderer state "
-                         "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time)")
+                         "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time).  0 (default): 3 or 4, "
+                         "whichever a short trial on this box finds faster (see pick_lanes)")
     return ap.parse_args()
 
 
@@ -97,7 +98,13 @@ def main():
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
 
-    S = max(1, args.in_flight)
+    trial = None
+    if args.in_flight > 0:
+        S = args.in_flight
+        lane_streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else None
+    else:
+        S, lane_streams, trial = pick_lanes(torch, dev, cam, (m_means, m_shs, m_op, m_sc, m_rot, lay), bg, W, H)
+        args.in_flight = S  # (the moving-camera extra runs with as many lanes)
     # compositing workgroups per CU: the library default (6: every tile quadrant resident at once) is the optimum
     # both for one frame and for 3 frames in flight (tools/sweep_bench.sh); the flag is for sweeps
     bpc = args.render_bpc
@@ -114,7 +121,7 @@ def main():
     # nothing a backward would read is written, instances are binned per 2 x 1 super-tile; the image is bit-identical
     # (tests/test_renderer_gpu.py, and checked against a default frame right below)
     rs_ = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
-    lanes = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    lanes = lane_streams if S > 1 else [torch.cuda.current_stream(dev)]
     r = rs_[0]
     # N, V, R of SURVEY.md 8d's byte model are those of the reference's own per-tile pipeline: one default frame gives them
     ref_r = FrameRenderer(dev)
@@ -320,6 +327,7 @@ def main():
                               "to the default frame, checked in this run)",
                 "sh_degree": 3, "launch": "hipGraph replay" if graph is not None else "eager",
                 "frames_in_flight": S,
+                "frames_in_flight_trial": trial,
                 # the same frame, strictly one at a time / under a camera that turns on every frame (extras below)
                 "one_frame_in_flight_frames_per_s": one_fps,
                 "moving_camera_frames_per_s": extras.get("moving_camera", {}).get("frames_per_s"),
@@ -375,6 +383,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pick_lanes(torch, dev, cam, model, bg, W, H):
+    """How many frames to keep in flight, decided by a short trial on THIS box: 3 lanes on the first three streams the
+    process uses, or 4 lanes on the next four.  Round 4 measured (tools/ab_frame.py --pre-streams, profiles/round4/
+    NOTES_compositor_scheduling.md): the HIP runtime treats the first three user streams of a process and all later ones as
+    two classes -- a group of lanes that lies inside one class overlaps its frames 2.3x, a group that straddles the two
+    1.5x (7.8-9.5 k instead of 11.2-12 k frames/s) -- and four lanes of the later class beat three of the first by ~4 %
+    on most boxes.  Instead of relying on either observation the bench measures both candidates (150 frames each, same
+    frame, hipGraph replay) and takes the faster.  -> (lanes, streams, record of the trial)."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    means, shs, op, sc, rot, lay = model
+    rec, best = {}, None
+    for S in (3, 4):
+        streams = [torch.cuda.Stream(dev) for _ in range(S)]
+        rs = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
+        outs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S)]
+        fns = [(lambda l=l: rs[l].render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=outs[l],
+                                         layout=lay)) for l in range(S)]
+        graphs = []
+        for l in range(S):
+            for _ in range(2):
+                fns[l]()
+                rs[l].ensure_valid(fns[l])
+            streams[l].wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(streams[l]):
+                fns[l]()
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=streams[l]):
+                fns[l]()
+            graphs.append(g)
+        torch.cuda.synchronize(dev)
+
+        def run(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % S]):
+                    graphs[i % S].replay()
+            torch.cuda.synchronize(dev)
+
+        run(40)
+        t0 = time.perf_counter()
+        run(150)
+        fps = 150 / (time.perf_counter() - t0)
+        rec[f"{S}_lanes_frames_per_s"] = fps
+        if best is None or fps > best[0]:
+            best = (fps, S, streams)
+        del graphs, rs, outs
+    rec["chosen"] = best[1]
+    return best[1], best[2], rec
 
 
 def _time_frames(torch, enqueue, steps, warmup=10):

@@ -34,6 +34,10 @@ dev = torch.device("cuda:0")
 W, H = 640, 480
 _keep = [torch.empty(args.pre_alloc << 20, dtype=torch.uint8, device=dev)] if args.pre_alloc else []
 _keep += [torch.cuda.Stream(dev) for _ in range(args.pre_streams)]
+for _s in _keep[1 if args.pre_alloc else 0:]:  # (a stream gets its hardware queue when it is first used)
+    with torch.cuda.stream(_s):
+        _keep.append(torch.zeros(1, device=dev))
+torch.cuda.synchronize()
 raw = scenes.tabletop_scene("xarm6_align")
 cam = (scenes.sensor_camera("xarm6_align", W, H) if args.view == "sensor"
        else scenes.dense_view_camera("xarm6_align", W, H)).to(dev)
