@@ -104,6 +104,14 @@ def main():
         lane_streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else None
     else:
         S, lane_streams, trial = pick_lanes(torch, dev, cam, (m_means, m_shs, m_op, m_sc, m_rot, lay), bg, W, H)
+        if world > 1:
+            # every rank must gather batches of the same size: rank 0's choice holds for all (each rank keeps the
+            # streams of both candidates)
+            choice = [S]
+            dist.broadcast_object_list(choice, src=0)
+            S, lane_streams = int(choice[0]), trial["streams"][int(choice[0])]
+            trial["chosen"] = S
+        trial.pop("streams", None)
         args.in_flight = S  # (the moving-camera extra runs with as many lanes)
     # compositing workgroups per CU: the library default (6: every tile quadrant resident at once) is the optimum
     # both for one frame and for 3 frames in flight (tools/sweep_bench.sh); the flag is for sweeps
@@ -278,7 +286,7 @@ def main():
         render_ms = stage_ms[-1]
         render_bytes = 40 * stats.num_rendered + 16 * W * H  # 40 B per composited instance + outputs
         ach = render_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
-        traffic = valu_frac = None
+        traffic = valu_frac = valu_frac_213 = None
         traffic_source = "none"
         pmc = os.path.join(ROOT, "profiles", "pmc_render.json")
         if os.path.exists(pmc):
@@ -299,8 +307,11 @@ def main():
                 insts = rec.get("counters", {}).get("SQ_INSTS_VALU")
                 if insts and render_ms > 0:
                     valu_frac = insts * 4.0 / (256 * 4 * 2.4e9 * render_ms * 1e-3)
+                    # (per-quadrant s_memtime stamps put the shader clock under this kernel at 2.13 GHz, not the nominal
+                    #  2.4: profiles/round4/stream_stamps_all_static.txt)
+                    valu_frac_213 = insts * 4.0 / (256 * 4 * 2.13e9 * render_ms * 1e-3)
             except Exception:  # noqa: BLE001
-                traffic = valu_frac = None
+                traffic = valu_frac = valu_frac_213 = None
         # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command (profiles/)
         rocprof_ms = None
         try:
@@ -357,7 +368,7 @@ def main():
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
                 "kernel_ms_rocprof_committed": rocprof_ms,
-                "valu_issue_frac": valu_frac,
+                "valu_issue_frac": valu_frac, "valu_issue_frac_at_measured_2.13GHz": valu_frac_213,
                 "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
                         "recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not HBM-bound: "
                         "saturated pixels stop reading their tile list early, so real traffic is far below the "
@@ -396,7 +407,7 @@ def pick_lanes(torch, dev, cam, model, bg, W, H):
     from gsworld_amd.renderer import FrameRenderer
 
     means, shs, op, sc, rot, lay = model
-    rec, best = {}, None
+    rec, best = {"streams": {}}, None
     for S in (3, 4):
         streams = [torch.cuda.Stream(dev) for _ in range(S)]
         rs = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
@@ -429,6 +440,7 @@ def pick_lanes(torch, dev, cam, model, bg, W, H):
         run(150)
         fps = 150 / (time.perf_counter() - t0)
         rec[f"{S}_lanes_frames_per_s"] = fps
+        rec["streams"][S] = streams
         if best is None or fps > best[0]:
             best = (fps, S, streams)
         del graphs, rs, outs
