@@ -584,6 +584,25 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     overflow = any(x.overflow for x in loop.ensure_valid())
+    # ---- the same rollout with consecutive steps in flight (PipelinedClosedLoop, depth 3: six frames instead of two).
+    # configs[2] is a RANDOM-ACTION rollout: gsworld_rand_action_tabletop.py:107-133 never looks at its observations, so
+    # step k + 1 may be enqueued while step k renders; a policy that needs frame k first gets the figure above.
+    pipe_fps = pipe_ovf = None
+    try:
+        pipe = cl.PipelinedClosedLoop(raw, parts, cams, depth=3, scaled_parts=actors, device=dev)
+        pipe.reset(*pinned[0])
+        pipe.capture()
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        pipe.step(*pinned[0], cameras={"wrist_cam": wrists[0]}, wait=False)
+        for (M, s_), w in zip(pinned[1:], wrists[1:]):
+            pipe.step(M, s_, cameras={"wrist_cam": w}, wait=False)
+        torch.cuda.synchronize()
+        pipe_fps = (ep_len + 1) * len(cams) / (time.perf_counter() - t0p)
+        pipe_ovf = pipe.overflow_frames()
+        del pipe
+    except Exception as ex:  # noqa: BLE001
+        pipe_fps = f"{type(ex).__name__}: {ex}"
     # the same steps through the wrapper's OWN glue (baseline leg, like cpu_baseline: oracle/wrapper_glue_ref.py restates
     # gs_world_wrapper.py:110-162, 232-275 op for op in torch -- deep copies, isin masks, masked write-backs, upstream
     # render()'s activations and SH concat) around this package's drop-in rasterizer in exact mode: what the loop costs
@@ -621,6 +640,9 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg):
         ref_glue = f"{type(ex).__name__}: {ex}"
     out["closed_loop"] = {
         "reference_glue_frames_per_s": ref_glue,
+        "three_steps_in_flight": {"frames_per_s": pipe_fps, "overflow_frames": pipe_ovf,
+                                "what": "PipelinedClosedLoop(depth=3): steps k + 1, k + 2 enqueued while step k renders (legitimate "
+                                        "for a random-action / scripted rollout, whose actions do not depend on the frames)"},
         "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity

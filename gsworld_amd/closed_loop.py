@@ -33,7 +33,7 @@ from .renderer import MultiCameraRenderer
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
-                 layout: bool = True, min_capacity: int | None = None):
+                 layout: bool = True, min_capacity: int | None = None, share_model_of=None):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -55,23 +55,36 @@ class ClosedLoopRenderer:
         ``layout`` (with ``fuse_transform``): the loop keeps its OWN copy of the model in Morton order per part and size
         class, with block bounds (:mod:`gsworld_amd.layout`): every frame's per-Gaussian pass skips the blocks of the
         model that the step's poses put outside the camera's frustum (two thirds of them from a sensor camera).  Same
-        frames, bit for bit (tests/test_layout_gpu.py, tests/test_closed_loop_gpu.py)."""
+        frames, bit for bit (tests/test_layout_gpu.py, tests/test_closed_loop_gpu.py).
+        ``share_model_of``: another loop over the SAME model on the same device whose (laid-out) model tensors this one
+        reads instead of making its own copy (:class:`PipelinedClosedLoop`); everything per step -- poses, cameras,
+        renderer states, frames, graph -- stays its own."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
         self.names = list(cameras.keys())
         self.cameras = [self._own(cameras[n], dev) for n in self.names]
         g = lambda a, b: getattr(raw, a) if hasattr(raw, a) else getattr(raw, b)  # noqa: E731
-        self.xyz = g("xyz", "_xyz").detach().to(dev, torch.float32).contiguous()
-        self.rotation = g("rotation", "_rotation").detach().to(dev, torch.float32).contiguous()
-        self.scaling = g("scaling", "_scaling").detach().to(dev, torch.float32).contiguous()
-        self.features_dc = g("features_dc", "_features_dc").detach().to(dev, torch.float32).contiguous()
-        self.features_rest = g("features_rest", "_features_rest").detach().to(dev, torch.float32).contiguous()
-        # opacity is never moved (new_opacity=None at both call sites of the wrapper): activate it once
-        self.opacity = torch.sigmoid(g("opacity", "_opacity").detach().to(dev, torch.float32).reshape(-1, 1)).contiguous()
-        semantics = g("semantics", "_semantics")
-        self.layout = None
-        if layout and fuse_transform:
+        other = share_model_of
+        if other is not None:
+            if other.device != dev or bool(other.layout is not None) != bool(layout and fuse_transform):
+                raise ValueError("share_model_of: the other loop must live on the same device and use the same layout option")
+            self.xyz, self.rotation, self.scaling = other.xyz, other.rotation, other.scaling
+            self.features_dc, self.features_rest, self.opacity = other.features_dc, other.features_rest, other.opacity
+            self.layout, semantics = other.layout, other._semantics
+            if other.layout is not None:
+                self.perm = other.perm
+        else:
+            self.xyz = g("xyz", "_xyz").detach().to(dev, torch.float32).contiguous()
+            self.rotation = g("rotation", "_rotation").detach().to(dev, torch.float32).contiguous()
+            self.scaling = g("scaling", "_scaling").detach().to(dev, torch.float32).contiguous()
+            self.features_dc = g("features_dc", "_features_dc").detach().to(dev, torch.float32).contiguous()
+            self.features_rest = g("features_rest", "_features_rest").detach().to(dev, torch.float32).contiguous()
+            # opacity is never moved (new_opacity=None at both call sites of the wrapper): activate it once
+            self.opacity = torch.sigmoid(g("opacity", "_opacity").detach().to(dev, torch.float32).reshape(-1, 1)).contiguous()
+            semantics = g("semantics", "_semantics")
+            self.layout = None
+        if other is None and layout and fuse_transform:
             from .layout import SceneLayout
 
             L = SceneLayout.build(self.xyz, self.scaling, self.rotation,
@@ -84,6 +97,7 @@ class ClosedLoopRenderer:
             semantics = a["labels"]
             self.layout = L.layout
             self.perm = L.perm  # (position in the loop's arrays -> number in the caller's model)
+        self._semantics = semantics
         self.op = tf.FusedPartTransform(part_labels, semantics.to(dev), scaled_parts=scaled_parts)
         self.rescaled = len(tuple(scaled_parts)) > 0
         if self.num_envs > 1:
@@ -309,6 +323,93 @@ class ClosedLoopRenderer:
         self._graph = g
         self._overflows_acknowledged()
         return g
+
+
+class PipelinedClosedLoop:
+    """``depth`` closed loops over ONE copy of the model that take the steps of a rollout in turn, each on its own HIP
+    stream with its own poses, cameras, renderer states, frames and graph: step k + 1 is enqueued while step k still
+    renders, so ``depth x cameras`` frames are in flight instead of ``cameras``.
+
+    A single :class:`ClosedLoopRenderer` replays one graph per step on one stream: the two frames of a step overlap,
+    consecutive steps do not, and at 640 x 480 two frames leave the chip half idle (section 4 of DESIGN.md: 9.7 k frames/s
+    with two identical frames in flight against 11.9 k with four).  Whether consecutive steps MAY overlap is the caller's
+    matter: a random-action or scripted rollout (BASELINE.json configs[2]: ``gsworld_rand_action_tabletop.py:107-133``
+    never looks at its observations), an open-loop replay, a data-collection run with a planner, or several environments
+    stepping independently can; a policy that needs frame k before it chooses action k + 1 cannot, and gains nothing
+    here.
+
+    :meth:`step` returns the frames of the step it enqueued -- tensors owned by that step's loop, overwritten ``depth``
+    steps later.  With ``wait=True`` (default) the CURRENT stream is made to wait for them, so whatever the caller
+    enqueues next may read them; poses handed over as DEVICE tensors are read after what the current stream has already
+    enqueued (a GPU simulator).  Both are stream dependencies, never host synchronisations; but a current stream that
+    waits for step k and then produces the poses of step k + 1 chains the steps together again -- hand host (pinned)
+    poses over, or ``wait=False`` and :meth:`wait_for` before reading, to keep them apart."""
+
+    def __init__(self, raw, part_labels: dict, cameras: dict, depth: int = 2, **kw):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        first = ClosedLoopRenderer(raw, part_labels, cameras, **kw)
+        self.loops = [first] + [ClosedLoopRenderer(raw, part_labels, cameras, share_model_of=first, **kw)
+                                for _ in range(depth - 1)]
+        self.device = first.device
+        self.streams = [torch.cuda.Stream(self.device) for _ in self.loops]
+        self._events = [None] * depth
+        self._k = 0
+
+    @property
+    def depth(self) -> int:
+        return len(self.loops)
+
+    def reset(self, matrices=None, scales=None) -> dict:
+        """Sizes every loop's lanes on the reset poses; returns the first loop's frames."""
+        cur = torch.cuda.current_stream(self.device)
+        out = None
+        for loop, st in zip(self.loops, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                f = loop.reset(matrices, scales)
+            out = out if out is not None else f
+        torch.cuda.synchronize(self.device)
+        self._k = 0
+        return out
+
+    def capture(self):
+        for loop, st in zip(self.loops, self.streams):
+            with torch.cuda.stream(st):
+                loop.capture()
+        torch.cuda.synchronize(self.device)
+
+    def step(self, matrices=None, scales=None, cameras: dict | None = None, wait: bool = True, ensure: bool = False) -> dict:
+        i = self._k % len(self.loops)
+        self._k += 1
+        loop, st = self.loops[i], self.streams[i]
+        cur = torch.cuda.current_stream(self.device)
+        on_device = any(isinstance(t, torch.Tensor) and t.is_cuda for t in (matrices, scales)) or \
+            any(c.world_view_transform.is_cuda for c in (cameras or {}).values())
+        if on_device:
+            st.wait_stream(cur)  # the poses were produced by what the current stream holds
+        with torch.cuda.stream(st):
+            frames = loop.step(matrices, scales, cameras, ensure=ensure)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._events[i] = ev
+        if wait:
+            cur.wait_event(ev)
+        return frames
+
+    def wait_for(self, frames: dict | None = None, stream=None):
+        """Makes ``stream`` (default: current) wait for the step that produced ``frames`` (default: every step enqueued so
+        far)."""
+        stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        for loop, ev in zip(self.loops, self._events):
+            if ev is not None and (frames is None or frames is loop.frames):
+                stream.wait_event(ev)
+
+    def overflow_frames(self) -> int:
+        return sum(loop.overflow_frames() for loop in self.loops)
+
+    def ensure_valid(self):
+        return [s for loop in self.loops for s in loop.ensure_valid()]
 
 
 def part_poses_from_sim(sim2gs_arm: torch.Tensor, link_now: torch.Tensor, link_scan: torch.Tensor, link_offset=None,

@@ -312,3 +312,49 @@ def test_overflow_under_graph_replay_is_never_returned(cuda_device):
     torch.cuda.synchronize()
     assert all(torch.equal(got[n], want[n]) for n in want)
     assert loose.recovered_steps > 0 and loose.overflow_frames() >= loose.late_overflow_frames
+
+
+def test_pipelined_loop_gives_the_plain_loop_s_frames(cuda_device):
+    """PipelinedClosedLoop(depth=2): consecutive steps on alternating loops over one shared copy of the model, enqueued
+    without waiting for each other.  Every step's frames are the plain loop's, bit for bit -- with host poses and
+    wait=False (the throughput mode of bench.py), with device poses and the default wait, eager and under graph replay,
+    with a wrist camera that moves every step."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=10)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    steps = 14
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=steps, seed=2))
+
+    def wrist(k):
+        return look_at_view([0.55 - 0.01 * k, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)
+
+    plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
+    plain.reset(*poses[0])
+    want = []
+    for k in range(1, steps):
+        f = plain.step(*poses[k], cameras={"wrist_cam": wrist(k)})
+        torch.cuda.synchronize()
+        want.append({n: t.clone() for n, t in f.items()})
+    for graph in (False, True):
+        pipe = cl.PipelinedClosedLoop(raw, parts, cams, depth=2, scaled_parts=actors, device=dev)
+        assert pipe.loops[1].xyz.data_ptr() == pipe.loops[0].xyz.data_ptr()  # one copy of the model
+        pipe.reset(*poses[0])
+        if graph:
+            pipe.capture()
+        got = []
+        for k in range(1, steps):
+            M, s = poses[k]
+            if k % 2:  # host poses, nobody waits
+                f = pipe.step(M.pin_memory(), s.pin_memory(), cameras={"wrist_cam": wrist(k)}, wait=False)
+                pipe.wait_for(f)
+            else:      # device poses, the current stream waits for the frames
+                f = pipe.step(M.to(dev), s.to(dev), cameras={"wrist_cam": wrist(k)})
+            got.append({n: t.clone() for n, t in f.items()})  # (cloned on the current stream, which waits for the step)
+        torch.cuda.synchronize()
+        for k, (g, w) in enumerate(zip(got, want)):
+            for n in w:
+                assert torch.equal(g[n], w[n]), f"graph={graph} step {k + 1} {n}"
+        assert pipe.overflow_frames() == 0
