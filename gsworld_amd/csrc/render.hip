@@ -313,6 +313,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef GSR_STREAM_MASKED_BLEND
 #define GSR_STREAM_MASKED_BLEND 1   // 0: the select-based blend everywhere (A/B)
 #endif
+#ifndef GSR_STREAM_ALIVE_BLEND
+#define GSR_STREAM_ALIVE_BLEND 2    // 0: stream_blend_masked (finished pixels carried in T's sign, round 4's first version)
+#endif
 #ifndef GSR_STREAM_STAMPS
 #define GSR_STREAM_STAMPS 0   // 1: tuning build that leaves per-quadrant cycle stamps in the image state
 #endif
@@ -323,6 +326,7 @@ struct StreamBatch {
     bool valid[kBatch];
     float4 col[kBatch];
     float araw[kBatch];  // min(0.99, opacity * exp(power)) before the alpha >= 1/255 test (stream_blend_masked)
+    v2f ao[kBatch];      // (araw, 1 - araw): one packed multiply by T gives the weight and the new T (stream_blend_alive)
 };
 
 // same operations in the same order as the scalar kernels, two survivors per packed instruction
@@ -369,6 +373,8 @@ __device__ __forceinline__ StreamBatch stream_eval(const float4 (*list)[6], int 
         b.alpha[2 * h + 1] = b.valid[2 * h + 1] ? a1 : 0.0f;
         b.araw[2 * h] = a0;
         b.araw[2 * h + 1] = a1;
+        b.ao[2 * h] = v2f{a0, 1.0f - a0};
+        b.ao[2 * h + 1] = v2f{a1, 1.0f - a1};
         b.pos[2 * h] = qpos.x;
         b.pos[2 * h + 1] = qpos.y;
     }
@@ -435,6 +441,73 @@ __device__ __forceinline__ void stream_blend_masked(const StreamBatch &b, float 
     }
 }
 
+// The masked blend with the FINISHED state as a wave mask too.  stream_blend_masked still pays, per survivor, a compare and
+// two selects for the saturation test (weight 0 and T = -|T| in the lanes that stop) and two multiplies for alpha T and
+// T (1 - alpha).  Here
+//   * `alive` (an SGPR pair) holds the lanes that still composite; every survivor starts from EXEC = alive;
+//   * v_cmpx narrows EXEC to the lanes the survivor touches (alpha >= 1/255), ONE packed multiply (alpha, 1 - alpha) x T
+//     gives the weight and test_T, a second v_cmpx narrows EXEC to the lanes that go on (not test_T < 1e-4): T and the
+//     four accumulators are updated in those only, and the lanes that stopped (touched, not going on) leave `alive` by
+//     two scalar instructions.  A lane that stops keeps the T it had, as the reference's `break` does.
+// 6 VALU per survivor (+ 1 for 1 - alpha) against 8 (+ 1/2); the scalar work rides in the shadow of the other waves'
+// VALU issue.  The same IEEE operations on the same operands in every lane that matters: bit-identical (tests:
+// forward_only frames against default frames, compositing variants).  T lives in v92 (the low half of the pinned pair
+// v[92:93]: the packed multiply wants a register pair, the update a single register); v94 / v95 = weight | test_T.
+#if GSR_STREAM_ALIVE_BLEND == 1
+// (first version: both tests as v_cmpx, the stopped lanes = touched ^ going-on: five scalar instructions per survivor)
+#define GSR_ALIVE_STEP(A, AO, CRG, CBD, NEXT)                                                                        \
+    "v_cmpx_le_f32 0x3b808081, " A "\n\t"                              /* EXEC = VCC = alive & 1/255 <= alpha */       \
+    "s_mov_b64 %[tmp], vcc\n\t"                                                                                       \
+    "v_pk_mul_f32 v[94:95], " AO ", v[92:93] op_sel_hi:[1,0]\n\t"      /* alpha T | (1 - alpha) T */                   \
+    "v_cmpx_ngt_f32 0x38d1b717, v95\n\t"                               /* EXEC = VCC = touched & !(test_T < 1e-4) */   \
+    "v_mov_b32 v92, v95\n\t"                                                                                          \
+    "v_pk_fma_f32 %[rg], " CRG ", v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"                                              \
+    "v_pk_fma_f32 %[bd], " CBD ", v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"                                              \
+    "s_xor_b64 %[tmp], %[tmp], vcc\n\t"                                /* touched and stopped */                       \
+    "s_andn2_b64 %[alive], %[alive], %[tmp]\n\t"                                                                      \
+    "s_mov_b64 exec, " NEXT "\n\t"
+#else
+// EXEC = alive on entry; leaves EXEC = NEXT (alive for the next survivor, the saved mask behind the last one).
+// Scalar instructions are not free on this chip (tools/scratch/ubench.hip, 5 waves per SIMD: one costs ~0.7 of a plain
+// VALU instruction's issue time, a packed fp32 one 1.8, v_exp_f32 5.1), hence three of them per survivor, not five:
+// the saturation test is a plain v_cmp whose VCC (= the touched lanes that stop; 0 in inactive lanes) leaves `alive` and
+// EXEC by one s_andn2 each.
+#define GSR_ALIVE_STEP(A, AO, CRG, CBD, NEXT)                                                                        \
+    "v_cmpx_le_f32 0x3b808081, " A "\n\t"                              /* EXEC = alive & 1/255 <= alpha */             \
+    "v_pk_mul_f32 v[94:95], " AO ", v[92:93] op_sel_hi:[1,0]\n\t"      /* alpha T | (1 - alpha) T */                   \
+    "v_cmp_gt_f32 vcc, 0x38d1b717, v95\n\t"                            /* VCC = touched & test_T < 1e-4 */             \
+    "s_andn2_b64 %[alive], %[alive], vcc\n\t"                                                                         \
+    "s_andn2_b64 exec, exec, vcc\n\t"                                                                                 \
+    "v_mov_b32 v92, v95\n\t"                                                                                          \
+    "v_pk_fma_f32 %[rg], " CRG ", v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"                                              \
+    "v_pk_fma_f32 %[bd], " CBD ", v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"                                              \
+    "s_mov_b64 exec, " NEXT "\n\t"
+#endif
+__device__ __forceinline__ void stream_blend_alive(const StreamBatch &b, v2f &Tp, v2f &acc_rg, v2f &acc_bd,
+                                                   uint64_t &alive, int &limit, const uint64_t saved) {
+    static_assert(kBatch == 4, "the block below takes four survivors");
+    const v2f crg0 = {b.col[0].x, b.col[0].y}, cbd0 = {b.col[0].z, b.col[0].w};
+    const v2f crg1 = {b.col[1].x, b.col[1].y}, cbd1 = {b.col[1].z, b.col[1].w};
+    const v2f crg2 = {b.col[2].x, b.col[2].y}, cbd2 = {b.col[2].z, b.col[2].w};
+    const v2f crg3 = {b.col[3].x, b.col[3].y}, cbd3 = {b.col[3].z, b.col[3].w};
+    uint64_t tmp;
+    asm volatile("s_mov_b64 exec, %[alive]\n\t"
+                 GSR_ALIVE_STEP("%[a0]", "%[ao0]", "%[crg0]", "%[cbd0]", "%[alive]")
+                 GSR_ALIVE_STEP("%[a1]", "%[ao1]", "%[crg1]", "%[cbd1]", "%[alive]")
+                 GSR_ALIVE_STEP("%[a2]", "%[ao2]", "%[crg2]", "%[cbd2]", "%[alive]")
+                 GSR_ALIVE_STEP("%[a3]", "%[ao3]", "%[crg3]", "%[cbd3]", "%[sv]")
+                 "s_cmp_eq_u64 %[alive], 0\n\t"
+                 "s_cmov_b32 %[lim], 0"
+                 : "+{v[92:93]}"(Tp), [rg] "+v"(acc_rg), [bd] "+v"(acc_bd), [alive] "+s"(alive), [tmp] "=&s"(tmp),
+                   [lim] "+s"(limit)
+                 : [a0] "v"(b.araw[0]), [ao0] "v"(b.ao[0]), [crg0] "v"(crg0), [cbd0] "v"(cbd0),
+                   [a1] "v"(b.araw[1]), [ao1] "v"(b.ao[1]), [crg1] "v"(crg1), [cbd1] "v"(cbd1),
+                   [a2] "v"(b.araw[2]), [ao2] "v"(b.ao[2]), [crg2] "v"(crg2), [cbd2] "v"(cbd2),
+                   [a3] "v"(b.araw[3]), [ao3] "v"(b.ao[3]), [crg3] "v"(crg3), [cbd3] "v"(cbd3),
+                   [sv] "s"(saved)
+                 : "vcc", "scc", "v94", "v95");  // (s_xor / s_andn2 write SCC)
+}
+
 // survivor number `rank` of the round -> its half of pair rank / 2 (layout: see s_list in render_stream_kernel)
 __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, float4 geo, float4 conic_op, float4 rgbd,
                                                 float pos) {
@@ -459,7 +532,7 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
 // wave composites exactly the depth-ordered list of its 16 x 16 tile and the image is bit-identical.  final_T /
 // n_contrib (read by the backward only) are not written.
 template <bool SUPER>
-__global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ point_list,
                                                                   const float4 *__restrict__ splat, int W, int H, int gx,
                                                                   int num_tiles, const uint32_t *__restrict__ tile_order,
@@ -630,6 +703,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_stream_kernel(const uint2 *_
             // of wave masks: +6 us, costs an occupancy step; batches of 2 / 8.)
             // (Evaluating batch i + 1 ahead of the blend of batch i -- one basic block, ping-pong registers -- was
             // measured: +17 % replay time; the loop is bound by instruction count, not by exposed latency.)
+#if GSR_STREAM_MASKED_BLEND && GSR_STREAM_ALIVE_BLEND
+            if (SUPER && unsafe == 0ull) {
+                // (the finished state moves from T's sign into a wave mask for the round and back: the rounds with an
+                // unsafe conic, and the exit test at the top of the round, read the sign)
+                uint64_t alive = __builtin_amdgcn_ballot_w64(T > 0.0f);
+                v2f Tp = {T, 0.0f};
+                int i = 0;
+                // (one scalar compare per batch decides the loop: the blend's last instructions drop `limit` to 0 once no
+                // lane is alive -- `i < n_surv && alive != 0` went through eight scalar instructions per batch)
+                int limit = n_surv;
+                const uint64_t full = __builtin_amdgcn_read_exec();
+                if (n_surv > 0) do {
+                    const StreamBatch b = stream_eval<false, false>(list, i, pf2x, pf2y);
+                    stream_blend_alive(b, Tp, acc_rg, acc_bd, alive, limit, full);
+                    work += (uint32_t)kBatch;
+                    i += kBatch;
+                } while (i < limit);
+                asm volatile("v_cndmask_b32_e64 %0, -|%1|, %1, %2" : "=v"(T) : "v"(Tp.x), "s"(alive));
+            } else
+#endif
             if (unsafe == 0ull) {
                 // (one exit test, at the bottom: with a second exit at the top the accumulators were copied through
                 // six v_mov per iteration)

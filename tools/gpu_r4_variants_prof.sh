@@ -10,7 +10,7 @@ for round in 1 2; do
 for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
   name=$(basename $lib .so); name=${name#libgsr_hip.}
   cp $lib gsworld_amd/libgsr_hip.so
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pv_$name -o k -- python $REPO/tools/prof_scene.py --frames 300 "$@" > $OUT/pv_$name.log 2>&1)
+  (cd /tmp && timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pv_$name -o k -- python $REPO/tools/prof_scene.py --frames 300 "$@" > $OUT/pv_$name.log 2>&1)
   f=$(find $OUT/pv_$name -name "*kernel_stats.csv" | head -1)
   echo "== $name round $round: $(python - "$f" <<'PY'
 import csv, sys
