@@ -272,7 +272,8 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         extras = secondary_measurements(args, dev, raw, name, (means, shs, op, sc, rot),
-                                        (m_means, m_shs, m_op, m_sc, m_rot, lay), bg)
+                                        (m_means, m_shs, m_op, m_sc, m_rot, lay), bg,
+                                        lane_streams if S > 1 else None)
     # strictly one frame at a time (hipGraph replay of one lane), for the line's config: the figure a caller sees who
     # needs frame k before it can ask for frame k + 1
     one_fps = None
@@ -459,7 +460,7 @@ def _time_frames(torch, enqueue, steps, warmup=10):
     return steps / (time.perf_counter() - t0)
 
 
-def secondary_measurements(args, dev, raw, name, model, laid, bg):
+def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=None):
     """SURVEY.md 8d's second numbers, N = 1 only, outside the headline's timed region, each a few hundred frames:
     * dense_view: the same scene and N from a camera that sees V = 0.6 N of it (8d's worked example; right_cam sees 0.12 N);
     * upstream_packing: the rasterizer figure INCLUDING what upstream render() does per frame before it
@@ -504,13 +505,51 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg):
     f = _time_frames(torch, g.replay, steps)
     if rd.ensure_valid(fr).overflow:
         raise SystemExit("dense view: capacity overflow")
+    # the same view the way the headline is measured: one frame per lane in flight on the headline's streams.  One frame
+    # at a time the dense compositor ends with a few quadrants alone on the chip (a wave is a latency chain: 220 cycles
+    # per unit of work alone against 76 when five share a SIMD, profiles/round4/NOTES_compositor_scheduling.md); with
+    # other frames in flight that tail is filled
+    f_lanes = None
+    if lane_streams:
+        S = len(lane_streams)
+        rds = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
+        outs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S)]
+        fns = [(lambda l=l: rds[l].render(cam_d, l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg,
+                                          rgb8_out=outs[l], layout=lay)) for l in range(S)]
+        graphs = []
+        for l in range(S):
+            for _ in range(2):
+                fns[l]()
+                rds[l].ensure_valid(fns[l])
+            lane_streams[l].wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(lane_streams[l]):
+                fns[l]()
+            torch.cuda.synchronize(dev)
+            gl = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gl, stream=lane_streams[l]):
+                fns[l]()
+            graphs.append(gl)
+        torch.cuda.synchronize(dev)
+        k = [0]
+
+        def enqueue_lane():
+            with torch.cuda.stream(lane_streams[k[0] % S]):
+                graphs[k[0] % S].replay()
+            k[0] += 1
+
+        f_lanes = _time_frames(torch, enqueue_lane, steps, warmup=4 * S)
+        if any(r_.ensure_valid(fn_).overflow for r_, fn_ in zip(rds, fns)):
+            raise SystemExit("dense view (lanes): capacity overflow")
+        del graphs, rds, outs
     rt = FrameRenderer(dev)  # N, V, R of the byte model: the reference's per-tile pipeline (one default frame)
     rt.render(cam_d, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, exact=True)
     st = rt.stats()
     del rt
     b_alg = st.algorithmic_bytes(W, H)
     out["dense_view"] = {
-        "frames_per_s": f, "frames_in_flight": 1, "num_visible": st.num_visible, "num_rendered": st.num_rendered,
+        "frames_per_s": f, "frames_in_flight": 1,
+        "frames_per_s_headline_lanes": f_lanes, "headline_lanes": len(lane_streams) if lane_streams else None,
+        "num_visible": st.num_visible, "num_rendered": st.num_rendered,
         "visible_fraction": st.num_visible / st.num_gaussians, "algorithmic_bytes_per_frame": b_alg,
         "frac_of_8TBs": b_alg * f / 1e9 / HBM_PEAK_GBS,
         "workload": f"same {st.num_gaussians} Gaussians, camera 1.5 m above the table centre looking down "

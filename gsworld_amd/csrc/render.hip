@@ -303,7 +303,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_queue_kernel(const uint2 *__
 // (48 B per survivor per wave) stays below the VALU time.  Which tiles share a CU is decided by their cost in the
 // previous frame on the same renderer state (quad_work, tile_starts_kernel).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kStreamLanesItems = 1;                              // candidates per lane per round (A/B: 1 ~ 2 > 3;
+#ifndef GSR_STREAM_ITEMS
+#define GSR_STREAM_ITEMS 1
+#endif
+constexpr int kStreamLanesItems = GSR_STREAM_ITEMS;                              // candidates per lane per round (A/B: 1 ~ 2 > 3;
                                                                   // 1 halves the LDS list: 13 KiB per workgroup)
 constexpr int kStreamRound = kStreamLanesItems * GSR_WAVE;        // 64 candidates per round
 constexpr int kStreamList = kStreamRound + kBatch;                // survivors + zero padding of the last batch

@@ -84,6 +84,8 @@ def main():
             tot["batches"] += (len(sv) + 3) // 4
             per_q_surv.append(len(sv)); per_q_rounds.append(rounds)
     s = np.array(per_q_surv); r = np.array(per_q_rounds)
+    if os.environ.get("CENSUS_NPZ"):
+        np.savez_compressed(os.environ["CENSUS_NPZ"], surv=s, rounds=r)  # (index = 4 * tile + quadrant)
     out = dict(view=view, **{k: int(v) for k, v in tot.items()},
                surv_per_quadrant_mean=float(s.mean()), surv_per_quadrant_p99=float(np.percentile(s, 99)),
                surv_per_quadrant_max=int(s.max()), rounds_per_quadrant_mean=float(r.mean()),

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/r4; export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r4; REPO=$PWD
 cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
-for round in 1 2; do
+for round in $(seq 1 ${ROUNDS:-2}); do
 for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
   name=$(basename $lib .so); name=${name#libgsr_hip.}
   cp $lib gsworld_amd/libgsr_hip.so
