@@ -317,7 +317,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GSR_STREAM_MASKED_BLEND 1   // 0: the select-based blend everywhere (A/B)
 #endif
 #ifndef GSR_STREAM_ALIVE_BLEND
-#define GSR_STREAM_ALIVE_BLEND 2    // 0: stream_blend_masked (finished pixels carried in T's sign, round 4's first version)
+#define GSR_STREAM_ALIVE_BLEND 1    // 0: stream_blend_masked (finished pixels carried in T's sign, round 4's first version)
 #endif
 #ifndef GSR_STREAM_STAMPS
 #define GSR_STREAM_STAMPS 0   // 1: tuning build that leaves per-quadrant cycle stamps in the image state
@@ -449,32 +449,17 @@ __device__ __forceinline__ void stream_blend_masked(const StreamBatch &b, float 
 // T (1 - alpha).  Here
 //   * `alive` (an SGPR pair) holds the lanes that still composite; every survivor starts from EXEC = alive;
 //   * v_cmpx narrows EXEC to the lanes the survivor touches (alpha >= 1/255), ONE packed multiply (alpha, 1 - alpha) x T
-//     gives the weight and test_T, a second v_cmpx narrows EXEC to the lanes that go on (not test_T < 1e-4): T and the
-//     four accumulators are updated in those only, and the lanes that stopped (touched, not going on) leave `alive` by
-//     two scalar instructions.  A lane that stops keeps the T it had, as the reference's `break` does.
-// 6 VALU per survivor (+ 1 for 1 - alpha) against 8 (+ 1/2); the scalar work rides in the shadow of the other waves'
-// VALU issue.  The same IEEE operations on the same operands in every lane that matters: bit-identical (tests:
-// forward_only frames against default frames, compositing variants).  T lives in v92 (the low half of the pinned pair
-// v[92:93]: the packed multiply wants a register pair, the update a single register); v94 / v95 = weight | test_T.
-#if GSR_STREAM_ALIVE_BLEND == 1
-// (first version: both tests as v_cmpx, the stopped lanes = touched ^ going-on: five scalar instructions per survivor)
-#define GSR_ALIVE_STEP(A, AO, CRG, CBD, NEXT)                                                                        \
-    "v_cmpx_le_f32 0x3b808081, " A "\n\t"                              /* EXEC = VCC = alive & 1/255 <= alpha */       \
-    "s_mov_b64 %[tmp], vcc\n\t"                                                                                       \
-    "v_pk_mul_f32 v[94:95], " AO ", v[92:93] op_sel_hi:[1,0]\n\t"      /* alpha T | (1 - alpha) T */                   \
-    "v_cmpx_ngt_f32 0x38d1b717, v95\n\t"                               /* EXEC = VCC = touched & !(test_T < 1e-4) */   \
-    "v_mov_b32 v92, v95\n\t"                                                                                          \
-    "v_pk_fma_f32 %[rg], " CRG ", v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"                                              \
-    "v_pk_fma_f32 %[bd], " CBD ", v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"                                              \
-    "s_xor_b64 %[tmp], %[tmp], vcc\n\t"                                /* touched and stopped */                       \
-    "s_andn2_b64 %[alive], %[alive], %[tmp]\n\t"                                                                      \
-    "s_mov_b64 exec, " NEXT "\n\t"
-#else
-// EXEC = alive on entry; leaves EXEC = NEXT (alive for the next survivor, the saved mask behind the last one).
-// Scalar instructions are not free on this chip (tools/scratch/ubench.hip, 5 waves per SIMD: one costs ~0.7 of a plain
-// VALU instruction's issue time, a packed fp32 one 1.8, v_exp_f32 5.1), hence three of them per survivor, not five:
-// the saturation test is a plain v_cmp whose VCC (= the touched lanes that stop; 0 in inactive lanes) leaves `alive` and
-// EXEC by one s_andn2 each.
+//     gives the weight and test_T, a plain v_cmp leaves the touched lanes that stop (test_T < 1e-4; 0 in inactive
+//     lanes) in VCC, and one s_andn2 each takes them out of `alive` and of EXEC: T and the four accumulators are updated
+//     in the lanes that go on only.  A lane that stops keeps the T it had, as the reference's `break` does.
+// 6 VALU + 3 scalar instructions per survivor (+ 1 VALU for 1 - alpha) against 8 + 1 (+ 1/2).  Scalar instructions are
+// not free on this chip (tools/ubench_issue.hip, profiles/round4/ubench_issue.txt; 5 waves per SIMD: one costs ~0.7 of a
+// plain VALU instruction's issue time, a packed fp32 one 1.8, v_exp_f32 5.1) -- a first version with both tests as v_cmpx
+// and the stopped lanes as touched ^ going-on took five and gained half as much.  The same IEEE operations on the same
+// operands in every lane that matters: bit-identical (tests: forward_only frames against default frames, compositing
+// variants).  T lives in v92 (the low half of the pinned pair v[92:93]: the packed multiply wants a register pair, the
+// update a single register); v94 / v95 = weight | test_T.
+// A step expects EXEC = alive and leaves EXEC = NEXT (alive for the next survivor, the saved mask behind the last one).
 #define GSR_ALIVE_STEP(A, AO, CRG, CBD, NEXT)                                                                        \
     "v_cmpx_le_f32 0x3b808081, " A "\n\t"                              /* EXEC = alive & 1/255 <= alpha */             \
     "v_pk_mul_f32 v[94:95], " AO ", v[92:93] op_sel_hi:[1,0]\n\t"      /* alpha T | (1 - alpha) T */                   \
@@ -485,7 +470,6 @@ __device__ __forceinline__ void stream_blend_masked(const StreamBatch &b, float 
     "v_pk_fma_f32 %[rg], " CRG ", v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"                                              \
     "v_pk_fma_f32 %[bd], " CBD ", v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"                                              \
     "s_mov_b64 exec, " NEXT "\n\t"
-#endif
 __device__ __forceinline__ void stream_blend_alive(const StreamBatch &b, v2f &Tp, v2f &acc_rg, v2f &acc_bd,
                                                    uint64_t &alive, int &limit, const uint64_t saved) {
     static_assert(kBatch == 4, "the block below takes four survivors");
@@ -493,7 +477,6 @@ __device__ __forceinline__ void stream_blend_alive(const StreamBatch &b, v2f &Tp
     const v2f crg1 = {b.col[1].x, b.col[1].y}, cbd1 = {b.col[1].z, b.col[1].w};
     const v2f crg2 = {b.col[2].x, b.col[2].y}, cbd2 = {b.col[2].z, b.col[2].w};
     const v2f crg3 = {b.col[3].x, b.col[3].y}, cbd3 = {b.col[3].z, b.col[3].w};
-    uint64_t tmp;
     asm volatile("s_mov_b64 exec, %[alive]\n\t"
                  GSR_ALIVE_STEP("%[a0]", "%[ao0]", "%[crg0]", "%[cbd0]", "%[alive]")
                  GSR_ALIVE_STEP("%[a1]", "%[ao1]", "%[crg1]", "%[cbd1]", "%[alive]")
@@ -501,14 +484,13 @@ __device__ __forceinline__ void stream_blend_alive(const StreamBatch &b, v2f &Tp
                  GSR_ALIVE_STEP("%[a3]", "%[ao3]", "%[crg3]", "%[cbd3]", "%[sv]")
                  "s_cmp_eq_u64 %[alive], 0\n\t"
                  "s_cmov_b32 %[lim], 0"
-                 : "+{v[92:93]}"(Tp), [rg] "+v"(acc_rg), [bd] "+v"(acc_bd), [alive] "+s"(alive), [tmp] "=&s"(tmp),
-                   [lim] "+s"(limit)
+                 : "+{v[92:93]}"(Tp), [rg] "+v"(acc_rg), [bd] "+v"(acc_bd), [alive] "+s"(alive), [lim] "+s"(limit)
                  : [a0] "v"(b.araw[0]), [ao0] "v"(b.ao[0]), [crg0] "v"(crg0), [cbd0] "v"(cbd0),
                    [a1] "v"(b.araw[1]), [ao1] "v"(b.ao[1]), [crg1] "v"(crg1), [cbd1] "v"(cbd1),
                    [a2] "v"(b.araw[2]), [ao2] "v"(b.ao[2]), [crg2] "v"(crg2), [cbd2] "v"(cbd2),
                    [a3] "v"(b.araw[3]), [ao3] "v"(b.ao[3]), [crg3] "v"(crg3), [cbd3] "v"(cbd3),
                    [sv] "s"(saved)
-                 : "vcc", "scc", "v94", "v95");  // (s_xor / s_andn2 write SCC)
+                 : "vcc", "scc", "v94", "v95");  // (s_andn2 / s_cmp write SCC)
 }
 
 // survivor number `rank` of the round -> its half of pair rank / 2 (layout: see s_list in render_stream_kernel)
