@@ -89,6 +89,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 : "+{v[92:93]}"(Tp), [rg] "+v"(p), [bd] "+v"(q)
                 : [a] "v"(ao.x), [ao] "v"(ao), [crg] "v"(r), [cbd] "v"(s), [sv] "s"(full) : "vcc", "v94", "v95");
             Tp.x = 1.0f;
+        } else if (V == 11) {
+            // the committed blend x 4: v_cmpx, pk_mul, v_cmp, 2 s_andn2, v_mov, 2 pk_fma, s_mov exec
+            asm volatile("s_mov_b64 exec, %[alive]\n\t" REP4(
+                "v_cmpx_le_f32 0x3b808081, %[a]\n\t"
+                "v_pk_mul_f32 v[94:95], %[ao], v[92:93] op_sel_hi:[1,0]\n\t"
+                "v_cmp_gt_f32 vcc, 0x38d1b717, v95\n\t"
+                "s_andn2_b64 %[alive], %[alive], vcc\n\t"
+                "s_andn2_b64 exec, exec, vcc\n\t"
+                "v_mov_b32 v92, v95\n\t"
+                "v_pk_fma_f32 %[rg], %[crg], v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %[bd], %[cbd], v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"
+                "s_mov_b64 exec, %[alive]\n\t")
+                "s_mov_b64 exec, %[sv]\n\t"
+                : "+{v[92:93]}"(Tp), [rg] "+v"(p), [bd] "+v"(q), [alive] "+s"(alive)
+                : [a] "v"(ao.x), [ao] "v"(ao), [crg] "v"(r), [cbd] "v"(s), [sv] "s"(full) : "vcc", "scc", "v94", "v95");
+            Tp.x = 1.0f; alive = ~0ull;
+        } else if (V == 12) {
+            // the same with a branch around the two s_andn2 (no lane stops: the common case)
+            asm volatile("s_mov_b64 exec, %[alive]\n\t" REP4(
+                "v_cmpx_le_f32 0x3b808081, %[a]\n\t"
+                "v_pk_mul_f32 v[94:95], %[ao], v[92:93] op_sel_hi:[1,0]\n\t"
+                "v_cmp_gt_f32 vcc, 0x38d1b717, v95\n\t"
+                "s_cbranch_vccz 1f\n\t"
+                "s_andn2_b64 %[alive], %[alive], vcc\n\t"
+                "s_andn2_b64 exec, exec, vcc\n\t"
+                "1:\n\t"
+                "v_mov_b32 v92, v95\n\t"
+                "v_pk_fma_f32 %[rg], %[crg], v[94:95], %[rg] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %[bd], %[cbd], v[94:95], %[bd] op_sel_hi:[1,0,1]\n\t"
+                "s_mov_b64 exec, %[alive]\n\t")
+                "s_mov_b64 exec, %[sv]\n\t"
+                : "+{v[92:93]}"(Tp), [rg] "+v"(p), [bd] "+v"(q), [alive] "+s"(alive)
+                : [a] "v"(ao.x), [ao] "v"(ao), [crg] "v"(r), [cbd] "v"(s), [sv] "s"(full) : "vcc", "scc", "v94", "v95");
+            Tp.x = 1.0f; alive = ~0ull;
+        } else if (V == 13) {
+            // T updated in place by the packed multiply (T in v93, weight in v92): no v_mov (valid when T's last value is not read)
+            asm volatile("s_mov_b64 exec, %[alive]\n\t" REP4(
+                "v_cmpx_le_f32 0x3b808081, %[a]\n\t"
+                "v_pk_mul_f32 v[92:93], %[ao], v[92:93] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                "v_cmp_gt_f32 vcc, 0x38d1b717, v93\n\t"
+                "s_andn2_b64 %[alive], %[alive], vcc\n\t"
+                "s_andn2_b64 exec, exec, vcc\n\t"
+                "v_pk_fma_f32 %[rg], %[crg], v[92:93], %[rg] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %[bd], %[cbd], v[92:93], %[bd] op_sel_hi:[1,0,1]\n\t"
+                "s_mov_b64 exec, %[alive]\n\t")
+                "s_mov_b64 exec, %[sv]\n\t"
+                : "+{v[92:93]}"(Tp), [rg] "+v"(p), [bd] "+v"(q), [alive] "+s"(alive)
+                : [a] "v"(ao.x), [ao] "v"(ao), [crg] "v"(r), [cbd] "v"(s), [sv] "s"(full) : "vcc", "scc");
+            Tp.y = 1.0f; alive = ~0ull;
         } else if (V == 10) {
             // 6 plain VALU x 4 (reference for 8 / 9)
             asm volatile(REP4("v_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %1, %2, %3, %1\n\tv_fma_f32 %0, %1, %2, %0\n\tv_fma_f32 %1, %2, %3, %1\n\tv_pk_fma_f32 %4, %5, %6, %4\n\tv_pk_fma_f32 %5, %6, %4, %5\n\t")
@@ -119,13 +168,13 @@ int main() {
     hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice);
     const int iters = 20000;
     const char *names[] = {"32 v_fma", "32 v_pk_fma", "48 v_fma", "24 fma + 8 exp", "24 fma + 8 cmpx + 4 s_mov exec", "24 fma + 8 v_cmp", "32 fma + 32 salu",
-                           "old blend x4 (32 VALU)", "new blend x4 (24 VALU + 20 SALU)", "new blend x4, no salu bookkeeping", "24 plain VALU"};
-    float ms[11];
+                           "old blend x4 (32 VALU)", "new blend x4 (24 VALU + 20 SALU)", "new blend x4, no salu bookkeeping", "24 plain VALU", "committed blend x4 (24 VALU + 13 SALU)", "committed blend + branch around s_andn2", "in-place T (20 VALU + 13 SALU)"};
+    float ms[14];
     ms[0] = run<0>(out, in, iters); ms[1] = run<1>(out, in, iters); ms[2] = run<2>(out, in, iters); ms[3] = run<3>(out, in, iters);
     ms[4] = run<4>(out, in, iters); ms[5] = run<5>(out, in, iters); ms[6] = run<6>(out, in, iters); ms[7] = run<7>(out, in, iters);
-    ms[8] = run<8>(out, in, iters); ms[9] = run<9>(out, in, iters); ms[10] = run<10>(out, in, iters);
+    ms[8] = run<8>(out, in, iters); ms[9] = run<9>(out, in, iters); ms[10] = run<10>(out, in, iters); ms[11] = run<11>(out, in, iters); ms[12] = run<12>(out, in, iters); ms[13] = run<13>(out, in, iters);
     // 5 waves per SIMD: cycles per iteration per SIMD = ms * clk / iters; per wave-instruction slot: / (5 * n)
-    for (int v = 0; v < 11; v++)
+    for (int v = 0; v < 14; v++)
         printf("%-40s %8.3f ms  -> %7.1f ns per iteration of 5 waves = %6.1f cycles @2.4GHz per wave-iteration\n", names[v], ms[v],
                ms[v] * 1e6 / iters, ms[v] * 1e6 / iters * 2.4 / 5.0);
     return 0;
