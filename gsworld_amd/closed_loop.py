@@ -343,7 +343,13 @@ class PipelinedClosedLoop:
     enqueues next may read them; poses handed over as DEVICE tensors are read after what the current stream has already
     enqueued (a GPU simulator).  Both are stream dependencies, never host synchronisations; but a current stream that
     waits for step k and then produces the poses of step k + 1 chains the steps together again -- hand host (pinned)
-    poses over, or ``wait=False`` and :meth:`wait_for` before reading, to keep them apart."""
+    poses over, or ``wait=False`` and :meth:`wait_for` before reading, to keep them apart.
+
+    Reading a step's frames: enqueue the reads (or a clone) on the stream that waited for them BEFORE the next call of
+    :meth:`step`.  That call marks the consumer stream, and the step that reuses the loop -- ``depth`` calls later, on
+    another stream -- waits for the mark before it overwrites the frames (write-after-read across streams: the step's
+    own stream knows nothing of the caller's reads).  The mark is taken before the consumer stream is made to wait for
+    the NEW step, so it orders against the reads only and consecutive steps still overlap."""
 
     def __init__(self, raw, part_labels: dict, cameras: dict, depth: int = 2, **kw):
         if depth < 1:
@@ -354,6 +360,8 @@ class PipelinedClosedLoop:
         self.device = first.device
         self.streams = [torch.cuda.Stream(self.device) for _ in self.loops]
         self._events = [None] * depth
+        self._released = [None] * depth   # per loop: event on its consumer stream, recorded behind the reads of its frames
+        self._consumer = [None] * depth   # per loop: the stream that was made to wait for its last step (None: nobody yet)
         self._k = 0
 
     @property
@@ -371,6 +379,8 @@ class PipelinedClosedLoop:
             out = out if out is not None else f
         torch.cuda.synchronize(self.device)
         self._k = 0
+        self._released = [None] * len(self.loops)
+        self._consumer = [None] * len(self.loops)
         return out
 
     def capture(self):
@@ -384,6 +394,16 @@ class PipelinedClosedLoop:
         self._k += 1
         loop, st = self.loops[i], self.streams[i]
         cur = torch.cuda.current_stream(self.device)
+        for j, consumer in enumerate(self._consumer):
+            if consumer is not None:
+                # whatever the caller has enqueued behind those frames on the stream that was made to wait for them
+                rel = torch.cuda.Event()
+                rel.record(consumer)
+                self._released[j] = rel
+                self._consumer[j] = None
+        if self._released[i] is not None:  # this loop's frames were handed out `depth` steps ago: their readers first
+            st.wait_event(self._released[i])
+            self._released[i] = None
         on_device = any(isinstance(t, torch.Tensor) and t.is_cuda for t in (matrices, scales)) or \
             any(c.world_view_transform.is_cuda for c in (cameras or {}).values())
         if on_device:
@@ -395,15 +415,17 @@ class PipelinedClosedLoop:
         self._events[i] = ev
         if wait:
             cur.wait_event(ev)
+            self._consumer[i] = cur
         return frames
 
     def wait_for(self, frames: dict | None = None, stream=None):
         """Makes ``stream`` (default: current) wait for the step that produced ``frames`` (default: every step enqueued so
         far)."""
         stream = stream if stream is not None else torch.cuda.current_stream(self.device)
-        for loop, ev in zip(self.loops, self._events):
+        for i, (loop, ev) in enumerate(zip(self.loops, self._events)):
             if ev is not None and (frames is None or frames is loop.frames):
                 stream.wait_event(ev)
+                self._consumer[i] = stream
 
     def overflow_frames(self) -> int:
         return sum(loop.overflow_frames() for loop in self.loops)

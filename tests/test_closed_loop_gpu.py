@@ -358,3 +358,34 @@ def test_pipelined_loop_gives_the_plain_loop_s_frames(cuda_device):
             for n in w:
                 assert torch.equal(g[n], w[n]), f"graph={graph} step {k + 1} {n}"
         assert pipe.overflow_frames() == 0
+
+
+def test_pipelined_loop_does_not_overwrite_frames_that_are_still_being_read(cuda_device):
+    """Write-after-read across streams: the consumer stream reads step k's frames LATE (a spin kernel sits in front of the
+    clone) while steps k + 1 and k + 2 are enqueued at once; with depth 2, step k + 2 renders into the buffers of step k on
+    another stream and has to wait for that read."""
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("torch.cuda._sleep not available")
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=60_000, seed=11)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align")}
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=6, seed=3))
+    plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
+    plain.reset(*poses[0])
+    want = plain.step(*poses[1])["right_cam"].clone()
+    other = plain.step(*poses[3])["right_cam"].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(want, other), "the arm did not move between the steps: the test proves nothing"
+    pipe = cl.PipelinedClosedLoop(raw, parts, cams, depth=2, scaled_parts=actors, device=dev)
+    pipe.reset(*poses[0])
+    pipe.capture()
+    f = pipe.step(poses[1][0].pin_memory(), poses[1][1].pin_memory())   # the current stream waits for step 1 ...
+    torch.cuda._sleep(200_000_000)                                       # ... and gets to its read ~0.1 s later
+    late = f["right_cam"].clone()
+    pipe.step(poses[2][0].pin_memory(), poses[2][1].pin_memory(), wait=False)
+    pipe.step(poses[3][0].pin_memory(), poses[3][1].pin_memory(), wait=False)  # same loop as step 1
+    torch.cuda.synchronize()
+    assert torch.equal(late, want)
+    assert torch.equal(pipe.loops[0].frames["right_cam"], other)
