@@ -125,6 +125,23 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
+    settings, inp, out, buf, _keep = _frame_structs(
+        settings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh,
+        campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer, sh_rest=sh_rest,
+        param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=forward_only, layout=layout)
+    stats = GsrFrameStats()
+    with torch.cuda.device(dev):
+        check(lib().gsr_forward(C.byref(settings), C.byref(inp), C.byref(out), C.byref(buf), C.c_int64(r_capacity),
+                                C.byref(stats) if want_stats else None, _stream(dev)))
+    return stats
+
+
+def _frame_structs(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
+                   viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
+                   imgBuffer, sh_rest=None, param_space: int = 0, rgb8_out=None, parts=None,
+                   forward_only: bool | None = False, layout=None):
+    """The four argument structs of one frame (include/gsr.h) from tensors; the fifth value keeps the resize callbacks
+    alive while the structs are in use."""
     settings.forward_only = int(bool(forward_only))
     _lib.apply_tuning(settings, allow_forward_only=forward_only is not None)
     inp = GsrInputs(
@@ -149,11 +166,54 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
                      _ptr(rgb8_out) if rgb8_out is not None else None)
     cbs = (_resizer(geomBuffer, header=True), _resizer(binningBuffer), _resizer(imgBuffer))
     buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
-    stats = GsrFrameStats()
+    return settings, inp, out, buf, cbs
+
+
+def forward_batch_raw(frames, device=None):
+    """B frames of one step through gsr_forward_batch: one set of launches whose grids span the frames (include/gsr.h;
+    GSWorld's per-step double loop over cameras and environments, gs_world_wrapper.py:238-267).  ``frames``: a list of
+    dicts with the keyword arguments of :func:`forward_raw` (``settings`` ... ``imgBuffer``, ``r_capacity`` > 0 for the
+    frames that are to share launches, no ``want_stats``: nothing is read back).  Enqueued on the current stream of the
+    frames' device; returns nothing -- ``gsr_frame_stats`` on a frame's geometry state tells V / R / overflow."""
+    if not frames:
+        return
+    dev = frames[0]["means3D"].device if device is None else device
+    B = len(frames)
+    if _ext is not None and hasattr(_ext, "forward_batch"):
+        e = torch.empty(0, device=dev)
+        ei = torch.empty(0, dtype=torch.int32, device=dev)
+        eb = torch.empty(0, dtype=torch.uint8, device=dev)
+        packed = []
+        for f in frames:
+            st, parts, layout = f["settings"], f.get("parts"), f.get("layout")
+            o = lambda k, d=e: f.get(k) if f.get(k) is not None else d  # noqa: E731
+            packed.append((
+                st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.scale_modifier, st.sh_degree, st.sh_coeffs,
+                bool(st.antialiasing), bool(st.debug), st.near_plane, f["background"], f["means3D"], o("colors"),
+                f["opacity"], o("scales"), o("rotations"), o("cov3D_precomp"), f["viewmatrix"], f["projmatrix"],
+                o("sh"), o("sh_rest"), f["campos"], f["out_color"], f["out_invdepth"], o("radii", ei), f["geomBuffer"],
+                f["binningBuffer"], f["imgBuffer"], o("rgb8_out", eb), int(f.get("r_capacity", 0)),
+                int(f.get("param_space", 0)), _tuning_list(f.get("forward_only", False)),
+                parts[0] if parts is not None else e, parts[1] if parts is not None else ei,
+                parts[2] if parts is not None else e,
+                parts[3] if (parts is not None and parts[3] is not None) else eb,
+                layout[0] if layout is not None else e,
+                layout[1] if (layout is not None and layout[1] is not None) else ei))
+        _ext.forward_batch(packed)
+        return
+    built, caps = [], (C.c_int64 * B)()
+    for k, f in enumerate(frames):
+        f = dict(f)
+        caps[k] = int(f.pop("r_capacity", 0))
+        f.pop("want_stats", None)
+        built.append(_frame_structs(**f))
+    St = (GsrSettings * B)(*[b[0] for b in built])
+    In = (GsrInputs * B)(*[b[1] for b in built])
+    Out = (GsrOutputs * B)(*[b[2] for b in built])
+    Buf = (GsrBuffers * B)(*[b[3] for b in built])
     with torch.cuda.device(dev):
-        check(lib().gsr_forward(C.byref(settings), C.byref(inp), C.byref(out), C.byref(buf), C.c_int64(r_capacity),
-                                C.byref(stats) if want_stats else None, _stream(dev)))
-    return stats
+        check(lib().gsr_forward_batch(B, St, In, Out, Buf, caps, _stream(dev)))
+    del built  # (the resize callbacks had to outlive the call)
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,

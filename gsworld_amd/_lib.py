@@ -18,6 +18,7 @@ GSR_E_HIP = -2
 GSR_E_ALLOC = -3
 GSR_E_OVERFLOW = -4
 GSR_NEAR_PLANE = 0.05  # /root/reference/README.md:33
+MAX_FRAMES_PER_LAUNCH = 8  # include/gsr.h GSR_MAX_FRAMES_PER_LAUNCH
 
 
 class GsrSettings(C.Structure):
@@ -156,6 +157,9 @@ def lib() -> C.CDLL:
     L.gsr_forward.restype = C.c_int
     L.gsr_forward.argtypes = [C.POINTER(GsrSettings), C.POINTER(GsrInputs), C.POINTER(GsrOutputs),
                               C.POINTER(GsrBuffers), C.c_int64, C.POINTER(GsrFrameStats), C.c_void_p]
+    L.gsr_forward_batch.restype = C.c_int
+    L.gsr_forward_batch.argtypes = [C.c_int32, C.POINTER(GsrSettings), C.POINTER(GsrInputs), C.POINTER(GsrOutputs),
+                                    C.POINTER(GsrBuffers), C.POINTER(C.c_int64), C.c_void_p]
     L.gsr_frame_stats.restype = C.c_int
     L.gsr_frame_stats.argtypes = [C.c_void_p, C.POINTER(GsrFrameStats), C.c_void_p]
     L.gsr_debug_sort_state.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]

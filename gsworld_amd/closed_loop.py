@@ -33,7 +33,7 @@ from .renderer import MultiCameraRenderer
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
-                 layout: bool = True, min_capacity: int | None = None, share_model_of=None):
+                 layout: bool = True, min_capacity: int | None = None, share_model_of=None, batched: bool = True):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -58,7 +58,10 @@ class ClosedLoopRenderer:
         frames, bit for bit (tests/test_layout_gpu.py, tests/test_closed_loop_gpu.py).
         ``share_model_of``: another loop over the SAME model on the same device whose (laid-out) model tensors this one
         reads instead of making its own copy (:class:`PipelinedClosedLoop`); everything per step -- poses, cameras,
-        renderer states, frames, graph -- stays its own."""
+        renderer states, frames, graph -- stays its own.
+        ``batched`` (default): the E x C frames of a step go through ``gsr_forward_batch`` -- one set of launches on the
+        step's stream whose grids span the frames -- instead of one pipeline per frame on its own stream
+        (:class:`gsworld_amd.renderer.MultiCameraRenderer`); same frames bit for bit (tests/test_batch_gpu.py)."""
         self.device = torch.device(device)
         dev = self.device
         self.num_envs = int(num_envs)
@@ -129,7 +132,7 @@ class ClosedLoopRenderer:
             bound_capacity = lanes * per_lane <= min(free // 4, 64 << 30)
         self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, growth=growth,
                                          min_capacity=(2 * int(self.xyz.shape[0]) if min_capacity is None else int(min_capacity)),
-                                         bound_capacity=bool(bound_capacity), overflow_mirror=True)
+                                         bound_capacity=bool(bound_capacity), overflow_mirror=True, batched=batched)
         self.recovered_steps = 0      # steps re-rendered because a lane had overflowed (see step())
         self.late_overflow_frames = 0  # overflowed frames that were only noticed after their step had been returned
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)

@@ -145,78 +145,99 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
     return GSR_OK;
 }
 
-int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out, const GsrBuffers *buf,
-                int64_t r_capacity, GsrFrameStats *stats, void *stream_) {
-    if (int e = validate(st, in, out, buf)) return e;
-    hipStream_t stream = (hipStream_t)stream_;
-    const bool debug = st->debug != 0;
-    const int W = st->image_width, H = st->image_height;
-    if (stats) memset(stats, 0, sizeof(*stats));
-    const int tiles = gsr_div_up(W, GSR_TILE) * gsr_div_up(H, GSR_TILE);
+}  // extern "C"
 
-    if (in->P == 0) {
-        // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
-        const size_t n = (size_t)W * H;
-        if (hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess ||
-            hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess ||
-            (out->out_rgb8 && hipMemsetAsync(out->out_rgb8, 0, 3 * n, stream) != hipSuccess)) {
-            gsr_set_error("gsr_forward: hipMemsetAsync(outputs) failed");
-            return GSR_E_HIP;
-        }
-        return GSR_OK;
-    }
+namespace {
+
+// How one frame runs: everything gsr_forward decides from the settings, the image size and the inputs before it touches
+// the device.  Frames with equal plans (and equal P / image size) can share their launches (gsr_forward_batch).
+struct Plan {
+    int W, H, tiles, tiles_x, tiles_y;
+    int mode;          // 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
+    bool chunk, band;  // which counting placement
+    bool exact;        // binning state sized from a read-back of num_rendered
+    bool infer, super, lean, order_early, lean_bin;
+    GsrSettings st_bin;  // the settings with the super-tile grid as image (inference frames on the default path)
+};
+
+int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Plan &p) {
+    p.W = st->image_width;
+    p.H = st->image_height;
+    p.tiles_x = gsr_div_up(p.W, GSR_TILE);
+    p.tiles = p.tiles_x * gsr_div_up(p.H, GSR_TILE);
+    p.tiles_y = p.tiles / p.tiles_x;
     if (r_capacity > 0xFFFFFFFFll) {
         gsr_set_error("gsr_forward: r_capacity exceeds 32-bit instance offsets");
         return GSR_E_INVALID;
     }
-
-    const int tiles_x = gsr_div_up(W, GSR_TILE);
     // binning path: 1 = depth sort + counting placement (default), 2 = bin-then-sort, 0 = depth sort + radix
     // (tile grids above GSR_MAX_COUNT_TILES, or wider than 2048 tiles -- one band row of counters must fit 64 KiB of
     // LDS -- always take 0)
     // GsrSettings.binning_path: 0 = default (mode 1, by tile rows where the grid allows), 1 = radix (mode 0),
     // 2 = bin-then-sort (mode 2), 3 = mode 1 by chunks of 256 depth ranks (round 1's counting placement)
     const int want = (st->binning_path == 0 || st->binning_path >= 3) ? 1 : (st->binning_path == 1 ? 0 : 2);
-    const int mode = GeomState::counting(tiles) && tiles_x <= 2048 ? want : 0;
+    p.mode = GeomState::counting(p.tiles) && p.tiles_x <= 2048 ? want : 0;
     // 4 = placement by chunks of the depth order (chunkplace.hip); grids it does not take fall back to the band placement
-    const bool chunk = mode == 1 && st->binning_path == 4 && gsr_chunk_supported(tiles_x, tiles / tiles_x);
-    const bool band = mode == 1 && (st->binning_path == 0 || (st->binning_path == 4 && !chunk)) &&
-                      gsr_band_supported(tiles_x);
-    const bool exact = r_capacity <= 0;
+    p.chunk = p.mode == 1 && st->binning_path == 4 && gsr_chunk_supported(p.tiles_x, p.tiles / p.tiles_x);
+    p.band = p.mode == 1 && (st->binning_path == 0 || (st->binning_path == 4 && !p.chunk)) &&
+             gsr_band_supported(p.tiles_x);
+    p.exact = r_capacity <= 0;
     // inference frames (GsrSettings.forward_only): binned per super-tile on the default path; the binning kernels take
     // their grid from a settings copy whose image is the super-tile grid
-    const int tiles_y = tiles / tiles_x;
     // infer: preprocess writes nothing a backward would read (the depth / radius words of the record carry tau / the
     // tile rect instead, which only the super-tile compositor looks at).  super: lists per super-tile -- needs the
     // compositor that has every quadrant resident and its order computed early (grids up to 1536 tiles on 256 CUs), and
     // tile coordinates that fit a byte; larger images keep per-tile lists.
-    const bool infer = st->forward_only != 0 && (band || chunk) && st->depth_sort != 1;
-    const bool super = infer && st->render_variant == 0 && tiles_x <= 255 && tiles_y <= 255 &&
-                       gsr_render_uses_quad_order(*st, tiles) && gsr_render_split_blocks(*st, tiles) == 0;
+    p.infer = st->forward_only != 0 && (p.band || p.chunk) && st->depth_sort != 1;
+    p.super = p.infer && st->render_variant == 0 && p.tiles_x <= 255 && p.tiles_y <= 255 &&
+              gsr_render_uses_quad_order(*st, p.tiles) && gsr_render_split_blocks(*st, p.tiles) == 0;
     // (the chunk placement keeps its table in an array the lean layout drops)
-    const bool lean = infer && !chunk;
-    GsrSettings st_bin = *st;
-    if (super) {
-        st_bin.image_width = gsr_div_up(tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
-        st_bin.image_height = gsr_div_up(tiles_y, 1 << GSR_SUPER_SY) * GSR_TILE;
+    p.lean = p.infer && !p.chunk;
+    p.st_bin = *st;
+    if (p.super) {
+        p.st_bin.image_width = gsr_div_up(p.tiles_x, 1 << GSR_SUPER_SX) * GSR_TILE;
+        p.st_bin.image_height = gsr_div_up(p.tiles_y, 1 << GSR_SUPER_SY) * GSR_TILE;
     }
-    if (in->orig_index != nullptr && !(infer && mode == 1)) {
+    if (in->orig_index != nullptr && !(p.infer && p.mode == 1)) {
         gsr_set_error("gsr_forward: orig_index (a permuted model) needs a forward_only frame on the default sort / "
                       "placement path");
         return GSR_E_INVALID;
     }
-    char *geom_mem = buf->geom_resize(buf->geom_user, GeomState::required(in->P, tiles, tiles_x, lean));
-    char *img_mem = buf->image_resize(buf->image_user, ImageState::required(W, H));
-    if (!geom_mem || !img_mem) {
-        gsr_set_error("gsr_forward: resize callback returned NULL");
-        return GSR_E_ALLOC;
-    }
-    const GeomState g = GeomState::carve(geom_mem, in->P, tiles, nullptr, tiles_x, lean);
-    const ImageState img = ImageState::carve(img_mem, W, H);
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
-    const bool order_early = (band || chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, tiles);
-    // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
-    const uint32_t cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity;
+    p.order_early = (p.band || p.chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, p.tiles);
+    // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
+    p.lean_bin = p.band || p.chunk;
+    return GSR_OK;
+}
+
+// B frames through one set of launches.  B > 1: the caller (gsr_forward_batch) has checked that every frame takes the
+// default path (sample sort + band placement + stream compositor) in no-sync mode with the same plan, P and image size.
+int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out, const GsrBuffers *buf,
+               const int64_t *r_capacity, const Plan *plans, GsrFrameStats *stats, hipStream_t stream) {
+    const Plan &p = plans[0];
+    const bool debug = st[0].debug != 0;
+    const int mode = p.mode;
+    const bool chunk = p.chunk, band = p.band, exact = p.exact, infer = p.infer, super = p.super;
+    GsrFrame fr[GSR_MAX_BATCH];
+    for (int k = 0; k < B; k++) {
+        GsrFrame &f = fr[k];
+        f.st = &st[k];
+        f.st_bin = &plans[k].st_bin;
+        f.in = &in[k];
+        f.out = &out[k];
+        char *geom_mem = buf[k].geom_resize(buf[k].geom_user, GeomState::required(in[k].P, p.tiles, p.tiles_x, p.lean));
+        char *img_mem = buf[k].image_resize(buf[k].image_user, ImageState::required(p.W, p.H));
+        if (!geom_mem || !img_mem) {
+            gsr_set_error("gsr_forward: resize callback returned NULL");
+            return GSR_E_ALLOC;
+        }
+        f.g = GeomState::carve(geom_mem, in[k].P, p.tiles, nullptr, p.tiles_x, p.lean);
+        f.img = ImageState::carve(img_mem, p.W, p.H);
+        // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
+        f.cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity[k];
+    }
+    const GeomState &g = fr[0].g;
+    const ImageState &img = fr[0].img;
 
     if (mode == 2) {
         // header + per-tile totals are adjacent and both accumulated by preprocess; the overflow count at the header's
@@ -230,39 +251,36 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
         }
     }
     prof_mark(0, stream);
-    if (int e = gsr_launch_preprocess(*st, *in, out->radii, g, mode == 2, infer, stream)) return e;
+    if (int e = gsr_launch_preprocess(B, fr, mode == 2, infer, stream)) return e;
     if (int e = gsr_check_launch("preprocess", debug, stream)) return e;
     prof_mark(1, stream);
     if (mode != 2) {
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
-        if (st->depth_sort == 1) {
-            if (int e = gsr_launch_compact_and_depth_sort(in->P, g, debug, stream)) return e;
+        if (st[0].depth_sort == 1) {
+            if (int e = gsr_launch_compact_and_depth_sort(in[0].P, g, debug, stream)) return e;
             if (band || chunk)
-                if (int e = gsr_launch_gather_rects(in->P, g, debug, stream)) return e;
+                if (int e = gsr_launch_gather_rects(in[0].P, g, debug, stream)) return e;
         } else {
-            if (int e = gsr_launch_sample_depth_sort(in->P, g, in->viewmatrix,
-                                                     order_early ? img.quad_work : (const uint32_t *)nullptr,
-                                                     4 * tiles, img.quad_order, super ? 1 : 0,
-                                                     in->orig_index, debug, stream))
+            if (int e = gsr_launch_sample_depth_sort(B, fr, p.order_early, 4 * p.tiles, super ? 1 : 0, debug, stream))
                 return e;
         }
     }
     prof_mark(2, stream);
     if (mode == 2) {
-        if (int e = gsr_launch_bin_starts(*st, g, img, cap32, debug, stream)) return e;
+        if (int e = gsr_launch_bin_starts(st[0], g, img, fr[0].cap32, debug, stream)) return e;
     } else if (chunk) {
-        if (int e = gsr_launch_chunk_count(st_bin, in->P, g, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(st_bin, g, img, cap32, order_early, debug, stream)) return e;
+        if (int e = gsr_launch_chunk_count(p.st_bin, in[0].P, g, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(1, fr, p.order_early, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_count(st_bin, in->P, g, st->depth_sort != 1, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(st_bin, g, img, cap32, order_early, debug, stream)) return e;
+        if (int e = gsr_launch_band_count(B, fr, st[0].depth_sort != 1, debug, stream)) return e;
+        if (int e = gsr_launch_tile_starts(B, fr, p.order_early, debug, stream)) return e;
     } else if (mode == 1) {
-        if (int e = gsr_launch_tile_count(*st, in->P, g, img, cap32, debug, stream)) return e;
+        if (int e = gsr_launch_tile_count(st[0], in[0].P, g, img, fr[0].cap32, debug, stream)) return e;
     } else {
-        if (int e = gsr_launch_tile_offsets(in->P, g, cap32, debug, stream)) return e;
+        if (int e = gsr_launch_tile_offsets(in[0].P, g, fr[0].cap32, debug, stream)) return e;
     }
     prof_mark(3, stream);
-    int64_t cap = r_capacity;
+    int64_t cap0 = r_capacity[0];
     if (exact) {
         GsrHeader h;
         if (hipMemcpyAsync(&h, g.hdr, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -270,7 +288,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             gsr_set_error("gsr_forward: header read-back failed: %s", hipGetErrorString(hipGetLastError()));
             return GSR_E_HIP;
         }
-        cap = h.R_raw;
+        cap0 = h.R_raw;
         if (stats) {
             stats->num_visible = h.V;
             stats->num_rendered = h.R_raw;
@@ -278,33 +296,106 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
             stats->overflow_frames = h.of_magic == GSR_OF_MAGIC ? (int32_t)h.overflow_frames : 0;
         }
     }
-    // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
-    const bool lean_bin = band || chunk;
-    char *bin_mem = buf->binning_resize(buf->binning_user, BinningState::required(cap, lean_bin));
-    if (!bin_mem) {
-        gsr_set_error("gsr_forward: binning resize callback returned NULL");
-        return GSR_E_ALLOC;
+    for (int k = 0; k < B; k++) {
+        const int64_t cap = k == 0 ? cap0 : r_capacity[k];
+        char *bin_mem = buf[k].binning_resize(buf[k].binning_user, BinningState::required(cap, p.lean_bin));
+        if (!bin_mem) {
+            gsr_set_error("gsr_forward: binning resize callback returned NULL");
+            return GSR_E_ALLOC;
+        }
+        fr[k].b = BinningState::carve(bin_mem, cap, nullptr, p.lean_bin);
     }
-    const BinningState b = BinningState::carve(bin_mem, cap, nullptr, lean_bin);
+    const BinningState &b = fr[0].b;
     if (mode == 2) {
-        if (int e = gsr_launch_bin_scatter_and_sort(*st, in->P, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_bin_scatter_and_sort(st[0], in[0].P, g, b, img, debug, stream)) return e;
     } else if (chunk) {
-        if (int e = gsr_launch_chunk_place(st_bin, in->P, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_chunk_place(p.st_bin, in[0].P, g, b, img, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_place(st_bin, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_band_place(B, fr, debug, stream)) return e;
     } else if (mode == 1) {
-        if (int e = gsr_launch_tile_place(*st, in->P, g, b, img, debug, stream)) return e;
+        if (int e = gsr_launch_tile_place(st[0], in[0].P, g, b, img, debug, stream)) return e;
     } else {
-        if (int e = gsr_launch_emit_and_tile_sort(*st, in->P, g, b, img, cap, debug, stream)) return e;
+        if (int e = gsr_launch_emit_and_tile_sort(st[0], in[0].P, g, b, img, cap0, debug, stream)) return e;
     }
     prof_mark(4, stream);
     // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
-    if (int e = gsr_launch_render(*st, g, b.gidx[0], img, in->background, out->out_color, out->out_invdepth,
-                                  out->out_rgb8, mode != 0, mode == 1, super, stream))
-        return e;
+    if (int e = gsr_launch_render(B, fr, mode != 0, mode == 1, super, stream)) return e;
     prof_mark(5, stream);
     prof_end_frame();
     return gsr_check_launch("render", debug, stream);
+}
+
+int zero_outputs(const GsrSettings *st, const GsrOutputs *out, hipStream_t stream) {
+    // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
+    const size_t n = (size_t)st->image_width * st->image_height;
+    if (hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess ||
+        hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess ||
+        (out->out_rgb8 && hipMemsetAsync(out->out_rgb8, 0, 3 * n, stream) != hipSuccess)) {
+        gsr_set_error("gsr_forward: hipMemsetAsync(outputs) failed");
+        return GSR_E_HIP;
+    }
+    return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out, const GsrBuffers *buf,
+                int64_t r_capacity, GsrFrameStats *stats, void *stream_) {
+    if (int e = validate(st, in, out, buf)) return e;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (in->P == 0) return zero_outputs(st, out, stream);
+    Plan p;
+    if (int e = make_plan(st, in, r_capacity, p)) return e;
+    return run_frames(1, st, in, out, buf, &r_capacity, &p, stats, stream);
+}
+
+// B frames (include/gsr.h).  Runs of consecutive frames that take the default path in no-sync mode with the same model
+// size, image size and selectors share their launches, GSR_MAX_BATCH at most per set; every other frame runs by itself,
+// exactly as gsr_forward would run it.
+int gsr_forward_batch(int32_t B, const GsrSettings *st, const GsrInputs *in, const GsrOutputs *out,
+                      const GsrBuffers *buf, const int64_t *r_capacity, void *stream_) {
+    if (B < 0 || (B > 0 && (!st || !in || !out || !buf || !r_capacity))) {
+        gsr_set_error("gsr_forward_batch: null argument array or negative B");
+        return GSR_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int k = 0; k < B; k++)
+        if (int e = validate(&st[k], &in[k], &out[k], &buf[k])) return e;
+    Plan plans[GSR_MAX_BATCH];
+    auto shares = [&](int a, int b, const Plan &pa, const Plan &pb) {
+        const GsrSettings &x = st[a], &y = st[b];
+        return in[a].P == in[b].P && pa.W == pb.W && pa.H == pb.H && pa.mode == pb.mode && pa.band == pb.band &&
+               pa.infer == pb.infer && pa.super == pb.super && pa.lean == pb.lean && pa.order_early == pb.order_early &&
+               x.sh_degree == y.sh_degree && x.sh_coeffs == y.sh_coeffs && x.debug == y.debug &&
+               x.render_variant == y.render_variant && x.render_blocks_per_cu == y.render_blocks_per_cu &&
+               x.render_split == y.render_split && x.depth_sort == y.depth_sort &&
+               (in[a].colors_precomp == nullptr) == (in[b].colors_precomp == nullptr);
+    };
+    int k = 0;
+    while (k < B) {
+        if (in[k].P == 0) {
+            if (int e = zero_outputs(&st[k], &out[k], stream)) return e;
+            k++;
+            continue;
+        }
+        if (int e = make_plan(&st[k], &in[k], r_capacity[k], plans[0])) return e;
+        int n = 1;
+        // (what can share launches: the default path -- sample sort, band placement, stream compositor -- with a
+        //  capacity; an exact-mode frame reads its instance count back in the middle of the frame)
+        const bool batchable = plans[0].mode == 1 && plans[0].band && st[k].depth_sort != 1 && !plans[0].exact &&
+                               st[k].render_variant == 0;
+        while (batchable && n < GSR_MAX_BATCH && k + n < B && in[k + n].P != 0 && r_capacity[k + n] > 0) {
+            if (int e = make_plan(&st[k + n], &in[k + n], r_capacity[k + n], plans[n])) return e;
+            if (!shares(k, k + n, plans[0], plans[n])) break;
+            n++;
+        }
+        if (int e = run_frames(n, st + k, in + k, out + k, buf + k, r_capacity + k, plans, nullptr, stream)) return e;
+        k += n;
+    }
+    return GSR_OK;
 }
 
 int gsr_profile_enable(int mode) {

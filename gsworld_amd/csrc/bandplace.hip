@@ -51,7 +51,7 @@ constexpr int kMaxSegments = 4;
 constexpr uint32_t kCutsMagic = 0x43555453u;  // 'CUTS'
 constexpr uint32_t kCutsMaxAge = 15u;
 
-__global__ __launch_bounds__(kBT) void band_ranges_kernel(GsrHeader *__restrict__ hdr, int bmax,
+__device__ __forceinline__ void band_ranges_body(GsrHeader *__restrict__ hdr, int bmax,
                                                           const uint32_t *__restrict__ bucket_start,
                                                           const uint32_t *__restrict__ bucket_tiles,
                                                           const uint32_t *__restrict__ tile_cum, int waves,
@@ -139,7 +139,7 @@ constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (70
 // Counting needs no order at all: a pair adds +1 at its first column and -1 behind its last one; the running sum over
 // the columns is the number of pairs covering each.  Two LDS atomics per pair, per-wave difference arrays.
 template <int NC>
-__global__ __launch_bounds__(kBT) void band_count_kernel(const uint2 *__restrict__ rect_sorted,
+__device__ __forceinline__ void band_count_body(const uint2 *__restrict__ rect_sorted,
                                                          const uint32_t *__restrict__ wave_lo, int gx, int NR,
                                                          uint32_t *__restrict__ table, uint32_t *__restrict__ wtable) {
     __shared__ int s_diff[kBW][NC * 64 + 1];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBT) void band_count_kernel(const uint2 *__restrict
 }
 
 // exclusive scan of every tile's NR (<= 64) entries by one wave; totals[t] = instances of tile t
-__global__ __launch_bounds__(kBT) void band_scan_kernel(uint32_t *__restrict__ table, int T,
+__device__ __forceinline__ void band_scan_body(uint32_t *__restrict__ table, int T,
                                                         uint32_t *__restrict__ totals) {
     constexpr int PL = (GSR_BAND_RANGES + GSR_WAVE - 1) / GSR_WAVE;  // consecutive entries per lane
     const int t = (int)blockIdx.x * kBW + gsr_wave();
@@ -289,7 +289,7 @@ __device__ __forceinline__ void band_place_round(uint32_t span, uint32_t g, bool
 constexpr int kPlaceBatch = 6;
 
 template <int NC>
-__global__ __launch_bounds__(kBT, 8) void band_place_kernel(const uint2 *__restrict__ rect_sorted,
+__device__ __forceinline__ void band_place_body(const uint32_t seg, const uint2 *__restrict__ rect_sorted,
                                                          const uint32_t *__restrict__ order,
                                                          const GsrHeader *__restrict__ hdr,
                                                          const uint32_t *__restrict__ wave_lo, int gx, int NR,
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBT, 8) void band_place_kernel(const uint2 *__restr
     __shared__ uint32_t s_cur[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
     if (hdr->overflow) return;
-    const uint32_t r = blockIdx.x, y = blockIdx.y, seg = blockIdx.z;
+    const uint32_t r = blockIdx.x, y = blockIdx.y;
     const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
     if (lo >= hi) return;
     uint2 *ring = s_ring[wave];
@@ -402,6 +402,43 @@ __global__ __launch_bounds__(kBT, 8) void band_place_kernel(const uint2 *__restr
     }
 }
 
+// ---- the four kernels with B frames per launch: the frame's argument block by blockIdx.y (ranges, scan) or, where the
+// grid already uses y for the tile row, by blockIdx.z (count: z = frame; place: z = 4 x frame + column segment) --------
+struct BandArgs {
+    GsrHeader *hdr;
+    int bmax;
+    const uint32_t *bucket_start, *bucket_tiles, *tile_cum;  // (tile_cum nullptr: equal rank shares)
+    int waves;
+    uint32_t *wave_lo, *wave_lo_base;
+    uint32_t sig;
+    const uint2 *rect_sorted;
+    int gx, NR, T;
+    uint32_t *table, *wtable, *totals;
+    const uint32_t *order;
+    const uint2 *ranges;
+    uint32_t *point_list;
+};
+
+__global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.y];
+    band_ranges_body(a.hdr, a.bmax, a.bucket_start, a.bucket_tiles, a.tile_cum, a.waves, a.wave_lo, a.wave_lo_base, a.sig);
+}
+template <int NC>
+__global__ __launch_bounds__(kBT) void band_count_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.z];
+    band_count_body<NC>(a.rect_sorted, a.wave_lo, a.gx, a.NR, a.table, a.wtable);
+}
+__global__ __launch_bounds__(kBT) void band_scan_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.y];
+    band_scan_body(a.table, a.T, a.totals);
+}
+template <int NC>
+__global__ __launch_bounds__(kBT, 8) void band_place_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.z / (uint32_t)kMaxSegments];
+    band_place_body<NC>(blockIdx.z % (uint32_t)kMaxSegments, a.rect_sorted, a.order, a.hdr, a.wave_lo, a.gx, a.NR, a.table,
+                        a.wtable, a.ranges, a.point_list);
+}
+
 // depth-ordered rects for depth sorts that do not write them themselves (the LSD radix variant)
 __global__ __launch_bounds__(kBT) void gather_rects_kernel(const uint32_t *__restrict__ order,
                                                            const uint2 *__restrict__ rects,
@@ -422,44 +459,67 @@ int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream
     return gsr_check_launch("gather_rects", debug, stream);
 }
 
+static void band_args(int B, const GsrFrame *fr, bool balanced, bool place, GsrBatch<BandArgs> &bt) {
+    for (int k = 0; k < B; k++) {
+        const GeomState &g = fr[k].g;
+        const GsrSettings &st = *fr[k].st_bin;
+        BandArgs &a = bt.f[k];
+        const int32_t P = fr[k].in->P;
+        a.hdr = g.hdr;
+        a.bmax = gsr_ss_bmax(P);
+        a.bucket_start = g.ss_bucket_start;
+        a.bucket_tiles = g.bucket_tiles;
+        a.tile_cum = balanced ? g.tile_cum : (const uint32_t *)nullptr;
+        a.waves = GSR_BAND_RANGES * kBW;
+        a.wave_lo = g.wave_lo;
+        a.wave_lo_base = g.wave_lo_base;
+        // (model size and state layout the kept cuts belong to: see gsr_launch_sample_depth_sort)
+        a.sig = (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.wave_lo_base - (char *)g.hdr);
+        a.rect_sorted = g.rect_sorted;
+        a.gx = gsr_div_up(st.image_width, GSR_TILE);
+        a.NR = GSR_BAND_RANGES;
+        a.T = a.gx * gsr_div_up(st.image_height, GSR_TILE);
+        a.table = g.band_table;
+        a.wtable = g.band_wtable;
+        a.totals = g.tile_totals;
+        a.order = g.order;
+        a.ranges = fr[k].img.ranges;
+        a.point_list = place ? fr[k].b.gidx[0] : (uint32_t *)nullptr;
+    }
+}
+
 // counts -> ranges, R (tile_starts_kernel lives in binning.hip)
-int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
-                          hipStream_t stream) {
+int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, hipStream_t stream) {
+    const GsrSettings &st = *fr[0].st_bin;
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    const dim3 grid(GSR_BAND_RANGES, gy);
-    hipLaunchKernelGGL(band_ranges_kernel, dim3(1), dim3(kBT), 0, stream, g.hdr, gsr_ss_bmax(P), g.ss_bucket_start,
-                       g.bucket_tiles, balanced ? g.tile_cum : (const uint32_t *)nullptr, GSR_BAND_RANGES * kBW,
-                       g.wave_lo, g.wave_lo_base,
-                       // (model size and state layout the kept cuts belong to: see gsr_launch_sample_depth_sort)
-                       (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.wave_lo_base - (char *)g.hdr));
+    GsrBatch<BandArgs> bt;
+    band_args(B, fr, balanced, false, bt);
+    const dim3 grid(GSR_BAND_RANGES, gy, B);
+    hipLaunchKernelGGL(band_ranges_kernel, dim3(1, B), dim3(kBT), 0, stream, bt);
     if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
-        hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
-                           g.band_table, g.band_wtable);
+        hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, bt);
     else if (gx <= 128)
-        hipLaunchKernelGGL(band_count_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
-                           g.band_table, g.band_wtable);
+        hipLaunchKernelGGL(band_count_kernel<2>, grid, dim3(kBT), 0, stream, bt);
     else
-        hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.wave_lo, gx, GSR_BAND_RANGES,
-                           g.band_table, g.band_wtable);
+        hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, bt);
     if (int e = gsr_check_launch("band_count", debug, stream)) return e;
     const int T = gx * gy;
-    hipLaunchKernelGGL(band_scan_kernel, dim3(gsr_div_up(T, kBW)), dim3(kBT), 0, stream, g.band_table, T, g.tile_totals);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(gsr_div_up(T, kBW), B), dim3(kBT), 0, stream, bt);
     return gsr_check_launch("band_scan", debug, stream);
 }
 
-int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
-                          bool debug, hipStream_t stream) {
+int gsr_launch_band_place(int B, const GsrFrame *fr, bool debug, hipStream_t stream) {
+    const GsrSettings &st = *fr[0].st_bin;
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    const dim3 grid(GSR_BAND_RANGES, gy, kMaxSegments);
+    GsrBatch<BandArgs> bt;
+    band_args(B, fr, true, true, bt);
+    const dim3 grid(GSR_BAND_RANGES, gy, kMaxSegments * B);
     if (gx <= 64)
-        hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
-                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+        hipLaunchKernelGGL(band_place_kernel<1>, grid, dim3(kBT), 0, stream, bt);
     else if (gx <= 128)
-        hipLaunchKernelGGL(band_place_kernel<2>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
-                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+        hipLaunchKernelGGL(band_place_kernel<2>, grid, dim3(kBT), 0, stream, bt);
     else
-        hipLaunchKernelGGL(band_place_kernel<4>, grid, dim3(kBT), 0, stream, g.rect_sorted, g.order, g.hdr, g.wave_lo, gx,
-                           GSR_BAND_RANGES, g.band_table, g.band_wtable, img.ranges, b.gidx[0]);
+        hipLaunchKernelGGL(band_place_kernel<4>, grid, dim3(kBT), 0, stream, bt);
     return gsr_check_launch("band_place", debug, stream);
 }

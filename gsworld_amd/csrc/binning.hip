@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NW * GSR_WAVE) void tile_count_kernel(const uint32_
 }
 
 // one workgroup: totals[T] -> ranges, R; untouched tiles keep (0,0) like the reference's memset
-__global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *__restrict__ totals, int T,
+__device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ totals, int T,
                                                                 GsrHeader *hdr, uint32_t r_capacity,
                                                                 uint2 *__restrict__ ranges,
                                                                 uint32_t *__restrict__ tile_order,
@@ -395,6 +395,26 @@ __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const uint32_t *
     if (tile_order == nullptr || keyed) return;
     __syncthreads();  // this workgroup's range stores are visible to all of its threads
     gsr_tile_order_block(ranges, T, tile_order, s_bins, s_w, quad_work);
+}
+
+// grid = (1 .. 3 workgroups, frames): blockIdx.y picks the frame's argument block (gsr_internal.h GsrBatch)
+struct TileStartsArgs {
+    const uint32_t *totals;
+    int T;
+    GsrHeader *hdr;
+    uint32_t r_capacity;
+    uint2 *ranges;
+    uint32_t *tile_order, *cursor_to_zero;
+    const uint32_t *quad_work, *quad_work_b;
+    uint32_t *split_flag, *split_list, *split_count;
+    int split_cap;
+    uint32_t *quad_order;
+    int cus_per_xcd;
+};
+__global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const GsrBatch<TileStartsArgs> bt) {
+    const TileStartsArgs &a = bt.f[blockIdx.y];
+    tile_starts_body(a.totals, a.T, a.hdr, a.r_capacity, a.ranges, a.tile_order, a.cursor_to_zero, a.quad_work,
+                     a.quad_work_b, a.split_flag, a.split_list, a.split_count, a.split_cap, a.quad_order, a.cus_per_xcd);
 }
 
 template <int NW>
@@ -607,21 +627,46 @@ int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, 
     return gsr_launch_tile_starts(st, g, img, r_capacity, false, debug, stream);
 }
 
-// per-tile totals -> ranges, R, capacity check, compositing order (shared by the two counting placements)
-int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
-                           bool order_done, bool debug, hipStream_t stream) {
+// per-tile totals -> ranges, R, capacity check, compositing order (shared by the counting placements)
+int gsr_launch_tile_starts(int B, const GsrFrame *fr, bool order_done, bool debug, hipStream_t stream) {
+    const GsrSettings &st = *fr[0].st_bin;
     const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
     const int split_blocks = T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
+    GsrBatch<TileStartsArgs> bt;
+    for (int k = 0; k < B; k++) {
+        const GeomState &g = fr[k].g;
+        const ImageState &img = fr[k].img;
+        TileStartsArgs &a = bt.f[k];
+        a.totals = g.tile_totals;
+        a.T = T;
+        a.hdr = g.hdr;
+        a.r_capacity = fr[k].cap32;
+        a.ranges = img.ranges;
+        a.tile_order = !order_done && gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr;
+        a.cursor_to_zero = nullptr;
+        a.quad_work = img.quad_work;
+        a.quad_work_b = img.quad_work_b;
+        a.split_flag = img.split_flag;
+        a.split_list = img.split_list;
+        a.split_count = img.split_count;
+        a.split_cap = split_blocks * (GSR_BLOCK / GSR_WAVE);
+        a.quad_order = !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr;
+        a.cus_per_xcd = gsr_render_cus_per_xcd();
+    }
     // (order_done: the compositing order was computed earlier in the frame, beside the depth sort's partition pass)
-    hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : (order_done ? 1 : 2)), dim3(GSR_BLOCK), 0, stream,
-                       g.tile_totals, T, g.hdr, r_capacity, img.ranges,
-                       !order_done && gsr_render_wants_tile_order(st, T) ? img.tile_order : (uint32_t *)nullptr,
-                       (uint32_t *)nullptr,
-                       (const uint32_t *)img.quad_work, (const uint32_t *)img.quad_work_b, img.split_flag,
-                       img.split_list, img.split_count, split_blocks * (GSR_BLOCK / GSR_WAVE),
-                       !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr,
-                       gsr_render_cus_per_xcd());
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : (order_done ? 1 : 2), B), dim3(GSR_BLOCK), 0, stream,
+                       bt);
     return gsr_check_launch("tile_starts", debug, stream);
+}
+int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
+                           bool order_done, bool debug, hipStream_t stream) {
+    GsrFrame f{};
+    f.st = &st;
+    f.st_bin = &st;
+    f.g = g;
+    f.img = img;
+    f.cap32 = r_capacity;
+    return gsr_launch_tile_starts(1, &f, order_done, debug, stream);
 }
 
 // default path, part 2: write the point list (tile-major, depth order, index order on ties)

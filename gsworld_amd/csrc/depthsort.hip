@@ -184,7 +184,7 @@ __device__ __forceinline__ void lds_radix_pass(const uint32_t *kin, const uint32
 // records are written as (index, key): the 64-bit little-endian view is key << 32 | index, the composite the
 // global-memory fallback of ss_buckets sorts.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw, int bmax,
+__device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bmax,
                                                         const uint2 *__restrict__ block_recs,
                                                         const uint32_t *__restrict__ block_counts,
                                                         const uint32_t *__restrict__ block_cand,
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kT) void ss_compact_kernel(int P, int nb1, int bpw,
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kColT = 1024;  // 16 waves: 256 rows are one batch of 16 loads per lane and pass
 
-__global__ __launch_bounds__(kColT) void ss_colscan_kernel(int bmax, int nbc, uint32_t *__restrict__ table,
+__device__ __forceinline__ void ss_colscan_body(int bmax, int nbc, uint32_t *__restrict__ table,
                                                            uint32_t *__restrict__ totals,
                                                            const GsrHeader *__restrict__ hdr) {
     constexpr int NWV = kColT / GSR_WAVE;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kColT) void ss_colscan_kernel(int bmax, int nbc, ui
 // ---------------------------------------------------------------------------------------------------------
 // ss_partition: bucket starts from the histogram rows, then the stable move of this workgroup's segment.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 *__restrict__ in,
+__device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restrict__ in,
                                                           uint2 *__restrict__ out, const uint32_t *__restrict__ table,
                                                           const uint32_t *__restrict__ totals,
                                                           const uint32_t *__restrict__ splitters,
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(int bmax, const uint2 
 // ---------------------------------------------------------------------------------------------------------
 // ss_buckets: one workgroup per bucket.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restrict__ recs, uint2 *__restrict__ scratch,
+__device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ recs, uint2 *__restrict__ scratch,
                                                         const uint32_t *__restrict__ bucket_start,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ splitters,
                                                         const uint2 *__restrict__ rects, uint2 *__restrict__ rect_sorted,
@@ -1023,6 +1023,48 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(int bmax, uint2 *__restr
     SS_STAMP(dbg, 4);
 }
 
+// ---- the four kernels: grid = (workgroups of one frame, frames); blockIdx.y picks the frame's argument block ----------
+struct SsArgs {
+    int P, nb1, bpw, bmax, nbc;
+    uint2 *pair0, *pair1;           // compacted records | block-local records, then the bucketed ones
+    const uint32_t *block_counts, *block_cand;
+    uint32_t *table, *splitters, *splitters_new, *seg, *totals, *bucket_start;
+    GsrHeader *hdr;
+    uint64_t *dbg;
+    const float *view;
+    uint32_t sig;
+    const uint32_t *quad_work;      // (nullptr: no spare workgroup in the partition pass)
+    int num_quads;
+    uint32_t *quad_order;
+    int cus_per_xcd;
+    uint32_t *order;
+    const uint2 *rects;
+    uint2 *rect_sorted;
+    uint32_t *tile_cum, *bucket_tiles;
+    int sshift;
+    const int32_t *orig;
+};
+
+__global__ __launch_bounds__(kT) void ss_compact_kernel(const GsrBatch<SsArgs> bt) {
+    const SsArgs &a = bt.f[blockIdx.y];
+    ss_compact_body(a.P, a.nb1, a.bpw, a.bmax, a.pair1, a.block_counts, a.block_cand, a.pair0, a.table, a.splitters,
+                    a.splitters_new, a.seg, a.hdr, a.dbg, a.view, a.sig);
+}
+__global__ __launch_bounds__(kColT) void ss_colscan_kernel(const GsrBatch<SsArgs> bt) {
+    const SsArgs &a = bt.f[blockIdx.y];
+    ss_colscan_body(a.bmax, a.nbc, a.table, a.totals, a.hdr);
+}
+__global__ __launch_bounds__(kT) void ss_partition_kernel(const GsrBatch<SsArgs> bt) {
+    const SsArgs &a = bt.f[blockIdx.y];
+    ss_partition_body(a.bmax, a.pair0, a.pair1, a.table, a.totals, a.splitters, a.splitters_new, a.seg, a.bucket_start,
+                      a.hdr, a.dbg, a.nbc, a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd);
+}
+__global__ __launch_bounds__(kT) void ss_buckets_kernel(const GsrBatch<SsArgs> bt) {
+    const SsArgs &a = bt.f[blockIdx.y];
+    ss_buckets_body(a.bmax, a.pair1, a.pair0, a.bucket_start, a.order, a.splitters, a.rects, a.rect_sorted, a.tile_cum,
+                    a.bucket_tiles, a.hdr, a.dbg, a.view, a.sig, a.sshift, a.orig);
+}
+
 }  // namespace
 
 // geometry of the sample sort for P Gaussians: compaction workgroups, preprocess blocks per workgroup, bucket capacity
@@ -1040,32 +1082,44 @@ int gsr_ss_bmax(int32_t P) {
 }
 
 // preprocess left the block-local records (pair[1]) / block_counts / block_cand; the sorted depth order ends in g.order
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, int super_shift, const int32_t *orig_index,
+// (order_early: a spare workgroup of the partition pass also deals the num_quads quadrants of the frame's compositor
+//  -> img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
+int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
                                  bool debug, hipStream_t stream) {
+    const int32_t P = fr[0].in->P;
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
+    GsrBatch<SsArgs> bt;
+    for (int k = 0; k < B; k++) {
+        const GeomState &g = fr[k].g;
+        SsArgs &a = bt.f[k];
+        a.P = P; a.nb1 = nb1; a.bpw = bpw; a.bmax = bmax; a.nbc = nbc;
+        a.pair0 = g.pair[0]; a.pair1 = g.pair[1];
+        a.block_counts = g.block_counts; a.block_cand = g.block_cand;
+        a.table = g.ss_table; a.splitters = g.ss_splitters; a.splitters_new = g.ss_splitters_new; a.seg = g.ss_seg;
+        a.totals = g.ss_totals; a.bucket_start = g.ss_bucket_start;
+        a.hdr = g.hdr; a.dbg = g.ss_dbg; a.view = fr[k].in->viewmatrix;
+        // what a kept splitter table is valid for: this model size AND this state layout (a buffer the allocator hands
+        // back can carry a plausible header of another layout over arrays that have moved: a lean inference state after a
+        // full one took a zero-filled "table" blind once, and one bucket of 175 k records went through the global-memory
+        // sort)
+        a.sig = (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.ss_splitters - (char *)g.hdr);
+        a.quad_work = order_early ? fr[k].img.quad_work : (const uint32_t *)nullptr;
+        a.num_quads = num_quads;
+        a.quad_order = fr[k].img.quad_order;
+        a.cus_per_xcd = gsr_render_cus_per_xcd();
+        a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
+        a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
+    }
     const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
-    // what a kept splitter table is valid for: this model size AND this state layout (a buffer the allocator hands back
-    // can carry a plausible header of another layout over arrays that have moved: a lean inference state after a full
-    // one took a zero-filled "table" blind once, and one bucket of 175 k records went through the global-memory sort)
-    const uint32_t sig = (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.ss_splitters - (char *)g.hdr);
-    hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc), dim3(kT), lds1, stream, P, nb1, bpw, bmax, g.pair[1],
-                       g.block_counts, g.block_cand, g.pair[0], g.ss_table, g.ss_splitters, g.ss_splitters_new, g.ss_seg, g.hdr,
-                       g.ss_dbg, viewmatrix, sig);
+    hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc, B), dim3(kT), lds1, stream, bt);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
-    hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE)), dim3(kColT), 0, stream, bmax, nbc, g.ss_table,
-                       g.ss_totals, g.hdr);
+    hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE), B), dim3(kColT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_colscan", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (quad_work ? 1 : 0)), dim3(kT), lds2, stream, bmax, g.pair[0],
-                       g.pair[1], g.ss_table, g.ss_totals, g.ss_splitters, g.ss_splitters_new, g.ss_seg,
-                       g.ss_bucket_start, g.hdr, g.ss_dbg, nbc, quad_work, num_quads, quad_order,
-                       gsr_render_cus_per_xcd());
+    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (order_early ? 1 : 0), B), dim3(kT), lds2, stream, bt);
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax), dim3(kT), lds3, stream, bmax, g.pair[1], g.pair[0], g.ss_bucket_start,
-                       g.order, g.ss_splitters, g.rects, g.rect_sorted, g.tile_cum, g.bucket_tiles, g.hdr, g.ss_dbg,
-                       viewmatrix, sig, super_shift, orig_index);
+    hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax, B), dim3(kT), lds3, stream, bt);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

@@ -353,13 +353,37 @@ __device__ __forceinline__ bool quadrant_may_hit(float cx, float cy, const float
 __device__ __forceinline__ float sigmoid_canonical(float x) { return 1.0f / (1.0f + exp_canonical(-x)); }
 #endif
 
+// ---- frames per launch (gsr_forward_batch) ------------------------------------------------------------------
+// Every kernel of the default path takes its arguments as a table of up to GSR_MAX_BATCH per-frame argument blocks in
+// the KERNARG segment and picks its frame's block by a grid index (blockIdx.y, or .z where .y is taken): B frames of
+// one model are B x the workgroups of every launch instead of B x the launches.  The index is wave-uniform, so the
+// block's fields arrive by scalar loads exactly as plain kernel arguments do (s_load from the kernarg base + a
+// computed offset; no scratch -- checked in the ISA), and a single frame is the table with one entry.
+#define GSR_MAX_BATCH GSR_MAX_FRAMES_PER_LAUNCH
+template <typename A>
+struct GsrBatch {
+    A f[GSR_MAX_BATCH];
+};
+
+// One frame of a (batched) set of launches as api.hip resolved it: the caller's structs and the carved state.
+struct GsrFrame {
+    const GsrSettings *st;      // the frame's settings
+    const GsrSettings *st_bin;  // the same with the SUPER-TILE grid as its image (inference frames), else == st
+    const GsrInputs *in;
+    const GsrOutputs *out;
+    GeomState g;
+    ImageState img;
+    BinningState b;             // (valid from the placement on)
+    uint32_t cap32;             // binning capacity the range kernel checks R against
+};
+
 // ---- error plumbing ------------------------------------------------------------------------------------
 void gsr_set_error(const char *fmt, ...);
 int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
 
 // ---- launchers implemented in the kernel files -----------------------------------------------------------
-int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          bool count_tiles, bool infer, hipStream_t stream);
+// (B frames of one model size and image size; every launcher below that takes `B, fr` spans them with one launch)
+int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream);
 // bin-then-sort path (default): unordered binning into tile segments, then a per-tile (depth, index) sort
 int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                           bool debug, hipStream_t stream);
@@ -368,22 +392,20 @@ int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const Geom
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 // (quad_work != nullptr: a spare workgroup of the partition pass also deals the num_quads quadrants -> quad_order)
 // (super_shift: 1 = rect_sorted in 2 x 2 super-tile units, GsrSettings.forward_only)
-int gsr_launch_sample_depth_sort(int32_t P, const GeomState &g, const float *viewmatrix, const uint32_t *quad_work,
-                                 int num_quads, uint32_t *quad_order, int super_shift, const int32_t *orig_index,
+int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
                                  bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-int gsr_launch_band_count(const GsrSettings &st, int32_t P, const GeomState &g, bool balanced, bool debug,
-                          hipStream_t stream);
-int gsr_launch_band_place(const GsrSettings &st, const GeomState &g, const BinningState &b, const ImageState &img,
-                          bool debug, hipStream_t stream);
+int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, hipStream_t stream);
+int gsr_launch_band_place(int B, const GsrFrame *fr, bool debug, hipStream_t stream);
 // placement by chunks of the depth order (chunkplace.hip)
 bool gsr_chunk_supported(int gx, int gy);
 int gsr_launch_chunk_count(const GsrSettings &st, int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_chunk_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                            const ImageState &img, bool debug, hipStream_t stream);
+int gsr_launch_tile_starts(int B, const GsrFrame *fr, bool order_done, bool debug, hipStream_t stream);
 int gsr_launch_tile_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
-                           bool order_done, bool debug, hipStream_t stream);
+                           bool order_done, bool debug, hipStream_t stream);  // (one frame: the fallback placements)
 int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
@@ -391,9 +413,9 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles);
 int gsr_render_split_blocks(const GsrSettings &st, int num_tiles);
 bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
 int gsr_render_cus_per_xcd();  // CUs of one XCD (the quadrant deal of gsr_quad_order_block)
-int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list,
-                      const ImageState &img, const float *background, float *out_color, float *out_invdepth,
-                      uint8_t *out_rgb8, bool order_ready, bool split_ready, bool super_tiles, hipStream_t stream);
+// (B > 1: the default compositor only -- api.hip batches nothing else)
+int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles,
+                      hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);
 int gsr_launch_tile_place(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,

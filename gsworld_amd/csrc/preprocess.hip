@@ -512,8 +512,10 @@ __device__ __forceinline__ bool prep_block_culled(const PreprocessArgs &a, int b
     return xhi + rb < -1.0f || xlo - rb > xend || yhi + rb < -1.0f || ylo - rb > yend;
 }
 
+// grid = (blocks of 256 Gaussians, frames): blockIdx.y picks the frame's argument block (gsr_internal.h GsrBatch)
 template <bool FAST_SH16, bool COUNT_TILES>
-__global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const PreprocessArgs a) {
+__global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const GsrBatch<PreprocessArgs> bt) {
+    const PreprocessArgs a = bt.f[blockIdx.y];  // (by value: every field is requested at the top, not at its first use)
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
     const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
     bool visible = false;
@@ -600,71 +602,79 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 
 }  // namespace
 
-int gsr_launch_preprocess(const GsrSettings &st, const GsrInputs &in, int32_t *radii, const GeomState &g,
-                          bool count_tiles, bool infer, hipStream_t stream) {
-    PreprocessArgs a;
-    a.infer = infer ? 1 : 0;
-    a.P = in.P;
-    a.D = st.sh_degree;
-    a.M = st.sh_coeffs;
-    a.W = st.image_width;
-    a.H = st.image_height;
-    a.gx = gsr_div_up(a.W, GSR_TILE);
-    a.gy = gsr_div_up(a.H, GSR_TILE);
-    a.tanfovx = st.tanfovx;
-    a.tanfovy = st.tanfovy;
-    a.fx = (float)a.W / (2.0f * st.tanfovx);
-    a.fy = (float)a.H / (2.0f * st.tanfovy);
-    a.scale_modifier = st.scale_modifier;
-    a.near_plane = st.near_plane;
-    a.antialiasing = st.antialiasing;
-    a.means3D = in.means3D;
-    a.shs = in.shs;
-    a.shs_rest = in.shs_rest;
-    a.param_space = in.param_space;
-    a.colors_precomp = in.colors_precomp;
-    a.opacities = in.opacities;
-    a.scales = in.scales;
-    a.rotations = in.rotations;
-    a.cov3D_precomp = in.cov3D_precomp;
-    a.view = in.viewmatrix;
-    a.proj = in.projmatrix;
-    a.campos = in.campos;
-    a.part_labels = in.part_labels;
-    a.part_lut = in.part_lut;
-    a.part_lut_size = in.part_lut_size;
-    a.part_transforms = in.part_transforms;
-    a.part_count = in.part_count;
-    a.part_rescale = in.part_rescale;
-    a.cull_blocks = in.cull_blocks;
-    a.orig_index = in.orig_index;
-    a.radii = radii;
-    a.splat = g.splat;
-    a.cov3D = g.cov3D;
-    a.clamped = g.clamped;
-    a.tiles_touched = g.tiles_touched;
-    a.rects = g.rects;
-    a.block_counts = g.block_counts;
-    a.block_recs = g.pair[1];  // (the sort's compaction gathers from here into pair[0]; its partition pass then
-                               //  overwrites this array with the bucketed records)
+int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream) {
+    GsrBatch<PreprocessArgs> bt;
+    bool fast = true;
+    for (int k = 0; k < B; k++) {
+        const GsrSettings &st = *fr[k].st;
+        const GsrInputs &in = *fr[k].in;
+        const GeomState &g = fr[k].g;
+        PreprocessArgs &a = bt.f[k];
+        a.infer = infer ? 1 : 0;
+        a.P = in.P;
+        a.D = st.sh_degree;
+        a.M = st.sh_coeffs;
+        a.W = st.image_width;
+        a.H = st.image_height;
+        a.gx = gsr_div_up(a.W, GSR_TILE);
+        a.gy = gsr_div_up(a.H, GSR_TILE);
+        a.tanfovx = st.tanfovx;
+        a.tanfovy = st.tanfovy;
+        a.fx = (float)a.W / (2.0f * st.tanfovx);
+        a.fy = (float)a.H / (2.0f * st.tanfovy);
+        a.scale_modifier = st.scale_modifier;
+        a.near_plane = st.near_plane;
+        a.antialiasing = st.antialiasing;
+        a.means3D = in.means3D;
+        a.shs = in.shs;
+        a.shs_rest = in.shs_rest;
+        a.param_space = in.param_space;
+        a.colors_precomp = in.colors_precomp;
+        a.opacities = in.opacities;
+        a.scales = in.scales;
+        a.rotations = in.rotations;
+        a.cov3D_precomp = in.cov3D_precomp;
+        a.view = in.viewmatrix;
+        a.proj = in.projmatrix;
+        a.campos = in.campos;
+        a.part_labels = in.part_labels;
+        a.part_lut = in.part_lut;
+        a.part_lut_size = in.part_lut_size;
+        a.part_transforms = in.part_transforms;
+        a.part_count = in.part_count;
+        a.part_rescale = in.part_rescale;
+        a.cull_blocks = in.cull_blocks;
+        a.orig_index = in.orig_index;
+        a.radii = fr[k].out->radii;
+        a.splat = g.splat;
+        a.cov3D = g.cov3D;
+        a.clamped = g.clamped;
+        a.tiles_touched = g.tiles_touched;
+        a.rects = g.rects;
+        a.block_counts = g.block_counts;
+        a.block_recs = g.pair[1];  // (the sort's compaction gathers from here into pair[0]; its partition pass then
+                                   //  overwrites this array with the bucketed records)
 
-    a.num_tiles = a.gx * a.gy;
-    a.tile_accum = g.tile_accum;
-    a.hdr = g.hdr;
-    const int blocks = GeomState::prep_blocks(in.P);
-    const bool fast = (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
-                      ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
-    const size_t lds = count_tiles ? (size_t)a.num_tiles * sizeof(uint32_t) : 0;
+        a.num_tiles = a.gx * a.gy;
+        a.tile_accum = g.tile_accum;
+        a.hdr = g.hdr;
+        // (the 12 x dwordx4 colour path needs every frame's SH array aligned)
+        fast = fast && (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
+               ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
+    }
+    const PreprocessArgs &a0 = bt.f[0];
+    const dim3 grid(GeomState::prep_blocks(a0.P), B);
+    const size_t lds = count_tiles ? (size_t)a0.num_tiles * sizeof(uint32_t) : 0;
     if (count_tiles) {
         if (fast)
-            hipLaunchKernelGGL((preprocess_kernel<true, true>), dim3(blocks), dim3(GSR_BLOCK), lds, stream, a);
+            hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, dim3(GSR_BLOCK), lds, stream, bt);
         else
-            hipLaunchKernelGGL((preprocess_kernel<false, true>), dim3(blocks), dim3(GSR_BLOCK), lds, stream, a);
+            hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, dim3(GSR_BLOCK), lds, stream, bt);
     } else {
         if (fast)
-            hipLaunchKernelGGL((preprocess_kernel<true, false>), dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, dim3(GSR_BLOCK), 0, stream, bt);
         else
-            hipLaunchKernelGGL((preprocess_kernel<false, false>), dim3(blocks), dim3(GSR_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, dim3(GSR_BLOCK), 0, stream, bt);
     }
     return GSR_OK;
 }

@@ -517,7 +517,7 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
 // wave composites exactly the depth-ordered list of its 16 x 16 tile and the image is bit-identical.  final_T /
 // n_contrib (read by the backward only) are not written.
 template <bool SUPER>
-__global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(const uint2 *__restrict__ ranges,
+__device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ point_list,
                                                                   const float4 *__restrict__ splat, int W, int H, int gx,
                                                                   int num_tiles, const uint32_t *__restrict__ tile_order,
@@ -770,6 +770,38 @@ __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) 
     }
 }
 
+// grid = (workgroups of one frame, rounded up to a multiple of 8 when frames share a launch, frames): blockIdx.y picks
+// the frame's argument block (gsr_internal.h GsrBatch).  Workgroups are dispatched x-fastest and round-robin over the
+// XCDs, so with a row length that is a multiple of 8 workgroup b of EVERY frame runs on XCD b mod 8 -- what the quadrant
+// deal (gsr_quad_order_block) assumes when it keeps a tile's four quadrants on one L2.  With more workgroups than the
+// chip holds the dispatcher hands a CU its next workgroup when one retires: frames later in the launch fill the tail the
+// costliest quadrants of the earlier ones leave.
+struct RenderStreamArgs {
+    const uint2 *ranges;
+    const uint32_t *point_list;
+    const float4 *splat;
+    int W, H, gx, num_tiles;
+    const uint32_t *tile_order;
+    const float *bg;
+    float *out_color, *out_invdepth, *final_T;
+    uint32_t *n_contrib;
+    uint8_t *rgb8;
+    uint32_t *quad_work;
+    int num_cus, main_blocks, total_blocks;
+    const uint32_t *split_flag, *split_list, *split_count;
+    uint32_t *quad_work_b;
+    const uint32_t *quad_order;
+};
+template <bool SUPER>
+__global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(
+    const GsrBatch<RenderStreamArgs> bt) {
+    const RenderStreamArgs &a = bt.f[blockIdx.y];
+    if ((int)blockIdx.x >= a.total_blocks) return;  // (padding of the row to a multiple of 8)
+    render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
+                              a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
+                              a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order);
+}
+
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
 __global__ __launch_bounds__(GSR_BLOCK) void tile_order_kernel(const uint2 *__restrict__ ranges, int num_tiles,
                                                                uint32_t *__restrict__ order) {
@@ -861,38 +893,67 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
     return c.variant == 4 || (c.variant >= 2 && num_tiles > render_num_cus() * c.blocks_per_cu);
 }
 
-int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t *point_list, const ImageState &img,
-                      const float *background, float *out_color, float *out_invdepth, uint8_t *out_rgb8,
-                      bool order_ready, bool split_ready, bool super_tiles, hipStream_t stream) {
+int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles,
+                      hipStream_t stream) {
+    const GsrSettings &st = *fr[0].st;
     const int W = st.image_width, H = st.image_height;
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
     // the default kernel writes the uint8 frame itself; the A/B variants get a separate conversion pass
     const RenderChoice rc = render_choice(st);
+    if (B > 1 && rc.variant != 4) {
+        gsr_set_error("gsr_launch_render: only the default compositor takes several frames per launch");
+        return GSR_E_INVALID;
+    }
+    const GeomState &g = fr[0].g;
+    const ImageState &img = fr[0].img;
+    const uint32_t *point_list = fr[0].b.gidx[0];
+    const float *background = fr[0].in->background;
+    float *out_color = fr[0].out->out_color, *out_invdepth = fr[0].out->out_invdepth;
+    uint8_t *out_rgb8 = fr[0].out->out_rgb8;
     const bool pack_after = out_rgb8 != nullptr && rc.variant != 4;
     if (rc.variant >= 2) {
         const int T = gx * gy;
         const bool ordered = gsr_render_wants_tile_order(st, T);
         const uint32_t *order = ordered ? img.tile_order : nullptr;
         if (ordered && !order_ready)
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, img.ranges, T, img.tile_order);
+            for (int k = 0; k < B; k++)
+                hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(GSR_BLOCK), 0, stream, fr[k].img.ranges, T,
+                                   fr[k].img.tile_order);
         const int blocks = min(T, render_num_cus() * rc.blocks_per_cu);
         if (rc.variant == 4) {
             // (the split list is built by tile_starts_kernel: counting placements, grids up to 2048 tiles)
             const int extra = split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
-            const uint32_t *qorder =
-                (split_ready && gsr_render_uses_quad_order(st, T)) ? img.quad_order : (const uint32_t *)nullptr;
+            const bool use_qorder = split_ready && gsr_render_uses_quad_order(st, T);
+            GsrBatch<RenderStreamArgs> bt;
+            for (int k = 0; k < B; k++) {
+                const ImageState &im = fr[k].img;
+                RenderStreamArgs &a = bt.f[k];
+                a.ranges = im.ranges;
+                a.point_list = fr[k].b.gidx[0];
+                a.splat = fr[k].g.splat;
+                a.W = W; a.H = H; a.gx = gx; a.num_tiles = T;
+                a.tile_order = ordered ? im.tile_order : (const uint32_t *)nullptr;
+                a.bg = fr[k].in->background;
+                a.out_color = fr[k].out->out_color;
+                a.out_invdepth = fr[k].out->out_invdepth;
+                a.final_T = im.final_T;
+                a.n_contrib = im.n_contrib;
+                a.rgb8 = fr[k].out->out_rgb8;
+                a.quad_work = im.quad_work;
+                a.num_cus = render_num_cus();
+                a.main_blocks = blocks;
+                a.total_blocks = blocks + extra;
+                a.split_flag = extra > 0 ? im.split_flag : (const uint32_t *)nullptr;
+                a.split_list = im.split_list;
+                a.split_count = im.split_count;
+                a.quad_work_b = im.quad_work_b;
+                a.quad_order = use_qorder ? im.quad_order : (const uint32_t *)nullptr;
+            }
+            const int row = B > 1 ? (blocks + extra + GSR_XCDS - 1) / GSR_XCDS * GSR_XCDS : blocks + extra;
             if (super_tiles)
-                hipLaunchKernelGGL(render_stream_kernel<true>, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream,
-                                   img.ranges, point_list, g.splat, W, H, gx, T, order, background, out_color,
-                                   out_invdepth, img.final_T, img.n_contrib, out_rgb8, img.quad_work, render_num_cus(),
-                                   blocks, extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list,
-                                   img.split_count, img.quad_work_b, qorder);
+                hipLaunchKernelGGL(render_stream_kernel<true>, dim3(row, B), dim3(GSR_BLOCK), 0, stream, bt);
             else
-                hipLaunchKernelGGL(render_stream_kernel<false>, dim3(blocks + extra), dim3(GSR_BLOCK), 0, stream,
-                                   img.ranges, point_list, g.splat, W, H, gx, T, order, background, out_color,
-                                   out_invdepth, img.final_T, img.n_contrib, out_rgb8, img.quad_work, render_num_cus(),
-                                   blocks, extra > 0 ? img.split_flag : (const uint32_t *)nullptr, img.split_list,
-                                   img.split_count, img.quad_work_b, qorder);
+                hipLaunchKernelGGL(render_stream_kernel<false>, dim3(row, B), dim3(GSR_BLOCK), 0, stream, bt);
         }
         else if (rc.variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,
@@ -913,4 +974,3 @@ int gsr_launch_render(const GsrSettings &st, const GeomState &g, const uint32_t 
     }
     return GSR_OK;
 }
-

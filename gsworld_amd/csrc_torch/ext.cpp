@@ -98,20 +98,29 @@ Tuning tuning_from(const std::vector<int> &v) {
 void *current_stream(const torch::Device &dev) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
 
 // ---- one frame into caller-owned tensors (FrameRenderer) ---------------------------------------------------------
-std::tuple<int64_t, int64_t, int64_t> forward_frame(
-    int H, int W, double tanfovx, double tanfovy, double scale_modifier, int degree, int M, bool antialiasing,
-    bool debug, double near_plane, const torch::Tensor &bg, const torch::Tensor &means3D, const torch::Tensor &colors,
-    const torch::Tensor &opacity, const torch::Tensor &scales, const torch::Tensor &rotations,
-    const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix,
-    const torch::Tensor &sh, const torch::Tensor &sh_rest, const torch::Tensor &campos, torch::Tensor out_color,
-    torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
-    const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning,
-    const torch::Tensor &part_labels, const torch::Tensor &part_lut, const torch::Tensor &part_table,
-    const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks, const torch::Tensor &orig_index) {
-    const auto dev = means3D.device();
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
-    GsrSettings st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false,
-                              antialiasing, debug, (float)near_plane, tuning_from(tuning));
+// The argument structs of one frame (include/gsr.h) from tensors.  The state tensors are referenced by the resize
+// callbacks: they must outlive the call into the library.
+struct FrameCall {
+    GsrSettings st;
+    GsrInputs in;
+    GsrOutputs out;
+    GsrBuffers buf;
+    torch::Tensor geom, binning, image;  // (handles: resized in place by the callbacks)
+};
+
+void fill_frame(FrameCall &f, int H, int W, double tanfovx, double tanfovy, double scale_modifier, int degree, int M,
+                bool antialiasing, bool debug, double near_plane, const torch::Tensor &bg, const torch::Tensor &means3D,
+                const torch::Tensor &colors, const torch::Tensor &opacity, const torch::Tensor &scales,
+                const torch::Tensor &rotations, const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix,
+                const torch::Tensor &projmatrix, const torch::Tensor &sh, const torch::Tensor &sh_rest,
+                const torch::Tensor &campos, const torch::Tensor &out_color, const torch::Tensor &out_invdepth,
+                const torch::Tensor &radii, const torch::Tensor &geom, const torch::Tensor &binning,
+                const torch::Tensor &image, const torch::Tensor &rgb8_out, int param_space,
+                const std::vector<int> &tuning, const torch::Tensor &part_labels, const torch::Tensor &part_lut,
+                const torch::Tensor &part_table, const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks,
+                const torch::Tensor &orig_index) {
+    f.st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false, antialiasing, debug,
+                    (float)near_plane, tuning_from(tuning));
     GsrInputs in{};
     in.P = (int32_t)means3D.size(0);
     in.background = fptr(bg);
@@ -143,14 +152,73 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
         TORCH_CHECK(orig_index.numel() == means3D.size(0), "orig_index must be (P,)");
         in.orig_index = orig_index.data_ptr<int32_t>();
     }
-    GsrOutputs out{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
-                   radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
-                   rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
-    GsrBuffers buf{resize_geom_cb, &geom, resize_cb, &binning, resize_cb, &image};
+    f.in = in;
+    f.out = GsrOutputs{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
+                       radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
+                       rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
+    f.geom = geom;
+    f.binning = binning;
+    f.image = image;
+    f.buf = GsrBuffers{resize_geom_cb, &f.geom, resize_cb, &f.binning, resize_cb, &f.image};
+}
+
+std::tuple<int64_t, int64_t, int64_t> forward_frame(
+    int H, int W, double tanfovx, double tanfovy, double scale_modifier, int degree, int M, bool antialiasing,
+    bool debug, double near_plane, const torch::Tensor &bg, const torch::Tensor &means3D, const torch::Tensor &colors,
+    const torch::Tensor &opacity, const torch::Tensor &scales, const torch::Tensor &rotations,
+    const torch::Tensor &cov3D_precomp, const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix,
+    const torch::Tensor &sh, const torch::Tensor &sh_rest, const torch::Tensor &campos, torch::Tensor out_color,
+    torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
+    const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning,
+    const torch::Tensor &part_labels, const torch::Tensor &part_lut, const torch::Tensor &part_table,
+    const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks, const torch::Tensor &orig_index) {
+    const auto dev = means3D.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    FrameCall f;
+    fill_frame(f, H, W, tanfovx, tanfovy, scale_modifier, degree, M, antialiasing, debug, near_plane, bg, means3D, colors,
+               opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, sh_rest, campos, out_color,
+               out_invdepth, radii, geom, binning, image, rgb8_out, param_space, tuning, part_labels, part_lut, part_table,
+               part_rescale, cull_blocks, orig_index);
     GsrFrameStats stats{};
-    const int rc = gsr_forward(&st, &in, &out, &buf, r_capacity, want_stats ? &stats : nullptr, current_stream(dev));
+    const int rc = gsr_forward(&f.st, &f.in, &f.out, &f.buf, r_capacity, want_stats ? &stats : nullptr, current_stream(dev));
     TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
     return {stats.num_visible, stats.num_rendered, (int64_t)stats.overflow};
+}
+
+// ---- the frames of one step through gsr_forward_batch (gsworld_amd._C.forward_batch_raw) ----------------------------
+// Every element of `frames` is the argument tuple of forward_frame without `want_stats` (nothing is read back).
+void forward_batch(const py::list &frames) {
+    const size_t B = frames.size();
+    if (B == 0) return;
+    std::vector<FrameCall> calls(B);  // (sized once: the callbacks keep pointers into it)
+    std::vector<int64_t> caps(B);
+    torch::Device dev(torch::kCPU);
+    for (size_t k = 0; k < B; k++) {
+        const py::tuple t = frames[k].cast<py::tuple>();
+        TORCH_CHECK(t.size() == 38, "forward_batch: a frame is a tuple of 38 values, got ", t.size());
+        auto T = [&](int i) { return t[i].cast<torch::Tensor>(); };
+        if (k == 0) dev = T(11).device();
+        caps[k] = t[29].cast<int64_t>();
+        fill_frame(calls[k], t[0].cast<int>(), t[1].cast<int>(), t[2].cast<double>(), t[3].cast<double>(),
+                   t[4].cast<double>(), t[5].cast<int>(), t[6].cast<int>(), t[7].cast<bool>(), t[8].cast<bool>(),
+                   t[9].cast<double>(), T(10), T(11), T(12), T(13), T(14), T(15), T(16), T(17), T(18), T(19), T(20), T(21),
+                   T(22), T(23), T(24), T(25), T(26), T(27), T(28), t[30].cast<int>(), t[31].cast<std::vector<int>>(),
+                   T(32), T(33), T(34), T(35), T(36), T(37));
+    }
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    std::vector<GsrSettings> st(B);
+    std::vector<GsrInputs> in(B);
+    std::vector<GsrOutputs> out(B);
+    std::vector<GsrBuffers> buf(B);
+    for (size_t k = 0; k < B; k++) {
+        st[k] = calls[k].st;
+        in[k] = calls[k].in;
+        out[k] = calls[k].out;
+        buf[k] = calls[k].buf;
+    }
+    const int rc = gsr_forward_batch((int32_t)B, st.data(), in.data(), out.data(), buf.data(), caps.data(),
+                                     current_stream(dev));
+    TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
 }
 
 std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
@@ -342,6 +410,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("mark_visible", &mark_visible, py::arg("means3D"), py::arg("viewmatrix"), py::arg("projmatrix"),
           py::arg("near_plane") = GSR_NEAR_PLANE);
     m.def("forward_frame", &forward_frame);
+    m.def("forward_batch", &forward_batch);
     m.def("frame_stats", &frame_stats);
     m.def("version", []() { return std::string(gsr_version()); });
 }

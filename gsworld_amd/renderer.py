@@ -105,6 +105,22 @@ class FrameRenderer:
         order, the original numbering (radii, lists and depth ties stay those of the original model; bit-identical frames).
         ``outputs``: optional caller-owned ``(color (3,H,W) f32, invdepth (1,H,W) f32, radii (P,) i32)`` on this device,
         written instead of the renderer's own buffers (every element is written)."""
+        call, color, radii, invd = self._prepare(
+            view, means3D, opacities, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+            cov3D_precomp=cov3D_precomp, bg=bg, sh_degree=sh_degree, scale_modifier=scale_modifier,
+            antialiasing=antialiasing, debug=debug, exact=exact, shs_rest=shs_rest, param_space=param_space,
+            rgb8_out=rgb8_out, parts=parts, outputs=outputs, layout=layout)
+        cap = call["r_capacity"]
+        stats = _C.forward_raw(want_stats=(cap == 0), **call)
+        self._finish(cap, stats)
+        return color, radii, invd
+
+    def _prepare(self, view, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                 cov3D_precomp=None, bg=None, sh_degree: int = 3, scale_modifier: float = 1.0,
+                 antialiasing: bool = False, debug: bool = False, exact: bool = False, shs_rest=None,
+                 param_space: int = 0, rgb8_out=None, parts=None, outputs=None, layout=None):
+        """Everything of :meth:`render` before the call into the library (same arguments): tensors normalised, outputs
+        and capacity chosen.  -> (keyword arguments of ``_C.forward_raw`` for this frame, color, radii, invdepth)."""
         dev = self.device
 
         def norm(t, what, allow_none=True):
@@ -169,19 +185,23 @@ class FrameRenderer:
             self._bound_for, self.bounded = (P, H, W), bound is not None
             self.r_capacity = bound if bound is not None else 0
         cap = self.r_capacity if self.bounded else (0 if (exact or self.r_capacity == 0) else self.r_capacity)
-        stats = _C.forward_raw(
-            st, bg, means3D, colors_precomp if colors_precomp is not None else empty, opacities,
-            scales if scales is not None else empty, rotations if rotations is not None else empty,
-            cov3D_precomp if cov3D_precomp is not None else empty, view_m,
-            proj_m, shs if shs is not None else empty, campos, color, invd, radii,
-            self.geom, self.binning, self.image, r_capacity=cap, want_stats=(cap == 0), sh_rest=shs_rest,
+        call = dict(
+            settings=st, background=bg, means3D=means3D, colors=colors_precomp if colors_precomp is not None else empty,
+            opacity=opacities, scales=scales if scales is not None else empty,
+            rotations=rotations if rotations is not None else empty,
+            cov3D_precomp=cov3D_precomp if cov3D_precomp is not None else empty, viewmatrix=view_m, projmatrix=proj_m,
+            sh=shs if shs is not None else empty, campos=campos, out_color=color, out_invdepth=invd, radii=radii,
+            geomBuffer=self.geom, binningBuffer=self.binning, imgBuffer=self.image, r_capacity=cap, sh_rest=shs_rest,
             param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout)
+        return call, color, radii, invd
+
+    def _finish(self, cap: int, stats=None):
+        """Bookkeeping behind a frame: capacity from an exact frame's count, the overflow mirror copy."""
         if cap == 0:
             self.r_capacity = self._capacity_for(stats.num_rendered)
         if self._mirror is not None and not self.bounded and self.geom.numel() >= 256:
             # (of_magic, overflow_frames): the last two words of the 256-byte frame header (csrc/gsr_internal.h GsrHeader)
             self._mirror.copy_(self.geom[248:256].view(torch.int32), non_blocking=True)
-        return color, radii, invd
 
     def overflows_seen(self) -> int:
         """Frames on this state whose instance count exceeded the capacity, as far as the host has been told (no
@@ -238,10 +258,16 @@ class MultiCameraRenderer:
     passed the join at the end of :meth:`render` (true for the per-step buffers of a closed loop).
     """
 
-    def __init__(self, num_cameras: int, device="cuda", **renderer_kw):
+    def __init__(self, num_cameras: int, device="cuda", batched: bool = True, **renderer_kw):
+        """``batched`` (default): the frames of a step go through ``gsr_forward_batch`` -- ONE set of launches on the
+        caller's stream whose grids span the frames (include/gsr.h; up to 8 frames per set) -- instead of one complete
+        pipeline per frame on its own HIP stream.  Same kernels, disjoint state: the frames are bit-identical either
+        way.  Frames that cannot share launches (the exact-mode frame that sizes a lane, A/B selectors) run one after
+        the other on the caller's stream.  ``False``: the stream-per-frame path of rounds 2-4."""
         self.device = torch.device(device)
+        self.batched = bool(batched)
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)] if not self.batched else []
 
     def render(self, views, means3D, opacities, rgb8_out=None, per_lane=None, **render_kw):
         """``views``: one :class:`gsworld_amd.camera.ViewParams` per camera.  Returns ``[(color, radii, invdepth)]``
@@ -252,6 +278,8 @@ class MultiCameraRenderer:
         transform) but share everything the step does not move (SH coefficients, opacity)."""
         if len(views) != len(self.lanes) or (per_lane is not None and len(per_lane) != len(self.lanes)):
             raise ValueError(f"expected {len(self.lanes)} cameras, got {len(views)}")
+        if self.batched:
+            return self._render_batched(views, means3D, opacities, rgb8_out, per_lane, render_kw)
         cur = torch.cuda.current_stream(self.device)
         outs = []
         for k, (lane, stream, view) in enumerate(zip(self.lanes, self.streams, views)):
@@ -264,6 +292,28 @@ class MultiCameraRenderer:
             outs.append((color, radii, invd))
         for stream in self.streams:
             cur.wait_stream(stream)  # join: the caller's stream sees every frame
+        return outs
+
+    def _render_batched(self, views, means3D, opacities, rgb8_out, per_lane, render_kw):
+        outs, calls, caps = [], [], []
+        for k, (lane, view) in enumerate(zip(self.lanes, views)):
+            kw = render_kw if per_lane is None else {**render_kw, **per_lane[k]}
+            m3d = kw.pop("means3D", means3D) if per_lane is not None else means3D
+            call, color, radii, invd = lane._prepare(view, m3d, opacities,
+                                                     rgb8_out=rgb8_out[k] if rgb8_out is not None else None, **kw)
+            outs.append((color, radii, invd))
+            cap = call["r_capacity"]
+            if cap == 0:
+                # exact mode: the frame reads its instance count back in the middle and sizes the lane from it
+                lane._finish(0, _C.forward_raw(want_stats=True, **call))
+            else:
+                calls.append(call)
+                caps.append((lane, cap))
+        if calls:
+            with torch.cuda.device(self.device):
+                _C.forward_batch_raw(calls, device=self.device)
+            for lane, cap in caps:
+                lane._finish(cap)
         return outs
 
     def ensure_valid(self, rerender) -> list:

@@ -6,6 +6,7 @@
  * point names the upstream pybind function of the un-vendored CUDA extension it replaces:
  *
  *   gsr_forward            <->  diff_gaussian_rasterization._C.rasterize_gaussians
+ *   gsr_forward_batch      <->  the wrapper's double loop of render() calls per step (gs_world_wrapper.py:238-267)
  *   gsr_backward           <->  diff_gaussian_rasterization._C.rasterize_gaussians_backward
  *   gsr_mark_visible       <->  diff_gaussian_rasterization._C.mark_visible
  *   gsr_knn_dist2          <->  simple_knn._C.distCUDA2
@@ -201,6 +202,27 @@ size_t gsr_image_bytes(int32_t width, int32_t height);
  */
 int gsr_forward(const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
                 const GsrBuffers *buffers, int64_t r_capacity, GsrFrameStats *stats, void *stream);
+
+/*
+ * B frames of ONE step in one set of launches: what GSWorld's render loop asks for per simulation step --
+ * `for cam_name, cam_param in self.camera_params.items(): for i in range(self.num_envs): render(...)`
+ * (gs_world_wrapper.py:238-267; SURVEY.md 8f-4 "render_batch(cameras[B])").  Frame k is described by settings[k], in[k],
+ * out[k], buffers[k], r_capacity[k] exactly as gsr_forward takes them: its own camera, pose table, outputs and state
+ * buffers; the model arrays are usually shared.  Consecutive frames that (a) take the default path (GsrSettings selectors
+ * 0) with a capacity (r_capacity[k] > 0: no mid-frame read-back), (b) have the same P, image size, SH layout and
+ * forward_only flag, go through every stage TOGETHER: each of the frame's eleven kernels is launched once with a grid
+ * that spans the frames (the per-frame argument blocks travel in the kernarg segment, at most GSR_MAX_FRAMES_PER_LAUNCH
+ * frames per set of launches; longer runs are cut into such sets).  The stages of a 640 x 480 frame that are chains of
+ * dependent round trips on a few hundred workgroups (compaction, bucket sort, range scans) then fill the chip with
+ * B x the workgroups instead of being overlapped by hand on B streams, and the compositor's tail -- its costliest
+ * quadrants running alone -- is filled by the next frame's workgroups.  Any other frame (exact mode, A/B selectors,
+ * P == 0, another image size) runs by itself as gsr_forward would run it, in the order given; every frame's outputs and
+ * state are bit-identical to a gsr_forward call with the same arguments.  Nothing is read back; gsr_frame_stats() on each
+ * frame's geometry state tells V, R and overflow afterwards.
+ */
+#define GSR_MAX_FRAMES_PER_LAUNCH 8
+int gsr_forward_batch(int32_t B, const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
+                      const GsrBuffers *buffers, const int64_t *r_capacity, void *stream);
 
 /* Tuning aid: cycle stamps of the depth-sort kernels (meaningful in builds with -DGSR_SS_TIMING only). */
 int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *geom, uint64_t *out64);

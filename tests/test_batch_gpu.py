@@ -1,0 +1,205 @@
+"""gsr_forward_batch (include/gsr.h): the frames of one step -- GSWorld's double loop over cameras and environments,
+gs_world_wrapper.py:238-267 -- through ONE set of launches whose grids span the frames.  Every frame must come out as a
+gsr_forward call with the same arguments leaves it: images, uint8 frames, radii AND the opaque state, bit for bit."""
+import pytest
+import torch
+
+from gsworld_amd import layout as gl, scenes
+from gsworld_amd.camera import look_at_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _cams(dev, n, W=640, H=480):
+    base = [scenes.sensor_camera("xarm6_align", W, H), scenes.dense_view_camera("xarm6_align", W, H),
+            look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H),
+            look_at_view([0.4, 0.0, 0.3], [2.0, 1.5, 0.2], [0, 0, 1], 0.9715089, 0.7551448, W, H)]
+    out = []
+    for k in range(n):
+        if k < len(base):
+            out.append(base[k])
+        else:  # a ring of wrist-like views around the table
+            import math
+
+            a = 2.0 * math.pi * k / n
+            out.append(look_at_view([0.35 + 0.5 * math.cos(a), 0.05 + 0.5 * math.sin(a), 0.3 + 0.02 * k],
+                                    [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H))
+    return [c.to(dev) for c in out]
+
+
+@pytest.mark.parametrize("B,forward_only,with_layout", [(2, False, False), (3, True, False), (4, True, True),
+                                                         (8, True, True), (11, True, True)])
+def test_batched_frames_equal_frames_rendered_one_by_one(cuda_device, B, forward_only, with_layout):
+    """B cameras through MultiCameraRenderer(batched=True) -- one gsr_forward_batch call per step, sets of up to 8 frames
+    per launch -- against the same cameras through one FrameRenderer each, one gsr_forward call per frame."""
+    from gsworld_amd.renderer import FrameRenderer, MultiCameraRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=250_000, seed=31)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    if with_layout:
+        L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+        a = L.arrays
+        means, op = a["means3D"], a["opacities"]
+        kw = dict(shs=a["shs"], scales=a["scales"], rotations=a["rotations"], layout=L.layout)
+    bg = torch.tensor([0.2, 0.05, 0.4], device=dev)
+    cams = _cams(dev, B)
+    rkw = dict(forward_only=forward_only, want_radii=True)
+    singles = [FrameRenderer(dev, **rkw) for _ in cams]
+    want = []
+    for r, cam in zip(singles, cams):
+        f8 = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+        for _ in range(3):  # exact frame, then two on the no-sync capacity path (kept splitters, kept cuts)
+            color, radii, invd = r.render(cam, means, op, bg=bg, rgb8_out=f8, **kw)
+        assert not r.ensure_valid(lambda: None).overflow
+        want.append((color.clone(), radii.clone(), invd.clone(), f8))
+    mc = MultiCameraRenderer(B, dev, batched=True, **rkw)
+    frames = [torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev) for _ in cams]
+    for _ in range(3):
+        outs = mc.render(cams, means, op, rgb8_out=frames, bg=bg, **kw)
+    stats = mc.ensure_valid(lambda: None)
+    torch.cuda.synchronize()
+    assert all(not s.overflow and s.num_rendered > 0 for s in stats)
+    for k, ((color, radii, invd), frame, (wc, wr, wi, wf)) in enumerate(zip(outs, frames, want)):
+        assert torch.equal(color, wc), f"colour of frame {k}"
+        assert torch.equal(invd, wi), f"inverse depth of frame {k}"
+        assert torch.equal(radii, wr), f"radii of frame {k}"
+        assert torch.equal(frame, wf), f"uint8 frame {k}"
+        s1 = singles[k].stats()
+        assert (stats[k].num_visible, stats[k].num_rendered) == (s1.num_visible, s1.num_rendered)
+    # the opaque state a default frame leaves for a backward: point list, ranges, per-pixel state -- through the views
+    if not forward_only:
+        from gsworld_amd import debug as dbg
+
+        for k in range(B):
+            st = stats[k]
+            va, vb = (dbg.state_view(raw.num, 640, 480, st.num_rendered, st.num_visible, r.geom, r.binning, r.image,
+                                     r_capacity=r.r_capacity) for r in (singles[k], mc.lanes[k]))
+            assert singles[k].r_capacity == mc.lanes[k].r_capacity
+            for name in ("point_list", "ranges", "final_T", "n_contrib", "depth_order", "tiles_touched"):
+                assert torch.equal(va[name], vb[name]), f"state array {name} of frame {k}"
+            vis = want[k][1] > 0  # (records of culled Gaussians are never written: whatever the buffer held)
+            assert torch.equal(va["splat"][vis], vb["splat"][vis]) and torch.equal(va["cov3D"][vis], vb["cov3D"][vis])
+
+
+def test_batch_and_stream_paths_agree_over_a_moving_rollout(cuda_device):
+    """The closed loop (two cameras, moving parts, wrist camera that moves every step, hipGraph replay) with its frames
+    batched per launch against the same loop with a stream per frame: every step's uint8 frames equal."""
+    from gsworld_amd import closed_loop as cl
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=5)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=25, seed=3))
+    loops = [cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=b, bound_capacity=False)
+             for b in (True, False)]
+    assert loops[0].multi.batched and not loops[1].multi.batched
+    for lp in loops:
+        lp.reset(*poses[0])
+        lp.capture()
+    for k, (M, s) in enumerate(poses[1:]):
+        import math
+
+        w = look_at_view([0.55 - 0.1 * math.sin(0.3 * k), 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089,
+                         0.7551448, 640, 480)
+        got = [{n: f.clone() for n, f in lp.step(M, s, cameras={"wrist_cam": w}, ensure=True).items()} for lp in loops]
+        for n in got[0]:
+            assert torch.equal(got[0][n], got[1][n]), f"step {k}, camera {n}"
+    assert all(lp.overflow_frames() == 0 for lp in loops)
+
+
+def test_environments_batch_into_one_launch_set(cuda_device):
+    """num_envs x cameras = 6 frames of one step (per-environment pose tables inside preprocess) in one batched call,
+    against the stream-per-frame path."""
+    from gsworld_amd import closed_loop as cl
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=8)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    E = 3
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=6, seed=1, num_envs=E))
+    loops = [cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E, batched=b)
+             for b in (True, False)]
+    for lp in loops:
+        lp.reset(*poses[0])
+    for k, (M, s) in enumerate(poses[1:]):
+        got = [{n: f.clone() for n, f in lp.step(M, s, ensure=True).items()} for lp in loops]
+        for n in got[0]:
+            assert got[0][n].shape[0] == E and torch.equal(got[0][n], got[1][n]), f"step {k}, camera {n}"
+            assert not torch.equal(got[0][n][0], got[0][n][1])  # the environments really differ
+
+
+def test_frames_that_cannot_share_launches_still_render(cuda_device):
+    """A batch call with frames of two image sizes, an exact-mode frame (capacity 0) and an empty model in the middle:
+    runs of compatible frames share launches, the rest go one by one -- every frame equal to its own gsr_forward call."""
+    from gsworld_amd import _C
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=80_000, seed=12)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    views = [scenes.sensor_camera("xarm6_align", 640, 480), scenes.dense_view_camera("xarm6_align", 640, 480),
+             scenes.sensor_camera("xarm6_align", 320, 240), scenes.dense_view_camera("xarm6_align", 320, 240),
+             scenes.sensor_camera("xarm6_align", 640, 480)]
+    views = [v.to(dev) for v in views]
+    want, lanes = [], []
+    for v in views:
+        r = FrameRenderer(dev, forward_only=True, want_radii=False)
+        for _ in range(2):
+            c, _, d = r.render(v, means, op, shs=shs, scales=sc, rotations=rot)
+        want.append((c.clone(), d.clone()))
+        lanes.append(FrameRenderer(dev, forward_only=True, want_radii=False))
+    # size the batch lanes (exact frame each), then one batched call over all five; lane 4 is forced back to exact mode
+    for r, v in zip(lanes, views):
+        r.render(v, means, op, shs=shs, scales=sc, rotations=rot)
+    lanes[4].r_capacity = 0
+    calls = []
+    for r, v in zip(lanes, views):
+        call, c, _, d = r._prepare(v, means, op, shs=shs, scales=sc, rotations=rot)
+        calls.append((call, c, d))
+    assert calls[4][0]["r_capacity"] == 0 and all(c[0]["r_capacity"] > 0 for c in calls[:4])
+    _C.forward_batch_raw([c[0] for c in calls], device=dev)
+    torch.cuda.synchronize()
+    for k, ((_, c, d), (wc, wd)) in enumerate(zip(calls, want)):
+        assert torch.equal(c, wc) and torch.equal(d, wd), f"frame {k}"
+
+
+def test_ctypes_and_compiled_bindings_issue_the_same_batch(cuda_device):
+    """gsworld_amd._C.forward_batch_raw through the compiled binding and through ctypes (the same C ABI)."""
+    import importlib
+    import os
+
+    from gsworld_amd import _C
+    from gsworld_amd.renderer import FrameRenderer
+
+    if _C._ext is None or not hasattr(_C._ext, "forward_batch"):
+        pytest.skip("compiled binding not built")
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=60_000, seed=14)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    views = _cams(dev, 3)
+    results = []
+    for use_ctypes in (False, True):
+        ext = _C._ext
+        if use_ctypes:
+            _C._ext = None
+        try:
+            lanes = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in views]
+            for r, v in zip(lanes, views):
+                r.render(v, means, op, shs=shs, scales=sc, rotations=rot)
+            calls = [r._prepare(v, means, op, shs=shs, scales=sc, rotations=rot) for r, v in zip(lanes, views)]
+            _C.forward_batch_raw([c[0] for c in calls], device=dev)
+            torch.cuda.synchronize()
+            results.append([(c[1].clone(), c[3].clone()) for c in calls])
+        finally:
+            _C._ext = ext
+    for (c0, d0), (c1, d1) in zip(*results):
+        assert torch.equal(c0, c1) and torch.equal(d0, d1)
+    del importlib, os

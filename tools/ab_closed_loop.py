@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""configs[2] surrogate (1 reset + 200 steps x 2 cameras, moving wrist camera, hipGraph replay per step): the frames of
+a step batched per launch (gsr_forward_batch) against a stream per frame, each with steps enqueued ahead (ensure=False: a
+random-action rollout) and with the policy in the loop (ensure=True: frame k is waited for before step k + 1 is issued).
+One JSON line per variant."""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gsworld_amd import closed_loop as cl, scenes  # noqa: E402
+from gsworld_amd.camera import look_at_view  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else scenes.XARM6_ALIGN_NUM_GAUSSIANS
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    W, H = 640, 480
+    raw = scenes.tabletop_scene("xarm6_align", n=n, seed=1)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align", W, H),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    ep_len = 200
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0, num_envs=E))
+    pinned = [(M.pin_memory(), s.pin_memory()) for M, s in poses]
+
+    def wrist_at(k):
+        a = 2.0 * math.pi * k / ep_len
+        v = look_at_view([0.55 - 0.10 * math.sin(a), 0.35, 0.25 + 0.05 * math.sin(2.0 * a)], [0.35, 0.05, 0.05], [0, 0, 1],
+                         0.9715089, 0.7551448, W, H)
+        v.world_view_transform = v.world_view_transform.pin_memory()
+        v.full_proj_transform = v.full_proj_transform.pin_memory()
+        v.camera_center = v.camera_center.pin_memory()
+        return v
+
+    wrists = [wrist_at(k) for k in range(ep_len + 1)]
+    for batched in (True, False):
+        loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E)
+        loop.reset(*pinned[0])
+        loop.capture()
+        for ensure in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for (M, s), w in zip(pinned, wrists):
+                loop.step(M, s, cameras={"wrist_cam": w}, ensure=ensure)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({"batched": batched, "policy_in_loop": ensure, "num_envs": E,
+                              "frames_per_s": (ep_len + 1) * len(cams) * E / dt, "steps_per_s": (ep_len + 1) / dt,
+                              "overflow_frames": loop.overflow_frames(), "recovered_steps": loop.recovered_steps}), flush=True)
+        del loop
+
+
+if __name__ == "__main__":
+    main()
