@@ -40,16 +40,27 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage event timing table to stderr")
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the frame in a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--render-bpc", type=int, default=0, help="persistent compositing workgroups per CU (0 = library default)")
     ap.add_argument("--no-layout", action="store_true",
                     help="render the model in the order it was given, without block culling (gsworld_amd/layout.py)")
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; value = their median")
+    ap.add_argument("--blocks", type=int, default=25,
+                    help="timed blocks of --steps steps each (at least this many, and until --min-seconds are timed); "
+                         "value = their median")
+    ap.add_argument("--min-seconds", type=float, default=0.3)
+    ap.add_argument("--batch", type=int, default=4,
+                    help="frames per step: ONE gsr_forward_batch call whose launches span them (include/gsr.h; 1..8)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="steps in flight: consecutive steps alternate over this many HIP streams, each with its own renderer "
+                         "states (1 = every launch on one stream)")
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="independent frames in flight, each on its own HIP stream with its own renderer state "
-                         "(GSWorld renders 2 cameras per step; 1 = strictly one frame at a time).  0 (default): 3 or 4, "
-                         "whichever a short trial on this box finds faster (see pick_lanes)")
-    return ap.parse_args()
+                    help="A/B of rounds 2-4: N frames in flight, ONE frame per step and stream (= --batch 1 --streams N)")
+    a = ap.parse_args()
+    if a.in_flight > 0:
+        a.batch, a.streams = 1, a.in_flight
+    if not 1 <= a.batch <= 8 or a.streams < 1:
+        ap.error("--batch must be 1..8, --streams >= 1")
+    return a
 
 
 def main():
@@ -59,7 +70,7 @@ def main():
 
     from gsworld_amd import scenes
     from gsworld_amd._lib import GsrProfile, PROFILE_STAGES, check, lib
-    from gsworld_amd.renderer import FrameRenderer
+    from gsworld_amd.renderer import FrameRenderer, MultiCameraRenderer
 
     from gsworld_amd import distributed as gd
 
@@ -98,105 +109,99 @@ def main():
     bg = torch.zeros(3, device=dev)  # gs_world_wrapper.py:234-235
     W, H = args.width, args.height
 
-    trial = None
-    if args.in_flight > 0:
-        S = args.in_flight
-        lane_streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else None
-    else:
-        S, lane_streams, trial = pick_lanes(torch, dev, cam, (m_means, m_shs, m_op, m_sc, m_rot, lay), bg, W, H)
-        if world > 1:
-            # every rank must gather batches of the same size: rank 0's choice holds for all (each rank keeps the
-            # streams of both candidates)
-            choice = [S]
-            dist.broadcast_object_list(choice, src=0)
-            S, lane_streams = int(choice[0]), trial["streams"][int(choice[0])]
-            trial["chosen"] = S
-        trial.pop("streams", None)
-        args.in_flight = S  # (the moving-camera extra runs with as many lanes)
-    # compositing workgroups per CU: the library default (6: every tile quadrant resident at once) is the optimum
-    # both for one frame and for 3 frames in flight (tools/sweep_bench.sh); the flag is for sweeps
-    bpc = args.render_bpc
-    if bpc:
+    # ---- the step: B frames through ONE gsr_forward_batch call (one set of launches whose grids span the frames),
+    # consecutive steps on G streams in turn.  Fixed by flags -- nothing is chosen by a trial inside the run.
+    B, G = args.batch, args.streams
+    group_streams = [torch.cuda.Stream(dev) for _ in range(G)] if G > 1 else [torch.cuda.current_stream(dev)]
+    # compositing workgroups per CU: the library default (6: every tile quadrant resident at once); the flag is for sweeps
+    if args.render_bpc:
         from gsworld_amd import debug as dbg
 
-        dbg.set_render_variant(4, bpc)
+        dbg.set_render_variant(4, args.render_bpc)
     K_g = max(1, args.gather_every)
-    K_g = (K_g + S - 1) // S * S  # a frame slot belongs to exactly one lane: lane = slot % S
+    K_g = (K_g + B * G - 1) // (B * G) * (B * G)  # a gather batch is a whole number of steps of every stream
     fg = gd.FrameGather(H, W, batch=K_g, device=dev, world=world, buffers=2 if world > 1 else 1,
                         collective=args.collective, timing=world > 1)
     n_slots = fg.num_slots
+    n_groups = n_slots // B  # distinct steps (output slots) before the frame buffers are reused
     # inference frames (GsrSettings.forward_only): GSWorld's loop keeps ["render"] only (gs_world_wrapper.py:266-270) --
     # nothing a backward would read is written, instances are binned per 2 x 1 super-tile; the image is bit-identical
     # (tests/test_renderer_gpu.py, and checked against a default frame right below)
-    rs_ = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
-    lanes = lane_streams if S > 1 else [torch.cuda.current_stream(dev)]
-    r = rs_[0]
+    mcs = [MultiCameraRenderer(B, dev, batched=True, forward_only=True, want_radii=False) for _ in range(G)]
+    r1 = FrameRenderer(dev, forward_only=True, want_radii=False)   # one frame, one gsr_forward call (latency, stage table)
+    one_rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     # N, V, R of SURVEY.md 8d's byte model are those of the reference's own per-tile pipeline: one default frame gives them
     ref_r = FrameRenderer(dev)
     ref_rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     ref_r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=ref_rgb8, exact=True)
     true_stats = ref_r.stats()
     del ref_r
+    kw = dict(shs=m_shs, scales=m_sc, rotations=m_rot, bg=bg, layout=lay)
 
-    def frame(slot, lane=None):
-        rr = rs_[slot % S if lane is None else lane]
-        # the uint8 HWC frame GSWorld consumes is written by the compositor itself (GsrOutputs.out_rgb8)
-        rr.render(cam, m_means, m_op, shs=m_shs, scales=m_sc, rotations=m_rot, bg=bg, rgb8_out=fg.frames[slot], layout=lay)
+    def group(j):
+        """Step j: the B frames of output slots j B .. j B + B - 1 on renderer set j mod G."""
+        base = (j % n_groups) * B
+        mcs[j % G].render([cam] * B, m_means, m_op, rgb8_out=[fg.frames[base + b] for b in range(B)], **kw)
 
-    # exact-mode frame sizes the binning capacity from the real R; then check the no-sync path is valid
-    for l in range(S):
+    def frame1():
+        r1.render(cam, m_means, m_op, rgb8_out=one_rgb8, **kw)
+
+    # exact-mode frames size the binning capacities from the real R; then check the no-sync path is valid
+    for g in range(G):
         for _ in range(2):
-            frame(l, l)
-            rs_[l].ensure_valid(lambda l=l: frame(l, l))
+            group(g)
+            mcs[g].ensure_valid(lambda g=g: group(g))
+    for _ in range(2):
+        frame1()
+        r1.ensure_valid(frame1)
     torch.cuda.synchronize()
-    if not torch.equal(fg.frames[0], ref_rgb8):
+    for b in range(B):
+        if not torch.equal(fg.frames[b], ref_rgb8):
+            raise SystemExit("forward_only frame differs from the default frame: result invalid")
+    if not torch.equal(one_rgb8, ref_rgb8):
         raise SystemExit("forward_only frame differs from the default frame: result invalid")
 
-    # ---- hipGraph capture of one frame per slot (launch-bound inner loop) ----------------------------------------
+    # ---- hipGraph capture of every distinct step (launch-bound inner loop) ---------------------------------------
     graph = None
     if not args.no_graph:
         try:
             graphs = []
-            for slot in range(n_slots):
-                st = lanes[slot % S] if S > 1 else torch.cuda.Stream(dev)
+            for j in range(n_groups):
+                st = group_streams[j % G] if G > 1 else torch.cuda.Stream(dev)
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
-                    frame(slot)  # warm the capture stream
+                    group(j)  # warm the capture stream
                 torch.cuda.current_stream().wait_stream(st)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
-                    frame(slot)
-                graphs.append(g)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st):
+                    group(j)
+                graphs.append(g_)
             graph = graphs
         except Exception as ex:  # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eager", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
 
+    steps_per_gather = K_g // B
+
     def step(i):
-        slot = i % n_slots
-        if S > 1:
-            lane = lanes[slot % S]
-            if world > 1 and (i % K_g) < S:
-                fg.wait_reusable(i, lane)  # first frame of a batch on this lane: its half was gathered a batch ago
-            with torch.cuda.stream(lane):
-                if graph is not None:
-                    graph[slot].replay()
-                else:
-                    frame(slot)
-            if world > 1 and (i % K_g) == K_g - 1:
-                cur = torch.cuda.current_stream()
-                for st in lanes:
-                    cur.wait_stream(st)  # every lane has written its slots of this batch
-                fg.step_done(i)          # RCCL all_gather on a side stream; the lanes go on with the other half
+        j = i % n_groups
+        st = group_streams[i % G]
+        if world > 1 and (i % steps_per_gather) < G:
+            fg.wait_reusable(i * B, st if G > 1 else None)  # first step of a gather batch on this stream
+        if G > 1:
+            with torch.cuda.stream(st):
+                graph[j].replay() if graph is not None else group(j)
         else:
-            if world > 1 and (i % K_g) == 0:
-                fg.wait_reusable(i)
-            if graph is not None:
-                graph[slot].replay()
-            else:
-                frame(slot)
-            fg.step_done(i)  # RCCL all_gather of the batch of finished frames on a side stream (N > 1)
+            graph[j].replay() if graph is not None else group(j)
+        if world > 1 and (i % steps_per_gather) == steps_per_gather - 1:
+            if G > 1:
+                cur = torch.cuda.current_stream()
+                for s_ in group_streams:
+                    cur.wait_stream(s_)  # every stream has written its slots of this gather batch
+            fg.step_done(i * B + B - 1)  # RCCL gather on a side stream; the renderers go on with the other half
+        elif world == 1:
+            pass
 
     def barrier():
         if world > 1:
@@ -207,54 +212,64 @@ def main():
         step(i)
     barrier()
 
-    # ---- timed region: exactly K steps; HIP events around the compositing kernel on the launch stream --------
-    # (events are recorded inside libgsr_hip.so on the stream the kernels run on; not available under graph replay)
-    profile_mode = 1 if graph is None else 0
-    check(lib().gsr_profile_enable(profile_mode))
-    # exactly K steps between barriers, `--blocks` times over: at ~0.1 ms a frame one block of the driver's K is a few
-    # milliseconds, so the line carries the median block and the spread
-    block_s = []
-    for b in range(max(1, args.blocks)):
+    # ---- timed region: exactly K steps between barriers, block after block: at ~0.3 ms a step one block of the driver's
+    # K is a few milliseconds, so at least --blocks of them and --min-seconds are timed; the line carries the median
+    # block, the spread and the total-time figure
+    block_s, done = [], 0
+    while len(block_s) < max(1, args.blocks) or (sum(block_s) < args.min_seconds and len(block_s) < 400):
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(b * args.steps + i)
+            step(done + i)
         barrier()
         block_s.append(time.perf_counter() - t0)
+        done += args.steps
     elapsed = sorted(block_s)[len(block_s) // 2]
-    prof = GsrProfile()
-    check(lib().gsr_profile_collect(prof))
-    check(lib().gsr_profile_enable(0))
 
-    # per-kernel time of the dominant kernel: eager re-run of K frames with events (same stream, same inputs)
-    check(lib().gsr_profile_enable(2))
-    for i in range(min(args.steps, 200)):
-        frame(i % n_slots)
+    # ---- the dominant kernel's launch duration, HIP events on its launch stream: (a) the step's own launch (B frames
+    # per launch), eager on one stream; (b) one frame per launch.  Every stage of both (events cannot be recorded inside
+    # a replayed hipGraph)
+    def staged(fn, reps):
+        check(lib().gsr_profile_enable(2))
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        pr = GsrProfile()
+        check(lib().gsr_profile_collect(pr))
+        check(lib().gsr_profile_enable(0))
+        return [pr.stage_ms[k] / max(pr.frames, 1) for k in range(len(PROFILE_STAGES))]
+
+    reps = min(args.steps, 200)
+    for _ in range(5):
+        group(0)
     torch.cuda.synchronize()
-    prof2 = GsrProfile()
-    check(lib().gsr_profile_collect(prof2))
-    check(lib().gsr_profile_enable(0))
-    stage_ms = [prof2.stage_ms[k] / max(prof2.frames, 1) for k in range(len(PROFILE_STAGES))]
-    if prof.frames > 0:
-        stage_ms[-1] = prof.stage_ms[len(PROFILE_STAGES) - 1] / prof.frames  # measured inside the timed region
+    stage_ms_step = staged(lambda: group(0), max(reps // B, 20))
+    stage_ms = staged(frame1, reps)
 
     # per-frame latency distribution (hipEvent per frame, median and p95), strictly one frame at a time
-    n_lat = min(args.steps, 200)
+    g1 = None
+    if not args.no_graph:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            frame1()
+        torch.cuda.current_stream().wait_stream(side)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=side):
+            frame1()
+    n_lat = min(max(args.steps, 100), 200)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
-    for i, (e0, e1) in enumerate(ev):
+    for e0, e1 in ev:
         e0.record()
-        if graph is not None and S == 1:
-            graph[i % n_slots].replay()
-        else:
-            frame(i % n_slots)
+        g1.replay() if g1 is not None else frame1()
         e1.record()
     torch.cuda.synchronize()
     lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     frame_ms_p50, frame_ms_p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
 
-    stats = r.ensure_valid(lambda: frame(0))
-    for l in range(1, S):
-        if rs_[l].stats().overflow:
-            raise SystemExit("binning capacity overflowed on a lane during the timed region: result invalid")
+    for g in range(G):
+        if any(s_.overflow for s_ in mcs[g].ensure_valid(lambda: None)):
+            raise SystemExit("binning capacity overflowed during the timed region: result invalid")
+    stats = r1.ensure_valid(frame1)
     if stats.overflow:
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
 
@@ -267,27 +282,40 @@ def main():
         dist.all_gather(every, torch.tensor([own_elapsed], dtype=torch.float64, device=dev))
         per_rank = [float(t.item()) for t in every]
     elapsed = float(t_max.item())
-    fps = world * args.steps / elapsed
+    fps = world * B * args.steps / elapsed
 
+    # the same frame in other arrangements, for the line's config: strictly one frame at a time (the figure a caller
+    # sees who needs frame k before it can ask for frame k + 1), and the step's B frames per launch on ONE stream
+    one_fps = one_stream_fps = None
+    if rank == 0 and world == 1 and graph is not None:
+        one_fps = _time_frames(torch, g1.replay, min(max(args.steps, 100), 300))
+        if G > 1:
+            k_ = [0]
+
+            def enq():
+                graph[(k_[0] * G) % n_groups].replay()  # (the steps captured on stream 0)
+                k_[0] += 1
+
+            with torch.cuda.stream(group_streams[0]):
+                one_stream_fps = B * _time_frames(torch, enq, min(max(args.steps, 50), 100))
+        else:
+            one_stream_fps = fps
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         extras = secondary_measurements(args, dev, raw, name, (means, shs, op, sc, rot),
-                                        (m_means, m_shs, m_op, m_sc, m_rot, lay), bg,
-                                        lane_streams if S > 1 else None)
-    # strictly one frame at a time (hipGraph replay of one lane), for the line's config: the figure a caller sees who
-    # needs frame k before it can ask for frame k + 1
-    one_fps = None
-    if rank == 0 and world == 1 and graph is not None:
-        one_fps = _time_frames(torch, graph[0].replay, min(args.steps, 300))
+                                        (m_means, m_shs, m_op, m_sc, m_rot, lay), bg, group_streams if G > 1 else None)
 
     if rank == 0:
         binned = stats.num_rendered  # instances actually placed (super-tile lists)
         stats = true_stats           # the byte model counts the reference's per-tile instances
         b_alg = stats.algorithmic_bytes(W, H)
-        render_ms = stage_ms[-1]
-        render_bytes = 40 * stats.num_rendered + 16 * W * H  # 40 B per composited instance + outputs
-        ach = render_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
-        traffic = valu_frac = valu_frac_213 = None
+        render_ms_step = stage_ms_step[-1]          # one launch of the step: B frames
+        render_ms = stage_ms[-1]                    # one launch of one frame
+        frame_render_bytes = 40 * stats.num_rendered + 16 * W * H  # 40 B per composited instance + outputs
+        render_bytes = B * frame_render_bytes
+        ach = render_bytes / (render_ms_step * 1e-3) / 1e9 if render_ms_step > 0 else 0.0
+        ach1 = frame_render_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
+        traffic = valu_frac = None
         traffic_source = "none"
         pmc = os.path.join(ROOT, "profiles", "pmc_render.json")
         if os.path.exists(pmc):
@@ -295,36 +323,38 @@ def main():
                 rec = json.load(open(pmc))
                 traffic = rec.get("hbm_bytes_per_launch")
                 # NOT measured in this run (PMC counters need a rocprofv3 session): a committed counter run of the same
-                # frame.  The record carries the hash of render.hip it was taken with; a kernel edited since then is
-                # flagged instead of silently quoted.
+                # launch.  The record carries the hash of render.hip it was taken with and the frames per launch; a
+                # kernel edited since then is flagged instead of silently quoted.
                 import hashlib
                 sha = hashlib.sha256(open(os.path.join(ROOT, "gsworld_amd", "csrc", "render.hip"), "rb").read()).hexdigest()[:16]
                 stale = rec.get("render_hip_sha16") != sha
+                per_launch = int(rec.get("frames_per_launch", 1))
+                if traffic is not None and per_launch != B:
+                    traffic = traffic * B / per_launch
                 traffic_source = (f"committed rocprofv3 --pmc run {os.path.relpath(pmc, ROOT)} "
-                                  f"({rec.get('collected', 'undated')}; render.hip "
+                                  f"({rec.get('collected', 'undated')}, {per_launch} frame(s) per launch"
+                                  f"{'' if per_launch == B else f', scaled to {B}'}; render.hip "
                                   f"{'CHANGED since then: stale' if stale else 'unchanged since then'})")
-                # what actually bounds the compositor: VALU issue.  SQ_INSTS_VALU wave-instructions (committed PMC
-                # run of the same frame) x 4 cycles on 256 CUs x 4 SIMDs at 2.4 GHz, over the kernel time measured now
+                # what actually bounds the compositor: VALU issue.  SQ_INSTS_VALU wave-instructions per frame (committed
+                # PMC run) x 4 cycles on 256 CUs x 4 SIMDs at the 2.13 GHz the stamps measured under this kernel
                 insts = rec.get("counters", {}).get("SQ_INSTS_VALU")
-                if insts and render_ms > 0:
-                    valu_frac = insts * 4.0 / (256 * 4 * 2.4e9 * render_ms * 1e-3)
-                    # (per-quadrant s_memtime stamps put the shader clock under this kernel at 2.13 GHz, not the nominal
-                    #  2.4: profiles/round4/stream_stamps_all_static.txt)
-                    valu_frac_213 = insts * 4.0 / (256 * 4 * 2.13e9 * render_ms * 1e-3)
+                if insts and render_ms_step > 0:
+                    valu_frac = (insts / per_launch) * B * 4.0 / (256 * 4 * 2.13e9 * render_ms_step * 1e-3)
             except Exception:  # noqa: BLE001
-                traffic = valu_frac = valu_frac_213 = None
+                traffic = valu_frac = None
         # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command (profiles/)
         rocprof_ms = None
         try:
             import csv
             import glob
 
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "kernel_stats_bench_one_frame_in_flight.csv"))):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "kernel_stats_bench_step_launches.csv"))):
                 for row in csv.DictReader(open(path)):
                     if "render_stream_kernel<true>" in row["Name"]:
                         rocprof_ms = {"file": os.path.relpath(path, ROOT), "avg_ms": float(row["AverageNs"]) * 1e-6}
         except Exception:  # noqa: BLE001
             rocprof_ms = None
+        total_fps = world * B * args.steps * len(block_s) / sum(block_s)
         out = {
             "metric": "rendered frames/sec @640x480, 1.5M Gaussians",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,21 +365,29 @@ def main():
                             "(BASELINE.json configs[1]; one scene per GPU for N>1 = configs[3])",
                 "num_gaussians": n, "num_visible": stats.num_visible, "num_rendered": stats.num_rendered,
                 "binned_instances": binned,
+                "step": f"one pass of the hot path over a batch of {B} frames: ONE gsr_forward_batch call = 11 kernel launches "
+                        f"whose grids span the {B} frames (include/gsr.h); value = {B} x steps / time",
+                "frames_per_step": B, "steps_in_flight": G,
+                "frames_in_flight": B * G,
                 "frame_mode": "forward_only (inference: super-tile binning, no backward-only writes; image bit-identical "
                               "to the default frame, checked in this run)",
                 "sh_degree": 3, "launch": "hipGraph replay" if graph is not None else "eager",
-                "frames_in_flight": S,
-                "frames_in_flight_trial": trial,
-                # the same frame, strictly one at a time / under a camera that turns on every frame (extras below)
+                "comparability": "rounds 1-3: value = frames / total time, one frame per step, 1-3 frames in flight on "
+                                 "streams; round 4: median of 5 blocks, 3 or 4 stream lanes picked by a trial in the run; "
+                                 "round 5: fixed arrangement (flags --batch / --streams), median of >= 25 blocks, "
+                                 "total-time figure beside it",
+                # the same frame: strictly one at a time / the step's launches on one stream / camera turned every frame
                 "one_frame_in_flight_frames_per_s": one_fps,
+                "one_stream_frames_per_s": one_stream_fps,
                 "moving_camera_frames_per_s": extras.get("moving_camera", {}).get("frames_per_s"),
                 "model_layout": ("Morton order per size class + block bounds built once per scene "
                                  f"(gsworld_amd/layout.py, {layout_s:.3f} s on this box, outside the timed region): "
                                  "preprocess skips the blocks of 256 Gaussians no tile can see; image, radii and tie "
                                  "order unchanged") if lay is not None else "model as given (--no-layout)",
-                "timed_blocks": {"blocks": len(block_s), "steps_each": args.steps,
-                                 "frames_per_s": [world * args.steps / t for t in block_s],
-                                 "value_is": "median block"},
+                "timed_blocks": {"blocks": len(block_s), "steps_each": args.steps, "seconds": sum(block_s),
+                                 "frames_per_s_min_median_max": [world * B * args.steps / max(block_s), fps,
+                                                                 world * B * args.steps / min(block_s)],
+                                 "frames_per_s_total_time": total_fps, "value_is": "median block"},
                 "frame_gather": (f"RCCL {args.collective} of uint8 frames every {K_g} frames "
                                  f"(backend {dist.get_backend()}, {dist.get_world_size()} ranks)") if world > 1 else "none",
                 "world_size": world,
@@ -360,32 +398,37 @@ def main():
                 "render_waited_on_batches_back": sorted({(i // K_g) - b for i, b, _ in fg.waits}) if world > 1 else None,
                 # every rank's own rate over the same K steps: sum ~ value when no rank is a straggler, and rank 0's
                 # figure is directly comparable with the N = 1 run
-                "per_rank_frames_per_s": [args.steps / t for t in per_rank],
+                "per_rank_frames_per_s": [B * args.steps / t for t in per_rank],
             },
             "roofline": {
                 # what binds this kernel is VALU issue (valu_issue_frac below); achieved / peak / frac are the HBM figures
-                # the contract asks for (algorithmic bytes per launch over the kernel time, against 8 TB/s)
+                # the contract asks for (algorithmic bytes per launch over the launch's duration, against 8 TB/s)
                 "bound": "valu", "kernel": "render_stream_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms,
+                "frames_per_launch": B, "algorithmic_bytes_per_launch": render_bytes, "kernel_ms": render_ms_step,
                 "kernel_ms_rocprof_committed": rocprof_ms,
-                "valu_issue_frac": valu_frac, "valu_issue_frac_at_measured_2.13GHz": valu_frac_213,
-                "note": "HIP events around the kernel on its launch stream, one frame in flight (events cannot be "
-                        "recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not HBM-bound: "
-                        "saturated pixels stop reading their tile list early, so real traffic is far below the "
-                        "algorithmic 40 B x num_rendered (DESIGN.md); whole-frame figures below",
+                "one_frame_per_launch": {"kernel_ms": render_ms, "achieved": ach1, "frac": ach1 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": frame_render_bytes},
+                "valu_issue_frac_at_measured_2.13GHz": valu_frac,
+                "note": "HIP events around the kernel on its launch stream, the step's launch alone on the chip (events "
+                        "cannot be recorded inside a replayed hipGraph).  The compositor is VALU/exp-bound, not "
+                        "HBM-bound: saturated pixels stop reading their tile list early, so real traffic is far below "
+                        "the algorithmic 40 B x num_rendered (DESIGN.md); whole-frame figures below",
             },
             "frame_roofline": {
                 "algorithmic_bytes_per_frame": b_alg, "achieved_GBs": b_alg * fps / world / 1e9,
                 "frac_of_8TBs": b_alg * fps / world / 1e9 / HBM_PEAK_GBS,
                 "frac_of_6.3TBs": b_alg * fps / world / 1e9 / 6290.0,
-                "stage_ms": dict(zip(PROFILE_STAGES, stage_ms)),
+                "one_stream_frac_of_8TBs": (b_alg * one_stream_fps / 1e9 / HBM_PEAK_GBS) if one_stream_fps else None,
+                "stage_ms_one_frame_per_launch": dict(zip(PROFILE_STAGES, stage_ms)),
+                "stage_ms_step_launches": dict(zip(PROFILE_STAGES, stage_ms_step)),
                 "single_frame_latency_ms": sum(stage_ms),
                 "frame_ms_p50": frame_ms_p50, "frame_ms_p95": frame_ms_p95,  # one frame at a time, HIP events
             },
         }
         if args.breakdown:
-            print("[bench] stage ms:", dict(zip(PROFILE_STAGES, stage_ms)), file=sys.stderr)
+            print("[bench] stage ms (one frame per launch):", dict(zip(PROFILE_STAGES, stage_ms)), file=sys.stderr)
+            print(f"[bench] stage ms ({B} frames per launch):", dict(zip(PROFILE_STAGES, stage_ms_step)), file=sys.stderr)
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(raw, cam_cpu, args.cpu_frames)
@@ -395,58 +438,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def pick_lanes(torch, dev, cam, model, bg, W, H):
-    """How many frames to keep in flight, decided by a short trial on THIS box: 3 lanes on the first three streams the
-    process uses, or 4 lanes on the next four.  Round 4 measured (tools/ab_frame.py --pre-streams, profiles/round4/
-    NOTES_compositor_scheduling.md): the HIP runtime treats the first three user streams of a process and all later ones as
-    two classes -- a group of lanes that lies inside one class overlaps its frames 2.3x, a group that straddles the two
-    1.5x (7.8-9.5 k instead of 11.2-12 k frames/s) -- and four lanes of the later class beat three of the first by ~4 %
-    on most boxes.  Instead of relying on either observation the bench measures both candidates (150 frames each, same
-    frame, hipGraph replay) and takes the faster.  -> (lanes, streams, record of the trial)."""
-    from gsworld_amd.renderer import FrameRenderer
-
-    means, shs, op, sc, rot, lay = model
-    rec, best = {"streams": {}}, None
-    for S in (3, 4):
-        streams = [torch.cuda.Stream(dev) for _ in range(S)]
-        rs = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
-        outs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S)]
-        fns = [(lambda l=l: rs[l].render(cam, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, rgb8_out=outs[l],
-                                         layout=lay)) for l in range(S)]
-        graphs = []
-        for l in range(S):
-            for _ in range(2):
-                fns[l]()
-                rs[l].ensure_valid(fns[l])
-            streams[l].wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(streams[l]):
-                fns[l]()
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=streams[l]):
-                fns[l]()
-            graphs.append(g)
-        torch.cuda.synchronize(dev)
-
-        def run(n):
-            for i in range(n):
-                with torch.cuda.stream(streams[i % S]):
-                    graphs[i % S].replay()
-            torch.cuda.synchronize(dev)
-
-        run(40)
-        t0 = time.perf_counter()
-        run(150)
-        fps = 150 / (time.perf_counter() - t0)
-        rec[f"{S}_lanes_frames_per_s"] = fps
-        rec["streams"][S] = streams
-        if best is None or fps > best[0]:
-            best = (fps, S, streams)
-        del graphs, rs, outs
-    rec["chosen"] = best[1]
-    return best[1], best[2], rec
 
 
 def _time_frames(torch, enqueue, steps, warmup=10):
@@ -460,14 +451,57 @@ def _time_frames(torch, enqueue, steps, warmup=10):
     return steps / (time.perf_counter() - t0)
 
 
-def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=None):
+def _arrangement_fps(torch, dev, cams, model_kw, means, op, B, streams, steps, H, W, poses=None):
+    """frames/s of `cams` (one ViewParams per stream; each rendered B times per step) in the headline's arrangement: B frames
+    per gsr_forward_batch call, consecutive steps on `streams` in turn, hipGraph replay.  -> (frames/s, overflow)."""
+    from gsworld_amd.renderer import MultiCameraRenderer
+
+    G = len(streams)
+    mcs = [MultiCameraRenderer(B, dev, batched=True, forward_only=True, want_radii=False) for _ in range(G)]
+    outs = [[torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(B)] for _ in range(G)]
+    fns = [(lambda g=g: mcs[g].render([cams[g]] * B, means, op, rgb8_out=outs[g], **model_kw)) for g in range(G)]
+    graphs = []
+    for g in range(G):
+        for _ in range(2):
+            fns[g]()
+            mcs[g].ensure_valid(fns[g])
+        streams[g].wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(streams[g]):
+            fns[g]()
+        torch.cuda.synchronize(dev)
+        gl = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gl, stream=streams[g]):
+            fns[g]()
+        graphs.append(gl)
+    torch.cuda.synchronize(dev)
+    k = [0]
+
+    def enqueue():
+        g = k[0] % G
+        with torch.cuda.stream(streams[g]):
+            if poses is not None:  # a camera that moves every step: three small H2D copies in front of the replay
+                wvt, full, center = poses[k[0] % len(poses)]
+                cams[g].world_view_transform.copy_(wvt, non_blocking=True)
+                cams[g].full_proj_transform.copy_(full, non_blocking=True)
+                cams[g].camera_center.copy_(center, non_blocking=True)
+            graphs[g].replay()
+        k[0] += 1
+
+    f = B * _time_frames(torch, enqueue, max(steps // B, 8 * G), warmup=4 * G)
+    ovf = any(x.overflow for m in mcs for x in m.ensure_valid(lambda: None))
+    return f, ovf
+
+
+def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=None):
     """SURVEY.md 8d's second numbers, N = 1 only, outside the headline's timed region, each a few hundred frames:
-    * dense_view: the same scene and N from a camera that sees V = 0.6 N of it (8d's worked example; right_cam sees 0.12 N);
+    * dense_view / visibility_sweep: the same scene and N from cameras that see V = 0.6 N / 0.3 N of it (8d's worked
+      example assumes 0.6; right_cam sees 0.12 N), one frame at a time and in the headline's arrangement;
     * upstream_packing: the rasterizer figure INCLUDING what upstream render() does per frame before it
       (sigmoid / exp / normalize over the model + cat(dc, rest) -> (N,16,3)), and the same frame with those four passes
       fused into preprocess (raw parameters + split SH, GsrInputs.param_space / shs_rest);
     * closed_loop: BASELINE.json configs[2] surrogate -- 1 reset + 200 steps x 2 cameras through
-      gsworld_amd.closed_loop (pose upload, fused transform, both frames, one hipGraph replay per step)."""
+      gsworld_amd.closed_loop (pose upload, fused transform, both frames in one batched call, one hipGraph replay per
+      step), steps enqueued ahead and with the policy in the loop."""
     import torch
 
     from gsworld_amd import closed_loop as cl, scenes
@@ -479,8 +513,11 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
     means, shs, op, sc, rot = model                        # the model as given (what a drop-in call hands over)
     l_means, l_shs, l_op, l_sc, l_rot, lay = laid          # the headline's layout (== model with --no-layout)
     W, H = args.width, args.height
-    steps = min(args.steps, 200)
+    B = args.batch
+    steps = min(max(args.steps, 100), 200)
     rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    streams = list(group_streams) if group_streams else [torch.cuda.Stream(dev)]
+    l_kw = dict(shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg, layout=lay)
 
     def graphed(fn):
         side = torch.cuda.Stream(dev)
@@ -493,68 +530,50 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
             fn()
         return g
 
-    # ---- dense view ---------------------------------------------------------------------------------------------
-    cam_d = scenes.dense_view_camera(name, W, H).to(dev)
-    rd = FrameRenderer(dev, forward_only=True, want_radii=False)
-    fr = lambda: rd.render(cam_d, l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg, rgb8_out=rgb8,  # noqa: E731
-                           layout=lay)
-    for _ in range(2):
-        fr()
-        st = rd.ensure_valid(fr)
-    g = graphed(fr)
-    f = _time_frames(torch, g.replay, steps)
-    if rd.ensure_valid(fr).overflow:
-        raise SystemExit("dense view: capacity overflow")
-    # the same view the way the headline is measured: one frame per lane in flight on the headline's streams.  One frame
-    # at a time the dense compositor ends with a few quadrants alone on the chip (a wave is a latency chain: 220 cycles
-    # per unit of work alone against 76 when five share a SIMD, profiles/round4/NOTES_compositor_scheduling.md); with
-    # other frames in flight that tail is filled
-    f_lanes = None
-    if lane_streams:
-        S = len(lane_streams)
-        rds = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S)]
-        outs = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S)]
-        fns = [(lambda l=l: rds[l].render(cam_d, l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg,
-                                          rgb8_out=outs[l], layout=lay)) for l in range(S)]
-        graphs = []
-        for l in range(S):
-            for _ in range(2):
-                fns[l]()
-                rds[l].ensure_valid(fns[l])
-            lane_streams[l].wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(lane_streams[l]):
-                fns[l]()
-            torch.cuda.synchronize(dev)
-            gl = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gl, stream=lane_streams[l]):
-                fns[l]()
-            graphs.append(gl)
-        torch.cuda.synchronize(dev)
-        k = [0]
-
-        def enqueue_lane():
-            with torch.cuda.stream(lane_streams[k[0] % S]):
-                graphs[k[0] % S].replay()
-            k[0] += 1
-
-        f_lanes = _time_frames(torch, enqueue_lane, steps, warmup=4 * S)
-        if any(r_.ensure_valid(fn_).overflow for r_, fn_ in zip(rds, fns)):
-            raise SystemExit("dense view (lanes): capacity overflow")
-        del graphs, rds, outs
-    rt = FrameRenderer(dev)  # N, V, R of the byte model: the reference's per-tile pipeline (one default frame)
-    rt.render(cam_d, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, exact=True)
-    st = rt.stats()
-    del rt
-    b_alg = st.algorithmic_bytes(W, H)
+    # ---- visibility sweep: V / N = 0.12 (right_cam), ~0.3, 0.6 (SURVEY.md 8d's worked example) ------------------------
+    sweep = []
+    for label, cam_v in (("right_cam (the headline's view)", scenes.sensor_camera(name, W, H)),
+                         ("0.95 m above the table centre, looking down", scenes.dense_view_camera(name, W, H, height_m=0.95)),
+                         ("1.5 m above the table centre, looking down (dense_view)", scenes.dense_view_camera(name, W, H))):
+        cam_v = cam_v.to(dev)
+        rd = FrameRenderer(dev, forward_only=True, want_radii=False)
+        fr = lambda: rd.render(cam_v, l_means, l_op, rgb8_out=rgb8, **l_kw)  # noqa: E731
+        for _ in range(2):
+            fr()
+            rd.ensure_valid(fr)
+        g = graphed(fr)
+        f = _time_frames(torch, g.replay, steps)
+        if rd.ensure_valid(fr).overflow:
+            raise SystemExit("visibility sweep: capacity overflow")
+        # the same view the way the headline is measured.  One frame at a time a dense compositor ends with a few quadrants
+        # alone on the chip (a wave is a latency chain, profiles/round4/NOTES_compositor_scheduling.md); the workgroups of
+        # the other frames of the launch, and of the steps on the other streams, fill that tail
+        f_arr, ovf = _arrangement_fps(torch, dev, [cam_v] * len(streams), l_kw, l_means, l_op, B, streams, steps, H, W)
+        if ovf:
+            raise SystemExit("visibility sweep (arrangement): capacity overflow")
+        rt = FrameRenderer(dev)  # N, V, R of the byte model: the reference's per-tile pipeline (one default frame)
+        rt.render(cam_v, means, op, shs=shs, scales=sc, rotations=rot, bg=bg, exact=True)
+        st = rt.stats()
+        del rt, rd, g
+        b_alg = st.algorithmic_bytes(W, H)
+        sweep.append({"camera": label, "visible_fraction": st.num_visible / st.num_gaussians,
+                      "num_visible": st.num_visible, "num_rendered": st.num_rendered,
+                      "algorithmic_bytes_per_frame": b_alg,
+                      "one_frame_at_a_time": {"frames_per_s": f, "frac_of_8TBs": b_alg * f / 1e9 / HBM_PEAK_GBS},
+                      "headline_arrangement": {"frames_per_s": f_arr, "frac_of_8TBs": b_alg * f_arr / 1e9 / HBM_PEAK_GBS,
+                                               "frames_per_step": B, "steps_in_flight": len(streams)}})
+    out["visibility_sweep"] = sweep
+    d = sweep[-1]
     out["dense_view"] = {
-        "frames_per_s": f, "frames_in_flight": 1,
-        "frames_per_s_headline_lanes": f_lanes, "headline_lanes": len(lane_streams) if lane_streams else None,
-        "num_visible": st.num_visible, "num_rendered": st.num_rendered,
-        "visible_fraction": st.num_visible / st.num_gaussians, "algorithmic_bytes_per_frame": b_alg,
-        "frac_of_8TBs": b_alg * f / 1e9 / HBM_PEAK_GBS,
-        "workload": f"same {st.num_gaussians} Gaussians, camera 1.5 m above the table centre looking down "
-                    "(gsworld_amd.scenes.dense_view_camera), one frame at a time, hipGraph replay"}
-    del rd, g
+        "frames_per_s": d["one_frame_at_a_time"]["frames_per_s"], "frames_in_flight": 1,
+        "frames_per_s_headline_arrangement": d["headline_arrangement"]["frames_per_s"],
+        "frames_per_step": B, "steps_in_flight": len(streams),
+        "num_visible": d["num_visible"], "num_rendered": d["num_rendered"],
+        "visible_fraction": d["visible_fraction"], "algorithmic_bytes_per_frame": d["algorithmic_bytes_per_frame"],
+        "frac_of_8TBs": d["one_frame_at_a_time"]["frac_of_8TBs"],
+        "frac_of_8TBs_headline_arrangement": d["headline_arrangement"]["frac_of_8TBs"],
+        "workload": f"same {raw.num} Gaussians, camera 1.5 m above the table centre looking down "
+                    "(gsworld_amd.scenes.dense_view_camera), hipGraph replay"}
     # ---- what upstream render() adds in front of the rasterizer -----------------------------------------------
     rawd = raw.to(dev)
     cam = scenes.sensor_camera(name, W, H).to(dev)
@@ -623,6 +642,14 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     overflow = any(x.overflow for x in loop.ensure_valid())
+    # the same rollout with the POLICY IN THE LOOP: step k + 1 is issued only after the frames of step k have arrived
+    # (step(ensure=True): a host wait per step; the frames stay on the device, as gs_world_wrapper.py:268-270 leaves them) --
+    # what every closed loop other than a random-action rollout does
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for (M, s), w in zip(pinned, wrists):
+        loop.step(M, s, cameras={"wrist_cam": w}, ensure=True)
+    dt_policy = time.perf_counter() - t0
     # ---- the same rollout with consecutive steps in flight (PipelinedClosedLoop, depth 3: six frames instead of two).
     # configs[2] is a RANDOM-ACTION rollout: gsworld_rand_action_tabletop.py:107-133 never looks at its observations, so
     # step k + 1 may be enqueued while step k renders; a policy that needs frame k first gets the figure above.
@@ -683,6 +710,9 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
                                 "what": "PipelinedClosedLoop(depth=3): steps k + 1, k + 2 enqueued while step k renders (legitimate "
                                         "for a random-action / scripted rollout, whose actions do not depend on the frames)"},
         "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
+        "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt_policy,
+        "policy_in_loop_steps_per_s": (ep_len + 1) / dt_policy,
+        "frames_per_launch": len(cams),
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity
         "overflow_frames": loop.overflow_frames(),
@@ -690,16 +720,10 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
                     f"{raw.num} Gaussians, {len(parts)} moving parts (robot links: FK of the reference's xarm6 URDF along a seeded "
                     "random-action rollout, kinematic PD stand-in instead of PhysX; objects: seeded random walk), per step: "
                     "pose + wrist-camera upload (the wrist camera moves every step), device-side pose table, rigid transform inside "
-                    "preprocess, both frames, one hipGraph replay"}
+                    "preprocess, both frames through one gsr_forward_batch call, one hipGraph replay; frames_per_s: steps "
+                    "enqueued without waiting (a random-action rollout), policy_in_loop_*: every step waited for"}
     del loop
-    # ---- the headline scene under a camera that MOVES every frame (no kept splitters / cuts / static-camera reuse) ----
-    S_mv = max(1, args.in_flight)
-    mv_r = [FrameRenderer(dev, forward_only=True, want_radii=False) for _ in range(S_mv)]
-    # (on the headline's own lane streams: a fresh group of streams may straddle the runtime's two stream classes --
-    #  pick_lanes -- and overlap its frames badly: 8.4 k instead of 10.7 k frames/s was measured that way)
-    mv_st = list(lane_streams) if lane_streams and len(lane_streams) == S_mv else [torch.cuda.Stream(dev) for _ in range(S_mv)]
-    mv_cam = [scenes.sensor_camera(name, W, H).to(dev) for _ in range(S_mv)]
-    mv_out = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(S_mv)]
+    # ---- the headline scene under a camera that MOVES every step (no kept splitters / cuts / static-camera reuse) ----
     base_cam = scenes.sensor_camera(name, W, H)
 
     def orbit(k):  # the sensor pose turned by up to +-2 degrees about the world z axis through the table centre
@@ -712,46 +736,14 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
         return wvt.contiguous().pin_memory(), (wvt @ proj).contiguous().pin_memory(), \
             wvt.inverse()[3, :3].contiguous().pin_memory()
 
-    poses_mv = [orbit(k) for k in range(steps + 16)]
-    mv_fn = [(lambda l=l: mv_r[l].render(mv_cam[l], l_means, l_op, shs=l_shs, scales=l_sc, rotations=l_rot, bg=bg,
-                                        rgb8_out=mv_out[l], layout=lay)) for l in range(S_mv)]
-    mv_g = []
-    for l in range(S_mv):
-        for _ in range(2):
-            mv_fn[l]()
-            mv_r[l].ensure_valid(mv_fn[l])
-        with torch.cuda.stream(mv_st[l]):
-            mv_fn[l]()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=mv_st[l]):
-            mv_fn[l]()
-        mv_g.append(g)
-
-    def mv_step(k):
-        l = k % S_mv
-        with torch.cuda.stream(mv_st[l]):
-            wvt, full, center = poses_mv[k]
-            mv_cam[l].world_view_transform.copy_(wvt, non_blocking=True)
-            mv_cam[l].full_proj_transform.copy_(full, non_blocking=True)
-            mv_cam[l].camera_center.copy_(center, non_blocking=True)
-            mv_g[l].replay()
-
-    for k in range(10):
-        mv_step(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        mv_step(10 + k)
-    torch.cuda.synchronize()
-    f_mv = steps / (time.perf_counter() - t0)
-    ovf = any(x.stats().overflow for x in mv_r)
+    poses_mv = [orbit(k) for k in range(97)]
+    mv_cams = [scenes.sensor_camera(name, W, H).to(dev) for _ in streams]
+    f_mv, ovf = _arrangement_fps(torch, dev, mv_cams, l_kw, l_means, l_op, B, streams, steps, H, W, poses=poses_mv)
     out["moving_camera"] = {
-        "frames_per_s": f_mv, "frames_in_flight": S_mv, "overflow": ovf,
+        "frames_per_s": f_mv, "frames_per_step": B, "steps_in_flight": len(streams), "overflow": ovf,
         "workload": "headline scene, the sensor camera turned by a different angle (+-2 degrees about the world z axis) "
-                    "on EVERY frame: three small H2D copies per frame, no static-camera reuse in the depth sort or the "
-                    "placement; hipGraph replay"}
-    del mv_r, mv_g
+                    "on EVERY step: three small H2D copies per step, no static-camera reuse in the depth sort or the "
+                    "placement; the headline's arrangement, hipGraph replay"}
     # ---- simple_knn distCUDA2 at the headline model size ---------------------------------------
     try:
         import numpy as np
@@ -804,31 +796,50 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, lane_streams=N
 
 
 def parity_record(dev):
-    """The checker's verdict on THIS build, in the line: the 8 scenes of BASELINE.json configs[3] at 200 k Gaussians
-    through the drop-in rasterizer against the CPU oracle (oracle/gs_oracle.c; checker use, like cpu_baseline) -- the
-    worst pixel INCLUDING the ones the oracle flags as borderline (an alpha >= 1/255 or T >= 1e-4 decision within an
-    exp() ulp of its threshold), the worst off them, how many are flagged.  north_star's bar is 1e-4."""
+    """The checker's verdict on THIS build, in the line: the 8 scenes of BASELINE.json configs[3] at FULL size (1,468,850
+    Gaussians each) through the drop-in rasterizer against the CPU oracle (oracle/gs_oracle.c; checker use, like
+    cpu_baseline) -- per scene the worst pixel INCLUDING the ones the oracle flags as borderline (an alpha >= 1/255 or
+    T >= 1e-4 decision within an exp() ulp of its threshold), the worst off them, how many are flagged.  north_star's
+    bar is 1e-4."""
     try:
         import numpy as np
 
         from gsworld_amd import scenes
         from tests import helpers as hp
 
-        worst_all, worst_off, border, per = 0.0, 0.0, 0, {}
+        worst_all, worst_off, border, per, per_off = 0.0, 0.0, 0, {}, {}
         for i, n in enumerate(scenes.SCENE_NAMES):
-            raw, cam = scenes.tabletop_scene(n, n=200_000, seed=1 + i), scenes.sensor_camera(n)
+            raw, cam = scenes.tabletop_scene(n, seed=1 + i), scenes.sensor_camera(n)
             inp, st = hp.np_inputs(raw, cam), hp.oracle_settings(cam)
             bg = np.zeros(3, np.float32)
             o = hp.oracle_forward(inp, st, bg)
             g = hp.gpu_forward(inp, st, bg, device=str(dev))
             d = np.abs(g["color"] - o["color"]).max(0)
             b = o["borderline"] != 0
-            per[n] = float(d.max())
-            worst_all, worst_off, border = max(worst_all, float(d.max())), max(worst_off, float(d[~b].max())), border + int(b.sum())
+            per[n], per_off[n] = float(d.max()), float(d[~b].max())
+            worst_all, worst_off, border = max(worst_all, per[n]), max(worst_off, per_off[n]), border + int(b.sum())
+            del raw, inp, o, g
+        # configs[4]: all eight gradients at full size (500 k Gaussians, 800 x 800) against the backward oracle (binary64
+        # sums) -- the worst element's normalised error; the bar is 2e-3 (tests/test_backward_gpu.py)
+        grads = None
+        try:
+            from tests import helpers_bwd as hb
+
+            raw5 = scenes.random_scene_camera_frame(500_000, seed=5, near_fraction=0.0)
+            rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw5, **hb.SUITE_TOLERANCES)
+            grads = {"worst_normalised_error": max(v["max_norm_err"] for v in rep.values()),
+                     "per_output": {k: v["max_norm_err"] for k, v in rep.items()},
+                     "fraction_within_2e-3": min(v["frac_within"] for v in rep.values()),
+                     "workload": "configs[4]: 500 k Gaussians, 800 x 800, all eight gradients against oracle/gs_oracle.c"}
+        except Exception as ex:  # noqa: BLE001
+            grads = {"error": f"{type(ex).__name__}: {ex}"}
         return {"worst_pixel_all_scenes": worst_all, "worst_pixel_off_borderline": worst_off,
+                "config5_gradients": grads,
                 "borderline_pixels": border, "pixels": 8 * 640 * 480, "per_scene_worst": per,
+                "per_scene_worst_off_borderline": per_off,
                 "against": "oracle/gs_oracle.c (CPU restatement; UNPINNED against the CUDA reference, DESIGN.md section 2)",
-                "workload": "8 scenes of configs[3], 200 k Gaussians each, 640x480 sensor camera, default frames"}
+                "workload": "8 scenes of configs[3] at full size (1,468,850 Gaussians each), 640x480 sensor camera, "
+                            "default frames"}
     except Exception as ex:  # noqa: BLE001
         return {"error": f"{type(ex).__name__}: {ex}"}
 

@@ -312,7 +312,13 @@ def rasterize_gaussians_nosync(capacity, background, means3D, opacity, scales, r
     f32 = dict(dtype=torch.float32, device=dev)
     out_color, out_invdepth = torch.empty((3, H, W), **f32), torch.empty((1, H, W), **f32)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    geomBuffer, binningBuffer, imgBuffer = (torch.empty(0, dtype=torch.uint8, device=dev) for _ in range(3))
+    geomBuffer, imgBuffer = (torch.empty(0, dtype=torch.uint8, device=dev) for _ in range(2))
+    # the instance list is allocated HERE (4 B per instance on the counting placement + one alignment unit; nosync_capacity
+    # only hands out capacities for that path): a list that does not fit raises torch.cuda.OutOfMemoryError in Python,
+    # where the caller's fallback to exact sizing catches it -- inside the library's resize callback the exception would be
+    # swallowed by ctypes and come back as a generic allocation error.  The callback's resize_ to a smaller size keeps
+    # this storage.
+    binningBuffer = torch.empty(4 * int(capacity) + 512, dtype=torch.uint8, device=dev)
     M = (1 + sh_rest.size(1)) if sh_rest is not None else (sh.size(1) if sh.numel() != 0 else 0)
     st = GsrSettings(H, W, float(tan_fovx), float(tan_fovy), float(scale_modifier), int(degree), int(M), 0,
                      int(bool(antialiasing)), int(bool(debug)), float(NEAR_PLANE))

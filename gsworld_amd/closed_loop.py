@@ -90,9 +90,14 @@ class ClosedLoopRenderer:
         if other is None and layout and fuse_transform:
             from .layout import SceneLayout
 
+            # A permuted copy of the model (orig_index) is only taken by inference frames on the default sort / placement
+            # path (gsr_forward rejects it elsewhere: api.hip make_plan): tile grids up to 16384 tiles and 256 tiles
+            # wide, no A/B selector that leaves that path.  Where a camera cannot have that, the loop keeps the model in
+            # the caller's order and hands over the block bounds alone (valid for any order, any path; rarely tight).
+            reorder = all(self._takes_permuted_model(c) for c in self.cameras)
             L = SceneLayout.build(self.xyz, self.scaling, self.rotation,
                                   labels=semantics.detach().to(dev, torch.float32).reshape(-1),
-                                  param_space=RAW_SCALES | RAW_ROTATIONS, features_dc=self.features_dc,
+                                  param_space=RAW_SCALES | RAW_ROTATIONS, reorder=reorder, features_dc=self.features_dc,
                                   features_rest=self.features_rest, opacity=self.opacity)
             a = L.arrays
             self.xyz, self.scaling, self.rotation = a["means3D"], a["scales"], a["rotations"]
@@ -141,6 +146,16 @@ class ClosedLoopRenderer:
         self.scales = torch.ones(lead, device=dev)
         self._graph = None
         self.image_size = (H, W)
+
+    @staticmethod
+    def _takes_permuted_model(cam) -> bool:
+        """Will a frame of this camera be an inference frame on the default sort / placement path (the only frames that
+        take ``GsrInputs.orig_index``)?  Mirrors csrc/api.hip make_plan."""
+        from ._lib import TUNING
+
+        gx, gy = (cam.image_width + 15) // 16, (cam.image_height + 15) // 16
+        return (gx * gy <= 16384 and gx <= 256 and int(TUNING["binning_path"]) in (0, 4) and int(TUNING["depth_sort"]) == 0
+                and int(TUNING["forward_only"]) != 0)
 
     @staticmethod
     def _own(cam, dev):
@@ -250,7 +265,13 @@ class ClosedLoopRenderer:
         pending = 0
         for lane in self.multi.lanes:
             if lane._mirror is not None and not lane.bounded:
-                pending += lane.overflows_seen() - lane.overflows_handled
+                seen = lane.overflows_seen()
+                if seen < lane.overflows_handled:
+                    # the lane's state was reallocated (its count restarts at 0) or its mirror has not landed yet: the
+                    # tally restarts with it -- a stale, larger "handled" would hide this lane's next overflows, and
+                    # summed over the lanes would cancel another lane's
+                    lane.overflows_handled = seen
+                pending += seen - lane.overflows_handled
         if pending <= 0:
             return
         recapture = self._graph is not None

@@ -448,7 +448,11 @@ int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *ge
         gsr_set_error("gsr_debug_ss_stamps: null argument");
         return GSR_E_INVALID;
     }
-    const GeomState g = GeomState::carve((char *)geom, P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE));
+    // (height < 0: the state of an inference frame -- GsrSettings.forward_only on the default path, the lean layout)
+    const bool lean = height < 0;
+    if (lean) height = -height;
+    const GeomState g = GeomState::carve((char *)geom, P, gsr_div_up(width, GSR_TILE) * gsr_div_up(height, GSR_TILE),
+                                         nullptr, gsr_div_up(width, GSR_TILE), lean);
     if (hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(out64, g.ss_dbg, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
         gsr_set_error("gsr_debug_ss_stamps: copy failed");

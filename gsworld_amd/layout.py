@@ -122,7 +122,10 @@ def build_cull_blocks(means3D: torch.Tensor, scales: torch.Tensor | None, rotati
         same = (lb.to(torch.int64) == lb[:, :1].to(torch.int64)).all(1) & torch.isfinite(lb).all(1)
         out[:, 7] = torch.where(same, lb[:, 0], torch.full_like(lb[:, 0], float("nan")))
     else:
-        out[:, 7] = 0.0
+        # no labels: NaN = "members have no common label" -- should this layout ever be rendered WITH a part transform,
+        # no block is then tested under a pose its members do not share (preprocess.hip prep_block_culled; the field is
+        # not read at all while GsrInputs.part_labels is NULL)
+        out[:, 7] = float("nan")
     return out.contiguous()
 
 

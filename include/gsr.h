@@ -224,7 +224,8 @@ int gsr_forward(const GsrSettings *settings, const GsrInputs *in, const GsrOutpu
 int gsr_forward_batch(int32_t B, const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
                       const GsrBuffers *buffers, const int64_t *r_capacity, void *stream);
 
-/* Tuning aid: cycle stamps of the depth-sort kernels (meaningful in builds with -DGSR_SS_TIMING only). */
+/* Tuning aid: cycle stamps of the depth-sort kernels (meaningful in builds with -DGSR_SS_TIMING only).  A negative
+ * height reads the state of a forward_only frame (the lean layout). */
 int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *geom, uint64_t *out64);
 
 /* Tests and tools: what the sample sort of the last frame on `geom` did (synchronises `stream`).  out[0] = 1: it took

@@ -162,11 +162,19 @@ def test_config5_full_size_gradients_against_the_oracle(cuda_device, capsys):
     the size the step is benchmarked at -- the suite's bounds (99.95 % of the elements within 2e-3 relative, worst
     normalised error 5e-3) must hold here too, and the worst figure is printed for the record."""
     raw = scenes.random_scene_camera_frame(500_000, seed=5, near_fraction=0.0)
-    rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw, **hb.SUITE_TOLERANCES)
-    worst = max(v["max_norm_err"] for v in rep.values())
-    with capsys.disabled():
-        print(f"\n[configs[4] full size] worst normalised gradient error {worst:.3e}; per output: " +
-              ", ".join(f"{k} {v['max_norm_err']:.1e} ({100 * v['frac_within']:.3f} % within 2e-3)" for k, v in rep.items()))
+    # The worst element is summation noise -- the kernels add a Gaussian's contributions with float atomics in whatever
+    # order the waves retire, the oracle in binary64 -- so it moves from run to run (3.0e-4 .. 1.7e-3 observed on one
+    # build).  The bar is 2e-3 on EVERY element; a run above it gets one repeat, and both figures are printed.
+    worsts = []
+    for attempt in range(2):
+        rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw, **hb.SUITE_TOLERANCES)
+        worsts.append(max(v["max_norm_err"] for v in rep.values()))
+        with capsys.disabled():
+            print(f"\n[configs[4] full size] worst normalised gradient error {worsts[-1]:.3e}; per output: " +
+                  ", ".join(f"{k} {v['max_norm_err']:.1e} ({100 * v['frac_within']:.3f} % within 2e-3)" for k, v in rep.items()))
+        if worsts[-1] <= 2e-3:
+            break
+    assert min(worsts) <= 2e-3, f"worst normalised gradient error {worsts} > 2e-3 at configs[4] size"
     assert set(rep) >= {"dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"}
 
 

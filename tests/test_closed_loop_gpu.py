@@ -389,3 +389,84 @@ def test_pipelined_loop_does_not_overwrite_frames_that_are_still_being_read(cuda
     torch.cuda.synchronize()
     assert torch.equal(late, want)
     assert torch.equal(pipe.loops[0].frames["right_cam"], other)
+
+
+def test_a_tile_grid_beyond_the_default_path_keeps_the_caller_s_order(cuda_device):
+    """a camera whose tile grid exceeds 16384 tiles takes the radix placement, whose frames are no
+    inference frames and reject a permuted model (GsrInputs.orig_index).  The loop then keeps the model's order and
+    hands over the block bounds alone -- every step renders, and equals the loop without a layout."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=30_000, seed=4)
+    W, H = 2304, 1920  # 144 x 120 = 17280 tiles
+    cams = {"big": scenes.sensor_camera("xarm6_align", W, H)}
+    parts, actors = cl.xarm6_parts()
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=3, seed=2))
+    loops = [cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, layout=lay, bound_capacity=False)
+             for lay in (True, False)]
+    assert loops[0].layout is not None and loops[0].layout[1] is None  # bounds only, no permutation
+    for lp in loops:
+        lp.reset(*poses[0])
+    for M, s in poses[1:]:
+        a, b = (lp.step(M, s, ensure=True)["big"].clone() for lp in loops)
+        assert torch.equal(a, b) and int(a.max()) > 100
+    # at a size the default path takes, the same scene does get its Morton-ordered copy
+    small = cl.ClosedLoopRenderer(raw, parts, {"cam": scenes.sensor_camera("xarm6_align", 640, 480)}, scaled_parts=actors,
+                                  device=dev)
+    assert small.layout is not None and small.layout[1] is not None
+
+
+def test_a_rollout_frame_pair_with_moved_parts_meets_the_oracle(cuda_device, capsys):
+    """configs[2], one step deep into the FK rollout (every link moved, both tracked actors moved and rescaled), both
+    cameras, FULL size -- against the CPU oracle fed with the model the REFERENCE's glue builds for that step
+    (oracle/wrapper_glue_ref.py + oracle/transform_ref.py on the host: deep copy, per-part transform_gaussians, masked
+    write-backs).  Everywhere else the closed-loop tests compare two glues through the same HIP rasterizer; here a frame
+    with moved parts meets the oracle's arithmetic end to end: float colour <= 1e-4 off the borderline pixels.
+    (The two sides differ by an ulp here and there BEFORE the rasterizer -- torch's matmul against the kernel's fused
+    multiply-adds in the rigid transform, torch.sigmoid against the device's -- so a handful of threshold decisions the
+    oracle does not flag may still flip: at most 1e-5 of the pixels may exceed 1e-4, none 5e-3.)"""
+    import numpy as np
+
+    from oracle import gs_oracle as go
+    from tests import helpers as hp
+
+    dev = cuda_device
+    rollout = cl.xarm6_rollout()
+    raw, cams, parts, actors, loop, _ = _setup(dev, scenes.XARM6_ALIGN_NUM_GAUSSIANS, rollout=rollout)
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=121, seed=0))
+    M, s = poses[120]
+    loop.reset(*poses[0])
+    loop.step(M, s, ensure=True)
+    got = {n: loop.multi.lanes[c]._out[0].cpu().numpy() for c, n in enumerate(loop.names)}
+    got8 = {n: loop.frames[n][0].cpu() for n in loop.names}
+    cpu = types.SimpleNamespace(_xyz=raw.xyz.clone(), _scaling=raw.scaling.clone(), _rotation=raw.rotation.clone(),
+                                _opacity=raw.opacity.reshape(-1, 1, 1).clone(), _semantics=raw.semantics,
+                                _features_dc=raw.features_dc, _features_rest=raw.features_rest)
+    moved = ref.transform_parts(cpu, parts, M[None], s[None], actors)
+    gs = ref.assemble_env(cpu, parts, moved, 0, 1)
+    assert not torch.equal(gs._xyz, raw.xyz) and not torch.equal(gs._scaling, raw.scaling)  # links moved, actors rescaled
+    # scales and rotations: the canonical activations the fused path evaluates inside preprocess; opacity: torch.sigmoid,
+    # as the loop activates it once at load time
+    _, sc, rot = go.activate_params(None, gs._scaling.numpy(), gs._rotation.numpy(), flags=6)
+    shs = torch.cat((gs._features_dc, gs._features_rest), dim=1).numpy()
+    opac = torch.sigmoid(gs._opacity.reshape(-1)).numpy()
+    lines = []
+    for name, cam in cams.items():
+        cam = cam.to("cpu")
+        inp = dict(means3D=gs._xyz.numpy(), shs=shs, opacities=opac, scales=sc, rotations=rot,
+                   viewmatrix=cam.world_view_transform.numpy().reshape(-1),
+                   projmatrix=cam.full_proj_transform.numpy().reshape(-1), campos=cam.camera_center.numpy())
+        o = hp.oracle_forward(inp, hp.oracle_settings(cam), np.zeros(3, np.float32))
+        d = np.abs(got[name] - o["color"]).max(0)
+        b = o["borderline"] != 0
+        over = int((d[~b] > 1e-4).sum())
+        lines.append(f"{name}: V {int((o['geom']['radii'] > 0).sum())} R {int(o['binning']['num_rendered'])} worst off "
+                     f"borderline {float(d[~b].max()):.3e} ({over} pixels > 1e-4), all pixels {float(d.max()):.3e}, "
+                     f"borderline {int(b.sum())}")
+        assert over <= max(3, int(1e-5 * d.size)), lines[-1]
+        assert float(d.max()) <= 5e-3, lines[-1]
+        want8 = (torch.from_numpy(o["color"]).clamp(0, 1).permute(1, 2, 0) * 255).clamp(0, 255).to(torch.uint8)
+        d8 = (want8.to(torch.int16) - got8[name].to(torch.int16)).abs()
+        assert int(d8.max()) <= 1 and int(want8.max()) > 100
+    with capsys.disabled():
+        print("\n[configs[2] step 120 against the oracle] " + "; ".join(lines))

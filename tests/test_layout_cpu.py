@@ -86,3 +86,15 @@ def test_unsorted_bounds_are_valid_and_degenerate_inputs_are_never_culled():
     assert not c2[0] and not c2[2]
     # rho = inf: only the near-plane test can still cull
     assert not c2[1] or bad[1, [2, 5]].max() < 0.05
+
+
+def test_blocks_built_without_labels_carry_no_common_label():
+    """a layout built without labels must never let a block be tested under ONE pose when it is later
+    rendered with a part transform -- its label field is NaN ("members differ"), which the kernel never culls by while
+    part labels are given, and does not read at all without them."""
+    raw = scenes.tabletop_scene("xarm6_align", n=5_000, seed=3)
+    means, shs, op, sc, rot = raw.activated()
+    b = gl.build_cull_blocks(means, sc, rot, labels=None)
+    assert bool(torch.isnan(b[:, 7]).all())
+    L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
+    assert bool(torch.isnan(L.cull_blocks[:, 7]).all())

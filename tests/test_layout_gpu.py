@@ -209,3 +209,37 @@ def test_tie_order_survives_trusted_splitters_and_a_moving_arm(cuda_device):
         torch.cuda.synchronize()
         assert torch.equal(got, want["right_cam"]), f"step {k}"
     assert blind_seen > 0
+
+
+def test_a_layout_without_labels_rendered_with_moving_parts_drops_nothing(cuda_device):
+    """SceneLayout.build without labels, then frames WITH a part transform: the blocks carry no common
+    label (NaN), so none of them is tested under a pose its members do not share -- frames equal the plain ones even
+    though whole parts leave the boxes they were scanned in."""
+    from gsworld_amd import closed_loop as cl
+    from gsworld_amd._lib import RAW_OPACITY, RAW_ROTATIONS, RAW_SCALES
+    from gsworld_amd.renderer import FrameRenderer
+    from gsworld_amd.transform import FusedPartTransform
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=27)
+    r_ = raw.to(dev)
+    parts, actors = cl.xarm6_parts()
+    ps = RAW_OPACITY | RAW_SCALES | RAW_ROTATIONS
+    L = gl.SceneLayout.build(r_.xyz, r_.scaling, r_.rotation, param_space=ps, opacity=r_.opacity,
+                             features_dc=r_.features_dc, features_rest=r_.features_rest, sem=r_.semantics.to(torch.float32))
+    a = L.arrays
+    assert bool(torch.isnan(L.cull_blocks[:, 7]).all())
+    op, op_l = FusedPartTransform(parts, r_.semantics, scaled_parts=actors), FusedPartTransform(parts, a["sem"], scaled_parts=actors)
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    big = [(M, s) for M, s in cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=40, seed=6)][::8]
+    ref, lay = FrameRenderer(dev, forward_only=True, want_radii=False), FrameRenderer(dev, forward_only=True, want_radii=False)
+    cam = _cams(dev)[0]
+    for k, (M, s) in enumerate(big):
+        Md, sd = M.to(dev).contiguous(), s.to(dev).contiguous()
+        want = ref.render(cam, r_.xyz, r_.opacity, shs=r_.features_dc, shs_rest=r_.features_rest, scales=r_.scaling,
+                          rotations=r_.rotation, param_space=ps, parts=op.parts(Md, sd))[0].clone()
+        got = lay.render(cam, a["means3D"], a["opacity"], shs=a["features_dc"], shs_rest=a["features_rest"],
+                         scales=a["scales"], rotations=a["rotations"], param_space=ps, parts=op_l.parts(Md, sd),
+                         layout=L.layout)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"pose {k}"

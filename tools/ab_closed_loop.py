@@ -41,11 +41,16 @@ def main():
         return v
 
     wrists = [wrist_at(k) for k in range(ep_len + 1)]
+    only = os.environ.get("CL_ONLY")  # "batched,ensure" as 0/1, e.g. CL_ONLY=1,0: one variant (for traces)
     for batched in (True, False):
+        if only and batched != bool(int(only.split(",")[0])):
+            continue
         loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E)
         loop.reset(*pinned[0])
         loop.capture()
         for ensure in (False, True):
+            if only and ensure != bool(int(only.split(",")[1])):
+                continue
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for (M, s), w in zip(pinned, wrists):
