@@ -214,7 +214,12 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
     // whole sort to a handful of workgroups: 328 us).  Samples are taken at equal steps of the running sum: uniform
     // over the visible Gaussians.
     const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
-    const int per = (nb1 + kT - 1) / kT;
+    constexpr int CB = 2 * kMaxSamples;  // blocks staged at a time (8192: 2.1 M Gaussians)
+    // (up to CB blocks -- 2.1 M Gaussians -- every count fits the LDS at once: the slice's counts are turned into their
+    // running sums in place and everything below works on those; larger models walk their slices chunk by chunk)
+    const bool all_staged = nb1 <= CB;
+    // blocks per thread slice; staged models round it up to a multiple of 8 (<= 32) so that a slice is whole 16-byte words
+    const int per = all_staged ? ((((nb1 + kT - 1) / kT) + 7) & ~7) : (nb1 + kT - 1) / kT;
     const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
     // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself
     // (up to 8 entries per thread): by the time the counts are summed it has all arrived, instead of costing three
@@ -231,7 +236,6 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
     // coalesced loads: a thread reading its own contiguous slice straight from global memory touches a cache line per
     // lane and load (that alone was 25 k cycles per workgroup)
     uint16_t *s_cnt16 = reinterpret_cast<uint16_t *>(s_key + kMaxSamples);
-    constexpr int CB = 2 * kMaxSamples;  // blocks staged at a time (8192: 2.1 M Gaussians)
     auto stage = [&](int cb) {
         const int n = min(CB, nb1 - cb);
         for (int i = tid; i < n; i += 8 * kT) {
@@ -243,17 +247,47 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
                 if (i + u * kT < n) s_cnt16[i + u * kT] = (uint16_t)c[u];
         }
     };
-    // (up to CB blocks -- 2.1 M Gaussians -- every count fits the LDS at once: the slice's counts are turned into their
-    // running sums in place and everything below is binary searches; larger models walk their slices chunk by chunk)
-    const bool all_staged = nb1 <= CB;
     uint32_t mine = 0;
-    for (int cb = 0; cb < nb1; cb += CB) {
-        if (cb > 0) __syncthreads();
-        stage(cb);
+    uint32_t inc[32];  // (staged models) running sums of the counts of this thread's slice, inc[k] = blocks j0 .. j0 + k
+    if (all_staged) {
+        // every count of the model in ONE batch of loads (up to 32 in flight per thread: one round trip, not four), zero
+        // behind the last block up to the end of the last slice
+        uint32_t c[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) c[u] = tid + u * kT < nb1 ? block_counts[tid + u * kT] : 0u;
+#pragma unroll
+        for (int u = 0; u < 32; u++)
+            if (tid + u * kT < per * kT) s_cnt16[tid + u * kT] = (uint16_t)c[u];
         __syncthreads();
-        for (int j = max(j0, cb); j < min(j1, cb + CB); j++) {
-            mine += s_cnt16[j - cb];
-            if (all_staged) s_cnt16[j] = (uint16_t)mine;  // (a slice holds <= 32 blocks x 256: fits 16 bits)
+        // the slice: per / 8 aligned 16-byte words (8 counts each), summed in registers, written back as running sums
+        // (a slice holds <= 32 blocks x 256: fits 16 bits)
+        uint4 *sl = reinterpret_cast<uint4 *>(s_cnt16 + tid * per);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (8 * w < per) {
+                const uint4 v = sl[w];
+                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    mine += x[h] & 0xffffu;
+                    inc[8 * w + 2 * h] = mine;
+                    mine += x[h] >> 16;
+                    inc[8 * w + 2 * h + 1] = mine;
+                    o[h] = inc[8 * w + 2 * h] | (inc[8 * w + 2 * h + 1] << 16);
+                }
+                sl[w] = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 8; h++) inc[8 * w + h] = mine;
+            }
+        }
+    } else {
+        for (int cb = 0; cb < nb1; cb += CB) {
+            if (cb > 0) __syncthreads();
+            stage(cb);
+            __syncthreads();
+            for (int j = max(j0, cb); j < min(j1, cb + CB); j++) mine += s_cnt16[j - cb];
         }
     }
     SS_STAMP(dbg, 1);
@@ -282,6 +316,7 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
         return;
     }
     __syncthreads();
+    SS_STAMP(dbg, 22);
     const int B = ss_num_buckets(V, bmax);
     // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
     // in a few hundred frames outgrows the LDS)
@@ -321,20 +356,30 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
         blind = __syncthreads_or((int)bad) == 0;
     }
     if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
+    SS_STAMP(dbg, 23);
     if (all_staged) {
-        // Sample s is the key of visible Gaussian floor(s V / S) in index order: uniform over the VISIBLE Gaussians.
+        // Sample s belongs to the preprocess block that holds visible Gaussian floor(s V / S) of the index order: uniform
+        // over the VISIBLE Gaussians.  (Until round 4 the sample was the FIRST visible key of that block: the same thing
+        // for a model in random order, but in a spatially sorted model -- gsworld_amd/layout.py -- the visible Gaussians
+        // sit in a fifth of the blocks, several samples drew the same key, the splitters came out uneven every frame and
+        // the buckets outgrew the LDS: ss_buckets 12 -> 72 us.)
         // Two binary searches per sample -- the thread slice (s_pex), then the block inside it (the slice's running
-        // sums) -- four samples side by side (walking the slices instead was 15 k cycles); the sample is then record
-        // (rank - records before the block) of the block's compacted records.  (Until round 4 the sample was the FIRST
-        // visible key of that block: the same thing for a model in random order, but in a spatially sorted model --
-        // gsworld_amd/layout.py -- the visible Gaussians sit in a fifth of the blocks, several samples drew the same
-        // key, the splitters came out uneven every frame and the buckets outgrew the LDS: ss_buckets 12 -> 72 us.)
+        // sums) -- EIGHT samples side by side per thread (rounds 2-4: four, i.e. four chains of thirteen dependent LDS
+        // round trips one after the other for 4096 samples, 16 k cycles of every workgroup's prologue by the stamps; a
+        // version in which every thread handed out the samples of its own slice in one walk was measured in round 5:
+        // 27-68 k, the visible Gaussians of a wrist camera sit in eight of the 256 slices).  A block's n samples are its
+        // FIRST n visible records -- one or two cache lines of the block's compacted records instead of a line per
+        // sample: the gather below touches ~700 lines instead of 4096, in every one of the 256 workgroups (11 k -> 3 k
+        // cycles); inside a block of 256 consecutive Gaussians -- neighbours in space for a laid-out model, a random
+        // subset otherwise -- any n records are as good a sample of the block's depths as any other.
+        constexpr int SW = 8;
+        const double s_per_rank = (double)S / (double)V;
 #pragma unroll 1
-        for (int q0 = 0; q0 < 16; q0 += 4) {
+        for (int q0 = 0; q0 < 16; q0 += SW) {
             if (blind || (uint32_t)(q0 * kT) >= S) break;
-            uint32_t tgt[4], u[4];
+            uint32_t tgt[SW], u[SW];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < SW; q++) {
                 const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
                 tgt[q] = (uint32_t)(((uint64_t)min(smp, S - 1u) * V) >> logS);
                 u[q] = 0u;
@@ -342,12 +387,12 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
 #pragma unroll
             for (int st = kT / 2; st > 0; st >>= 1) {
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < SW; q++)
                     if (s_pex[u[q] + (uint32_t)st] <= tgt[q]) u[q] += (uint32_t)st;  // last slice that starts at or before
             }
-            uint32_t pos[4], base[4], n[4], lt[4];
+            uint32_t pos[SW], base[SW], n[SW], lt[SW];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < SW; q++) {
                 base[q] = min((uint32_t)nb1, u[q] * (uint32_t)per);
                 n[q] = min((uint32_t)nb1, base[q] + (uint32_t)per) - base[q];
                 lt[q] = tgt[q] - s_pex[u[q]];
@@ -356,20 +401,24 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
 #pragma unroll
             for (int st = 16; st > 0; st >>= 1) {  // first block of the slice whose running sum exceeds lt (per <= 32)
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < SW; q++)
                     if (pos[q] + (uint32_t)st <= n[q] && (uint32_t)s_cnt16[base[q] + pos[q] + (uint32_t)st - 1u] <= lt[q])
                         pos[q] += (uint32_t)st;
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < SW; q++) {
                 const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
                 const uint32_t pb = min(pos[q], n[q] - 1u), blk = base[q] + pb;
                 const uint32_t before_b = pb > 0u ? (uint32_t)s_cnt16[blk - 1u] : 0u;
                 const uint32_t cnt_b = (uint32_t)s_cnt16[blk] - before_b;
-                const uint32_t off = cnt_b > 0u ? min(lt[q] - min(lt[q], before_b), cnt_b - 1u) : 0u;
+                // how many samples before this one fall into the same block: the block's first sample is the first whose
+                // rank reaches the records before the block (a last-bit error of the quotient only picks a neighbour)
+                const uint32_t s_first = (uint32_t)__builtin_ceil((double)(s_pex[u[q]] + before_b) * s_per_rank);
+                const uint32_t off = cnt_b > 0u ? min(min(smp, S - 1u) - min(min(smp, S - 1u), s_first), cnt_b - 1u) : 0u;
                 if (smp < S) s_key[smp] = blk * (uint32_t)GSR_BLOCK + off;  // the record that lends its key
             }
         }
+        SS_STAMP(dbg, 24);
         // the two ends of my run of blocks: one lane each
         if ((tid == 0 && me > 0) || (tid == GSR_WAVE && me + 1 < nbc)) {
             const uint32_t t = tid == 0 ? t_lo : t_hi;
@@ -465,13 +514,17 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
         // (s_split was filled when the table was checked)
     } else if (reuse) {
         uint32_t bad = 0;
-        for (int i = tid; i < B; i += kT) {
-            const uint32_t sp = i < B - 1 ? splitters[i] : 0xFFFFFFFFu;
-            s_split[i] = sp;
-            s_hist[i] = 0u;
-            if (i + 1 < B - 1 && splitters[i + 1] < sp) bad = 1u;
+        // (the kept table was requested at the top of the kernel, 8 entries per thread: no round trip here)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = tid + k * kT;
+            if (i < B) {
+                s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
+                s_hist[i] = 0u;
+            }
         }
         __syncthreads();
+        for (int i = tid; i + 1 < B - 1; i += kT) bad |= s_split[i + 1] < s_split[i] ? 1u : 0u;
         for (uint32_t i0 = (uint32_t)tid; i0 < S; i0 += 4u * kT) {
             uint32_t tk[4], bk[4];
 #pragma unroll
@@ -487,22 +540,40 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
         reuse = __syncthreads_or((int)bad) == 0;
     }
     if (!reuse && !blind) {
-        const uint32_t *sorted;
-        if ((kKeyMask & 0xFFu) != 0u) {  // (four digits when the low byte takes part)
-            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 0, s_cur, s_w);
-            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 8, s_cur, s_w);
-            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 16, s_cur, s_w);
-            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 24, s_cur, s_w);
-            sorted = s_key;
-        } else {
-            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 8, s_cur, s_w);
-            lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 16, s_cur, s_w);
-            lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 24, s_cur, s_w);
-            sorted = s_key + kMaxSamples;
+        // New splitters: the (i + 1) S / B-th smallest samples.  Splitters only decide the balance of the buckets, so the
+        // samples are sorted by a 16-bit code -- their offset from the smallest sample, shifted until the largest fits
+        // 16 bits: 1 / 65536 of the samples' range, exact when the range is below that (a plane seen from straight above)
+        // -- in TWO 8-bit LSD passes instead of four over the full keys (45 k -> 25 k cycles of every workgroup's
+        // prologue on a frame that samples, by the stamps); a splitter is its code put back on the smallest sample:
+        // ascending, and equal keys classify alike whatever the table.
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for (int i = tid; i < (int)S; i += kT) {
+            mn = min(mn, s_key[i]);
+            mx = max(mx, s_key[i]);
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+        __shared__ uint32_t s_mm[8];
+        if (lane == 0) {
+            s_mm[wave] = mn;
+            s_mm[4 + wave] = mx;
+        }
+        __syncthreads();
+        mn = min(min(s_mm[0], s_mm[1]), min(s_mm[2], s_mm[3]));
+        mx = max(max(s_mm[4], s_mm[5]), max(s_mm[6], s_mm[7]));
+        const uint32_t range = mx - mn;
+        const int shift = range < 65536u ? 0 : (32 - __builtin_clz(range)) - 16;
+        for (int i = tid; i < (int)S; i += kT) s_key[i] = (s_key[i] - mn) >> shift;
+        __syncthreads();
+        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 0, s_cur, s_w);
+        lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 8, s_cur, s_w);
+        const uint32_t *sorted = s_key;
         for (int i = tid; i < B; i += kT) {
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
-            const uint32_t sp = (i < B - 1 && q < S) ? sorted[q] : 0xFFFFFFFFu;
+            const uint32_t sp = (i < B - 1 && q < S) ? (((sorted[q] << shift) + mn) & kKeyMask) : 0xFFFFFFFFu;
             s_split[i] = sp;
             // NOT into the table the other workgroups may still be reading (a workgroup dispatched late would see it
             // half rewritten and could validate a mixture nobody else classified with): the drawn table goes to its

@@ -424,7 +424,8 @@ def test_a_rollout_frame_pair_with_moved_parts_meets_the_oracle(cuda_device, cap
     with moved parts meets the oracle's arithmetic end to end: float colour <= 1e-4 off the borderline pixels.
     (The two sides differ by an ulp here and there BEFORE the rasterizer -- torch's matmul against the kernel's fused
     multiply-adds in the rigid transform, torch.sigmoid against the device's -- so a handful of threshold decisions the
-    oracle does not flag may still flip: at most 1e-5 of the pixels may exceed 1e-4, none 5e-3.)"""
+    oracle does not flag could still flip; none does on this step: every pixel off the oracle's borderline set within
+    1e-4, measured 4.8e-7, and every pixel within 1e-3, measured 1.0e-5.)"""
     import numpy as np
 
     from oracle import gs_oracle as go
@@ -463,8 +464,8 @@ def test_a_rollout_frame_pair_with_moved_parts_meets_the_oracle(cuda_device, cap
         lines.append(f"{name}: V {int((o['geom']['radii'] > 0).sum())} R {int(o['binning']['num_rendered'])} worst off "
                      f"borderline {float(d[~b].max()):.3e} ({over} pixels > 1e-4), all pixels {float(d.max()):.3e}, "
                      f"borderline {int(b.sum())}")
-        assert over <= max(3, int(1e-5 * d.size)), lines[-1]
-        assert float(d.max()) <= 5e-3, lines[-1]
+        assert over == 0, lines[-1]                 # (measured: 4.8e-7 off the borderline pixels, 1.0e-5 on all)
+        assert float(d.max()) <= 1e-3, lines[-1]
         want8 = (torch.from_numpy(o["color"]).clamp(0, 1).permute(1, 2, 0) * 255).clamp(0, 255).to(torch.uint8)
         d8 = (want8.to(torch.int16) - got8[name].to(torch.int16)).abs()
         assert int(d8.max()) <= 1 and int(want8.max()) > 100

@@ -83,7 +83,7 @@ def test_block_bounds_alone_leave_the_reference_state_untouched(cuda_device):
     L = gl.SceneLayout.build(means, sc, rot, shs=shs, opacities=op)
     a = L.arrays
     blocks = gl.build_cull_blocks(a["means3D"], a["scales"], a["rotations"])
-    assert torch.equal(blocks, L.cull_blocks)
+    assert torch.allclose(blocks, L.cull_blocks, rtol=0.0, atol=0.0, equal_nan=True)  # (label field: NaN, no labels given)
     cam = scenes.sensor_camera("xarm6_align").to(dev)
     P, W, H = raw.num, 640, 480
     outs = []

@@ -43,6 +43,7 @@ for k, (M, s) in enumerate(poses[1:]):
             print(f"step {k} {name}: V {st.num_visible} R {st.num_rendered} sort {dbg.sort_state(lane.geom)}")
             print(f"   compact wg64: counts+sums {d(0, 1)} | samples+ranges {d(1, 21)} | sample keys {d(21, 2)} | splitters {d(2, 3)} "
                   f"| offsets {d(3, 4)} | walk {d(4, 5)} | classify {d(5, 6)} | table {d(6, 7)} | total {d(0, 7)}")
+            print(f"   compact wg64 inside samples+ranges: scan {d(1, 22)} | blind decision {d(22, 23)} | sample search {d(23, 24)} | range ends {d(24, 21)}")
             print(f"   compact slowest wg: {v[10]} clk (wg {v[11]}, {v[12]} blocks, {v[13]} records); wg0 {v[14]} clk")
             print(f"   partition wg64: setup {int(v[17] - v[16])} move {int(v[18] - v[17])} | buckets wg100: hdr {int(v[33] - v[32])} "
                   f"sort {int(v[35] - v[33])} emit {int(v[36] - v[35])} bits {v[40]} n {v[41]}")
