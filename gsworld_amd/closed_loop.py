@@ -66,7 +66,8 @@ class ClosedLoopRenderer:
         dev = self.device
         self.num_envs = int(num_envs)
         self.names = list(cameras.keys())
-        self.cameras = [self._own(cameras[n], dev) for n in self.names]
+        self._given_cameras = [cameras[n] for n in self.names]
+        self.cameras = self._given_cameras  # (image sizes; replaced by device-resident copies once the staging vector exists)
         g = lambda a, b: getattr(raw, a) if hasattr(raw, a) else getattr(raw, b)  # noqa: E731
         other = share_model_of
         if other is not None:
@@ -141,9 +142,45 @@ class ClosedLoopRenderer:
         self.recovered_steps = 0      # steps re-rendered because a lane had overflowed (see step())
         self.late_overflow_frames = 0  # overflowed frames that were only noticed after their step had been returned
         lead = (self.num_envs, self.K) if self.num_envs > 1 else (self.K,)
+        # Everything a step reads that changes from step to step -- part matrices, uniform scales, camera matrices --
+        # lives in ONE device vector: `matrices`, `scales` and the cameras' tensors are views into it.  Values handed over
+        # as HOST tensors (the usual case: a CPU simulator, a test) are collected in a host mirror and go up in one copy
+        # per step (round 4: five small copies, 5 us each on the step's stream, 8 % of a step); device tensors (ManiSkill
+        # link poses on the GPU) are copied view by view, device to device.
+        nm, ns = self.num_envs * self.K * 16, self.num_envs * self.K
+        self._seg = {"poses": (0, nm + (ns + 3) // 4 * 4)}
+        off = self._seg["poses"][1]
+        for n in self.names:
+            self._seg[n] = (off, off + 36)  # world_view (16) | full_proj (16) | centre (3) + pad
+            off += 36
+        self._stage = torch.zeros(off, device=dev)
+        self._host = torch.zeros(off)
+        pin = dev.type == "cuda" and torch.cuda.is_available()
+        self._ring = [torch.zeros(off).pin_memory() if pin else torch.zeros(off) for _ in range(8)]
+        self._ring_ev, self._ring_k = [None] * len(self._ring), 0
+        self._dirty, self._stale = set(), set()  # segments changed on the host / last written from a device tensor
+
+        def views(buf):
+            v = {"matrices": buf[:nm].view(*lead, 4, 4), "scales": buf[nm:nm + ns].view(lead)}
+            for n in self.names:
+                o = self._seg[n][0]
+                v[n] = (buf[o:o + 16].view(4, 4), buf[o + 16:o + 32].view(4, 4), buf[o + 32:o + 35])
+            return v
+
+        self._hv, dv = views(self._host), views(self._stage)
+        self._hv["matrices"].copy_(torch.eye(4).expand(*lead, 4, 4))
+        self._hv["scales"].fill_(1.0)
+        from .camera import ViewParams
+
+        cams_dev = []
+        for n, cam in zip(self.names, self._given_cameras):
+            for dst, src in zip(self._hv[n], (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)):
+                dst.copy_(src.detach().to("cpu", torch.float32))
+            cams_dev.append(ViewParams(cam.image_width, cam.image_height, cam.FoVx, cam.FoVy, *dv[n]))
+        self.cameras = cams_dev
+        self._stage.copy_(self._host)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
-        self.matrices = torch.eye(4, device=dev).repeat(*lead, 1, 1).contiguous()
-        self.scales = torch.ones(lead, device=dev)
+        self.matrices, self.scales = dv["matrices"], dv["scales"]
         self._graph = None
         self.image_size = (H, W)
 
@@ -157,19 +194,12 @@ class ClosedLoopRenderer:
         return (gx * gy <= 16384 and gx <= 256 and int(TUNING["binning_path"]) in (0, 4) and int(TUNING["depth_sort"]) == 0
                 and int(TUNING["forward_only"]) != 0)
 
-    @staticmethod
-    def _own(cam, dev):
-        """A private, dense device copy of a camera (set_cameras writes into it in place)."""
-        from .camera import ViewParams
-
-        c = lambda t: t.detach().to(dev, torch.float32).clone().contiguous()  # noqa: E731
-        return ViewParams(cam.image_width, cam.image_height, cam.FoVx, cam.FoVy, c(cam.world_view_transform),
-                          c(cam.full_proj_transform), c(cam.camera_center))
-
     # ---- one step ------------------------------------------------------------------------------------------------
     def _gpu_step(self):
         """Everything the GPU does per step: pose table, fused transform, E x C frames (reads self.matrices / scales)."""
         E, C = self.num_envs, len(self.cameras)
+        if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self._flush()
         if self.fuse_transform:
             parts = self.op.parts(self.matrices, self.scales)  # device-side pose table(s), nothing else
             views, outs, per_lane = [], [], []
@@ -205,14 +235,62 @@ class ClosedLoopRenderer:
                               shs_rest=self.features_rest, param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg,
                               per_lane=per_lane)
 
+    def _flush(self):
+        """Host-side changes since the last flush go up in as few copies as possible: one contiguous run of the staging
+        vector from the first to the last changed segment, unless a segment in between was last written from a DEVICE
+        tensor (its host mirror is stale: the run is cut around it).  Every copy reads from its own pinned slot of a
+        ring, so the caller may overwrite its tensors -- and this object its mirror -- right away."""
+        if not self._dirty:
+            return
+        order = ["poses"] + self.names
+        runs, cur = [], None
+        first = min(order.index(n) for n in self._dirty)
+        last = max(order.index(n) for n in self._dirty)
+        for n in order[first:last + 1]:
+            if n in self._stale and n not in self._dirty:
+                cur = None
+                continue
+            lo, hi = self._seg[n]
+            if cur is None:
+                cur = [lo, hi]
+                runs.append(cur)
+            else:
+                cur[1] = hi
+        for lo, hi in runs:
+            k = self._ring_k % len(self._ring)
+            self._ring_k += 1
+            if self._ring_ev[k] is not None:
+                self._ring_ev[k].synchronize()  # (eight copies ago: long done)
+            slot = self._ring[k]
+            slot[lo:hi].copy_(self._host[lo:hi])
+            self._stage[lo:hi].copy_(slot[lo:hi], non_blocking=True)
+            if self.device.type == "cuda" and torch.cuda.is_available():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._ring_ev[k] = ev
+        self._stale -= self._dirty
+        self._dirty.clear()
+
     def set_poses(self, matrices: torch.Tensor, scales: torch.Tensor | None = None):
-        """Copies this step's part poses ((K,4,4) or (E,K,4,4), host or device; + uniform scales) into the persistent
-        device buffers the (possibly captured) step reads."""
+        """This step's part poses ((K,4,4) or (E,K,4,4), host or device; + uniform scales) for the persistent device
+        buffers the (possibly captured) step reads.  Host tensors are taken over at once (the caller may reuse them) and
+        uploaded with the step's other host values in one copy; device tensors are copied device to device."""
         if tuple(matrices.shape) != tuple(self.matrices.shape):
             raise ValueError(f"expected poses of shape {tuple(self.matrices.shape)}, got {tuple(matrices.shape)}")
-        self.matrices.copy_(matrices.to(torch.float32), non_blocking=True)
+        if matrices.is_cuda or (scales is not None and scales.is_cuda):
+            self._flush()  # (host values set earlier keep their order with respect to this write)
+            self.matrices.copy_(matrices.to(torch.float32), non_blocking=True)
+            if scales is not None:
+                self.scales.copy_(scales.to(torch.float32).reshape(self.scales.shape), non_blocking=True)
+            self._stale.add("poses")
+            return
+        if "poses" in self._stale and scales is None:
+            raise RuntimeError("set_poses: the poses were last written from device tensors; hand matrices AND scales over "
+                               "on the host so that the host mirror is whole again (or keep handing device tensors over)")
+        self._hv["matrices"].copy_(matrices.to(torch.float32))
         if scales is not None:
-            self.scales.copy_(scales.to(torch.float32).reshape(self.scales.shape), non_blocking=True)
+            self._hv["scales"].copy_(scales.to(torch.float32).reshape(self.scales.shape))
+        self._dirty.add("poses")
 
     def set_cameras(self, cameras: dict):
         """This step's camera poses: ``{name: ViewParams}`` for any subset of the cameras given at construction -- the
@@ -227,9 +305,16 @@ class ClosedLoopRenderer:
             if (cam.image_width, cam.image_height) != (mine.image_width, mine.image_height) or \
                     abs(cam.FoVx - mine.FoVx) > 1e-9 or abs(cam.FoVy - mine.FoVy) > 1e-9:
                 raise ValueError(f"camera {name!r}: image size / field of view are fixed at construction")
-            mine.world_view_transform.copy_(cam.world_view_transform.to(torch.float32), non_blocking=True)
-            mine.full_proj_transform.copy_(cam.full_proj_transform.to(torch.float32), non_blocking=True)
-            mine.camera_center.copy_(cam.camera_center.to(torch.float32), non_blocking=True)
+            src = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+            if any(t.is_cuda for t in src):
+                self._flush()
+                for dst, t in zip((mine.world_view_transform, mine.full_proj_transform, mine.camera_center), src):
+                    dst.copy_(t.to(torch.float32), non_blocking=True)
+                self._stale.add(name)
+            else:
+                for dst, t in zip(self._hv[name], src):
+                    dst.copy_(t.to(torch.float32))
+                self._dirty.add(name)
 
     def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None,
              cameras: dict | None = None, ensure: bool = False) -> dict:
@@ -253,6 +338,7 @@ class ClosedLoopRenderer:
         if cameras:
             self.set_cameras(cameras)
         if self._graph is not None:
+            self._flush()  # this step's host values: one copy on the step's stream, ahead of the replay
             self._graph.replay()
         else:
             self._gpu_step()

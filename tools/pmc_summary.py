@@ -40,6 +40,7 @@ if json_out:
     sha = hashlib.sha256(open(os.path.join(here, "gsworld_amd", "csrc", "render.hip"), "rb").read()).hexdigest()[:16]
     rec = {
         "kernel": "render_stream_kernel",
+        "frames_per_launch": int(os.environ.get("PMC_BATCH", "1")),
         "workload": "config 2 frame (N=1468850, 640x480, right_cam)",
         "collected": datetime.date.today().isoformat(),
         "render_hip_sha16": sha,
