@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="steps in flight: consecutive steps alternate over this many HIP streams, each with its own renderer "
                          "states (1 = every launch on one stream)")
+    ap.add_argument("--only-steps", action="store_true",
+                    help="profiling aid: nothing but the step's own launches after the set-up (no one-frame-per-launch stage "
+                         "table, latency loop or one-frame figure), so that a rocprofv3 --stats average of this command is "
+                         "the average of the step's launches")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="A/B of rounds 2-4: N frames in flight, ONE frame per step and stream (= --batch 1 --streams N)")
     a = ap.parse_args()
@@ -243,11 +247,11 @@ def main():
         group(0)
     torch.cuda.synchronize()
     stage_ms_step = staged(lambda: group(0), max(reps // B, 20))
-    stage_ms = staged(frame1, reps)
+    stage_ms = staged(frame1, reps) if not args.only_steps else [0.0] * len(PROFILE_STAGES)
 
     # per-frame latency distribution (hipEvent per frame, median and p95), strictly one frame at a time
     g1 = None
-    if not args.no_graph:
+    if not args.no_graph and not args.only_steps:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -256,20 +260,20 @@ def main():
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=side):
             frame1()
-    n_lat = min(max(args.steps, 100), 200)
+    n_lat = min(max(args.steps, 100), 200) if not args.only_steps else 0
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
     for e0, e1 in ev:
         e0.record()
         g1.replay() if g1 is not None else frame1()
         e1.record()
     torch.cuda.synchronize()
-    lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    lat = sorted(e0.elapsed_time(e1) for e0, e1 in ev) or [0.0]
     frame_ms_p50, frame_ms_p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
 
     for g in range(G):
         if any(s_.overflow for s_ in mcs[g].ensure_valid(lambda: None)):
             raise SystemExit("binning capacity overflowed during the timed region: result invalid")
-    stats = r1.ensure_valid(frame1)
+    stats = r1.ensure_valid(frame1) if not args.only_steps else r1.stats()
     if stats.overflow:
         raise SystemExit("binning capacity overflowed during the timed region: result invalid")
 

@@ -141,7 +141,8 @@ constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (70
 template <int NC>
 __device__ __forceinline__ void band_count_body(const uint2 *__restrict__ rect_sorted,
                                                          const uint32_t *__restrict__ wave_lo, int gx, int NR,
-                                                         uint32_t *__restrict__ table, uint32_t *__restrict__ wtable) {
+                                                         uint32_t *__restrict__ table, uint32_t *__restrict__ wtable,
+                                                         uint32_t *__restrict__ nseg_tab) {
     __shared__ int s_diff[kBW][NC * 64 + 1];
     __shared__ uint32_t s_tot[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
@@ -171,14 +172,22 @@ __device__ __forceinline__ void band_count_body(const uint2 *__restrict__ rect_s
     __builtin_amdgcn_wave_barrier();
     // running sum over the columns: lane l of round k = column 64 k + l
     uint32_t *wrow = wtable + ((size_t)(y * (uint32_t)NR + r) * kBW + (uint32_t)wave) * (NC * 64);
-    uint32_t carry = 0;
+    uint32_t carry = 0, unit = 0;
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         const uint32_t incl = gsr_wave_incl_scan((uint32_t)diff[k * 64 + lane]) + carry;
         wrow[k * 64 + lane] = incl;
         s_tot[wave][k * 64 + lane] = incl;
         carry = (uint32_t)__shfl((int)incl, 63, 64);
+        unit += k * 64 + lane < gx ? incl : 0u;
     }
+    // instances of this wave's (share, row) unit -> into how many column segments the placement cuts it (band_place_body:
+    // a byte per wave; three of its four workgroups per unit leave on this byte alone)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) unit += (uint32_t)__shfl_xor((int)unit, o, 64);
+    if (lane == 0)
+        reinterpret_cast<uint8_t *>(nseg_tab)[((size_t)y * (uint32_t)NR + r) * kBW + (uint32_t)wave] =
+            unit > kSplit4 ? 4 : (unit > kSplit2 ? 2 : 1);
     __syncthreads();
     for (int x = (int)threadIdx.x; x < gx; x += kBT)
         table[((size_t)y * gx + x) * NR + r] = s_tot[0][x] + s_tot[1][x] + s_tot[2][x] + s_tot[3][x];
@@ -296,13 +305,18 @@ __device__ __forceinline__ void band_place_body(const uint32_t seg, const uint2 
                                                          const uint32_t *__restrict__ table,
                                                          const uint32_t *__restrict__ wtable,
                                                          const uint2 *__restrict__ ranges,
-                                                         uint32_t *__restrict__ point_list) {
+                                                         uint32_t *__restrict__ point_list,
+                                                         const uint32_t *__restrict__ nseg_tab) {
     __shared__ uint2 s_ring[kBW][kRing];
     __shared__ unsigned long long s_mask[kBW][NC * 64];
     __shared__ uint32_t s_cur[kBW][NC * 64];
     const int lane = gsr_lane(), wave = gsr_wave();
-    if (hdr->overflow) return;
     const uint32_t r = blockIdx.x, y = blockIdx.y;
+    // (the counting pass left, per wave of every unit, into how many column segments the unit is cut: the waves of the
+    //  spare segment workgroups -- three in four -- leave on one scalar word)
+    const uint32_t nseg = (nseg_tab[(size_t)y * (uint32_t)NR + r] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane(wave))) & 255u;
+    if (seg >= nseg) return;
+    if (hdr->overflow) return;
     const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
     if (lo >= hi) return;
     uint2 *ring = s_ring[wave];
@@ -316,7 +330,7 @@ __device__ __forceinline__ void band_place_body(const uint32_t seg, const uint2 
     // instance count, each placed by its own wave (grid z): the cursors are per column, so a wave that only takes
     // the pairs overlapping its columns, clipped to them, writes exactly the slots the whole unit's wave would.
     uint32_t x0 = 0u, x1 = (uint32_t)gx;
-    {
+    if (nseg > 1u) {
         uint32_t mine[NC], total = 0u;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
@@ -327,9 +341,7 @@ __device__ __forceinline__ void band_place_body(const uint32_t seg, const uint2 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_xor((int)total, o, 64);
         // (measured: thresholds of 768 / 1536 the same, 512 / 1024 and 350 / 700 slower -- more waves repeat the filter)
-        const uint32_t nseg = total > kSplit4 ? 4u : (total > kSplit2 ? 2u : 1u);
-        if (seg >= nseg) return;
-        if (nseg > 1u) {
+        {
             // column x belongs to segment floor(instances before x * nseg / total): contiguous, equal-count segments
             uint32_t before = 0u, first = 0xFFFFFFFFu, last = 0u;
 #pragma unroll
@@ -413,7 +425,7 @@ struct BandArgs {
     uint32_t sig;
     const uint2 *rect_sorted;
     int gx, NR, T;
-    uint32_t *table, *wtable, *totals;
+    uint32_t *table, *wtable, *totals, *nseg;
     const uint32_t *order;
     const uint2 *ranges;
     uint32_t *point_list;
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrBatch<BandArg
 template <int NC>
 __global__ __launch_bounds__(kBT) void band_count_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.z];
-    band_count_body<NC>(a.rect_sorted, a.wave_lo, a.gx, a.NR, a.table, a.wtable);
+    band_count_body<NC>(a.rect_sorted, a.wave_lo, a.gx, a.NR, a.table, a.wtable, a.nseg);
 }
 __global__ __launch_bounds__(kBT) void band_scan_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.y];
@@ -436,7 +448,7 @@ template <int NC>
 __global__ __launch_bounds__(kBT, 8) void band_place_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.z / (uint32_t)kMaxSegments];
     band_place_body<NC>(blockIdx.z % (uint32_t)kMaxSegments, a.rect_sorted, a.order, a.hdr, a.wave_lo, a.gx, a.NR, a.table,
-                        a.wtable, a.ranges, a.point_list);
+                        a.wtable, a.ranges, a.point_list, a.nseg);
 }
 
 // depth-ordered rects for depth sorts that do not write them themselves (the LSD radix variant)
@@ -482,6 +494,7 @@ static void band_args(int B, const GsrFrame *fr, bool balanced, bool place, GsrB
         a.table = g.band_table;
         a.wtable = g.band_wtable;
         a.totals = g.tile_totals;
+        a.nseg = g.band_nseg;
         a.order = g.order;
         a.ranges = fr[k].img.ranges;
         a.point_list = place ? fr[k].b.gidx[0] : (uint32_t *)nullptr;

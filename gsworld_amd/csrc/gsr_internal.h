@@ -124,6 +124,8 @@ struct GeomState {
     uint32_t *bucket_tiles;   // [bmax] tiles touched per sort bucket
     uint32_t *wave_lo;        // [GSR_BAND_RANGES * 4 + 1] first depth rank of every placement wave (equal cost shares)
     uint32_t *wave_lo_base;   // [GSR_BAND_RANGES * 4 + 1] the last exactly computed cuts (rescaled while the camera rests)
+    uint32_t *band_nseg;      // [tile rows * GSR_BAND_RANGES] column segments (1 / 2 / 4) of the four placement waves of
+                              //   every (tile row, rank range), one byte per wave: written by the counting pass
 
     static int sort_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_SORT_CHUNK); }
     static int prep_blocks(int32_t P) { return gsr_div_up(P > 0 ? P : 1, GSR_BLOCK); }
@@ -184,6 +186,7 @@ struct GeomState {
         g.wave_lo_base = take<uint32_t>(p, (size_t)GSR_BAND_RANGES * 4 + 1);
         g.ss_splitters_new = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.ss_totals = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
+        g.band_nseg = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES);  // (rows <= tiles: sized for the narrowest grid)
         // LAST: the only array whose size depends on tiles_x, which the read-only carvers (gsr_backward,
         // gsr_state_view, gsr_debug_ss_stamps) do not pass -- nothing may follow it
         g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));

@@ -37,9 +37,9 @@ PY
 fi
 if has stats; then
   # the step's own launches, alone on the chip: B = 4 frames per launch, one stream, eager (what roofline.kernel_ms times)
-  stats bench_step_launches bench.py --steps 50 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 4 --streams 1 --blocks 1 --min-seconds 0
+  stats bench_step_launches bench.py --steps 200 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 4 --streams 1 --blocks 1 --min-seconds 0 --only-steps
   stats bench_one_frame_per_launch bench.py --steps 100 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 1 --streams 1 --blocks 1 --min-seconds 0
-  stats bench_headline_arrangement bench.py --steps 50 --warmup 10 --no-graph --no-cpu-baseline --no-extras --blocks 1 --min-seconds 0
+  stats bench_headline_arrangement bench.py --steps 200 --warmup 10 --no-graph --no-cpu-baseline --no-extras --blocks 1 --min-seconds 0 --only-steps
   stats dense_view tools/prof_scene.py --view dense
   stats dense_view_step_launches tools/ab_batch.py --eager --view dense --steps 200 --configs batch4
   stats moving_camera tools/prof_scene.py --view sensor --moving
