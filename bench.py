@@ -48,7 +48,7 @@ def parse():
                     help="timed blocks of --steps steps each (at least this many, and until --min-seconds are timed); "
                          "value = their median")
     ap.add_argument("--min-seconds", type=float, default=0.3)
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="frames per step: ONE gsr_forward_batch call whose launches span them (include/gsr.h; 1..8)")
     ap.add_argument("--streams", type=int, default=3,
                     help="steps in flight: consecutive steps alternate over this many HIP streams, each with its own renderer "
@@ -654,6 +654,28 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
     for (M, s), w in zip(pinned, wrists):
         loop.step(M, s, cameras={"wrist_cam": w}, ensure=True)
     dt_policy = time.perf_counter() - t0
+    # ---- the same rollout with E environments per step (the wrapper's `for i in range(self.num_envs)`, gs_world_wrapper.py:
+    # 241-242): E x 2 frames per gsr_forward_batch call, environment e playing the trajectory 17 e steps ahead
+    env_sweep = {}
+    for E in (2, 4):
+        try:
+            lp = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
+            pe = [(M.pin_memory(), s_.pin_memory()) for M, s_ in cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0, num_envs=E)]
+            lp.reset(*pe[0])
+            lp.capture()
+            rec = {}
+            for label, ensure in (("frames_per_s", False), ("policy_in_loop_frames_per_s", True)):
+                torch.cuda.synchronize()
+                t0e = time.perf_counter()
+                for (M, s_), w in zip(pe, wrists):
+                    lp.step(M, s_, cameras={"wrist_cam": w}, ensure=ensure)
+                torch.cuda.synchronize()
+                rec[label] = (ep_len + 1) * len(cams) * E / (time.perf_counter() - t0e)
+            rec["frames_per_launch"], rec["overflow_frames"] = E * len(cams), lp.overflow_frames()
+            env_sweep[f"num_envs_{E}"] = rec
+            del lp, pe
+        except Exception as ex:  # noqa: BLE001
+            env_sweep[f"num_envs_{E}"] = {"error": f"{type(ex).__name__}: {ex}"}
     # ---- the same rollout with consecutive steps in flight (PipelinedClosedLoop, depth 3: six frames instead of two).
     # configs[2] is a RANDOM-ACTION rollout: gsworld_rand_action_tabletop.py:107-133 never looks at its observations, so
     # step k + 1 may be enqueued while step k renders; a policy that needs frame k first gets the figure above.
@@ -716,6 +738,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
         "frames_per_s": (ep_len + 1) * len(cams) / dt, "steps_per_s": (ep_len + 1) / dt,
         "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt_policy,
         "policy_in_loop_steps_per_s": (ep_len + 1) / dt_policy,
+        "environments_per_step": env_sweep,
         "frames_per_launch": len(cams),
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity

@@ -157,6 +157,7 @@ struct Plan {
     bool chunk, band;  // which counting placement
     bool exact;        // binning state sized from a read-back of num_rendered
     bool infer, super, lean, order_early, lean_bin;
+    bool radix_depth;  // the 3-pass LSD radix depth sort (GsrSettings.depth_sort = 1, or a model beyond the sample sort)
     GsrSettings st_bin;  // the settings with the super-tile grid as image (inference frames on the default path)
 };
 
@@ -188,7 +189,8 @@ int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Pl
     // tile rect instead, which only the super-tile compositor looks at).  super: lists per super-tile -- needs the
     // compositor that has every quadrant resident and its order computed early (grids up to 1536 tiles on 256 CUs), and
     // tile coordinates that fit a byte; larger images keep per-tile lists.
-    p.infer = st->forward_only != 0 && (p.band || p.chunk) && st->depth_sort != 1;
+    p.radix_depth = st->depth_sort == 1 || !gsr_ss_supported(in->P);  // (sample sort: every block count in one LDS)
+    p.infer = st->forward_only != 0 && (p.band || p.chunk) && !p.radix_depth;
     p.super = p.infer && st->render_variant == 0 && p.tiles_x <= 255 && p.tiles_y <= 255 &&
               gsr_render_uses_quad_order(*st, p.tiles) && gsr_render_split_blocks(*st, p.tiles) == 0;
     // (the chunk placement keeps its table in an array the lean layout drops)
@@ -204,7 +206,7 @@ int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Pl
         return GSR_E_INVALID;
     }
     // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
-    p.order_early = (p.band || p.chunk) && st->depth_sort != 1 && gsr_render_uses_quad_order(*st, p.tiles);
+    p.order_early = (p.band || p.chunk) && !p.radix_depth && gsr_render_uses_quad_order(*st, p.tiles);
     // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
     p.lean_bin = p.band || p.chunk;
     return GSR_OK;
@@ -256,7 +258,7 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
     prof_mark(1, stream);
     if (mode != 2) {
         // (the frame header is reset by the first kernel that writes it: the scan of the block counts)
-        if (st[0].depth_sort == 1) {
+        if (p.radix_depth) {
             if (int e = gsr_launch_compact_and_depth_sort(in[0].P, g, debug, stream)) return e;
             if (band || chunk)
                 if (int e = gsr_launch_gather_rects(in[0].P, g, debug, stream)) return e;
@@ -272,7 +274,7 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
         if (int e = gsr_launch_chunk_count(p.st_bin, in[0].P, g, debug, stream)) return e;
         if (int e = gsr_launch_tile_starts(1, fr, p.order_early, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_count(B, fr, st[0].depth_sort != 1, debug, stream)) return e;
+        if (int e = gsr_launch_band_count(B, fr, !p.radix_depth, debug, stream)) return e;
         if (int e = gsr_launch_tile_starts(B, fr, p.order_early, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(st[0], in[0].P, g, img, fr[0].cap32, debug, stream)) return e;
@@ -385,7 +387,7 @@ int gsr_forward_batch(int32_t B, const GsrSettings *st, const GsrInputs *in, con
         int n = 1;
         // (what can share launches: the default path -- sample sort, band placement, stream compositor -- with a
         //  capacity; an exact-mode frame reads its instance count back in the middle of the frame)
-        const bool batchable = plans[0].mode == 1 && plans[0].band && st[k].depth_sort != 1 && !plans[0].exact &&
+        const bool batchable = plans[0].mode == 1 && plans[0].band && !plans[0].radix_depth && !plans[0].exact &&
                                st[k].render_variant == 0;
         while (batchable && n < GSR_MAX_BATCH && k + n < B && in[k + n].P != 0 && r_capacity[k + n] > 0) {
             if (int e = make_plan(&st[k + n], &in[k + n], r_capacity[k + n], plans[n])) return e;

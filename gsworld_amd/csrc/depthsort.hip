@@ -180,129 +180,159 @@ __device__ __forceinline__ void lds_radix_pass(const uint32_t *kin, const uint32
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ss_compact: compaction + sampling + classification.  Workgroup b owns the preprocess blocks [b bpw, (b+1) bpw).
-// records are written as (index, key): the 64-bit little-endian view is key << 32 | index, the composite the
-// global-memory fallback of ss_buckets sorts.
+// ss_prepare: ONE workgroup of 1024 threads per frame decides everything the compaction workgroups have in common --
+// V, the bucket count, which splitter table classifies this frame (the kept one taken blind, the kept one validated
+// against samples, or a new one drawn from them) and which run of preprocess blocks every compaction workgroup owns.
+// Rounds 2-4 had every one of the 256 compaction workgroups repeat this chain for itself (no launch in between): by
+// round 5's cycle stamps 20 k (kept table) to 70 k cycles (new table) of one wave per SIMD per workgroup at 8-10 cycles
+// per dependent instruction, against 10 k for the compaction itself.  Sixteen waves on one CU hide each other's LDS
+// round trips and carry a quarter of the per-thread work each; the price is one launch boundary.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bmax,
-                                                        const uint2 *__restrict__ block_recs,
-                                                        const uint32_t *__restrict__ block_counts,
-                                                        const uint32_t *__restrict__ block_cand,
-                                                        uint2 *__restrict__ pairs, uint32_t *__restrict__ table,
-                                                        const uint32_t *__restrict__ splitters,
-                                                        uint32_t *__restrict__ splitters_new,
-                                                        uint32_t *__restrict__ seg_off, GsrHeader *__restrict__ hdr,
-                                                        uint64_t *__restrict__ dbg, const float *__restrict__ view,
-                                                        uint32_t sig) {
-    extern __shared__ uint32_t smem[];
-    const unsigned dbg_wg = 64; (void)dbg_wg;
+constexpr int kPT = 1024;            // threads of the prepare workgroup
+constexpr int kPW = kPT / GSR_WAVE;  // 16 waves
+
+// inclusive scan over the 1024 threads; s_w16: 16 words of LDS.  Two barriers.
+__device__ __forceinline__ uint32_t ss_scan1024(uint32_t v, uint32_t *s_w16, uint32_t &total) {
+    const uint32_t incl = gsr_wave_incl_scan(v);
+    const int lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
+    if (lane == 63) s_w16[wave] = incl;
+    __syncthreads();
+    uint32_t add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kPW; w++) {
+        const uint32_t x = s_w16[w];
+        add += w < wave ? x : 0u;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return incl + add;
+}
+
+// One stable LSD pass (8-bit digit at `shift`) over n keys in LDS by the 16 waves of the prepare workgroup (the sixteen-
+// wave form of lds_radix_pass: wave w owns a contiguous sixteenth).  s_cur: 16 x 256 words, s_w16: 16 words.
+__device__ __forceinline__ void ss_radix_pass16(const uint32_t *kin, uint32_t *kout, int n, int shift, uint32_t *s_cur,
+                                                uint32_t *s_w16) {
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = gsr_lane();
+    const int q = (((n + kPW - 1) / kPW) + 63) & ~63;
+    const int rounds = q >> 6, lo = wave * q;
+    const uint64_t lt = gsr_lanemask_lt();
+    for (int i = tid; i < kPW * 256; i += kPT) s_cur[i] = 0u;
+    __syncthreads();
+    for (int r = 0; r < rounds; r++) {
+        const int i = lo + (r << 6) + lane;
+        if (i < n) atomicAdd(&s_cur[wave * 256 + (int)((kin[i] >> shift) & 255u)], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t c[kPW], tot = 0;
+#pragma unroll
+        for (int w = 0; w < kPW; w++) {
+            c[w] = tid < 256 ? s_cur[w * 256 + tid] : 0u;
+            tot += c[w];
+        }
+        uint32_t all;
+        uint32_t run = ss_scan1024(tot, s_w16, all) - tot;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < kPW; w++) {
+                s_cur[w * 256 + tid] = run;
+                run += c[w];
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *cur = s_cur + wave * 256;
+    for (int r = 0; r < rounds; r++) {
+        const int i = lo + (r << 6) + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? kin[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        const uint64_t same = ss_match(d, 8, valid);
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        if (valid) kout[cur[d] + rank] = key;
+        __builtin_amdgcn_wave_barrier();  // every lane has read its cursor before the group leader moves it
+        if (valid && rank == 0u) cur[d] += (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+}
+
+// The prepare workgroup keeps every block count of the model in LDS as 16-bit running sums: up to kPrepBlocks preprocess
+// blocks (8.4 M Gaussians; larger models take the LSD radix depth sort: api.hip).  Static LDS: 132 KB of the CU's 160
+// (a launch may not ask for more than 64 KB dynamically).
+constexpr int kPrepBlocks = 32 * kPT;
+__host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1) / kPT) + 7) & ~7; }
+
+__device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nbc,
+                                                const uint2 *__restrict__ block_recs,
+                                                const uint32_t *__restrict__ block_counts,
+                                                const uint32_t *__restrict__ splitters,
+                                                uint32_t *__restrict__ splitters_new, uint32_t *__restrict__ seg_off,
+                                                uint32_t *__restrict__ seg_first, GsrHeader *__restrict__ hdr,
+                                                uint64_t *__restrict__ dbg, const float *__restrict__ view,
+                                                uint32_t sig) {
+    const unsigned dbg_wg = 0; (void)dbg_wg;
     SS_STAMP(dbg, 0);
-#ifdef GSR_SS_TIMING
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#endif
-    uint32_t *s_key = smem;                       // [2][kMaxSamples]
-    uint32_t *s_cur = s_key + 2 * kMaxSamples;    // [4][256]
-    uint32_t *s_split = s_cur + 4 * 256;          // [bmax]
-    uint32_t *s_hist = s_split + bmax;            // [bmax]
-    uint32_t *s_boff = s_hist + bmax;             // [4 kT + 1] offsets of up to 1024 blocks
-    __shared__ uint32_t s_w[4];
-    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
-    // ---- who owns what.  Thread t sums the counts of its contiguous slice of preprocess blocks; a block scan of the 256
-    // slice sums gives V and every slice's position in the running sum of VISIBLE Gaussians.  Workgroups own
-    // consecutive runs of blocks of equal cost (below), however the visible Gaussians are spread over the index range (a
-    // scan stored in spatial order has them all in a few thousand consecutive blocks; equal BLOCK shares then left the
-    // whole sort to a handful of workgroups: 328 us).  Samples are taken at equal steps of the running sum: uniform
-    // over the visible Gaussians.
-    const int nbc = (int)gridDim.x, me = (int)blockIdx.x;
-    constexpr int CB = 2 * kMaxSamples;  // blocks staged at a time (8192: 2.1 M Gaussians)
-    // (up to CB blocks -- 2.1 M Gaussians -- every count fits the LDS at once: the slice's counts are turned into their
-    // running sums in place and everything below works on those; larger models walk their slices chunk by chunk)
-    const bool all_staged = nb1 <= CB;
-    // blocks per thread slice; staged models round it up to a multiple of 8 (<= 32) so that a slice is whole 16-byte words
-    const int per = all_staged ? ((((nb1 + kT - 1) / kT) + 7) & ~7) : (nb1 + kT - 1) / kT;
-    const int j0 = min(nb1, tid * per), j1 = min(nb1, j0 + per);
-    // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself
-    // (up to 8 entries per thread): by the time the counts are summed it has all arrived, instead of costing three
-    // dependent round trips (header, view, table) in the middle of the kernel.
+    __shared__ uint32_t s_key[2 * kMaxSamples];
+    __shared__ uint32_t s_cur[kPW * 256];
+    __shared__ uint32_t s_split[2048], s_hist[2048];  // (bmax <= 2048)
+    __shared__ uint32_t s_pex[kPT + 8];               // visible Gaussians before every thread's slice
+    __shared__ __attribute__((aligned(16))) uint16_t s_cnt16[kPrepBlocks];  // running sums inside every slice
+    __shared__ uint32_t s_w16[kPW];
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = gsr_lane();
+    // ---- who owns what.  Thread t sums the counts of its contiguous slice of `per` preprocess blocks (a multiple of 8:
+    // whole 16-byte LDS words); a scan of the 1024 slice sums gives V and every slice's position in the running sum of
+    // VISIBLE Gaussians.  Compaction workgroups own consecutive runs of blocks of equal cost (below), however the visible
+    // Gaussians are spread over the index range; samples are taken at equal steps of the running sum: uniform over the
+    // visible Gaussians.
+    const int per = ss_prepare_per(nb1);
+    // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself: by
+    // the time the counts are summed it has all arrived.
     const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_trust = hdr->ss_trust,
                    h_P = hdr->ss_P;
     bool same_view = true;
 #pragma unroll
     for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
-    uint32_t pre_sp[8];
+    uint32_t pre_sp[2];
 #pragma unroll
-    for (int k = 0; k < 8; k++) pre_sp[k] = tid + k * kT < bmax - 1 ? splitters[tid + k * kT] : 0xFFFFFFFFu;
-    // the counts are staged in LDS (16 bits each, in the half of the sample buffer the sort only needs later) with
-    // coalesced loads: a thread reading its own contiguous slice straight from global memory touches a cache line per
-    // lane and load (that alone was 25 k cycles per workgroup)
-    uint16_t *s_cnt16 = reinterpret_cast<uint16_t *>(s_key + kMaxSamples);
-    auto stage = [&](int cb) {
-        const int n = min(CB, nb1 - cb);
-        for (int i = tid; i < n; i += 8 * kT) {
-            uint32_t c[8];
+    for (int k = 0; k < 2; k++) pre_sp[k] = tid + k * kPT < bmax - 1 ? splitters[tid + k * kPT] : 0xFFFFFFFFu;
+    // the counts: coalesced loads, eight in flight per thread, into LDS as 16-bit words (zero behind the last block)
+    for (int i0 = tid; i0 < per * kPT; i0 += 8 * kPT) {
+        uint32_t c[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) c[u] = i + u * kT < n ? block_counts[cb + i + u * kT] : 0u;
+        for (int u = 0; u < 8; u++) c[u] = i0 + u * kPT < nb1 ? block_counts[i0 + u * kPT] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (i + u * kT < n) s_cnt16[i + u * kT] = (uint16_t)c[u];
-        }
-    };
+        for (int u = 0; u < 8; u++)
+            if (i0 + u * kPT < per * kPT) s_cnt16[i0 + u * kPT] = (uint16_t)c[u];
+    }
+    __syncthreads();
     uint32_t mine = 0;
-    uint32_t inc[32];  // (staged models) running sums of the counts of this thread's slice, inc[k] = blocks j0 .. j0 + k
-    if (all_staged) {
-        // every count of the model in ONE batch of loads (up to 32 in flight per thread: one round trip, not four), zero
-        // behind the last block up to the end of the last slice
-        uint32_t c[32];
+    {
+        // the slice: per / 8 aligned 16-byte words (8 counts each), turned into their running sums in place (a slice holds
+        // <= 32 blocks x 256: fits 16 bits)
+        uint4 *sl = reinterpret_cast<uint4 *>(s_cnt16 + (size_t)tid * per);
+        for (int w = 0; w < (per >> 3); w++) {
+            const uint4 v = sl[w];
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
 #pragma unroll
-        for (int u = 0; u < 32; u++) c[u] = tid + u * kT < nb1 ? block_counts[tid + u * kT] : 0u;
-#pragma unroll
-        for (int u = 0; u < 32; u++)
-            if (tid + u * kT < per * kT) s_cnt16[tid + u * kT] = (uint16_t)c[u];
-        __syncthreads();
-        // the slice: per / 8 aligned 16-byte words (8 counts each), summed in registers, written back as running sums
-        // (a slice holds <= 32 blocks x 256: fits 16 bits)
-        uint4 *sl = reinterpret_cast<uint4 *>(s_cnt16 + tid * per);
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (8 * w < per) {
-                const uint4 v = sl[w];
-                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-                uint32_t o[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    mine += x[h] & 0xffffu;
-                    inc[8 * w + 2 * h] = mine;
-                    mine += x[h] >> 16;
-                    inc[8 * w + 2 * h + 1] = mine;
-                    o[h] = inc[8 * w + 2 * h] | (inc[8 * w + 2 * h + 1] << 16);
-                }
-                sl[w] = make_uint4(o[0], o[1], o[2], o[3]);
-            } else {
-#pragma unroll
-                for (int h = 0; h < 8; h++) inc[8 * w + h] = mine;
+            for (int h = 0; h < 4; h++) {
+                mine += x[h] & 0xffffu;
+                const uint32_t a = mine;
+                mine += x[h] >> 16;
+                o[h] = a | (mine << 16);
             }
-        }
-    } else {
-        for (int cb = 0; cb < nb1; cb += CB) {
-            if (cb > 0) __syncthreads();
-            stage(cb);
-            __syncthreads();
-            for (int j = max(j0, cb); j < min(j1, cb + CB); j++) mine += s_cnt16[j - cb];
+            sl[w] = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     SS_STAMP(dbg, 1);
     uint32_t V;
-    const uint32_t p_incl = gsr_block_incl_scan(mine, s_w, V), p_excl = p_incl - mine;
-    uint32_t *s_pex = s_cur;  // [kT + 1] visible Gaussians before every thread's slice (the cursors are not in use yet)
+    const uint32_t p_incl = ss_scan1024(mine, s_w16, V), p_excl = p_incl - mine;
+    (void)p_incl;
     s_pex[tid] = p_excl;
-    if (tid == 0) s_pex[kT] = V;
-    __shared__ uint32_t s_range[4];  // first block, records before it, end block, (unused)
-    if (tid == 0) {
-        s_range[0] = 0u;
-        s_range[1] = 0u;
-        s_range[2] = (uint32_t)nb1;
-    }
-    if (blockIdx.x == 0 && tid == 0) {  // first kernel of the frame that touches the header
+    if (tid == 0) s_pex[kPT] = V;
+    if (tid == 0) {  // first kernel of the frame that touches the header
         hdr->V = V;
         hdr->R = 0u;
         hdr->overflow = 0u;
@@ -311,8 +341,11 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
         hdr->tile_queue = 0u;
     }
     if (V == 0u) {
-        if (tid == 0) seg_off[me] = 0u;
-        if (me == nbc - 1 && tid == 0) seg_off[nbc] = 0u;
+        for (int j = tid; j <= nbc; j += kPT) {
+            seg_off[j] = 0u;
+            seg_first[j] = (uint32_t)nb1;
+        }
+        if (tid == 0) hdr->ss_fresh = 0u;
         return;
     }
     __syncthreads();
@@ -321,15 +354,6 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
     // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
     // in a few hundred frames outgrows the LDS)
     const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
-    // Ownership follows a COST: a block costs its visible Gaussians (records to classify and move) + kBlockCost (its 256
-    // keys have to be fetched and tested whatever they hold) -- equal record shares alone hand a workgroup in an empty
-    // stretch of the model a thousand blocks to sweep.  The cost before block j is (records before j) + kBlockCost j;
-    // a workgroup's run starts at the block in which that crosses its share boundary.
-    // (boundaries in binary64: products below 2^53 are exact, and the only requirement is that share b's upper boundary
-    // and share b + 1's lower one are the same number -- they are the same expression)
-    const uint32_t W = V + kBlockCost * (uint32_t)nb1;
-    const uint32_t t_lo = (uint32_t)((double)W * (double)me / (double)nbc);
-    const uint32_t t_hi = (uint32_t)((double)W * (double)(me + 1) / (double)nbc);
     const int logS = ss_log2((int)S);  // (S is a power of two)
     // A fixed sensor camera (GSWorld's right_cam and the like) over a scene that stands still: the view matrix is bit
     // for bit the one the splitters in the state were built under and the last frames that classified with the kept
@@ -339,92 +363,43 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
     // depth range that was empty a frame ago, where the kept buckets are wide) can put ten thousand records into one
     // bucket, far beyond the LDS, and that bucket's workgroup then sorts in global memory for a millisecond.  Such a
     // scene never earns the trust; its frames check the kept table against samples below.
-    bool blind = all_staged && same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
+    bool blind = same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
                  (GSR_SS_IGNORE_BAD || h_bad == 0u) && h_trust >= (uint32_t)GSR_SS_TRUST_MIN && h_trust <= 255u &&
                  h_P == sig;
-    if (blind) {
-        // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else
-        // wrote in between: what is taken unchecked for BALANCE must still be an ascending table, or the order breaks)
+    // the kept table into LDS (used blind, or validated below)
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = tid + k * kT;
-            if (i < B) s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
+    for (int k = 0; k < 2; k++) {
+        const int i = tid + k * kPT;
+        if (i < B) {
+            s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
+            s_hist[i] = 0u;
         }
-        __syncthreads();
-        uint32_t bad = 0u;
-        for (int i = tid; i + 1 < B - 1; i += kT) bad |= s_split[i + 1] < s_split[i] ? 1u : 0u;
-        blind = __syncthreads_or((int)bad) == 0;
     }
-    if (me == 0 && tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
+    __syncthreads();
+    // (a state buffer handed back by the allocator can carry a valid-looking header over arrays somebody else wrote in
+    // between: what is taken for BALANCE must still be an ascending table, or the order breaks)
+    uint32_t unsorted = 0u;
+    for (int i = tid; i + 1 < B - 1; i += kPT) unsorted |= s_split[i + 1] < s_split[i] ? 1u : 0u;
+    const bool ascending = __syncthreads_or((int)unsorted) == 0;
+    blind = blind && ascending;
+    if (tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
     SS_STAMP(dbg, 23);
-    if (all_staged) {
-        // Sample s belongs to the preprocess block that holds visible Gaussian floor(s V / S) of the index order: uniform
-        // over the VISIBLE Gaussians.  (Until round 4 the sample was the FIRST visible key of that block: the same thing
-        // for a model in random order, but in a spatially sorted model -- gsworld_amd/layout.py -- the visible Gaussians
-        // sit in a fifth of the blocks, several samples drew the same key, the splitters came out uneven every frame and
-        // the buckets outgrew the LDS: ss_buckets 12 -> 72 us.)
-        // Two binary searches per sample -- the thread slice (s_pex), then the block inside it (the slice's running
-        // sums) -- EIGHT samples side by side per thread (rounds 2-4: four, i.e. four chains of thirteen dependent LDS
-        // round trips one after the other for 4096 samples, 16 k cycles of every workgroup's prologue by the stamps; a
-        // version in which every thread handed out the samples of its own slice in one walk was measured in round 5:
-        // 27-68 k, the visible Gaussians of a wrist camera sit in eight of the 256 slices).  A block's n samples are its
-        // FIRST n visible records -- one or two cache lines of the block's compacted records instead of a line per
-        // sample: the gather below touches ~700 lines instead of 4096, in every one of the 256 workgroups (11 k -> 3 k
-        // cycles); inside a block of 256 consecutive Gaussians -- neighbours in space for a laid-out model, a random
-        // subset otherwise -- any n records are as good a sample of the block's depths as any other.
-        constexpr int SW = 8;
-        const double s_per_rank = (double)S / (double)V;
-#pragma unroll 1
-        for (int q0 = 0; q0 < 16; q0 += SW) {
-            if (blind || (uint32_t)(q0 * kT) >= S) break;
-            uint32_t tgt[SW], u[SW];
-#pragma unroll
-            for (int q = 0; q < SW; q++) {
-                const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
-                tgt[q] = (uint32_t)(((uint64_t)min(smp, S - 1u) * V) >> logS);
-                u[q] = 0u;
-            }
-#pragma unroll
-            for (int st = kT / 2; st > 0; st >>= 1) {
-#pragma unroll
-                for (int q = 0; q < SW; q++)
-                    if (s_pex[u[q] + (uint32_t)st] <= tgt[q]) u[q] += (uint32_t)st;  // last slice that starts at or before
-            }
-            uint32_t pos[SW], base[SW], n[SW], lt[SW];
-#pragma unroll
-            for (int q = 0; q < SW; q++) {
-                base[q] = min((uint32_t)nb1, u[q] * (uint32_t)per);
-                n[q] = min((uint32_t)nb1, base[q] + (uint32_t)per) - base[q];
-                lt[q] = tgt[q] - s_pex[u[q]];
-                pos[q] = 0u;
-            }
-#pragma unroll
-            for (int st = 16; st > 0; st >>= 1) {  // first block of the slice whose running sum exceeds lt (per <= 32)
-#pragma unroll
-                for (int q = 0; q < SW; q++)
-                    if (pos[q] + (uint32_t)st <= n[q] && (uint32_t)s_cnt16[base[q] + pos[q] + (uint32_t)st - 1u] <= lt[q])
-                        pos[q] += (uint32_t)st;
-            }
-#pragma unroll
-            for (int q = 0; q < SW; q++) {
-                const uint32_t smp = (uint32_t)(tid + (q0 + q) * kT);
-                const uint32_t pb = min(pos[q], n[q] - 1u), blk = base[q] + pb;
-                const uint32_t before_b = pb > 0u ? (uint32_t)s_cnt16[blk - 1u] : 0u;
-                const uint32_t cnt_b = (uint32_t)s_cnt16[blk] - before_b;
-                // how many samples before this one fall into the same block: the block's first sample is the first whose
-                // rank reaches the records before the block (a last-bit error of the quotient only picks a neighbour)
-                const uint32_t s_first = (uint32_t)__builtin_ceil((double)(s_pex[u[q]] + before_b) * s_per_rank);
-                const uint32_t off = cnt_b > 0u ? min(min(smp, S - 1u) - min(min(smp, S - 1u), s_first), cnt_b - 1u) : 0u;
-                if (smp < S) s_key[smp] = blk * (uint32_t)GSR_BLOCK + off;  // the record that lends its key
-            }
-        }
-        SS_STAMP(dbg, 24);
-        // the two ends of my run of blocks: one lane each
-        if ((tid == 0 && me > 0) || (tid == GSR_WAVE && me + 1 < nbc)) {
-            const uint32_t t = tid == 0 ? t_lo : t_hi;
+    // ---- the run of blocks of every compaction workgroup.  Ownership follows a COST: a block costs its visible Gaussians
+    // (records to classify and move) + kBlockCost (its 256 keys have to be fetched and tested whatever they hold) -- equal
+    // record shares alone hand a workgroup in an empty stretch of the model a thousand blocks to sweep.  The cost before
+    // block j is (records before j) + kBlockCost j; workgroup b's run starts at the block in which that crosses b's
+    // share boundary: thread b finds boundary b.
+    if (tid <= nbc) {
+        uint32_t j = 0u, before_j = 0u;
+        if (tid == nbc) {
+            j = (uint32_t)nb1;
+            before_j = V;
+        } else if (tid > 0) {
+            const uint32_t W = V + kBlockCost * (uint32_t)nb1;
+            const uint32_t t = (uint32_t)((double)W * (double)tid / (double)nbc);
             uint32_t us = 0u;  // last slice whose cost-before is <= t
 #pragma unroll
-            for (int st = kT / 2; st > 0; st >>= 1)
+            for (int st = kPT / 2; st > 0; st >>= 1)
                 if (s_pex[us + (uint32_t)st] + kBlockCost * min((uint32_t)nb1, (us + (uint32_t)st) * (uint32_t)per) <= t)
                     us += (uint32_t)st;
             const uint32_t jb = min((uint32_t)nb1, us * (uint32_t)per), je = min((uint32_t)nb1, jb + (uint32_t)per);
@@ -432,122 +407,118 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
 #pragma unroll
             for (int st = 16; st > 0; st >>= 1) {
                 const uint32_t k = jb + pos + (uint32_t)st;
-                if (k < je && s_pex[us] + (uint32_t)s_cnt16[k - 1u] + kBlockCost * k <= t) pos += (uint32_t)st;
+                if (pos + (uint32_t)st < (uint32_t)per && k < je &&
+                    s_pex[us] + (uint32_t)s_cnt16[k - 1u] + kBlockCost * k <= t)
+                    pos += (uint32_t)st;
             }
-            const uint32_t j = jb + pos, before_j = s_pex[us] + (pos > 0u ? (uint32_t)s_cnt16[j - 1u] : 0u);
-            if (tid == 0) {
-                s_range[0] = j;
-                s_range[1] = before_j;
-            } else {
-                s_range[2] = j;
-            }
+            j = jb + pos;
+            before_j = s_pex[us] + (pos > 0u ? (uint32_t)s_cnt16[j - 1u] : 0u);
         }
-    } else {
-        const uint32_t w_excl = p_excl + kBlockCost * (uint32_t)j0, w_incl = p_incl + kBlockCost * (uint32_t)j1;
-        const bool has_lo = me > 0 && w_excl <= t_lo && t_lo < w_incl;
-        const bool has_hi = me + 1 < nbc && w_excl <= t_hi && t_hi < w_incl;
-        // samples s with  p_excl <= s V / S < p_incl  are mine:  s in [ceil(p_excl S / V), ceil(p_incl S / V))
-        // (targets advance by V / S in 32.32 fixed point: one division per thread, none per sample; a target only picks
-        // WHICH block of the slice lends its key, so its last bit does not matter)
-        const uint64_t step = ((uint64_t)V << 32) >> logS;
-        const uint32_t s_lo = min(S, (uint32_t)__builtin_ceil((double)p_excl * (double)S / (double)V));
-        const uint32_t s_hi = min(S, (uint32_t)__builtin_ceil((double)p_incl * (double)S / (double)V));
-        uint64_t acc = step * s_lo;
-        uint32_t run = p_excl, smp = s_lo;
-        for (int cb = 0; cb < nb1; cb += CB) {
-            __syncthreads();
-            stage(cb);
-            __syncthreads();
-            if (!(has_lo || has_hi || s_lo < s_hi)) continue;
-            for (int j = max(j0, cb); j < min(j1, cb + CB); j++) {
-                const uint32_t c = s_cnt16[j - cb];
-                const uint32_t wrun = run + kBlockCost * (uint32_t)j;
-                if (has_lo && wrun <= t_lo && t_lo < wrun + c + kBlockCost) {
-                    s_range[0] = (uint32_t)j;
-                    s_range[1] = run;
-                }
-                if (has_hi && wrun <= t_hi && t_hi < wrun + c + kBlockCost) s_range[2] = (uint32_t)j;
-                if (c == 0u) continue;
-                const bool last_live = run + c == p_incl;  // the slice's last block with records takes the rest
-                while (smp < s_hi && ((uint32_t)(acc >> 32) < run + c || last_live)) {
-                    const uint32_t r = (uint32_t)(acc >> 32);
-                    // the record that lends its key; the keys are fetched together below
-                    s_key[smp] = (uint32_t)j * (uint32_t)GSR_BLOCK + min(r - min(r, run), c - 1u);
-                    smp++;
-                    acc += step;
-                }
-                run += c;
-            }
-        }
+        seg_off[tid] = before_j;
+        seg_first[tid] = j;
     }
-    SS_STAMP(dbg, 21);
-    __syncthreads();
-    if (!blind) {  // sample slot -> key (top 24 bits): every gather of the thread in flight at once (S <= 16 kT)
-        static_assert(kMaxSamples <= 16 * kT, "one batch of gathers covers the samples");
-        uint32_t k[16];
+    if (blind) {
+        if (tid == 0) hdr->ss_fresh = 0u;
+        return;
+    }
+    // ---- samples.  Sample s belongs to the preprocess block that holds visible Gaussian floor(s V / S) of the index
+    // order: uniform over the VISIBLE Gaussians.  (Until round 4 the sample was the FIRST visible key of that block: the
+    // same thing for a model in random order, but in a spatially sorted model -- gsworld_amd/layout.py -- the visible
+    // Gaussians sit in a fifth of the blocks, several samples drew the same key, the splitters came out uneven every
+    // frame and the buckets outgrew the LDS: ss_buckets 12 -> 72 us.)  Two binary searches per sample -- the thread slice
+    // (s_pex), then the block inside it (the slice's running sums) -- four samples side by side per thread.  (Measured in
+    // round 5 and dropped: every thread handing out the samples of its own slice in one walk -- the visible Gaussians of a
+    // wrist camera sit in a handful of slices, whose threads then do all the work.)  A block's n samples are its FIRST n
+    // visible records -- one or two cache lines of the block's compacted records instead of a line per sample; inside a
+    // block of 256 consecutive Gaussians -- neighbours in space for a laid-out model, a random subset otherwise -- any n
+    // records are as good a sample of the block's depths as any other.
+    {
+        constexpr int SW = kMaxSamples / kPT;  // 4
+        const double s_per_rank = (double)S / (double)V;
+        uint32_t tgt[SW], u[SW];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const uint32_t i = (uint32_t)(tid + u * kT);
-            k[u] = i < S ? block_recs[s_key[i]].y : 0u;
+        for (int q = 0; q < SW; q++) {
+            const uint32_t smp = (uint32_t)(tid + q * kPT);
+            tgt[q] = (uint32_t)(((uint64_t)min(smp, S - 1u) * V) >> logS);
+            u[q] = 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const uint32_t i = (uint32_t)(tid + u * kT);
-            if (i < S) s_key[i] = k[u] & kKeyMask;
+        for (int st = kPT / 2; st > 0; st >>= 1) {
+#pragma unroll
+            for (int q = 0; q < SW; q++)
+                if (s_pex[u[q] + (uint32_t)st] <= tgt[q]) u[q] += (uint32_t)st;  // last slice that starts at or before
         }
+        uint32_t pos[SW], base[SW], n[SW], lt[SW];
+#pragma unroll
+        for (int q = 0; q < SW; q++) {
+            base[q] = min((uint32_t)nb1, u[q] * (uint32_t)per);
+            n[q] = min((uint32_t)nb1, base[q] + (uint32_t)per) - base[q];
+            lt[q] = tgt[q] - s_pex[u[q]];
+            pos[q] = 0u;
+        }
+#pragma unroll
+        for (int st = 16; st > 0; st >>= 1) {  // first block of the slice whose running sum exceeds lt (per <= 32)
+#pragma unroll
+            for (int q = 0; q < SW; q++)
+                if (pos[q] + (uint32_t)st <= n[q] && (uint32_t)s_cnt16[base[q] + pos[q] + (uint32_t)st - 1u] <= lt[q])
+                    pos[q] += (uint32_t)st;
+        }
+        uint32_t rec[SW];
+#pragma unroll
+        for (int q = 0; q < SW; q++) {
+            const uint32_t smp = min((uint32_t)(tid + q * kPT), S - 1u);
+            const uint32_t pb = min(pos[q], n[q] - 1u), blk = base[q] + pb;
+            const uint32_t before_b = pb > 0u ? (uint32_t)s_cnt16[blk - 1u] : 0u;
+            const uint32_t cnt_b = (uint32_t)s_cnt16[blk] - before_b;
+            // how many samples before this one fall into the same block: the block's first sample is the first whose
+            // rank reaches the records before the block (a last-bit error of the quotient only picks a neighbour)
+            const uint32_t s_first = (uint32_t)__builtin_ceil((double)(s_pex[u[q]] + before_b) * s_per_rank);
+            const uint32_t off = cnt_b > 0u ? min(smp - min(smp, s_first), cnt_b - 1u) : 0u;
+            rec[q] = blk * (uint32_t)GSR_BLOCK + off;  // the record that lends its key
+        }
+        SS_STAMP(dbg, 24);
+        // the keys: every gather of the thread in flight at once
+        uint32_t k[SW];
+#pragma unroll
+        for (int q = 0; q < SW; q++) k[q] = (uint32_t)(tid + q * kPT) < S ? block_recs[rec[q]].y : 0u;
+#pragma unroll
+        for (int q = 0; q < SW; q++)
+            if ((uint32_t)(tid + q * kPT) < S) s_key[tid + q * kPT] = k[q] & kKeyMask;
     }
     __syncthreads();
-    const int first = (int)s_range[0], last = (int)s_range[2];
-    const uint32_t before = s_range[1];
-    if (me == nbc - 1 && tid == 0) seg_off[nbc] = V;
-    if (tid == 0) seg_off[me] = before;
     SS_STAMP(dbg, 2);
-    __syncthreads();
     // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
     // previous frame usually still cut THIS frame's samples evenly.  Check that (the table must be ascending -- a fresh
-    // state holds garbage -- and no bucket may draw more than four times its share of the samples) and skip the sample sort
-    // when it holds; every workgroup sees the same samples and the same table, so all take the same branch.
+    // state holds garbage -- and no bucket may draw more than four times its share of the samples) and skip the sample
+    // sort when it holds.
     // (the largest of B Poisson(2) sample counts grows with B: 8 passes for 512 buckets 9 times out of 10, 12 for 2048)
     const uint32_t reuse_max = 4u * (S / (uint32_t)B) + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
-    bool reuse = hdr->ss_magic == kSplitMagic && hdr->ss_buckets == (uint32_t)B && S >= (uint32_t)B && h_P == sig;
-    if (blind) {
-        // (s_split was filled when the table was checked)
-    } else if (reuse) {
+    bool reuse = h_magic == kSplitMagic && h_buckets == (uint32_t)B && S >= (uint32_t)B && h_P == sig && ascending;
+    if (reuse) {
         uint32_t bad = 0;
-        // (the kept table was requested at the top of the kernel, 8 entries per thread: no round trip here)
+        {
+            constexpr int SW = kMaxSamples / kPT;
+            uint32_t tk[SW], bk[SW];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = tid + k * kT;
-            if (i < B) {
-                s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
-                s_hist[i] = 0u;
-            }
+            for (int q = 0; q < SW; q++) tk[q] = (uint32_t)(tid + q * kPT) < S ? s_key[tid + q * kPT] : kNoKey;
+            ss_bucketN<SW>(s_split, B, tk, bk);
+#pragma unroll
+            for (int q = 0; q < SW; q++)
+                if (tk[q] != kNoKey) atomicAdd(&s_hist[bk[q]], 1u);
         }
         __syncthreads();
-        for (int i = tid; i + 1 < B - 1; i += kT) bad |= s_split[i + 1] < s_split[i] ? 1u : 0u;
-        for (uint32_t i0 = (uint32_t)tid; i0 < S; i0 += 4u * kT) {
-            uint32_t tk[4], bk[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) tk[u] = i0 + (uint32_t)(u * kT) < S ? s_key[i0 + (uint32_t)(u * kT)] : kNoKey;
-            ss_bucketN<4>(s_split, B, tk, bk);
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (tk[u] != kNoKey) atomicAdd(&s_hist[bk[u]], 1u);
-        }
-        __syncthreads();
-        for (int i = tid; i < B; i += kT)
+        for (int i = tid; i < B; i += kPT)
             if (s_hist[i] > reuse_max) bad = 1u;
         reuse = __syncthreads_or((int)bad) == 0;
     }
-    if (!reuse && !blind) {
+    if (!reuse) {
         // New splitters: the (i + 1) S / B-th smallest samples.  Splitters only decide the balance of the buckets, so the
         // samples are sorted by a 16-bit code -- their offset from the smallest sample, shifted until the largest fits
         // 16 bits: 1 / 65536 of the samples' range, exact when the range is below that (a plane seen from straight above)
-        // -- in TWO 8-bit LSD passes instead of four over the full keys (45 k -> 25 k cycles of every workgroup's
-        // prologue on a frame that samples, by the stamps); a splitter is its code put back on the smallest sample:
-        // ascending, and equal keys classify alike whatever the table.
+        // -- in TWO 8-bit LSD passes instead of four over the full keys; a splitter is its code put back on the smallest
+        // sample: ascending, and equal keys classify alike whatever the table.
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-        for (int i = tid; i < (int)S; i += kT) {
+        for (int i = tid; i < (int)S; i += kPT) {
             mn = min(mn, s_key[i]);
             mx = max(mx, s_key[i]);
         }
@@ -556,35 +527,79 @@ __device__ __forceinline__ void ss_compact_body(int P, int nb1, int bpw, int bma
             mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
         }
-        __shared__ uint32_t s_mm[8];
+        __shared__ uint32_t s_mm[2 * kPW];
         if (lane == 0) {
             s_mm[wave] = mn;
-            s_mm[4 + wave] = mx;
+            s_mm[kPW + wave] = mx;
         }
         __syncthreads();
-        mn = min(min(s_mm[0], s_mm[1]), min(s_mm[2], s_mm[3]));
-        mx = max(max(s_mm[4], s_mm[5]), max(s_mm[6], s_mm[7]));
+#pragma unroll
+        for (int w = 0; w < kPW; w++) {
+            mn = min(mn, s_mm[w]);
+            mx = max(mx, s_mm[kPW + w]);
+        }
         const uint32_t range = mx - mn;
         const int shift = range < 65536u ? 0 : (32 - __builtin_clz(range)) - 16;
-        for (int i = tid; i < (int)S; i += kT) s_key[i] = (s_key[i] - mn) >> shift;
+        for (int i = tid; i < (int)S; i += kPT) s_key[i] = (s_key[i] - mn) >> shift;
         __syncthreads();
-        lds_radix_pass<false>(s_key, nullptr, s_key + kMaxSamples, nullptr, (int)S, 0, s_cur, s_w);
-        lds_radix_pass<false>(s_key + kMaxSamples, nullptr, s_key, nullptr, (int)S, 8, s_cur, s_w);
+        ss_radix_pass16(s_key, s_key + kMaxSamples, (int)S, 0, s_cur, s_w16);
+        ss_radix_pass16(s_key + kMaxSamples, s_key, (int)S, 8, s_cur, s_w16);
         const uint32_t *sorted = s_key;
-        for (int i = tid; i < B; i += kT) {
+        // NOT into the table a later frame's validation reads before ss_buckets rewrites it: the drawn table goes to its
+        // own array, which this frame's compaction and partition passes read; `splitters` is written by ss_buckets alone
+        for (int i = tid; i < B; i += kPT) {
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
-            const uint32_t sp = (i < B - 1 && q < S) ? (((sorted[q] << shift) + mn) & kKeyMask) : 0xFFFFFFFFu;
-            s_split[i] = sp;
-            // NOT into the table the other workgroups may still be reading (a workgroup dispatched late would see it
-            // half rewritten and could validate a mixture nobody else classified with): the drawn table goes to its
-            // own array, which only the partition pass reads; `splitters` is written by ss_buckets alone
-            if (blockIdx.x == 0) splitters_new[i] = sp;
+            splitters_new[i] = (i < B - 1 && q < S) ? (((sorted[q] << shift) + mn) & kKeyMask) : 0xFFFFFFFFu;
         }
     }
-    if (me == 0 && tid == 0) hdr->ss_fresh = (!reuse && !blind) ? 1u : 0u;
-    __syncthreads();
-    for (int i = tid; i < B; i += kT) s_hist[i] = 0u;
+    if (tid == 0) hdr->ss_fresh = reuse ? 0u : 1u;
     SS_STAMP(dbg, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_compact: compaction + classification.  Workgroup b owns the preprocess blocks [seg_first[b], seg_first[b + 1]) that
+// ss_prepare cut out for it; records are written as (index, key): the 64-bit little-endian view is key << 32 | index, the
+// composite the global-memory fallback of ss_buckets sorts.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ss_compact_body(int bmax, const uint2 *__restrict__ block_recs,
+                                                const uint32_t *__restrict__ block_counts, uint2 *__restrict__ pairs,
+                                                uint32_t *__restrict__ table, const uint32_t *__restrict__ splitters,
+                                                const uint32_t *__restrict__ splitters_new,
+                                                const uint32_t *__restrict__ seg_off,
+                                                const uint32_t *__restrict__ seg_first,
+                                                const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
+    extern __shared__ uint32_t smem[];
+    uint64_t *dbg = dbg0; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
+    SS_STAMP(dbg, 8);
+#ifdef GSR_SS_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t *s_split = smem;                     // [bmax]
+    uint32_t *s_hist = s_split + bmax;            // [bmax]
+    uint32_t *s_boff = s_hist + bmax;             // [4 kT + 1] offsets of up to 1024 blocks
+    __shared__ uint32_t s_w[4];
+    const int tid = (int)threadIdx.x, wave = gsr_wave(), lane = gsr_lane();
+    const int me = (int)blockIdx.x;
+    // everything this workgroup needs of the frame's plan in one round trip
+    const uint32_t V = hdr->V;
+    const uint32_t *__restrict__ split_src = hdr->ss_fresh != 0u ? splitters_new : splitters;
+    const int first = (int)seg_first[me], last = (int)seg_first[me + 1];
+    const uint32_t before = seg_off[me];
+    if (V == 0u) return;
+    const int B = ss_num_buckets(V, bmax);
+    {
+        uint32_t sp[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) sp[k] = tid + k * kT < B - 1 ? split_src[tid + k * kT] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (tid + k * kT < B) {
+                s_split[tid + k * kT] = sp[k];
+                s_hist[tid + k * kT] = 0u;
+            }
+    }
+    __syncthreads();
+    SS_STAMP(dbg, 9);
     // ---- the walk over this workgroup's blocks [first, last), at most 1024 at a time (their offsets sit in LDS): one
     // wave per block of 256 Gaussians, no workgroup barrier inside.  A wave requests the keys of its next kWalk blocks
     // in one go (4 kWalk loads in flight per lane) and only then ranks them: a wave is a chain of HBM round trips
@@ -1099,7 +1114,7 @@ struct SsArgs {
     int P, nb1, bpw, bmax, nbc;
     uint2 *pair0, *pair1;           // compacted records | block-local records, then the bucketed ones
     const uint32_t *block_counts, *block_cand;
-    uint32_t *table, *splitters, *splitters_new, *seg, *totals, *bucket_start;
+    uint32_t *table, *splitters, *splitters_new, *seg, *first, *totals, *bucket_start;
     GsrHeader *hdr;
     uint64_t *dbg;
     const float *view;
@@ -1116,10 +1131,15 @@ struct SsArgs {
     const int32_t *orig;
 };
 
+__global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
+    const SsArgs &a = bt.f[blockIdx.y];
+    ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
+                    a.hdr, a.dbg, a.view, a.sig);
+}
 __global__ __launch_bounds__(kT) void ss_compact_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
-    ss_compact_body(a.P, a.nb1, a.bpw, a.bmax, a.pair1, a.block_counts, a.block_cand, a.pair0, a.table, a.splitters,
-                    a.splitters_new, a.seg, a.hdr, a.dbg, a.view, a.sig);
+    ss_compact_body(a.bmax, a.pair1, a.block_counts, a.pair0, a.table, a.splitters, a.splitters_new, a.seg, a.first,
+                    a.hdr, a.dbg);
 }
 __global__ __launch_bounds__(kColT) void ss_colscan_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
@@ -1146,6 +1166,9 @@ int gsr_ss_nbc(int32_t P) {
     const int need = gsr_div_up(nb1, 1024);  // at most 1024 blocks per workgroup (LDS offsets)
     return nbc > need ? nbc : need;
 }
+// the sample sort's prepare workgroup keeps every block count of the model in LDS: models beyond that (8.4 M Gaussians)
+// take the LSD radix depth sort (api.hip)
+bool gsr_ss_supported(int32_t P) { return GeomState::prep_blocks(P) <= kPrepBlocks; }
 int gsr_ss_bmax(int32_t P) {
     int b = 256;
     while (b < 2048 && (int64_t)b * 512 < (int64_t)P) b <<= 1;
@@ -1168,6 +1191,7 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.pair0 = g.pair[0]; a.pair1 = g.pair[1];
         a.block_counts = g.block_counts; a.block_cand = g.block_cand;
         a.table = g.ss_table; a.splitters = g.ss_splitters; a.splitters_new = g.ss_splitters_new; a.seg = g.ss_seg;
+        a.first = g.ss_first;
         a.totals = g.ss_totals; a.bucket_start = g.ss_bucket_start;
         a.hdr = g.hdr; a.dbg = g.ss_dbg; a.view = fr[k].in->viewmatrix;
         // what a kept splitter table is valid for: this model size AND this state layout (a buffer the allocator hands
@@ -1182,7 +1206,9 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
     }
-    const size_t lds1 = (size_t)(2 * kMaxSamples + 4 * 256 + 2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ss_prepare_kernel, dim3(1, B), dim3(kPT), 0, stream, bt);
+    if (int e = gsr_check_launch("ss_prepare", debug, stream)) return e;
+    const size_t lds1 = (size_t)(2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc, B), dim3(kT), lds1, stream, bt);
     if (int e = gsr_check_launch("ss_compact", debug, stream)) return e;
     hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE), B), dim3(kColT), 0, stream, bt);

@@ -83,6 +83,7 @@ static inline int gsr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 // sample sort geometry (depthsort.hip): compaction workgroups and bucket capacity for P Gaussians
 int gsr_ss_nbc(int32_t P);
 int gsr_ss_bmax(int32_t P);
+bool gsr_ss_supported(int32_t P);
 
 // ---- geometry state (per Gaussian) -------------------------------------------------------------------
 struct GeomState {
@@ -115,6 +116,7 @@ struct GeomState {
     uint32_t *ss_splitters_new; // [bmax] the table a sampling frame draws (written by ss_compact, read by ss_partition)
     uint32_t *ss_bucket_start;// [bmax + 1]
     uint32_t *ss_seg;         // [nbc + 1]      first output slot of every compaction workgroup
+    uint32_t *ss_first;       // [nbc + 1]      first preprocess block of every compaction workgroup (ss_prepare)
     uint64_t *ss_dbg;         // [64] cycle stamps of workgroup 0 (builds with -DGSR_SS_TIMING only)
     // band placement (bandplace.hip)
     uint2 *rect_sorted;       // [P]   tile rects in depth order (written by the depth sort)
@@ -187,6 +189,7 @@ struct GeomState {
         g.ss_splitters_new = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.ss_totals = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.band_nseg = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES);  // (rows <= tiles: sized for the narrowest grid)
+        g.ss_first = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) + 1);
         // LAST: the only array whose size depends on tiles_x, which the read-only carvers (gsr_backward,
         // gsr_state_view, gsr_debug_ss_stamps) do not pass -- nothing may follow it
         g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));

@@ -22,7 +22,6 @@ struct PreprocessArgs {
     int antialiasing;
     int param_space;  // GSR_RAW_* flags: activations evaluated here instead of three torch passes per frame
     int infer;        // GsrSettings.forward_only: nothing a backward would read is written; rec2.w = packed tile rect
-    int nframes;      // frames this launch spans (the same in every frame's block)
     const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;
     // optional rigid transform of labelled Gaussians (GsrInputs.part_*): same arithmetic as transform.hip
@@ -513,19 +512,14 @@ __device__ __forceinline__ bool prep_block_culled(const PreprocessArgs &a, int b
     return xhi + rb < -1.0f || xlo - rb > xend || yhi + rb < -1.0f || ylo - rb > yend;
 }
 
-// grid = 8 B x groups workgroups in a row: workgroup
-// g x 8 B + x takes block 8 g + (x & 7) of frame x >> 3 -- the frame's argument block by that index (gsr_internal.h GsrBatch).  Workgroups are dispatched x-fastest and round-robin over
-// the XCDs, so the workgroups that read the SAME block of the model for the B frames of the step run one after the other on
-// the SAME XCD: the model's arrays -- shared by the cameras and environments of a step -- come out of that XCD's L2 for
-// every frame after the first instead of out of HBM B times (frame-major order: 4 x 64 MB of HBM-side traffic per
-// four-frame step, the kernel at 4.5 TB/s).
+// grid = (blocks of 256 Gaussians, frames): blockIdx.y picks the frame's argument block (gsr_internal.h GsrBatch).
+// (Measured in round 5 and not kept: the workgroups that read one block of the model for the B frames of a step as
+// neighbours on one XCD, so that the model comes out of that L2 after the first frame: 57.3 -> 55.0 us for four identical
+// frames, but 38.7 -> 42.3 us for the two different cameras of a closed-loop step.)
 template <bool FAST_SH16, bool COUNT_TILES>
 __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const GsrBatch<PreprocessArgs> bt) {
-    // (one-dimensional grid of 8 B x groups workgroups: a y dimension would cap the model at 65535 x 8 blocks)
-    const uint32_t row = 8u * (uint32_t)bt.f[0].nframes, grp = blockIdx.x / row, x = blockIdx.x - grp * row;
-    const PreprocessArgs a = bt.f[x >> 3];  // (by value: every field is requested at the top, not at its first use)
-    const uint32_t blk = grp * 8u + (x & 7u);
-    if ((int)blk * GSR_BLOCK >= a.P) return;  // (the last group of eight may hold fewer blocks)
+    const PreprocessArgs a = bt.f[blockIdx.y];  // (by value: every field is requested at the top, not at its first use)
+    const uint32_t blk = blockIdx.x;
     extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
     const int i = (int)blk * GSR_BLOCK + (int)threadIdx.x;
     bool visible = false;
@@ -621,7 +615,6 @@ int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infe
         const GeomState &g = fr[k].g;
         PreprocessArgs &a = bt.f[k];
         a.infer = infer ? 1 : 0;
-        a.nframes = B;
         a.P = in.P;
         a.D = st.sh_degree;
         a.M = st.sh_coeffs;
@@ -674,7 +667,7 @@ int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infe
                ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
     }
     const PreprocessArgs &a0 = bt.f[0];
-    const dim3 grid(8 * B * gsr_div_up(GeomState::prep_blocks(a0.P), 8));
+    const dim3 grid(GeomState::prep_blocks(a0.P), B);
     const size_t lds = count_tiles ? (size_t)a0.num_tiles * sizeof(uint32_t) : 0;
     if (count_tiles) {
         if (fast)

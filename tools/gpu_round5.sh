@@ -36,12 +36,12 @@ for f in ("bench_default", "bench_driver_flags"):
 PY
 fi
 if has stats; then
-  # the step's own launches, alone on the chip: B = 4 frames per launch, one stream, eager (what roofline.kernel_ms times)
-  stats bench_step_launches bench.py --steps 200 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 4 --streams 1 --blocks 1 --min-seconds 0 --only-steps
+  # the step's own launches, alone on the chip: B = 8 frames per launch, one stream, eager (what roofline.kernel_ms times)
+  stats bench_step_launches bench.py --steps 200 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 8 --streams 1 --blocks 1 --min-seconds 0 --only-steps
   stats bench_one_frame_per_launch bench.py --steps 100 --warmup 10 --no-graph --no-cpu-baseline --no-extras --batch 1 --streams 1 --blocks 1 --min-seconds 0
   stats bench_headline_arrangement bench.py --steps 200 --warmup 10 --no-graph --no-cpu-baseline --no-extras --blocks 1 --min-seconds 0 --only-steps
   stats dense_view tools/prof_scene.py --view dense
-  stats dense_view_step_launches tools/ab_batch.py --eager --view dense --steps 200 --configs batch4
+  stats dense_view_step_launches tools/ab_batch.py --eager --view dense --steps 200 --configs batch8
   stats moving_camera tools/prof_scene.py --view sensor --moving
   CL_ONLY=1,0 stats closed_loop tools/ab_closed_loop.py
   stats default_mode_frame tools/prof_scene.py --view sensor --default-mode
@@ -50,9 +50,9 @@ if has train; then
   stats train_step_fused tools/bench_train.py --fused --steps 30
 fi
 if has pmc; then
-  echo "== pmc (the step's launches: 4 frames per launch)"
-  PMC_BATCH=4 bash tools/gpu_pmc.sh round5/pmc_raw 4 > $OUT/pmc/step_config2.txt 2>&1
-  PMC_BATCH=4 python tools/pmc_summary.py gpurun_out/round5/pmc_raw --json $OUT/pmc_render.json | tail -1
+  echo "== pmc (the step's launches: 8 frames per launch)"
+  PMC_BATCH=8 bash tools/gpu_pmc.sh round5/pmc_raw 4 > $OUT/pmc/step_config2.txt 2>&1
+  PMC_BATCH=8 python tools/pmc_summary.py gpurun_out/round5/pmc_raw --json $OUT/pmc_render.json | tail -1
   grep -E "render_stream|preprocess|band_place|ss_compact|ss_buckets" $OUT/pmc/step_config2.txt | cut -c1-420
   rm -rf gpurun_out/round5/pmc_raw/p*/
 fi
