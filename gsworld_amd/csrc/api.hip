@@ -205,7 +205,8 @@ int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Pl
                       "placement path");
         return GSR_E_INVALID;
     }
-    // the compositor's quadrant order depends on the previous frame only: a spare workgroup of the depth sort computes it
+    // the compositor's quadrant order depends on the previous frame only: a second workgroup of the depth sort's prepare
+    // launch computes it
     p.order_early = (p.band || p.chunk) && !p.radix_depth && gsr_render_uses_quad_order(*st, p.tiles);
     // (the counting placements need the list only; the fallbacks their keys / ping-pong sides too)
     p.lean_bin = p.band || p.chunk;

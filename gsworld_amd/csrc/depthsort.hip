@@ -264,6 +264,72 @@ __device__ __forceinline__ void ss_radix_pass16(const uint32_t *kin, uint32_t *k
 constexpr int kPrepBlocks = 32 * kPT;
 __host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1) / kPT) + 7) & ~7; }
 
+// gsr_quad_order_block (gsr_internal.h: which compositing workgroup takes which quadrants, from their costs in the previous
+// frame) for the 1024 threads of the prepare launch's SECOND workgroup: eight quadrants per thread instead of 32.  It
+// depends on nothing of the current frame, and as the one long workgroup of a later, shorter kernel -- tile_starts in
+// round 3, the partition pass in round 4 -- it set that kernel's time one frame at a time (ss_partition 12.2 -> 8.2 us
+// without it); beside the prepare workgroup it is free.  (Measured on the way: as an extra workgroup of preprocess it
+// raised that kernel's registers from 72 to 113 -- 27.3 instead of 20.5 us.)
+__device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ quad_work, int Q,
+                                                   uint32_t *__restrict__ quad_order, int cus_per_xcd) {
+    __shared__ uint32_t s_qb[GSR_XCDS * 256];
+    __shared__ uint32_t s_xbase[GSR_XCDS];
+    __shared__ uint32_t s_w16[kPW];
+    constexpr int KQ = 32 * GSR_BLOCK / kPT;  // 8 quadrants per thread: Q <= 32 x 256
+    const int tid = (int)threadIdx.x;
+    const int T = Q >> 2;
+    uint32_t c[KQ], qmx = 0;
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+        const int q = tid + k * kPT;
+        c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
+        qmx = max(qmx, c[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
+    if ((tid & 63) == 0) s_w16[tid >> 6] = qmx;
+    for (int i = tid; i < GSR_XCDS * 256; i += kPT) s_qb[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kPW; w++) qmx = max(qmx, s_w16[w]);
+    // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
+    const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
+    const uint32_t div = (qmx >> sh) + 1u;
+    const float inv = 256.0f / (float)div;
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+        const int q = tid + k * kPT;
+        const uint32_t xcd = (uint32_t)(q >> 2) % GSR_XCDS;
+        c[k] = xcd * 256u + 255u - min(255u, (uint32_t)((float)(c[k] >> sh) * inv));  // bin = (XCD, cost class)
+        if (q < Q) atomicAdd(&s_qb[c[k]], 1u);
+    }
+    __syncthreads();
+    {  // exclusive running sum over the 2048 bins: thread t owns bins 2 t, 2 t + 1 (XCD t / 128)
+        const uint32_t v0 = s_qb[2 * tid], v1 = s_qb[2 * tid + 1];
+        uint32_t tot;
+        uint32_t run = ss_scan1024(v0 + v1, s_w16, tot) - (v0 + v1);
+        if ((tid & 127) == 0) s_xbase[tid >> 7] = run;  // first slot of the XCD's list
+        s_qb[2 * tid] = run;
+        s_qb[2 * tid + 1] = run + v0;
+    }
+    __syncthreads();
+    const uint32_t cus = (uint32_t)max(cus_per_xcd, 1);
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+        const int q = tid + k * kPT;
+        if (q < Q) {
+            const uint32_t xcd = c[k] >> 8;
+            const uint32_t p = atomicAdd(&s_qb[c[k]], 1u) - s_xbase[xcd];        // position in the XCD's sorted list
+            const uint32_t nwg = ((uint32_t)T - 1u - xcd) / GSR_XCDS + 1u;         // workgroups (= tiles) of this XCD
+            const uint32_t slot = p >> 2, round = slot / cus, idx = slot - round * cus;
+            const uint32_t size = min(cus, nwg - round * cus);
+            const uint32_t cu = (round & 1u) ? size - 1u - idx : idx;
+            const uint32_t b = GSR_XCDS * (round * cus + cu) + xcd;
+            quad_order[4u * b + (p & 3u)] = (uint32_t)q;
+        }
+    }
+}
+
 __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nbc,
                                                 const uint2 *__restrict__ block_recs,
                                                 const uint32_t *__restrict__ block_counts,
@@ -747,15 +813,9 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
                                                           const uint32_t *__restrict__ splitters_new,
                                                           const uint32_t *__restrict__ seg_off,
                                                           uint32_t *__restrict__ bucket_start,
-                                                          GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
-                                                          int nbc, const uint32_t *__restrict__ quad_work, int num_quads,
-                                                          uint32_t *__restrict__ quad_order, int cus_per_xcd) {
+                                                          GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
     extern __shared__ uint32_t smem[];
     __shared__ uint32_t s_w[4];
-    if ((int)blockIdx.x == nbc) {  // the spare workgroup: the compositor's quadrant order (see gsr_quad_order_block)
-        gsr_quad_order_block(quad_work, num_quads, quad_order, s_w, cus_per_xcd);
-        return;
-    }
     uint64_t *dbg = dbg0 + 16; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
     uint32_t *s_split = smem;            // [bmax]
@@ -807,14 +867,22 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
     const uint32_t s0 = seg_off[me], s1 = seg_off[me + 1];
     const uint64_t lt = gsr_lanemask_lt();
     constexpr int kPR = 8;  // rounds per wave and tile: a tile is 4 x kPR x 64 = 2048 records (most segments: one tile)
-    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(4 * kPR * GSR_WAVE)) {
+    for (uint32_t tile = s0; tile < s1; tile += (uint32_t)(4 * kPR * GSR_WAVE)) {  // (a full tile: rounds = kPR)
         for (int i = tid; i < 4 * B; i += kT) s_cnt[(i >> nbits) * bmax + (i & (B - 1))] = 0u;
         __syncthreads();  // (also: s_run / s_split of the set-up above, cursors of the previous tile)
+        // the tile's records are dealt to the four waves in contiguous quarters of `rounds` x 64 -- as many rounds as the
+        // tile needs, not always kPR: a compaction workgroup's segment is ~700 records at config 2, which used to be eight
+        // ranking rounds on wave 0, three on wave 1 and none on the others; now three on each (order: wave, round, lane --
+        // the index order, as before)
+        const uint32_t left = s1 - tile;
+        const int rounds = (int)min((uint32_t)kPR, (left + 4u * GSR_WAVE - 1u) / (4u * GSR_WAVE));
+        const uint32_t wbase = tile + (uint32_t)(wave * rounds * GSR_WAVE);
+        const uint32_t tend = min(s1, tile + (uint32_t)(4 * rounds * GSR_WAVE));
         uint32_t idx[kPR], key[kPR], dig[kPR], tk[kPR];
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
-            const uint2 rec = i < s1 ? in[i] : make_uint2(0u, 0u);
+            const uint32_t i = wbase + (uint32_t)(r * GSR_WAVE + lane);
+            const uint2 rec = (r < rounds && i < tend) ? in[i] : make_uint2(0u, 0u);
             idx[r] = rec.x;
             key[r] = rec.y;
             tk[r] = rec.y & kKeyMask;
@@ -822,8 +890,8 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
         ss_bucketN<kPR>(s_split, B, tk, dig);
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
-            if (i < s1) atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
+            const uint32_t i = wbase + (uint32_t)(r * GSR_WAVE + lane);
+            if (r < rounds && i < tend) atomicAdd(&s_cnt[wave * bmax + (int)dig[r]], 1u);
         }
         __syncthreads();
 #pragma unroll
@@ -842,8 +910,9 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
         uint32_t *cur = s_cnt + wave * bmax;
 #pragma unroll
         for (int r = 0; r < kPR; r++) {
-            const uint32_t i = tile + (uint32_t)(wave * kPR * GSR_WAVE + r * GSR_WAVE + lane);
-            const bool valid = i < s1;
+            if (r >= rounds) break;
+            const uint32_t i = wbase + (uint32_t)(r * GSR_WAVE + lane);
+            const bool valid = i < tend;
             const uint64_t same = ss_match(dig[r], nbits, valid);
             const uint32_t rank = (uint32_t)__popcll(same & lt);
             if (valid) out[cur[dig[r]] + rank] = make_uint2(idx[r], key[r]);
@@ -904,49 +973,86 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
             const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
             if (q >= abs && q < abs + (uint32_t)cnt) splitters[i] = at((int)(q - abs)).y & kKeyMask;
         }
-        for (int i0 = 0; i0 < cnt; i0 += kT) {
-            const int i = i0 + tid;
-            uint32_t t = 0;
-            if (i < cnt) {
-                const uint32_t gi = at(i).x;
-                const uint2 rc = ss_super_rect(rects[gi], sshift);
-                order[abs + i] = gi;
-                rect_sorted[abs + i] = rc;
-                t = ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16)) + kRankCost;
+        // (every rect gather of the thread goes out before the first is used: kBucketCap / kT per thread and chunk; a
+        //  piece of equal keys that went through the global-memory network can be longer than one chunk)
+        constexpr int kPerE = kBucketCap / kT;
+        for (int c0 = 0; c0 < cnt; c0 += kBucketCap) {
+            uint32_t gi[kPerE];
+            uint2 rc[kPerE];
+#pragma unroll
+            for (int e = 0; e < kPerE; e++) {
+                const int i = c0 + e * kT + tid;
+                gi[e] = i < cnt ? at(i).x : 0u;
+                rc[e] = i < cnt ? rects[gi[e]] : make_uint2(0u, 0u);
             }
-            uint32_t tot;
-            const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
-            if (i < cnt) tile_cum[abs + i] = carry + incl;
-            carry += tot;
+#pragma unroll
+            for (int e = 0; e < kPerE; e++) {
+                if (c0 + e * kT >= cnt) break;
+                const int i = c0 + e * kT + tid;
+                uint32_t t = 0;
+                if (i < cnt) {
+                    const uint2 r2 = ss_super_rect(rc[e], sshift);
+                    order[abs + i] = gi[e];
+                    rect_sorted[abs + i] = r2;
+                    t = ((r2.y & 0xffffu) - (r2.x & 0xffffu)) * ((r2.y >> 16) - (r2.x >> 16)) + kRankCost;
+                }
+                uint32_t tot;
+                const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
+                if (i < cnt) tile_cum[abs + i] = carry + incl;
+                carry += tot;
+            }
         }
         return carry;
     };
     // ---- cnt <= kBucketCap records from global memory into the LDS, sorted there by key (stable: LSD passes over the
     // bits in which the keys differ); `by_index` first sorts them by index the same way, for records that did not
     // arrive in index order.  -> which half of s_k / s_v holds the result
+    // The keys go to the LDS as OFFSETS from the smallest key of the piece (kbase): the passes then cover the bits of the
+    // piece's RANGE -- 14-16 for a bucket that holds 1 / 512 of the depth order -- not the bits in which any two of its keys
+    // differ (17-20 by the stamps: two keys either side of a power of two differ in every bit below it): two 8-bit passes
+    // where rounds 2-4 ran three.
+    uint32_t kbase = 0u;
+    __shared__ uint32_t s_e[4];
     auto sort_in_lds = [&](const uint2 *from, int cnt, bool by_index) -> int {
-        const uint2 r0 = from[0];
-        uint32_t kdiff = 0, vdiff = 0;
-        for (int i = tid; i < cnt; i += kT) {
-            const uint2 r = from[i];
-            s_v[i] = r.x;
-            s_k[i] = r.y;
-            kdiff |= r.y ^ r0.y;
-            vdiff |= r.x ^ r0.x;
+        constexpr int kPer = kBucketCap / kT;
+        uint2 r[kPer];
+        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u, vdiff = 0;
+        const uint32_t v0 = from[0].x;
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int i = tid + e * kT;
+            r[e] = i < cnt ? from[i] : make_uint2(v0, 0xFFFFFFFFu);
+            if (i < cnt) {
+                kmn = min(kmn, r[e].y);
+                kmx = max(kmx, r[e].y);
+                vdiff |= r[e].x ^ v0;
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            kdiff |= (uint32_t)__shfl_xor((int)kdiff, o, 64);
+            kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, o, 64));
+            kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o, 64));
             vdiff |= (uint32_t)__shfl_xor((int)vdiff, o, 64);
         }
         __syncthreads();  // (s_w may still be read by the scan of an earlier emit)
         if (gsr_lane() == 0) {
-            s_w[gsr_wave()] = kdiff;
+            s_w[gsr_wave()] = kmn;
+            s_e[gsr_wave()] = kmx;
             s_d[gsr_wave()] = vdiff;
         }
         __syncthreads();
-        kdiff = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+        kmn = min(min(s_w[0], s_w[1]), min(s_w[2], s_w[3]));
+        kmx = max(max(s_e[0], s_e[1]), max(s_e[2], s_e[3]));
         vdiff = s_d[0] | s_d[1] | s_d[2] | s_d[3];
+        kbase = kmn;
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int i = tid + e * kT;
+            if (i < cnt) {
+                s_v[i] = r[e].x;
+                s_k[i] = r[e].y - kmn;
+            }
+        }
         __syncthreads();
         int src = 0;
         if (by_index) {
@@ -957,7 +1063,8 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
                 src ^= 1;
             }
         }
-        const int bits = kdiff == 0u ? 0 : 32 - __builtin_clz(kdiff);
+        const uint32_t range = kmx - kmn;
+        const int bits = range == 0u ? 0 : 32 - __builtin_clz(range);
 #ifdef GSR_SS_TIMING
         if (blockIdx.x == dbg_wg && tid == 0) { dbg[8] = (uint64_t)bits; dbg[9] = (uint64_t)cnt; }
 #endif
@@ -977,33 +1084,51 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
         if (orig == nullptr) return;
         uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap, *oo = s_v + (src ^ 1) * kBucketCap;
         constexpr int kPer = kBucketCap / kT;
-        // pair (i, i + 1) holds equal keys: fixed for the whole fix-up (keys do not move); its members' original numbers
-        // are staged once
-        bool eq[kPer];
-        int any = 0;
+        // pair (i, i + 1) holds equal keys: fixed for the whole fix-up (keys do not move).  A run of EXACTLY two equal keys --
+        // nearly every tie there is -- is put in order by the thread of its first member on the spot: it fetches both
+        // original numbers itself and nobody else touches the two slots.  Only members of runs of three and more stage
+        // their original numbers for the rounds below.  (Round 4 ran the rounds for every tie: three barriers and the
+        // staging pass in nearly every bucket, 4.6 k of a bucket workgroup's ~25 k cycles by the stamps.)
+        bool eq[kPer], two[kPer];
+        uint32_t pa[kPer], pb[kPer];
+        int longrun = 0;
 #pragma unroll
         for (int e = 0; e < kPer; e++) {
             const int i = tid + e * kT;
             eq[e] = i + 1 < cnt && kk[i] == kk[i + 1];
-            const bool tied = eq[e] || (i > 0 && i < cnt && kk[i - 1] == kk[i]);
-            if (tied) oo[i] = (uint32_t)orig[vv[i]];
-            any |= tied ? 1 : 0;
+            const bool prev = i > 0 && i < cnt && kk[i - 1] == kk[i];
+            const bool next2 = eq[e] && i + 2 < cnt && kk[i + 1] == kk[i + 2];
+            two[e] = eq[e] && !prev && !next2;
+            // member of a run of three or more: as a pair's first element, or as the last element of such a run
+            const bool in_long = (eq[e] && !two[e]) || (prev && !eq[e] && i >= 2 && kk[i - 2] == kk[i - 1]);
+            pa[e] = (two[e] || in_long) ? (uint32_t)orig[vv[i]] : 0u;
+            pb[e] = two[e] ? (uint32_t)orig[vv[i + 1]] : 0u;
+            if (in_long) oo[i] = pa[e];
+            longrun |= in_long ? 1 : 0;
         }
-        if (__syncthreads_or(any) == 0) return;  // (no tie in this bucket)
-        // Odd-even transposition restricted to the tied pairs: in a round the pairs that start at even (odd) positions
-        // are disjoint, each is put in order by one thread, a barrier ends the round; done when an even and an odd round
-        // in a row moved nothing.  A run of L equal keys takes at most L rounds -- two or three almost always; thousands
-        // of equal depths (a plane facing the camera) cost a barrier each and stay exact.  (Measured against it: ranking
-        // every member inside a +-6 window with straight-line code and falling back to the rounds for longer runs --
-        // slower on both views, ss_buckets 13.6 -> 14.5 us and 40.5 -> 58 us: the window is probed whether or not a run
-        // is long.)
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const int i = tid + e * kT;
+            if (two[e] && pa[e] > pb[e]) {
+                const uint32_t v0 = vv[i], v1 = vv[i + 1];
+                vv[i] = v1;
+                vv[i + 1] = v0;
+            }
+        }
+        if (__syncthreads_or(longrun) == 0) return;  // (no run of three or more in this bucket; the swaps are visible)
+        // Odd-even transposition restricted to the pairs of the long runs: in a round the pairs that start at even (odd)
+        // positions are disjoint, each is put in order by one thread, a barrier ends the round; done when an even and an odd
+        // round in a row moved nothing.  A run of L equal keys takes at most L rounds; thousands of equal depths (a plane
+        // facing the camera) cost a barrier each and stay exact.  (Measured against it in round 4: ranking every member
+        // inside a +-6 window with straight-line code and falling back to the rounds for longer runs -- slower on both
+        // views: the window is probed whether or not a run is long.)
         int quiet = 0;
         for (int round = 0; quiet < 2; round++) {
             int moved = 0;
 #pragma unroll
             for (int e = 0; e < kPer; e++) {
                 const int i = tid + e * kT;
-                if (eq[e] && ((i ^ round) & 1) == 0) {
+                if (eq[e] && !two[e] && ((i ^ round) & 1) == 0) {
                     const uint32_t o0 = oo[i], o1 = oo[i + 1];
                     if (o0 > o1) {
                         const uint32_t v0 = vv[i], v1 = vv[i + 1];
@@ -1071,7 +1196,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
                 const int src = sort_in_lds(tmp + o, nj, true);
                 fix_ties(src, nj);
                 const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
-                carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s + o, nj, carry);
+                carry = emit([&](int i) { return make_uint2(vv[i], kk[i] + kbase); }, s + o, nj, carry);
             } else {
                 int N = 2;
                 while (N < nj) N <<= 1;
@@ -1104,7 +1229,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     SS_STAMP(dbg, 3);
     fix_ties(src, n);
     const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
-    const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i]); }, s, n, 0u);
+    const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i] + kbase); }, s, n, 0u);
     if (tid == 0) bucket_tiles[blockIdx.x] = carry;
     SS_STAMP(dbg, 4);
 }
@@ -1119,7 +1244,7 @@ struct SsArgs {
     uint64_t *dbg;
     const float *view;
     uint32_t sig;
-    const uint32_t *quad_work;      // (nullptr: no spare workgroup in the partition pass)
+    const uint32_t *quad_work;      // (the prepare launch's second workgroup: the compositor's quadrant deal)
     int num_quads;
     uint32_t *quad_order;
     int cus_per_xcd;
@@ -1133,6 +1258,10 @@ struct SsArgs {
 
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
+    if (blockIdx.x == 1) {  // (only launched with a deal to make)
+        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd);
+        return;
+    }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
                     a.hdr, a.dbg, a.view, a.sig);
 }
@@ -1148,7 +1277,7 @@ __global__ __launch_bounds__(kColT) void ss_colscan_kernel(const GsrBatch<SsArgs
 __global__ __launch_bounds__(kT) void ss_partition_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     ss_partition_body(a.bmax, a.pair0, a.pair1, a.table, a.totals, a.splitters, a.splitters_new, a.seg, a.bucket_start,
-                      a.hdr, a.dbg, a.nbc, a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd);
+                      a.hdr, a.dbg);
 }
 __global__ __launch_bounds__(kT) void ss_buckets_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
@@ -1176,8 +1305,8 @@ int gsr_ss_bmax(int32_t P) {
 }
 
 // preprocess left the block-local records (pair[1]) / block_counts / block_cand; the sorted depth order ends in g.order
-// (order_early: a spare workgroup of the partition pass also deals the num_quads quadrants of the frame's compositor
-//  -> img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
+// (order_early: the prepare launch's second workgroup deals the num_quads quadrants of the frame's compositor ->
+//  img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
                                  bool debug, hipStream_t stream) {
     const int32_t P = fr[0].in->P;
@@ -1199,14 +1328,14 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         // full one took a zero-filled "table" blind once, and one bucket of 175 k records went through the global-memory
         // sort)
         a.sig = (uint32_t)P * 2654435761u ^ (uint32_t)((char *)g.ss_splitters - (char *)g.hdr);
-        a.quad_work = order_early ? fr[k].img.quad_work : (const uint32_t *)nullptr;
+        a.quad_work = fr[k].img.quad_work;
         a.num_quads = num_quads;
         a.quad_order = fr[k].img.quad_order;
         a.cus_per_xcd = gsr_render_cus_per_xcd();
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
     }
-    hipLaunchKernelGGL(ss_prepare_kernel, dim3(1, B), dim3(kPT), 0, stream, bt);
+    hipLaunchKernelGGL(ss_prepare_kernel, dim3(order_early ? 2 : 1, B), dim3(kPT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_prepare", debug, stream)) return e;
     const size_t lds1 = (size_t)(2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc, B), dim3(kT), lds1, stream, bt);
@@ -1214,7 +1343,7 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
     hipLaunchKernelGGL(ss_colscan_kernel, dim3(gsr_div_up(bmax, GSR_WAVE), B), dim3(kColT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_colscan", debug, stream)) return e;
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
-    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc + (order_early ? 1 : 0), B), dim3(kT), lds2, stream, bt);
+    hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc, B), dim3(kT), lds2, stream, bt);
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
     const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax, B), dim3(kT), lds3, stream, bt);

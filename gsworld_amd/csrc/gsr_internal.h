@@ -396,8 +396,9 @@ int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const Image
 int gsr_launch_bin_scatter_and_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                     const ImageState &img, bool debug, hipStream_t stream);
 int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-// (quad_work != nullptr: a spare workgroup of the partition pass also deals the num_quads quadrants -> quad_order)
 // (super_shift: 1 = rect_sorted in 2 x 2 super-tile units, GsrSettings.forward_only)
+// (order_early: a second workgroup of the prepare launch deals the num_quads quadrants of the frame's compositor by their
+//  cost in the previous frame -> img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
                                  bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);

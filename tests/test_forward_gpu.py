@@ -435,3 +435,23 @@ def test_wild_inputs_stay_bit_exact(cuda_device, case):
     g = hp.gpu_forward(inp, st, bg, **kw)
     rep = hp.compare_forward(o, g, st, check_image=(case != "cov3d_precomp"))
     assert 500 < rep["V"] < rep["P"], rep["V"]
+
+
+def test_a_model_of_more_than_8192_blocks(cuda_device):
+    """2.4 M Gaussians = 9 375 preprocess blocks: the depth sort's prepare workgroup then keeps 16 block counts per thread
+    slice instead of 8 (depthsort.hip ss_prepare_per) -- every index against the oracle, inference frames (the path the
+    closed loop takes) against the default frame."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    raw = scenes.random_scene_camera_frame(2_400_000, seed=17)
+    cam = scenes.identity_camera(96, 64, 70.0)
+    rep = _run(raw, cam)
+    assert rep["P"] == 2_400_000 and rep["V"] > 100_000
+    dev = cuda_device
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    camd = cam.to(dev)
+    a = FrameRenderer(dev).render(camd, means, op, shs=shs, scales=sc, rotations=rot)
+    b = FrameRenderer(dev, forward_only=True)
+    for _ in range(3):  # exact frame, then kept splitters validated / taken blind
+        out = b.render(camd, means, op, shs=shs, scales=sc, rotations=rot)
+    assert torch.equal(a[0], out[0]) and torch.equal(a[2], out[2]) and torch.equal(a[1], out[1])
