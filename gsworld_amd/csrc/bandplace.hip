@@ -82,8 +82,7 @@ __device__ __forceinline__ void band_ranges_body(GsrHeader *__restrict__ hdr, in
         if (tid == 0) hdr->br_age = age + 1u;
         return;
     }
-    int B = 256;
-    while (B < bmax && (uint32_t)B * (uint32_t)GSR_SS_PER_BUCKET < V) B <<= 1;  // (ss_num_buckets of depthsort.hip)
+    const int B = (int)hdr->ss_B;  // (the frame's bucket count: depthsort.hip ss_prepare)
     const int PER = B / kBT;
     uint32_t t[8], sum = 0;
 #pragma unroll

@@ -75,9 +75,9 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // (never a depth key: those are posit
 #endif
 constexpr int kBucketCap = GSR_SS_BUCKET_CAP;
 
-__device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax) {
+__device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax, uint32_t per) {
     int B = 256;
-    while (B < bmax && (uint32_t)B * (uint32_t)GSR_SS_PER_BUCKET < V) B <<= 1;
+    while (B < bmax && (uint32_t)B * per < V) B <<= 1;
     return B;
 }
 __device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
@@ -411,16 +411,15 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
             seg_off[j] = 0u;
             seg_first[j] = (uint32_t)nb1;
         }
-        if (tid == 0) hdr->ss_fresh = 0u;
+        if (tid == 0) {
+            hdr->ss_fresh = 0u;
+            hdr->ss_B = 256u;
+            hdr->ss_stride = 1u;
+        }
         return;
     }
     __syncthreads();
     SS_STAMP(dbg, 22);
-    const int B = ss_num_buckets(V, bmax);
-    // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
-    // in a few hundred frames outgrows the LDS)
-    const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
-    const int logS = ss_log2((int)S);  // (S is a power of two)
     // A fixed sensor camera (GSWorld's right_cam and the like) over a scene that stands still: the view matrix is bit
     // for bit the one the splitters in the state were built under and the last frames that classified with the kept
     // table came out as balanced as exact quantiles of an unchanged scene do (ss_trust, kept by ss_partition /
@@ -429,16 +428,61 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // depth range that was empty a frame ago, where the kept buckets are wide) can put ten thousand records into one
     // bucket, far beyond the LDS, and that bucket's workgroup then sorts in global memory for a millisecond.  Such a
     // scene never earns the trust; its frames check the kept table against samples below.
-    bool blind = same_view && h_magic == kSplitMagic && h_buckets == (uint32_t)B &&
-                 (GSR_SS_IGNORE_BAD || h_bad == 0u) && h_trust >= (uint32_t)GSR_SS_TRUST_MIN && h_trust <= 255u &&
-                 h_P == sig;
+    //
+    // Bucket count (left in the header: every later kernel of the frame, and band_ranges, read it there).  A frame that
+    // SAMPLES aims at GSR_SS_PER_BUCKET records per bucket: its table is an estimate, buckets come out at up to a few
+    // times their share, and the slowest bucket workgroup sets the time of a launch that does not fill the chip.  A BLIND
+    // frame's table holds exact quantiles of the same scene: every bucket gets its share to within the depth ties, so it
+    // takes buckets of GSR_SS_PER_BUCKET_FULL records -- half as many workgroups with half the fixed cost per record
+    // (measured, round 5: 1024 against 512 everywhere, static camera: eight frames per launch +3.1 % on the sensor view,
+    // +5.7 % on the dense one, dense view alone +5.5 %, sensor view alone -0.4 %; the closed loop, whose frames sample,
+    // -5.5 %).  The first blind frame after sampling ones finds a table of twice its count and takes every second entry
+    // (the 2i-th of 2B quantiles is the i-th of B): `stride`.  A frame that samples again finds a table of half its count,
+    // which fails `reuse` below: one drawn table per change from resting to moving.
+    const int B0 = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET);
+    const int Bf = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET_FULL);  // (B0 or B0 / 2)
+    bool blind = same_view && h_magic == kSplitMagic && (h_buckets == (uint32_t)Bf || h_buckets == 2u * (uint32_t)Bf) &&
+                 h_buckets <= (uint32_t)bmax && (GSR_SS_IGNORE_BAD || h_bad == 0u) &&
+                 h_trust >= (uint32_t)GSR_SS_TRUST_MIN && h_trust <= 255u && h_P == sig;
+    const int B = blind ? Bf : B0;
+    const uint32_t stride = blind ? h_buckets / (uint32_t)Bf : 1u;
+    if (tid == 0) {
+        hdr->ss_B = (uint32_t)B;
+        hdr->ss_stride = stride;
+    }
+    // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
+    // in a few hundred frames outgrows the LDS)
+    const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
+    const int logS = ss_log2((int)S);  // (S is a power of two)
     // the kept table into LDS (used blind, or validated below)
+    if (stride == 1u) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int i = tid + k * kPT;
-        if (i < B) {
-            s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
-            s_hist[i] = 0u;
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * kPT;
+            if (i < B) {
+                s_split[i] = i < B - 1 ? pre_sp[k] : 0xFFFFFFFFu;
+                s_hist[i] = 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid + k * kPT < bmax) s_hist[tid + k * kPT] = pre_sp[k];
+        __syncthreads();
+        uint32_t v[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * kPT;
+            v[k] = i < B - 1 ? s_hist[2 * i + 1] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * kPT;
+            if (i < B) {
+                s_split[i] = v[k];
+                s_hist[i] = 0u;
+            }
         }
     }
     __syncthreads();
@@ -652,11 +696,13 @@ __device__ __forceinline__ void ss_compact_body(int bmax, const uint2 *__restric
     const int first = (int)seg_first[me], last = (int)seg_first[me + 1];
     const uint32_t before = seg_off[me];
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax);
+    const int B = (int)hdr->ss_B;
+    const uint32_t stride = hdr->ss_fresh != 0u ? 1u : hdr->ss_stride;  // (a drawn table is read entry by entry)
     {
         uint32_t sp[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) sp[k] = tid + k * kT < B - 1 ? split_src[tid + k * kT] : 0xFFFFFFFFu;
+        for (int k = 0; k < 8; k++)  // (stride: 2 when a blind frame takes every second entry of the kept table)
+            sp[k] = tid + k * kT < B - 1 ? split_src[(uint32_t)(tid + k * kT + 1) * stride - 1u] : 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (tid + k * kT < B) {
@@ -768,7 +814,7 @@ __device__ __forceinline__ void ss_colscan_body(int bmax, int nbc, uint32_t *__r
     const int lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
     const uint32_t V = hdr->V;
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax);
+    const int B = (int)hdr->ss_B;
     const int b = (int)blockIdx.x * GSR_WAVE + lane;
     if ((int)blockIdx.x * GSR_WAVE >= B) return;
     const int q = (nbc + NWV - 1) / NWV, r0 = min(nbc, wave * q), r1 = min(nbc, r0 + q);
@@ -838,7 +884,8 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
         hdr->ss_bad = 0u;
     }
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax), nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
+    const int B = (int)hdr->ss_B, nbits = ss_log2(B), PER = B / kT;  // 1, 2, 4 or 8 buckets per thread
+    const uint32_t stride = hdr->ss_fresh != 0u ? 1u : hdr->ss_stride;
     const int me = (int)blockIdx.x;
     (void)lane;
     {
@@ -857,7 +904,7 @@ __device__ __forceinline__ void ss_partition_body(int bmax, const uint2 *__restr
             if (k < PER) {
                 const int d = tid * PER + k;
                 s_run[d] = run + M[k];
-                s_split[d] = split_src[d];
+                s_split[d] = d < B - 1 ? split_src[(uint32_t)(d + 1) * stride - 1u] : 0xFFFFFFFFu;
                 if (me == 0) bucket_start[d] = run;
                 run += T[k];
             }
@@ -946,7 +993,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     const int tid = (int)threadIdx.x;
     const uint32_t V = hdr->V;
     if (V == 0u) return;
-    const int B = ss_num_buckets(V, bmax);
+    const int B = (int)hdr->ss_B;
     if ((int)blockIdx.x >= B) return;
     if (blockIdx.x == 0 && tid == 0) {
         hdr->ss_magic = kSplitMagic;

@@ -18,8 +18,10 @@
 #define GSR_DEPTH_RADIX_BINS 2048
 #define GSR_BIN_SLOTS 16              // replicated per-tile counters of the bin-then-sort path
 #ifndef GSR_SS_PER_BUCKET
-#define GSR_SS_PER_BUCKET 512          // depth sort: records per bucket the bucket count aims at (B = 256 .. 2048).
-                                       // Measured with 1024: headline +2 %, dense view +12 %, closed loop -8 %: kept at 512
+#define GSR_SS_PER_BUCKET 512          // depth sort: records per bucket the bucket count aims at (B = 256 .. 2048) in a
+#endif                                 // frame that samples ...
+#ifndef GSR_SS_PER_BUCKET_FULL
+#define GSR_SS_PER_BUCKET_FULL 1024    // ... and in one that takes the kept exact quantiles unchecked (depthsort.hip ss_prepare)
 #endif
 #define GSR_BAND_RANGES 64            // band placement (bandplace.hip): depth-rank ranges per tile row
 // forward_only frames bin per (2^SX x 2^SY)-tile super-tile.  Measured at config 2 (one frame at a time; default
@@ -56,7 +58,9 @@ struct GsrHeader {
     uint32_t ss_trust;    // consecutive frames that classified with the KEPT table and came out balanced (blind needs 2)
     uint32_t ss_prev_fresh;  // the previous frame drew its own splitters (says nothing about the kept table)
     uint32_t ss_fresh;    // this frame's compaction drew new splitters: the partition pass reads ss_splitters_new
-    uint32_t pad[28];
+    uint32_t ss_B;        // depth buckets of THIS frame (chosen by ss_prepare: every later kernel of the frame reads it)
+    uint32_t ss_stride;   // 2: this (blind) frame takes every second entry of a kept table of 2 ss_B quantiles; else 1
+    uint32_t pad[26];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)

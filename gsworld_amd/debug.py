@@ -95,9 +95,11 @@ def sort_state(geomBuffer: torch.Tensor) -> dict:
     """What the sample sort of the last frame on this geometry state did with the splitters it found there
     (``gsr_debug_sort_state``; synchronises the current stream): ``blind`` -- taken unchecked, ``fresh`` -- drawn anew from
     samples, neither -- the kept ones checked against samples and kept; ``bad`` -- some depth bucket came out above what
-    quantiles of an unchanged scene give; ``trust`` -- consecutive balanced frames on kept splitters before this one."""
-    out = (C.c_int32 * 4)()
+    quantiles of an unchanged scene give; ``trust`` -- consecutive balanced frames on kept splitters before this one;
+    ``buckets`` -- depth buckets of the frame; ``stride`` -- 2 when it took every second entry of a kept table."""
+    out = (C.c_int32 * 6)()
     with torch.cuda.device(geomBuffer.device):
         check(lib().gsr_debug_sort_state(C.c_void_p(geomBuffer.data_ptr()), out,
                                          C.c_void_p(torch.cuda.current_stream(geomBuffer.device).cuda_stream)))
-    return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]))
+    return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]), buckets=int(out[4]),
+                stride=int(out[5]))

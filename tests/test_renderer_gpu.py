@@ -398,6 +398,47 @@ def test_fixed_camera_takes_kept_splitters_blind_only_while_the_scene_stands_sti
     assert dbg.sort_state(r.geom)["blind"]
 
 
+def test_resting_camera_halves_its_bucket_count_and_a_moving_one_takes_it_back(cuda_device):
+    """Frames that sample cut the depth order into buckets of <= 512 records, frames that take the kept exact quantiles
+    unchecked into buckets of <= 1024 (depthsort.hip ss_prepare): the first blind frame reads every second entry of the
+    kept table (stride 2), the following ones a table of their own count; a camera that moves again draws a table of
+    the larger count.  Every frame is the exact-mode frame of a fresh renderer bit for bit, state included."""
+    from gsworld_amd.renderer import FrameRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align")  # full size: 1 468 850 Gaussians, about 176 k of them visible
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot)
+    want = FrameRenderer(dev)
+    w_color, w_radii, w_invd = (t.clone() for t in want.render(cam, means, op, exact=True, **kw))
+    V = want.stats().num_visible
+    assert 131072 < V <= 262144, V  # 512 buckets of <= 512 records, 256 of <= 1024
+    r = FrameRenderer(dev)  # (a default-mode renderer: the point list and the ranges are there to compare)
+    seen = []
+    for k in range(8):
+        color, radii, invd = r.render(cam, means, op, **kw)
+        st = dbg.sort_state(r.geom)
+        seen.append((st["blind"], st["buckets"], st["stride"]))
+        assert torch.equal(color, w_color) and torch.equal(invd, w_invd) and torch.equal(radii, w_radii), f"frame {k}"
+        sa, sb = (dbg.state_view(raw.num, 640, 480, x.stats().num_rendered, x.stats().num_visible, x.geom, x.binning,
+                                 x.image, r_capacity=x.r_capacity) for x in (want, r))
+        for name in ("point_list", "ranges", "depth_order"):
+            assert torch.equal(sa[name], sb[name]), f"frame {k}: {name}"
+    assert seen[0] == (False, 512, 1), seen
+    first_blind = next(k for k, s in enumerate(seen) if s[0])
+    assert seen[first_blind] == (True, 256, 2), seen            # every second entry of the 512-quantile table
+    assert all(s == (True, 256, 1) for s in seen[first_blind + 1:]) and first_blind + 1 < len(seen), seen
+    moved = scenes.dense_view_camera("xarm6_align").to(dev)  # another view: most of the scene on screen
+    r.render(moved, means, op, **kw)
+    st = dbg.sort_state(r.geom)
+    assert not st["blind"] and st["fresh"] and st["stride"] == 1 and st["buckets"] > 256, st
+    r.ensure_valid(lambda: r.render(moved, means, op, **kw))  # (the new view holds more instances than the old capacity)
+    got = r.render(moved, means, op, **kw)[0].clone()
+    assert not r.stats().overflow
+    assert torch.equal(got, FrameRenderer(dev).render(moved, means, op, exact=True, **kw)[0])
+
+
 @pytest.mark.parametrize("case", ["ten_thousand_into_one_bucket", "forty_thousand_into_one_bucket", "five_thousand_equal_depths"])
 def test_depth_bucket_beyond_the_lds_is_still_sorted_exactly(cuda_device, case):
     """A depth bucket of the sample sort that outgrows the LDS (kBucketCap = 2048 records): the kept splitters were
