@@ -10,5 +10,5 @@ for f in bench_default.json bench_driver_flags.json bench_two_ranks_gloo.json; d
 cp $S/kernel_stats_*.csv $D/ 2>/dev/null || true
 cp $S/pmc/step_config2.txt $D/pmc/ 2>/dev/null || true
 [ -f $D/pmc_render.json ] && cp $D/pmc_render.json profiles/pmc_render.json
-[ -f gpurun_out/r5/c_stamps.txt ] && grep -v amdgpu.ids gpurun_out/r5/c_stamps.txt > $D/ss_stamps_closed_loop.txt
+[ -f gpurun_out/r5/n_stamps.txt ] && grep -v amdgpu.ids gpurun_out/r5/n_stamps.txt > $D/ss_stamps_closed_loop.txt
 ls -la $D
