@@ -25,3 +25,13 @@ def test_random_forward_only_slice(cuda_device):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "40 cases x 2 frames bit-identical" in out.stdout
+
+
+def test_random_batch_slice(cuda_device):
+    """A slice of tools/fuzz_batch.py: B = 1 ... 19 frames through one gsr_forward_batch call against one gsr_forward call
+    each, bit for bit, over random sizes / image shapes / cameras / options / layouts and four consecutive steps (exact,
+    capacity path, kept splitters, blind splitters with the halved bucket count); 400 cases = 12 900 frames clean in round 5."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_batch.py"), "24", "77"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "batch fuzz: 24 cases" in out.stdout
