@@ -221,6 +221,9 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
     const bool debug = st[0].debug != 0;
     const int mode = p.mode;
     const bool chunk = p.chunk, band = p.band, exact = p.exact, infer = p.infer, super = p.super;
+    // cooperative quadrants: workgroups behind the compositor's main grid for last frame's costliest quadrants (render.hip);
+    // the deal that names them rides in the depth sort's prepare launch
+    const int coop = super && band && mode == 1 && !p.radix_depth && p.order_early ? gsr_render_coop_blocks(st[0], p.tiles, B) : 0;
     GsrFrame fr[GSR_MAX_BATCH];
     for (int k = 0; k < B; k++) {
         GsrFrame &f = fr[k];
@@ -264,7 +267,7 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
             if (band || chunk)
                 if (int e = gsr_launch_gather_rects(in[0].P, g, debug, stream)) return e;
         } else {
-            if (int e = gsr_launch_sample_depth_sort(B, fr, p.order_early, 4 * p.tiles, super ? 1 : 0, debug, stream))
+            if (int e = gsr_launch_sample_depth_sort(B, fr, p.order_early, 4 * p.tiles, super ? 1 : 0, coop, debug, stream))
                 return e;
         }
     }
@@ -322,7 +325,7 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
     }
     prof_mark(4, stream);
     // every binning path leaves the point list in gidx[0]; modes 1 and 2 also computed the tile order
-    if (int e = gsr_launch_render(B, fr, mode != 0, mode == 1, super, stream)) return e;
+    if (int e = gsr_launch_render(B, fr, mode != 0, mode == 1, super, coop, stream)) return e;
     prof_mark(5, stream);
     prof_end_frame();
     return gsr_check_launch("render", debug, stream);

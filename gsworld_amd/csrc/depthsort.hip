@@ -270,28 +270,44 @@ __host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1
 // round 3, the partition pass in round 4 -- it set that kernel's time one frame at a time (ss_partition 12.2 -> 8.2 us
 // without it); beside the prepare workgroup it is free.  (Measured on the way: as an extra workgroup of preprocess it
 // raised that kernel's registers from 72 to 113 -- 27.3 instead of 20.5 us.)
+// With `coop_cap` > 0 the deal also names the COOPERATIVE quadrants of the frame (render.hip render_coop_quadrant): the
+// first coop_cap / 8 of every XCD's cost order whose cost was above GSR_COOP_FACTOR_X16 / 16 of the mean quadrant's get a
+// workgroup in front of the compositor's main grid each (coop_list[j]: the quadrant of workgroup j, on the quadrant's own
+// XCD; 0xFFFFFFFF: none) and a flag that tells the wave the deal gave them to in the main grid to leave them alone.
 __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ quad_work, int Q,
-                                                   uint32_t *__restrict__ quad_order, int cus_per_xcd) {
+                                                   uint32_t *__restrict__ quad_order, int cus_per_xcd,
+                                                   uint32_t *__restrict__ coop_flag, uint32_t *__restrict__ coop_list,
+                                                   int coop_cap) {
     __shared__ uint32_t s_qb[GSR_XCDS * 256];
     __shared__ uint32_t s_xbase[GSR_XCDS];
     __shared__ uint32_t s_w16[kPW];
     constexpr int KQ = 32 * GSR_BLOCK / kPT;  // 8 quadrants per thread: Q <= 32 x 256
     const int tid = (int)threadIdx.x;
     const int T = Q >> 2;
-    uint32_t c[KQ], qmx = 0;
+    uint32_t c[KQ], qmx = 0, csum = 0;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
         const int q = tid + k * kPT;
         c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
         qmx = max(qmx, c[k]);
+        csum += c[k] >> 4;  // (in sixteenths: 8192 costs below 2^24 stay below 2^32)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
     if ((tid & 63) == 0) s_w16[tid >> 6] = qmx;
     for (int i = tid; i < GSR_XCDS * 256; i += kPT) s_qb[i] = 0u;
+    if (coop_flag != nullptr)
+        for (int i = tid; i < coop_cap; i += kPT) coop_list[i] = 0xFFFFFFFFu;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < kPW; w++) qmx = max(qmx, s_w16[w]);
+    uint32_t coop_thr = 0xFFFFFFFFu;
+    if (coop_flag != nullptr) {  // (wave-uniform: a kernel argument)
+        uint32_t total16;
+        (void)ss_scan1024(csum, s_w16, total16);
+        // cost > factor x mean  <=>  cost > factor_x16 x (sum / 16) / Q
+        coop_thr = (uint32_t)min((uint64_t)0xFFFFFFFEull, ((uint64_t)total16 * GSR_COOP_FACTOR_X16) / (uint32_t)max(Q, 1));
+    }
     // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
     const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
     const uint32_t div = (qmx >> sh) + 1u;
@@ -325,7 +341,13 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
             const uint32_t size = min(cus, nwg - round * cus);
             const uint32_t cu = (round & 1u) ? size - 1u - idx : idx;
             const uint32_t b = GSR_XCDS * (round * cus + cu) + xcd;
-            quad_order[4u * b + (p & 3u)] = (uint32_t)q;
+            // (the cooperative workgroups come FIRST in the compositor's grid: workgroup j runs on XCD j mod 8, and the
+            //  quadrant's list is in the L2 of XCD tile mod 8 = xcd; the wave the deal gives the quadrant to in the main grid
+            //  finds it marked and leaves it alone -- in the entry it reads anyway, not behind one more round trip)
+            const bool co = coop_flag != nullptr && p < (uint32_t)(coop_cap / GSR_XCDS) &&
+                            min(quad_work[q], (1u << 24) - 1u) > coop_thr;
+            quad_order[4u * b + (p & 3u)] = (uint32_t)q | (co ? 0x80000000u : 0u);
+            if (co) coop_list[xcd + GSR_XCDS * p] = (uint32_t)q;
         }
     }
 }
@@ -1295,6 +1317,8 @@ struct SsArgs {
     int num_quads;
     uint32_t *quad_order;
     int cus_per_xcd;
+    uint32_t *coop_flag, *coop_list;  // cooperative quadrants of the compositor (null / 0: none)
+    int coop_cap;
     uint32_t *order;
     const uint2 *rects;
     uint2 *rect_sorted;
@@ -1306,7 +1330,7 @@ struct SsArgs {
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     if (blockIdx.x == 1) {  // (only launched with a deal to make)
-        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd);
+        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_flag, a.coop_list, a.coop_cap);
         return;
     }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
@@ -1355,7 +1379,7 @@ int gsr_ss_bmax(int32_t P) {
 // (order_early: the prepare launch's second workgroup deals the num_quads quadrants of the frame's compositor ->
 //  img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
-                                 bool debug, hipStream_t stream) {
+                                 int coop_blocks, bool debug, hipStream_t stream) {
     const int32_t P = fr[0].in->P;
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
@@ -1379,6 +1403,9 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.num_quads = num_quads;
         a.quad_order = fr[k].img.quad_order;
         a.cus_per_xcd = gsr_render_cus_per_xcd();
+        a.coop_flag = coop_blocks > 0 ? fr[k].img.split_flag : (uint32_t *)nullptr;  // (the split arrays, reused)
+        a.coop_list = fr[k].img.split_list;
+        a.coop_cap = coop_blocks;
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
     }

@@ -23,6 +23,15 @@
 #ifndef GSR_SS_PER_BUCKET_FULL
 #define GSR_SS_PER_BUCKET_FULL 1024    // ... and in one that takes the kept exact quantiles unchecked (depthsort.hip ss_prepare)
 #endif
+#ifndef GSR_COOP_MAX_FRAMES
+#define GSR_COOP_MAX_FRAMES 2          // cooperative quadrants (render.hip): launches of at most this many frames ...
+#endif
+#ifndef GSR_COOP_MAX_BLOCKS
+#define GSR_COOP_MAX_BLOCKS 64         // ... get up to this many of them (a multiple of 8: as many per XCD) ...
+#endif
+#ifndef GSR_COOP_FACTOR_X16
+#define GSR_COOP_FACTOR_X16 40         // ... whose cost in the previous frame was above 40 / 16 of the mean quadrant's
+#endif
 #define GSR_BAND_RANGES 64            // band placement (bandplace.hip): depth-rank ranges per tile row
 // forward_only frames bin per (2^SX x 2^SY)-tile super-tile.  Measured at config 2 (one frame at a time; default
 // per-tile binning 195 us): 2 x 1 tiles (32 x 16 px) 168 us -- 0.58 of the instances, compositor unchanged at 54 us;
@@ -404,7 +413,7 @@ int gsr_launch_compact_and_depth_sort(int32_t P, const GeomState &g, bool debug,
 // (order_early: a second workgroup of the prepare launch deals the num_quads quadrants of the frame's compositor by their
 //  cost in the previous frame -> img.quad_order; super_shift: 1 = rect_sorted in super-tile units, GsrSettings.forward_only)
 int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, int num_quads, int super_shift,
-                                 bool debug, hipStream_t stream);
+                                 int coop_blocks, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
 int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, hipStream_t stream);
@@ -425,7 +434,8 @@ int gsr_render_split_blocks(const GsrSettings &st, int num_tiles);
 bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
 int gsr_render_cus_per_xcd();  // CUs of one XCD (the quadrant deal of gsr_quad_order_block)
 // (B > 1: the default compositor only -- api.hip batches nothing else)
-int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles,
+int gsr_render_coop_blocks(const GsrSettings &st, int num_tiles, int frames);
+int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles, int coop_blocks,
                       hipStream_t stream);
 int gsr_launch_tile_count(const GsrSettings &st, int32_t P, const GeomState &g, const ImageState &img,
                           uint32_t r_capacity, bool debug, hipStream_t stream);

@@ -511,6 +511,187 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
     f[20] = pos;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cooperative quadrants (inference frames).  A wave is one in-order instruction stream: cull a round of 64 candidates
+// (one exposed gather latency, ~1 500 cycles when the wave is alone on its SIMD), replay the survivors, next round.
+// The kernel lasts as long as its longest such chain, and under a camera that sees most of the scene the longest ones
+// are mostly CULL: a quadrant on the robot's base walks a 4 900-entry super-tile list in 77 rounds for 448 survivors
+// (profiles/round4/stream_stamps_dense_view.txt: 197 k cycles of which 115 k are the cull; the compositor lasts 96 us
+// for 36 us of mean SIMD time).  The quadrants that were costliest in the previous frame on this state
+// (ss_quad_order_1024: the first few of every XCD's cost order, if clearly above the average) therefore get a WORKGROUP
+// behind the main grid instead of a wave in it: waves 1-3 cull the rounds r = w - 1 (mod 3) into their own LDS lists --
+// three gathers in flight instead of one, and none of them waits for a replay -- and wave 0 replays the lists in round
+// order, exactly the batches the quadrant's own wave would have replayed: same operations in the same order on the same
+// operands, the image does not change by a bit.  Hand-off through two counters per culling wave in LDS (rounds
+// published / rounds consumed): LDS operations of a CU execute in issue order, so a list written before the counter
+// is complete when the counter is seen; workgroup-scope fences keep the compiler from moving accesses across them.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kCoopCullers = GSR_BLOCK / GSR_WAVE - 1;  // 3
+
+struct CoopFlags {
+    uint32_t ready[4], done[4], n_surv[4], unsafe_lo[4], unsafe_hi[4], stop;
+};
+
+__device__ __forceinline__ uint32_t coop_load(volatile uint32_t *p) { return *p; }
+
+template <bool SUPER>
+__device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamList / 2][6], CoopFlags *fl, const uint32_t q,
+                                                     const uint2 *__restrict__ ranges,
+                                                     const uint32_t *__restrict__ point_list,
+                                                     const float4 *__restrict__ splat, int W, int H, int gx,
+                                                     const float *__restrict__ bg, float *__restrict__ out_color,
+                                                     float *__restrict__ out_invdepth, uint8_t *__restrict__ rgb8,
+                                                     uint32_t *__restrict__ quad_work) {
+    static_assert(SUPER, "cooperative quadrants are an inference-frame path");
+    const int lane = gsr_lane(), wave = gsr_wave();
+    const int tile = (int)(q >> 2), quad = (int)(q & 3u);
+    const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3);
+    const int qy0 = (tile / gx) * GSR_TILE + ((quad >> 1) << 3);
+    const uint32_t tx = (uint32_t)(tile % gx), ty = (uint32_t)(tile / gx);
+    constexpr int kSX = GSR_SUPER_SX, kSY = GSR_SUPER_SY;
+    const uint2 range = ranges[(int)((ty >> kSY) * (uint32_t)((gx + (1 << kSX) - 1) >> kSX) + (tx >> kSX))];
+    const int n_inst = (int)(range.y - range.x);
+    const uint32_t *src = point_list + range.x;
+    const int rounds = (n_inst + GSR_WAVE - 1) / GSR_WAVE;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    volatile uint32_t *ready = fl->ready, *done = fl->done, *stop = &fl->stop;
+    if (wave != 0) {
+        // ---- a culling wave: rounds c, c + 3, c + 6 ...
+        const int c = wave - 1;
+        float4(*list)[6] = s_list[wave];
+        const float qxf = (float)qx0, qyf = (float)qy0;
+        float4 f0 = zero4, f1 = zero4, f2 = zero4;
+        uint32_t g_next = 0;
+        {
+            const int p = c * GSR_WAVE + lane;
+            if (p < n_inst) {
+                const float4 *rec = splat + 3 * (size_t)src[p];
+                f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
+            }
+            if (p + kCoopCullers * GSR_WAVE < n_inst) g_next = src[p + kCoopCullers * GSR_WAVE];
+        }
+        uint32_t produced = 0;
+        for (int rd = c; rd < rounds; rd += kCoopCullers) {
+            const int p = rd * GSR_WAVE + lane;
+            bool keep = p < n_inst;
+            {  // getRect of upstream: rect_min <= tile < rect_max on both axes
+                const uint32_t rb = __float_as_uint(f2.w);
+                keep = keep && tx - (rb & 255u) < ((rb >> 16) & 255u) - (rb & 255u) &&
+                       ty - ((rb >> 8) & 255u) < (rb >> 24) - ((rb >> 8) & 255u);
+            }
+            keep = keep && quadrant_may_hit<true>(f0.x, f0.y, f1, qxf, qyf, 7.0f, f0.z);
+            const uint64_t unsafe = __builtin_amdgcn_ballot_w64(keep && (__float_as_uint(f0.z) & 1u) == 0u);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int n_surv = (int)__builtin_popcountll(mask);
+            // my list is free once the replay has consumed what I published last
+            while (coop_load(&done[wave]) != produced && coop_load(stop) == 0u) __builtin_amdgcn_s_sleep(1);
+            if (coop_load(stop) != 0u) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (keep)
+                stream_list_put(list, rank, f0, f1, make_float4(f2.x, f2.y, f2.z, f0.w), __uint_as_float((uint32_t)p + 1u));
+            if (lane < kBatch) stream_list_put(list, n_surv + lane, zero4, zero4, zero4, 0.0f);
+            if (lane == 0) {
+                fl->n_surv[wave] = (uint32_t)n_surv;
+                fl->unsafe_lo[wave] = (uint32_t)unsafe;
+                fl->unsafe_hi[wave] = (uint32_t)(unsafe >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            produced++;
+            if (lane == 0) ready[wave] = produced;
+            // my next round's records (its indices were requested a round ago)
+            const int pn = (rd + kCoopCullers) * GSR_WAVE + lane;
+            f0 = zero4; f1 = zero4; f2 = zero4;
+            if (pn < n_inst) {
+                const float4 *rec = splat + 3 * (size_t)g_next;
+                f0 = rec[0]; f1 = rec[1]; f2 = rec[2];
+            }
+            if (pn + kCoopCullers * GSR_WAVE < n_inst) g_next = src[pn + kCoopCullers * GSR_WAVE];
+        }
+        return;
+    }
+    // ---- the replaying wave
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pfx = (float)px, pfy = (float)py;
+    const v2f pf2x = {pfx, pfx}, pf2y = {pfy, pfy};
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    float T = inside ? 1.0f : -1.0f;
+    v2f acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};
+    uint32_t work = 0;
+    for (int rd = 0; rd < rounds; rd++) {
+        if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
+        const int w = 1 + rd % kCoopCullers;
+        const uint32_t want = (uint32_t)(rd / kCoopCullers) + 1u;  // (culling wave w has published rounds w - 1, w + 2, ... )
+        while (coop_load(&ready[w]) != want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int n_surv = (int)__builtin_amdgcn_readfirstlane((int)fl->n_surv[w]);
+        const uint64_t unsafe = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)fl->unsafe_hi[w]) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)fl->unsafe_lo[w]);
+        const float4(*list)[6] = s_list[w];
+        work += 8u;
+#if GSR_STREAM_MASKED_BLEND && GSR_STREAM_ALIVE_BLEND
+        if (unsafe == 0ull) {
+            uint64_t alive = __builtin_amdgcn_ballot_w64(T > 0.0f);
+            v2f Tp = {T, 0.0f};
+            int i = 0;
+            int limit = n_surv;
+            const uint64_t full = __builtin_amdgcn_read_exec();
+            if (n_surv > 0) do {
+                const StreamBatch b = stream_eval<false, false>(list, i, pf2x, pf2y);
+                stream_blend_alive(b, Tp, acc_rg, acc_bd, alive, limit, full);
+                work += (uint32_t)kBatch;
+                i += kBatch;
+            } while (i < limit);
+            asm volatile("v_cndmask_b32_e64 %0, -|%1|, %1, %2" : "=v"(T) : "v"(Tp.x), "s"(alive));
+        } else
+#endif
+        if (unsafe == 0ull) {
+            int i = 0;
+            if (n_surv > 0) do {
+                const StreamBatch b = stream_eval<false, false>(list, i, pf2x, pf2y);
+#if GSR_STREAM_MASKED_BLEND
+                stream_blend_masked(b, T, acc_rg, acc_bd);
+#else
+                uint32_t last = 0;
+                stream_blend<false>(b, T, acc_rg, acc_bd, last);
+#endif
+                work += (uint32_t)kBatch;
+                i += kBatch;
+            } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);
+        } else {
+            int i = 0;
+            uint32_t last = 0;
+            if (n_surv > 0) do {
+                const StreamBatch b = stream_eval<true, false>(list, i, pf2x, pf2y);
+                stream_blend<false>(b, T, acc_rg, acc_bd, last);
+                work += (uint32_t)kBatch;
+                i += kBatch;
+            } while (i < n_surv && __builtin_amdgcn_ballot_w64(T > 0.0f) != 0ull);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) done[w] = want;
+    }
+    if (lane == 0) *stop = 1u;
+    if (quad_work != nullptr && lane == 0) quad_work[q] = work;
+    if (inside) {
+        const size_t pid = (size_t)py * W + px;
+        const size_t plane = (size_t)H * W;
+        T = fabsf(T);
+        const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
+        out_color[pid] = r;
+        out_color[plane + pid] = g;
+        out_color[2 * plane + pid] = b;
+        out_invdepth[pid] = acc_bd.y;
+        if (rgb8) {
+            uint8_t *o = rgb8 + 3 * pid;
+            o[0] = (uint8_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
+            o[1] = (uint8_t)fminf(fmaxf(g * 255.0f, 0.0f), 255.0f);
+            o[2] = (uint8_t)fminf(fmaxf(b * 255.0f, 0.0f), 255.0f);
+        }
+    }
+}
+
 // SUPER (GsrSettings.forward_only): `ranges` / `point_list` are the lists of SUPER-TILES (2 x 1 tiles: 0.58 of the
 // instances to place and fetch at config 2; gsr_internal.h GSR_SUPER_SX / SY).  A candidate then passes the reference's own tile test first -- its tile
 // rect (four bytes in the spare word of the colour record, preprocess.hip) must contain this wave's tile -- so the
@@ -533,13 +714,33 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                                                                   const uint32_t *__restrict__ split_list,
                                                                   const uint32_t *__restrict__ split_count,
                                                                   uint32_t *__restrict__ quad_work_b,
-                                                                  const uint32_t *__restrict__ quad_order) {
+                                                                  const uint32_t *__restrict__ quad_order,
+                                                                  const uint32_t *__restrict__ coop_flag,
+                                                                  const uint32_t *__restrict__ coop_list,
+                                                                  int coop_blocks) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
     //   [0] x0 x1 y0 y1   [1] A0 A1 C0 C1   [2] B0 B1 o0 o1   [3] r0 g0 b0 d0   [4] r1 g1 b1 d1   [5] pos0 pos1 - -
     __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList / 2][6];
     const int lane = gsr_lane(), wave = gsr_wave();
+    if constexpr (SUPER) {
+        // the FIRST coop_blocks workgroups each take ONE of last frame's costliest quadrants (render_coop_quadrant).  First,
+        // not last: the main grid fills the chip to a few workgroups short of what is resident at once, and a workgroup the
+        // dispatcher cannot place waits for another to retire -- behind the grid a few of the longest chains of the frame
+        // started 35 us late (sensor view 6.7 -> 6.1 k frames/s); in front, what may wait is the main grid's tail, which the
+        // deal fills with the cheapest quadrants
+        if (coop_list != nullptr && (int)blockIdx.x < coop_blocks) {
+            __shared__ CoopFlags s_coop;
+            if (threadIdx.x < sizeof(CoopFlags) / sizeof(uint32_t)) reinterpret_cast<uint32_t *>(&s_coop)[threadIdx.x] = 0u;
+            __syncthreads();
+            const uint32_t q = coop_list[blockIdx.x];
+            if (q >= 4u * (uint32_t)num_tiles) return;  // (no quadrant for this workgroup: 0xFFFFFFFF)
+            render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg, out_color, out_invdepth,
+                                       rgb8, quad_work);
+            return;
+        }
+    }
     float4(*list)[6] = s_list[wave];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -558,15 +759,16 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
     // frame on this state (tile_starts_kernel, workgroup 2) are therefore cut in two 8 x 4 halves: the quadrant's own
     // wave keeps rows 0-3 (its lanes 0-31), a wave of the EXTRA workgroups behind the main grid takes rows 4-7, each
     // with its own, tighter cull rectangle.  Pixels are independent, so the image state does not change by a bit.
-    const bool extra = (int)blockIdx.x >= main_blocks;
+    const uint32_t bx = blockIdx.x - (uint32_t)coop_blocks;  // (coop_blocks is a multiple of 8: workgroup bx on XCD bx mod 8)
+    const bool extra = (int)bx >= main_blocks;
     uint32_t extra_q = 0;
     if (extra) {
-        const uint32_t e = (blockIdx.x - (uint32_t)main_blocks) * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
+        const uint32_t e = (bx - (uint32_t)main_blocks) * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
         if (split_count == nullptr || e >= *split_count) return;
         extra_q = split_list[e];
     }
     const uint32_t ticket_stride = (uint32_t)main_blocks * (uint32_t)(GSR_BLOCK / GSR_WAVE);
-    const uint32_t wave_global = blockIdx.x * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
+    const uint32_t wave_global = bx * (uint32_t)(GSR_BLOCK / GSR_WAVE) + (uint32_t)wave;
     for (uint32_t pass = 0, ticket = extra ? 0u : wave_global; ticket < num_tickets;
          pass++, ticket = extra ? num_tickets
                                 : pass * ticket_stride + ((pass & 1u) ? ticket_stride - 1u - wave_global : wave_global)) {
@@ -589,6 +791,7 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
             // carries the same load; dealing tiles (four quadrants of unequal cost) left the SIMD loads a sum of five
             // random quadrant costs each -- +-11 %, and the most loaded of 1024 SIMDs sets the kernel time.
             const uint32_t q = quad_order[4u * unit + (ticket & 3u)];
+            if (SUPER && (q & 0x80000000u) != 0u) continue;  // (a cooperative workgroup has it: the deal marks the entry)
             tile = (int)(q >> 2);
             quad = (int)(q & 3u);
         }
@@ -791,6 +994,8 @@ struct RenderStreamArgs {
     const uint32_t *split_flag, *split_list, *split_count;
     uint32_t *quad_work_b;
     const uint32_t *quad_order;
+    const uint32_t *coop_flag, *coop_list;  // cooperative quadrants (null: none); their workgroups come first
+    int coop_blocks;
 };
 template <bool SUPER>
 __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(
@@ -799,7 +1004,8 @@ __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) 
     if ((int)blockIdx.x >= a.total_blocks) return;  // (padding of the row to a multiple of 8)
     render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
                               a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
-                              a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order);
+                              a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order,
+                              a.coop_flag, a.coop_list, a.coop_blocks);
 }
 
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
@@ -893,7 +1099,21 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
     return c.variant == 4 || (c.variant >= 2 && num_tiles > render_num_cus() * c.blocks_per_cu);
 }
 
-int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles,
+// Workgroups behind the compositor's main grid that take one of last frame's costliest quadrants each
+// (render_coop_quadrant; the quadrants are picked by the deal of ss_quad_order_1024, depthsort.hip).  GsrSettings.
+// render_split: 0 = when at most GSR_COOP_MAX_FRAMES frames share the launch (with more, later frames fill the tail the
+// long quadrants leave, and a workgroup per quadrant only costs), 2 = always, 3 = never (1 = round 3's split halves).
+int gsr_render_coop_blocks(const GsrSettings &st, int num_tiles, int frames) {
+    const RenderChoice c = render_choice(st);
+    if (c.variant != 4 || st.render_split == 1 || st.render_split == 3) return 0;
+    if (st.render_split != 2 && frames > GSR_COOP_MAX_FRAMES) return 0;
+    if (!gsr_render_uses_quad_order(st, num_tiles)) return 0;
+    const int spare = render_num_cus() * 5 - num_tiles;  // (five workgroups per CU are resident: amdgpu_waves_per_eu(5))
+    const int blocks = (spare < GSR_COOP_MAX_BLOCKS ? spare : GSR_COOP_MAX_BLOCKS) / GSR_XCDS * GSR_XCDS;
+    return blocks > 0 ? blocks : 0;
+}
+
+int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_ready, bool super_tiles, int coop_blocks,
                       hipStream_t stream) {
     const GsrSettings &st = *fr[0].st;
     const int W = st.image_width, H = st.image_height;
@@ -922,7 +1142,8 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
         const int blocks = min(T, render_num_cus() * rc.blocks_per_cu);
         if (rc.variant == 4) {
             // (the split list is built by tile_starts_kernel: counting placements, grids up to 2048 tiles)
-            const int extra = split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
+            const int coop = super_tiles && split_ready ? coop_blocks : 0;
+            const int extra = coop > 0 ? coop : (split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0);
             const bool use_qorder = split_ready && gsr_render_uses_quad_order(st, T);
             GsrBatch<RenderStreamArgs> bt;
             for (int k = 0; k < B; k++) {
@@ -943,7 +1164,10 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
                 a.num_cus = render_num_cus();
                 a.main_blocks = blocks;
                 a.total_blocks = blocks + extra;
-                a.split_flag = extra > 0 ? im.split_flag : (const uint32_t *)nullptr;
+                a.split_flag = extra > 0 && coop == 0 ? im.split_flag : (const uint32_t *)nullptr;
+                a.coop_flag = coop > 0 ? im.split_flag : (const uint32_t *)nullptr;  // (the split arrays, reused)
+                a.coop_list = coop > 0 ? im.split_list : (const uint32_t *)nullptr;
+                a.coop_blocks = coop;
                 a.split_list = im.split_list;
                 a.split_count = im.split_count;
                 a.quad_work_b = im.quad_work_b;
