@@ -468,7 +468,7 @@ int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *ge
 }
 
 // What the depth sort of the last frame on this state did with the splitters it found there (tests, tools).
-int gsr_debug_sort_state(const void *geom, int32_t out[6], void *stream_) {
+int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream_) {
     if (!geom || !out) {
         gsr_set_error("gsr_debug_sort_state: null argument");
         return GSR_E_INVALID;
@@ -486,6 +486,8 @@ int gsr_debug_sort_state(const void *geom, int32_t out[6], void *stream_) {
     out[3] = (int32_t)h.ss_trust;
     out[4] = (int32_t)h.ss_B;
     out[5] = (int32_t)h.ss_stride;
+    out[6] = (int32_t)h.coop_quads;
+    out[7] = 0;
     return GSR_OK;
 }
 

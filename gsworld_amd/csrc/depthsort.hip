@@ -277,13 +277,15 @@ __host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1
 __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ quad_work, int Q,
                                                    uint32_t *__restrict__ quad_order, int cus_per_xcd,
                                                    uint32_t *__restrict__ coop_flag, uint32_t *__restrict__ coop_list,
-                                                   int coop_cap) {
+                                                   int coop_cap, GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_qb[GSR_XCDS * 256];
     __shared__ uint32_t s_xbase[GSR_XCDS];
     __shared__ uint32_t s_w16[kPW];
+    __shared__ uint32_t s_coop_n;
     constexpr int KQ = 32 * GSR_BLOCK / kPT;  // 8 quadrants per thread: Q <= 32 x 256
     const int tid = (int)threadIdx.x;
     const int T = Q >> 2;
+    if (tid == 0) s_coop_n = 0u;
     uint32_t c[KQ], qmx = 0, csum = 0;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
@@ -347,9 +349,14 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
             const bool co = coop_flag != nullptr && p < (uint32_t)(coop_cap / GSR_XCDS) &&
                             min(quad_work[q], (1u << 24) - 1u) > coop_thr;
             quad_order[4u * b + (p & 3u)] = (uint32_t)q | (co ? 0x80000000u : 0u);
-            if (co) coop_list[xcd + GSR_XCDS * p] = (uint32_t)q;
+            if (co) {
+                coop_list[xcd + GSR_XCDS * p] = (uint32_t)q;
+                atomicAdd(&s_coop_n, 1u);
+            }
         }
     }
+    __syncthreads();
+    if (tid == 0) hdr->coop_quads = s_coop_n;  // (tests and tools: gsr_debug_sort_state)
 }
 
 __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nbc,
@@ -1330,7 +1337,7 @@ struct SsArgs {
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     if (blockIdx.x == 1) {  // (only launched with a deal to make)
-        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_flag, a.coop_list, a.coop_cap);
+        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_flag, a.coop_list, a.coop_cap, a.hdr);
         return;
     }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,

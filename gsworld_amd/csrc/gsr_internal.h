@@ -69,7 +69,8 @@ struct GsrHeader {
     uint32_t ss_fresh;    // this frame's compaction drew new splitters: the partition pass reads ss_splitters_new
     uint32_t ss_B;        // depth buckets of THIS frame (chosen by ss_prepare: every later kernel of the frame reads it)
     uint32_t ss_stride;   // 2: this (blind) frame takes every second entry of a kept table of 2 ss_B quantiles; else 1
-    uint32_t pad[26];
+    uint32_t coop_quads;  // quadrants the compositor of this frame hands to cooperative workgroups (render.hip)
+    uint32_t pad[25];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)

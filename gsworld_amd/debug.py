@@ -26,9 +26,15 @@ def set_depth_sort(variant: int) -> None:
     _lib.TUNING["depth_sort"] = variant
 
 
-def set_render_split(on: bool) -> None:
-    """A/B and tests: the compositor cuts the costliest quadrants of the previous frame into two 8x4 halves (default off)."""
-    _lib.TUNING["render_split"] = 1 if on else 0
+def set_render_split(on) -> None:
+    """A/B and tests: what the compositor does with the costliest quadrants of the previous frame (GsrSettings.render_split).
+    ``False`` / 0 = default: inference frames that share their launches with at most one other frame hand them to
+    cooperative workgroups (three waves cull, one composites); ``True`` / 1 = two 8x4 halves on two waves (round 3's
+    experiment); 2 = cooperative workgroups whatever the launch holds; 3 = one wave per quadrant, always."""
+    mode = int(on)
+    if mode not in (0, 1, 2, 3):
+        raise ValueError("render_split must be 0 (default), 1 (halves), 2 (cooperative always) or 3 (neither)")
+    _lib.TUNING["render_split"] = mode
 
 
 def set_render_variant(variant: int, blocks_per_cu: int = 0) -> None:
@@ -96,10 +102,11 @@ def sort_state(geomBuffer: torch.Tensor) -> dict:
     (``gsr_debug_sort_state``; synchronises the current stream): ``blind`` -- taken unchecked, ``fresh`` -- drawn anew from
     samples, neither -- the kept ones checked against samples and kept; ``bad`` -- some depth bucket came out above what
     quantiles of an unchanged scene give; ``trust`` -- consecutive balanced frames on kept splitters before this one;
-    ``buckets`` -- depth buckets of the frame; ``stride`` -- 2 when it took every second entry of a kept table."""
-    out = (C.c_int32 * 6)()
+    ``buckets`` -- depth buckets of the frame; ``stride`` -- 2 when it took every second entry of a kept table;
+    ``coop_quads`` -- quadrants the frame's compositor handed to cooperative workgroups."""
+    out = (C.c_int32 * 8)()
     with torch.cuda.device(geomBuffer.device):
         check(lib().gsr_debug_sort_state(C.c_void_p(geomBuffer.data_ptr()), out,
                                          C.c_void_p(torch.cuda.current_stream(geomBuffer.device).cuda_stream)))
     return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]), buckets=int(out[4]),
-                stride=int(out[5]))
+                stride=int(out[5]), coop_quads=int(out[6]))

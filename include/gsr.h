@@ -232,8 +232,9 @@ int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *ge
  * the kept splitters unchecked (fixed camera, scene standing still); out[1] = 1: it drew new splitters from samples;
  * (both 0: it checked the kept ones against samples and kept them); out[2] = 1: a depth bucket came out above what
  * quantiles of an unchanged scene give; out[3]: consecutive balanced frames on kept splitters before this one; out[4]:
- * depth buckets of the frame; out[5] = 2: it took every second entry of a kept table of twice as many quantiles. */
-int gsr_debug_sort_state(const void *geom, int32_t out[6], void *stream);
+ * depth buckets of the frame; out[5] = 2: it took every second entry of a kept table of twice as many quantiles;
+ * out[6]: quadrants the frame's compositor handed to cooperative workgroups; out[7]: reserved (0). */
+int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream);
 
 /* Reads V / R / overflow of the frame whose geometry state is `geom` (synchronises `stream`). */
 int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream);

@@ -188,6 +188,56 @@ def test_split_quadrants_leave_the_image_state_bit_identical(cuda_device):
         assert torch.equal(rgb8, ref[2])
 
 
+@pytest.mark.parametrize("view", ["dense", "sensor"])
+def test_cooperative_quadrants_leave_the_frame_bit_identical(cuda_device, view):
+    """Inference frames hand the quadrants that were costliest in the previous frame to cooperative workgroups (render.hip
+    render_coop_quadrant: three waves cull the rounds of 64 candidates in turn, the fourth composites their survivor lists in
+    round order).  Frame after frame on one state -- so the choice is the real one -- colour, inverse depth and the uint8
+    frame equal those of a compositor with one wave per quadrant (render_split = 3) bit for bit; from above the table the
+    robot's base makes some quadrants cooperative, and a batch of four frames (more than two per launch) none."""
+    from gsworld_amd.renderer import FrameRenderer, MultiCameraRenderer
+
+    dev = cuda_device
+    cam = (scenes.dense_view_camera("xarm6_align") if view == "dense" else scenes.sensor_camera("xarm6_align")).to(dev)
+    raw = scenes.tabletop_scene("xarm6_align", n=700_000, seed=4)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    bg = torch.tensor([0.1, 0.3, 0.2], device=dev)
+    kw = dict(shs=shs, scales=sc, rotations=rot, bg=bg)
+
+    def frames(n, mode):
+        dbg.set_render_split(mode)
+        try:
+            r = FrameRenderer(dev, forward_only=True, want_radii=False)
+            out, used = [], []
+            for _ in range(n):
+                rgb8 = torch.zeros((480, 640, 3), dtype=torch.uint8, device=dev)
+                color, _, invd = r.render(cam, means, op, rgb8_out=rgb8, **kw)
+                r.ensure_valid(lambda: r.render(cam, means, op, rgb8_out=rgb8, **kw))
+                used.append(dbg.sort_state(r.geom)["coop_quads"])
+                out.append((color.clone(), invd.clone(), rgb8))
+            assert not r.stats().overflow
+            return out, used
+        finally:
+            dbg.set_render_split(0)
+
+    (ref,), used_off = frames(1, 3)
+    assert used_off == [0]
+    got, used = frames(5, 0)
+    for color, invd, rgb8 in got:
+        assert torch.equal(color.view(torch.int32), ref[0].view(torch.int32))
+        assert torch.equal(invd.view(torch.int32), ref[1].view(torch.int32))
+        assert torch.equal(rgb8, ref[2])
+    assert all(0 <= u <= 64 for u in used), used
+    if view == "dense":
+        assert used[-1] > 0, used  # (the first frames of a state see no costs yet)
+    mc = MultiCameraRenderer(4, dev, batched=True, forward_only=True, want_radii=False)
+    for _ in range(3):
+        outs = mc.render([cam] * 4, means, op, **kw)
+    mc.ensure_valid(lambda: None)
+    assert all(dbg.sort_state(lane.geom)["coop_quads"] == 0 for lane in mc.lanes)
+    assert all(torch.equal(o[0], ref[0]) for o in outs)
+
+
 def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
     """Under a bit-identical view matrix the depth sort takes the splitters the state holds without sampling
     (depthsort.hip).  Splitters only balance the buckets, never decide the order: a scene that changes completely under
