@@ -280,36 +280,43 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
                                                    int coop_cap, GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_qb[GSR_XCDS * 256];
     __shared__ uint32_t s_xbase[GSR_XCDS];
-    __shared__ uint32_t s_w16[kPW];
+    __shared__ uint32_t s_w16[kPW], s_cs16[kPW];
     __shared__ uint32_t s_coop_n;
     constexpr int KQ = 32 * GSR_BLOCK / kPT;  // 8 quadrants per thread: Q <= 32 x 256
     const int tid = (int)threadIdx.x;
     const int T = Q >> 2;
     if (tid == 0) s_coop_n = 0u;
-    uint32_t c[KQ], qmx = 0, csum = 0;
+    uint32_t c[KQ], cost[KQ], qmx = 0, csum = 0;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
         const int q = tid + k * kPT;
         c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
+        cost[k] = c[k];
         qmx = max(qmx, c[k]);
         csum += c[k] >> 4;  // (in sixteenths: 8192 costs below 2^24 stay below 2^32)
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
-    if ((tid & 63) == 0) s_w16[tid >> 6] = qmx;
+    for (int o = 32; o > 0; o >>= 1) {
+        qmx = max(qmx, (uint32_t)__shfl_xor((int)qmx, o, 64));
+        csum += (uint32_t)__shfl_xor((int)csum, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        s_w16[tid >> 6] = qmx;
+        s_cs16[tid >> 6] = csum;
+    }
     for (int i = tid; i < GSR_XCDS * 256; i += kPT) s_qb[i] = 0u;
     if (coop_flag != nullptr)
         for (int i = tid; i < coop_cap; i += kPT) coop_list[i] = 0xFFFFFFFFu;
     __syncthreads();
+    uint32_t total16 = 0u;
 #pragma unroll
-    for (int w = 0; w < kPW; w++) qmx = max(qmx, s_w16[w]);
-    uint32_t coop_thr = 0xFFFFFFFFu;
-    if (coop_flag != nullptr) {  // (wave-uniform: a kernel argument)
-        uint32_t total16;
-        (void)ss_scan1024(csum, s_w16, total16);
-        // cost > factor x mean  <=>  cost > factor_x16 x (sum / 16) / Q
-        coop_thr = (uint32_t)min((uint64_t)0xFFFFFFFEull, ((uint64_t)total16 * GSR_COOP_FACTOR_X16) / (uint32_t)max(Q, 1));
+    for (int w = 0; w < kPW; w++) {
+        qmx = max(qmx, s_w16[w]);
+        total16 += s_cs16[w];
     }
+    // cost > factor x mean  <=>  cost > factor_x16 x (sum / 16) / Q
+    const uint32_t coop_thr =
+        (uint32_t)min((uint64_t)0xFFFFFFFEull, ((uint64_t)total16 * GSR_COOP_FACTOR_X16) / (uint32_t)max(Q, 1));
     // bucket = 255 - floor(cost * 256 / (max + 1)): cost < 2^24, so the product fits 32 bits after the shift
     const int sh = qmx >= (1u << 16) ? 8 : 0;  // (keeps cost * 256 below 2^32 and the divisor non-zero)
     const uint32_t div = (qmx >> sh) + 1u;
@@ -346,8 +353,7 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
             // (the cooperative workgroups come FIRST in the compositor's grid: workgroup j runs on XCD j mod 8, and the
             //  quadrant's list is in the L2 of XCD tile mod 8 = xcd; the wave the deal gives the quadrant to in the main grid
             //  finds it marked and leaves it alone -- in the entry it reads anyway, not behind one more round trip)
-            const bool co = coop_flag != nullptr && p < (uint32_t)(coop_cap / GSR_XCDS) &&
-                            min(quad_work[q], (1u << 24) - 1u) > coop_thr;
+            const bool co = coop_flag != nullptr && p < (uint32_t)(coop_cap / GSR_XCDS) && cost[k] > coop_thr;
             quad_order[4u * b + (p & 3u)] = (uint32_t)q | (co ? 0x80000000u : 0u);
             if (co) {
                 coop_list[xcd + GSR_XCDS * p] = (uint32_t)q;
