@@ -273,11 +273,12 @@ __host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1
 // With `coop_cap` > 0 the deal also names the COOPERATIVE quadrants of the frame (render.hip render_coop_quadrant): the
 // first coop_cap / 8 of every XCD's cost order whose cost was above GSR_COOP_FACTOR_X16 / 16 of the mean quadrant's get a
 // workgroup in front of the compositor's main grid each (coop_list[j]: the quadrant of workgroup j, on the quadrant's own
-// XCD; 0xFFFFFFFF: none) and a flag that tells the wave the deal gave them to in the main grid to leave them alone.
+// XCD; 0xFFFFFFFF: none), and bit 31 of their entry in quad_order tells the wave the deal gave them to in the main grid to
+// leave them alone.
 __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ quad_work, int Q,
                                                    uint32_t *__restrict__ quad_order, int cus_per_xcd,
-                                                   uint32_t *__restrict__ coop_flag, uint32_t *__restrict__ coop_list,
-                                                   int coop_cap, GsrHeader *__restrict__ hdr) {
+                                                   uint32_t *__restrict__ coop_list, int coop_cap,
+                                                   GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_qb[GSR_XCDS * 256];
     __shared__ uint32_t s_xbase[GSR_XCDS];
     __shared__ uint32_t s_w16[kPW], s_cs16[kPW];
@@ -305,8 +306,7 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
         s_cs16[tid >> 6] = csum;
     }
     for (int i = tid; i < GSR_XCDS * 256; i += kPT) s_qb[i] = 0u;
-    if (coop_flag != nullptr)
-        for (int i = tid; i < coop_cap; i += kPT) coop_list[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < coop_cap; i += kPT) coop_list[i] = 0xFFFFFFFFu;  // (coop_cap = 0: no cooperative quadrants)
     __syncthreads();
     uint32_t total16 = 0u;
 #pragma unroll
@@ -353,7 +353,7 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
             // (the cooperative workgroups come FIRST in the compositor's grid: workgroup j runs on XCD j mod 8, and the
             //  quadrant's list is in the L2 of XCD tile mod 8 = xcd; the wave the deal gives the quadrant to in the main grid
             //  finds it marked and leaves it alone -- in the entry it reads anyway, not behind one more round trip)
-            const bool co = coop_flag != nullptr && p < (uint32_t)(coop_cap / GSR_XCDS) && cost[k] > coop_thr;
+            const bool co = p < (uint32_t)(coop_cap / GSR_XCDS) && cost[k] > coop_thr;
             quad_order[4u * b + (p & 3u)] = (uint32_t)q | (co ? 0x80000000u : 0u);
             if (co) {
                 coop_list[xcd + GSR_XCDS * p] = (uint32_t)q;
@@ -1330,7 +1330,7 @@ struct SsArgs {
     int num_quads;
     uint32_t *quad_order;
     int cus_per_xcd;
-    uint32_t *coop_flag, *coop_list;  // cooperative quadrants of the compositor (null / 0: none)
+    uint32_t *coop_list;  // cooperative quadrants of the compositor: one entry per cooperative workgroup (coop_cap; 0: none)
     int coop_cap;
     uint32_t *order;
     const uint2 *rects;
@@ -1343,7 +1343,7 @@ struct SsArgs {
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     if (blockIdx.x == 1) {  // (only launched with a deal to make)
-        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_flag, a.coop_list, a.coop_cap, a.hdr);
+        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_list, a.coop_cap, a.hdr);
         return;
     }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
@@ -1416,8 +1416,7 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.num_quads = num_quads;
         a.quad_order = fr[k].img.quad_order;
         a.cus_per_xcd = gsr_render_cus_per_xcd();
-        a.coop_flag = coop_blocks > 0 ? fr[k].img.split_flag : (uint32_t *)nullptr;  // (the split arrays, reused)
-        a.coop_list = fr[k].img.split_list;
+        a.coop_list = fr[k].img.split_list;  // (the split list, reused)
         a.coop_cap = coop_blocks;
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;

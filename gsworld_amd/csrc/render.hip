@@ -527,6 +527,7 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
 // is complete when the counter is seen; workgroup-scope fences keep the compiler from moving accesses across them.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCoopCullers = GSR_BLOCK / GSR_WAVE - 1;  // 3
+constexpr uint32_t kCoopSpinLimit = 1u << 20;           // polls of 64+ cycles each: ~50 ms
 
 struct CoopFlags {
     uint32_t ready[4], done[4], n_surv[4], unsafe_lo[4], unsafe_hi[4], stop;
@@ -585,6 +586,7 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const int n_surv = (int)__builtin_popcountll(mask);
             // my list is free once the replay has consumed what I published last
+            // (the replaying wave bounds ITS waits -- kCoopSpinLimit -- and raises `stop` when it leaves, whatever the reason)
             while (coop_load(&done[wave]) != produced && coop_load(stop) == 0u) __builtin_amdgcn_s_sleep(1);
             if (coop_load(stop) != 0u) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -623,8 +625,17 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
         if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
         const int w = 1 + rd % kCoopCullers;
         const uint32_t want = (uint32_t)(rd / kCoopCullers) + 1u;  // (culling wave w has published rounds w - 1, w + 2, ... )
-        while (coop_load(&ready[w]) != want) __builtin_amdgcn_s_sleep(1);
+        // (a hand-off that never comes -- none can, by the counters' construction -- must not hang the GPU)
+        uint32_t spin;  // (a vector register: the kernel has no scalar one to spare)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(spin));
+        while (coop_load(&ready[w]) != want && spin < kCoopSpinLimit) {
+            __builtin_amdgcn_s_sleep(1);
+            spin++;
+        }
+        if (spin >= kCoopSpinLimit) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (plain loads behind the acquire fence, one wait for the three: as volatile ones they were three LDS round trips in a
+        //  row per round -- dense view alone -2 %)
         const int n_surv = (int)__builtin_amdgcn_readfirstlane((int)fl->n_surv[w]);
         const uint64_t unsafe = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)fl->unsafe_hi[w]) << 32) |
                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)fl->unsafe_lo[w]);
@@ -715,7 +726,6 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                                                                   const uint32_t *__restrict__ split_count,
                                                                   uint32_t *__restrict__ quad_work_b,
                                                                   const uint32_t *__restrict__ quad_order,
-                                                                  const uint32_t *__restrict__ coop_flag,
                                                                   const uint32_t *__restrict__ coop_list,
                                                                   int coop_blocks) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
@@ -994,7 +1004,7 @@ struct RenderStreamArgs {
     const uint32_t *split_flag, *split_list, *split_count;
     uint32_t *quad_work_b;
     const uint32_t *quad_order;
-    const uint32_t *coop_flag, *coop_list;  // cooperative quadrants (null: none); their workgroups come first
+    const uint32_t *coop_list;  // cooperative quadrants (null: none): the quadrant of each of the first coop_blocks workgroups
     int coop_blocks;
 };
 template <bool SUPER>
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) 
     render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
                               a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
                               a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order,
-                              a.coop_flag, a.coop_list, a.coop_blocks);
+                              a.coop_list, a.coop_blocks);
 }
 
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
@@ -1165,8 +1175,7 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
                 a.main_blocks = blocks;
                 a.total_blocks = blocks + extra;
                 a.split_flag = extra > 0 && coop == 0 ? im.split_flag : (const uint32_t *)nullptr;
-                a.coop_flag = coop > 0 ? im.split_flag : (const uint32_t *)nullptr;  // (the split arrays, reused)
-                a.coop_list = coop > 0 ? im.split_list : (const uint32_t *)nullptr;
+                a.coop_list = coop > 0 ? im.split_list : (const uint32_t *)nullptr;  // (the split list, reused)
                 a.coop_blocks = coop;
                 a.split_list = im.split_list;
                 a.split_count = im.split_count;
