@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Soak test: the headline scene rendered N times on three renderer states in flight; every frame (colour, radii,
 uint8 frame) must be the same bytes as the first one.  Catches rare races in the paths that keep state from frame to
-frame (splitters, placement cuts, quadrant deal).  Usage: soak_static_scene.py [frames]"""
+frame (splitters, placement cuts, quadrant deal, cooperative quadrants).  Usage: soak_static_scene.py [frames] [inference];
+SOAK_VIEW=dense in the environment: the camera above the table (V = 0.6 N) instead of right_cam."""
 import os
 import sys
 
@@ -18,7 +19,8 @@ def main():
     infer = len(sys.argv) > 2 and sys.argv[2] == "inference"
     dev = torch.device("cuda:0")
     raw = scenes.tabletop_scene("xarm6_align")
-    cam = scenes.sensor_camera("xarm6_align").to(dev)
+    cam = (scenes.dense_view_camera("xarm6_align") if os.environ.get("SOAK_VIEW") == "dense"
+           else scenes.sensor_camera("xarm6_align")).to(dev)
     means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
     lay = None
     if infer:
