@@ -24,7 +24,7 @@
 #define GSR_SS_PER_BUCKET_FULL 1024    // ... and in one that takes the kept exact quantiles unchecked (depthsort.hip ss_prepare)
 #endif
 #ifndef GSR_COOP_MAX_FRAMES
-#define GSR_COOP_MAX_FRAMES 2          // cooperative quadrants (render.hip): launches of at most this many frames ...
+#define GSR_COOP_MAX_FRAMES 8          // cooperative quadrants (render.hip): launches of at most this many frames (= all) ...
 #endif
 #ifndef GSR_COOP_MAX_BLOCKS
 #define GSR_COOP_MAX_BLOCKS 64         // ... get up to this many of them (a multiple of 8: as many per XCD) ...

@@ -1109,10 +1109,13 @@ bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles) {
     return c.variant == 4 || (c.variant >= 2 && num_tiles > render_num_cus() * c.blocks_per_cu);
 }
 
-// Workgroups behind the compositor's main grid that take one of last frame's costliest quadrants each
+// Workgroups in front of the compositor's main grid that take one of last frame's costliest quadrants each
 // (render_coop_quadrant; the quadrants are picked by the deal of ss_quad_order_1024, depthsort.hip).  GsrSettings.
-// render_split: 0 = when at most GSR_COOP_MAX_FRAMES frames share the launch (with more, later frames fill the tail the
-// long quadrants leave, and a workgroup per quadrant only costs), 2 = always, 3 = never (1 = round 3's split halves).
+// render_split: 0 = inference frames on the default path, 2 = the same, 3 = never (1 = round 3's split halves).  Measured
+// per frames per launch (profiles/round5/ab_coop_by_frames_per_launch.txt): dense view +12.5 / +7.8 / +6.2 / +4.9 / +2.4 %
+// at 1 / 2 / 3 / 4 / 8 frames per launch from one stream, the same within the noise with three streams in flight (other
+// launches fill the tail the long quadrants leave); sensor view and closed loop (1 / 2 / 4 environments) within +-0.6 %
+// everywhere.  GSR_COOP_MAX_FRAMES (= all) is what is left of a first version that kept to launches of one or two frames.
 int gsr_render_coop_blocks(const GsrSettings &st, int num_tiles, int frames) {
     const RenderChoice c = render_choice(st);
     if (c.variant != 4 || st.render_split == 1 || st.render_split == 3) return 0;

@@ -28,9 +28,8 @@ def set_depth_sort(variant: int) -> None:
 
 def set_render_split(on) -> None:
     """A/B and tests: what the compositor does with the costliest quadrants of the previous frame (GsrSettings.render_split).
-    ``False`` / 0 = default: inference frames that share their launches with at most one other frame hand them to
-    cooperative workgroups (three waves cull, one composites); ``True`` / 1 = two 8x4 halves on two waves (round 3's
-    experiment); 2 = cooperative workgroups whatever the launch holds; 3 = one wave per quadrant, always."""
+    ``False`` / 0 = default: inference frames hand them to cooperative workgroups (three waves cull, one composites);
+    ``True`` / 1 = two 8x4 halves on two waves (round 3's experiment); 2 = as 0; 3 = one wave per quadrant, always."""
     mode = int(on)
     if mode not in (0, 1, 2, 3):
         raise ValueError("render_split must be 0 (default), 1 (halves), 2 (cooperative always) or 3 (neither)")

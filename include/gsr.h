@@ -72,10 +72,9 @@ typedef struct GsrSettings {
      *   order. */
     int32_t depth_sort;
     /* render_split: what the compositor does with the quadrants that were costliest in the previous frame on the same
-     *   state (image state bit-identical in every mode).  0 = default: inference frames that share their launches with at
-     *   most one other frame give each of them a workgroup of its own -- three waves cull the quadrant's candidates, the
-     *   fourth composites the survivors; 1 = two 8x4 halves on two waves (measured slower, kept for A/B); 2 = the
-     *   cooperative workgroups whatever the launch holds; 3 = one wave per quadrant, always. */
+     *   state (image state bit-identical in every mode).  0 = default: inference frames give each of them a workgroup of
+     *   its own -- three waves cull the quadrant's candidates, the fourth composites the survivors; 1 = two 8x4 halves on
+     *   two waves (measured slower, kept for A/B); 2 = as 0; 3 = one wave per quadrant, always. */
     int32_t render_split;
     /* forward_only: 1 = inference frame (GSWorld's closed loop never runs a backward: gs_world_wrapper.py:266-270 keeps
      * ["render"] only).  The image is bit-identical to forward_only = 0; what changes is the work behind it:

@@ -193,8 +193,8 @@ def test_cooperative_quadrants_leave_the_frame_bit_identical(cuda_device, view):
     """Inference frames hand the quadrants that were costliest in the previous frame to cooperative workgroups (render.hip
     render_coop_quadrant: three waves cull the rounds of 64 candidates in turn, the fourth composites their survivor lists in
     round order).  Frame after frame on one state -- so the choice is the real one -- colour, inverse depth and the uint8
-    frame equal those of a compositor with one wave per quadrant (render_split = 3) bit for bit; from above the table the
-    robot's base makes some quadrants cooperative, and a batch of four frames (more than two per launch) none."""
+    frame equal those of a compositor with one wave per quadrant (render_split = 3) bit for bit, one frame per launch and
+    four; from above the table the robot's base makes some quadrants cooperative."""
     from gsworld_amd.renderer import FrameRenderer, MultiCameraRenderer
 
     dev = cuda_device
@@ -234,8 +234,9 @@ def test_cooperative_quadrants_leave_the_frame_bit_identical(cuda_device, view):
     for _ in range(3):
         outs = mc.render([cam] * 4, means, op, **kw)
     mc.ensure_valid(lambda: None)
-    assert all(dbg.sort_state(lane.geom)["coop_quads"] == 0 for lane in mc.lanes)
-    assert all(torch.equal(o[0], ref[0]) for o in outs)
+    used4 = [dbg.sort_state(lane.geom)["coop_quads"] for lane in mc.lanes]
+    assert all(0 <= u <= 64 for u in used4) and (view != "dense" or all(u > 0 for u in used4)), used4
+    assert all(torch.equal(o[0], ref[0]) and torch.equal(o[2], ref[1]) for o in outs)
 
 
 def test_static_camera_keeps_its_splitters_whatever_the_scene_does(cuda_device):
