@@ -542,8 +542,11 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
                                                      const float4 *__restrict__ splat, int W, int H, int gx,
                                                      const float *__restrict__ bg, float *__restrict__ out_color,
                                                      float *__restrict__ out_invdepth, uint8_t *__restrict__ rgb8,
-                                                     uint32_t *__restrict__ quad_work) {
+                                                     uint32_t *__restrict__ quad_work, float *__restrict__ final_T) {
     static_assert(SUPER, "cooperative quadrants are an inference-frame path");
+#if GSR_STREAM_STAMPS
+    const uint64_t stamp0 = __builtin_readcyclecounter();
+#endif
     const int lane = gsr_lane(), wave = gsr_wave();
     const int tile = (int)(q >> 2), quad = (int)(q & 3u);
     const int qx0 = (tile % gx) * GSR_TILE + ((quad & 1) << 3);
@@ -685,6 +688,14 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
     }
     if (lane == 0) *stop = 1u;
     if (quad_work != nullptr && lane == 0) quad_work[q] = work;
+#if GSR_STREAM_STAMPS
+    if (lane == 0) {  // (tuning build: the replaying wave's life, as the quadrant's own wave reports it in the main grid)
+        const uint64_t stamp1 = __builtin_readcyclecounter();
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0x0fffffffu;
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        reinterpret_cast<uint4 *>(final_T)[q] = make_uint4((uint32_t)stamp0, (uint32_t)stamp1, hw | (xcc << 28), work);
+    }
+#endif
     if (inside) {
         const size_t pid = (size_t)py * W + px;
         const size_t plane = (size_t)H * W;
@@ -747,7 +758,7 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
             const uint32_t q = coop_list[blockIdx.x];
             if (q >= 4u * (uint32_t)num_tiles) return;  // (no quadrant for this workgroup: 0xFFFFFFFF)
             render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg, out_color, out_invdepth,
-                                       rgb8, quad_work);
+                                       rgb8, quad_work, final_T);
             return;
         }
     }
