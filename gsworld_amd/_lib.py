@@ -17,6 +17,7 @@ GSR_E_INVALID = -1
 GSR_E_HIP = -2
 GSR_E_ALLOC = -3
 GSR_E_OVERFLOW = -4
+GSR_E_TRUNCATED = -5
 GSR_NEAR_PLANE = 0.05  # /root/reference/README.md:33
 MAX_FRAMES_PER_LAUNCH = 8  # include/gsr.h GSR_MAX_FRAMES_PER_LAUNCH
 
@@ -100,7 +101,7 @@ class GsrBuffers(C.Structure):
 
 class GsrFrameStats(C.Structure):
     _fields_ = [("num_visible", C.c_int64), ("num_rendered", C.c_int64), ("overflow", C.c_int32),
-                ("overflow_frames", C.c_int32)]
+                ("overflow_frames", C.c_int32), ("truncated", C.c_int32), ("coop_timeouts", C.c_int32)]
 
 
 class GsrStateView(C.Structure):
@@ -171,6 +172,12 @@ def lib() -> C.CDLL:
     L.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.gsr_pack_rgb8.restype = C.c_int
     L.gsr_pack_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.gsr_plan_query.restype = C.c_int
+    L.gsr_plan_query.argtypes = [C.POINTER(GsrSettings), C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
+    L.gsr_pinned_device_address.restype = C.c_int
+    L.gsr_pinned_device_address.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.gsr_stage_step.restype = C.c_int
+    L.gsr_stage_step.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.gsr_profile_enable.restype = C.c_int
     L.gsr_profile_enable.argtypes = [C.c_int]
     L.gsr_profile_collect.restype = C.c_int
@@ -182,6 +189,22 @@ def lib() -> C.CDLL:
 def check(code: int) -> None:
     if code != GSR_OK:
         raise GsrError(code, lib().gsr_last_error().decode("utf-8", "replace"))
+
+
+def plan_query(width: int, height: int, P: int, permuted: bool = False, forward_only: bool = True,
+               r_capacity: int = 1, tuned: bool = True) -> dict | None:
+    """How ``gsr_forward`` would run a frame of this size on a model of ``P`` Gaussians under the current ``TUNING``
+    selectors (``tuned``) -- the library's own ``make_plan`` (csrc/api.hip), asked on the host; ``None``: it would refuse the frame
+    (a permuted model on a path that does not take one)."""
+    st = GsrSettings(int(height), int(width), 1.0, 1.0, 1.0, 3, 16, 0, 0, 0, float(GSR_NEAR_PLANE))
+    st.forward_only = int(bool(forward_only))
+    if tuned:  # (False: the library's defaults, whatever A/B selectors this process runs under)
+        apply_tuning(st)
+    out = (C.c_int32 * 8)()
+    if lib().gsr_plan_query(C.byref(st), int(P), int(bool(permuted)), int(r_capacity), out) != GSR_OK:
+        return None
+    keys = ("mode", "placement", "infer", "super", "lean", "radix_depth", "order_early", "exact")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def exported_symbols() -> list[str]:

@@ -30,7 +30,8 @@ from .renderer import MultiCameraRenderer
 class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
-                 layout: bool = True, min_capacity: int | None = None, share_model_of=None, batched: bool = True):
+                 layout: bool = True, min_capacity: int | None = None, share_model_of=None, batched: bool = True,
+                 keep_float: bool = False):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -56,6 +57,9 @@ class ClosedLoopRenderer:
         ``share_model_of``: another loop over the SAME model on the same device whose (laid-out) model tensors this one
         reads instead of making its own copy (:class:`PipelinedClosedLoop`); everything per step -- poses, cameras,
         renderer states, frames, graph -- stays its own.
+        ``keep_float``: the loop returns GSWorld's uint8 frames and, by default, writes nothing else -- the float colour /
+        inverse-depth images of its lanes (16 bytes per pixel nobody reads) are left out (``GsrOutputs``: NULL images for an
+        inference frame with ``out_rgb8``).  True keeps them in ``multi.lanes[k]._out`` (tests that compare float colour).
         ``batched`` (default): the E x C frames of a step go through ``gsr_forward_batch`` -- one set of launches on the
         step's stream whose grids span the frames -- instead of one pipeline per frame on its own stream
         (:class:`gsworld_amd.renderer.MultiCameraRenderer`); same frames bit for bit (tests/test_batch_gpu.py)."""
@@ -92,7 +96,7 @@ class ClosedLoopRenderer:
             # path (gsr_forward rejects it elsewhere: api.hip make_plan): tile grids up to 16384 tiles and 256 tiles
             # wide, no A/B selector that leaves that path.  Where a camera cannot have that, the loop keeps the model in
             # the caller's order and hands over the block bounds alone (valid for any order, any path; rarely tight).
-            reorder = all(self._takes_permuted_model(c) for c in self.cameras)
+            reorder = all(self._takes_permuted_model(c, int(self.xyz.shape[0])) for c in self.cameras)
             L = SceneLayout.build(self.xyz, self.scaling, self.rotation,
                                   labels=semantics.detach().to(dev, torch.float32).reshape(-1),
                                   param_space=RAW_SCALES | RAW_ROTATIONS, reorder=reorder, features_dc=self.features_dc,
@@ -133,7 +137,13 @@ class ClosedLoopRenderer:
                            for c in self.cameras)
             free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" and torch.cuda.is_available() else 0
             bound_capacity = lanes * per_lane <= min(free // 4, 64 << 30)
-        self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, growth=growth,
+        # (... and keeps the uint8 frames only: where the frames take the compositor that can leave the float images out --
+        #  inference frames on the default path, the library's own answer -- they are not written either)
+        from ._lib import plan_query
+
+        plans = [plan_query(c.image_width, c.image_height, int(self.xyz.shape[0]), forward_only=True) for c in self.cameras]
+        no_float = not keep_float and all(p is not None and p["super"] for p in plans)
+        self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, want_float=not no_float, growth=growth,
                                          min_capacity=(2 * int(self.xyz.shape[0]) if min_capacity is None else int(min_capacity)),
                                          bound_capacity=bool(bound_capacity), overflow_mirror=True, batched=batched)
         self.recovered_steps = 0      # steps re-rendered because a lane had overflowed (see step())
@@ -178,18 +188,41 @@ class ClosedLoopRenderer:
         self._stage.copy_(self._host)
         # device-resident pose buffers: what a GPU simulator hands over (ManiSkill link poses are device tensors)
         self.matrices, self.scales = dv["matrices"], dv["scales"]
-        self._graph = None
+        # The 17-float pose table(s) the frames read (fuse_transform) live in one persistent buffer and are packed WHERE THE
+        # POSES ARRIVE, not inside the step: host poses by the kernel that brings the step's host values to the device
+        # (gsr_stage_step reads the pinned slot directly: one launch instead of an H2D copy + the pack kernel), device
+        # poses by gsr_pack_part_transforms right behind their device-to-device copy (set_poses).
+        self._table = None
+        self._ring_dev = None  # device-visible addresses of the pinned slots (gsr_pinned_device_address), resolved once
+        if self.fuse_transform and pin:
+            import ctypes as C
+
+            from ._lib import lib
+
+            self._table = self.op.pack_on_device(self.matrices, self.scales)
+            addr = []
+            for slot in self._ring:
+                d = C.c_void_p()
+                if lib().gsr_pinned_device_address(C.c_void_p(slot.data_ptr()), C.byref(d)) != 0:
+                    addr = None  # (not device-visible: the steps' host values go up by copies, the table by its own kernel)
+                    break
+                addr.append(d.value)
+            self._ring_dev = addr
+        self._graph = None    # the captured step (host values staged OUTSIDE it: a copy / a launch between two replays) ...
+        self._graphs = None   # ... or one captured step per ring slot, each staging its slot itself (see capture())
         self.image_size = (H, W)
 
     @staticmethod
-    def _takes_permuted_model(cam) -> bool:
-        """Will a frame of this camera be an inference frame on the default sort / placement path (the only frames that
-        take ``GsrInputs.orig_index``)?  Mirrors csrc/api.hip make_plan."""
-        from ._lib import TUNING
+    def _takes_permuted_model(cam, P: int) -> bool:
+        """Will a frame of this camera over a model of ``P`` Gaussians be an inference frame on the default sort /
+        placement path (the only frames that take ``GsrInputs.orig_index``)?  The library's own decision
+        (``gsr_plan_query`` = csrc/api.hip make_plan, asked on the host): tile grids up to 16384 tiles and 256 tiles wide,
+        no A/B selector that leaves the path, and a model the sample sort takes (up to 8 388 608 Gaussians -- beyond that
+        the frames fall back to the LSD radix depth sort, which knows nothing of a permutation)."""
+        from ._lib import plan_query
 
-        gx, gy = (cam.image_width + 15) // 16, (cam.image_height + 15) // 16
-        return (gx * gy <= 16384 and gx <= 256 and int(TUNING["binning_path"]) in (0, 4) and int(TUNING["depth_sort"]) == 0
-                and int(TUNING["forward_only"]) != 0)
+        plan = plan_query(cam.image_width, cam.image_height, P, permuted=True, forward_only=True)
+        return plan is not None and bool(plan["infer"])
 
     # ---- one step ------------------------------------------------------------------------------------------------
     def _gpu_step(self):
@@ -198,7 +231,9 @@ class ClosedLoopRenderer:
         if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             self._flush()
         if self.fuse_transform:
-            parts = self.op.parts(self.matrices, self.scales)  # device-side pose table(s), nothing else
+            # (the pose table was packed when the poses arrived: _flush / set_poses)
+            parts = self.op.parts_of_table(self._table) if self._table is not None else \
+                self.op.parts(self.matrices, self.scales)
             views, outs, per_lane = [], [], []
             for e in range(E):
                 for c in range(C):
@@ -260,13 +295,35 @@ class ClosedLoopRenderer:
                 self._ring_ev[k].synchronize()  # (eight copies ago: long done)
             slot = self._ring[k]
             slot[lo:hi].copy_(self._host[lo:hi])
-            self._stage[lo:hi].copy_(slot[lo:hi], non_blocking=True)
+            if not self._stage_poses(k, lo, hi):
+                self._stage[lo:hi].copy_(slot[lo:hi], non_blocking=True)
             if self.device.type == "cuda" and torch.cuda.is_available():
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self._ring_ev[k] = ev
         self._stale -= self._dirty
         self._dirty.clear()
+
+    def _stage_poses(self, k: int, lo: int, hi: int) -> bool:
+        """A run of the staging vector that holds this step's poses goes up through ``gsr_stage_step``: the kernel reads
+        pinned slot ``k`` itself, writes the device twin and packs the pose table(s) in the same launch.  -> False: not
+        such a run (cameras only), or no pose table to pack -- the caller copies."""
+        if self._table is None or self._ring_dev is None or lo != 0 or "poses" not in self._dirty:
+            return False
+        self._launch_stage(k, hi)
+        return True
+
+    def _launch_stage(self, k: int, n: int):
+        """``gsr_stage_step`` of the first ``n`` floats of ring slot ``k`` on the current stream (capturable)."""
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        nm, ns = self.num_envs * self.K * 16, self.num_envs * self.K
+        with torch.cuda.device(self.device):
+            check(lib().gsr_stage_step(n, C.c_void_p(self._ring_dev[k]), C.c_void_p(self._stage.data_ptr()), ns, 0, nm,
+                                       C.c_void_p(self._table.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def set_poses(self, matrices: torch.Tensor, scales: torch.Tensor | None = None):
         """This step's part poses ((K,4,4) or (E,K,4,4), host or device; + uniform scales) for the persistent device
@@ -279,11 +336,15 @@ class ClosedLoopRenderer:
             self.matrices.copy_(matrices.to(torch.float32), non_blocking=True)
             if scales is not None:
                 self.scales.copy_(scales.to(torch.float32).reshape(self.scales.shape), non_blocking=True)
+            if self._table is not None:
+                self.op.pack_on_device(self.matrices, self.scales)  # (into self._table: the buffer is persistent)
             self._stale.add("poses")
             return
         if "poses" in self._stale and scales is None:
-            raise RuntimeError("set_poses: the poses were last written from device tensors; hand matrices AND scales over "
-                               "on the host so that the host mirror is whole again (or keep handing device tensors over)")
+            # the poses were last written from device tensors: the mirror's scales are read back once (a host
+            # synchronisation on the change from device to host poses only -- a GPU simulator that falls back to host
+            # poses in mid-rollout keeps going)
+            self._hv["scales"].copy_(self.scales.detach().to("cpu"))
         self._hv["matrices"].copy_(matrices.to(torch.float32))
         if scales is not None:
             self._hv["scales"].copy_(scales.to(torch.float32).reshape(self.scales.shape))
@@ -334,8 +395,23 @@ class ClosedLoopRenderer:
             self.set_poses(matrices, scales)
         if cameras:
             self.set_cameras(cameras)
-        if self._graph is not None:
-            self._flush()  # this step's host values: one copy on the step's stream, ahead of the replay
+        if self._graphs is not None and self._stale:
+            self.capture()  # (device tensors arrived since the capture: their values must not be staged over)
+        if self._graphs is not None:
+            # this step's host values travel INSIDE its graph: the whole mirror into the next pinned slot (a host copy of a
+            # kilobyte), then the replay of the graph that was captured reading that slot
+            k = self._ring_k % len(self._ring)
+            self._ring_k += 1
+            if self._ring_ev[k] is not None:
+                self._ring_ev[k].synchronize()  # (eight steps ago: long done)
+            self._ring[k].copy_(self._host)
+            self._dirty.clear()
+            self._graphs[k].replay()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._ring_ev[k] = ev
+        elif self._graph is not None:
+            self._flush()  # this step's host values: one copy / launch on the step's stream, ahead of the replay
             self._graph.replay()
         else:
             self._gpu_step()
@@ -357,7 +433,7 @@ class ClosedLoopRenderer:
                 pending += seen - lane.overflows_handled
         if pending <= 0:
             return
-        recapture = self._graph is not None
+        recapture = self._graph is not None or self._graphs is not None
         torch.cuda.synchronize(self.device)
         for lane in self.multi.lanes:
             if lane._mirror is not None and not lane.bounded:
@@ -366,7 +442,8 @@ class ClosedLoopRenderer:
         seen_now = sum(1 for lane in self.multi.lanes if lane.stats().overflow)
         if late:
             self.late_overflow_frames += max(pending - seen_now, 0)
-        self._graph = None
+        self._graph = self._graphs = None
+        self._flush_all()
         for lane in self.multi.lanes:
             st = lane.stats()
             if st.overflow:
@@ -402,7 +479,8 @@ class ClosedLoopRenderer:
         """Overflow check of the last step (synchronises); re-renders exactly if a lane's capacity was exceeded.  A
         captured graph is dropped in that case (its capacities are baked in): call :meth:`capture` again."""
         def again():
-            self._graph = None
+            self._graph = self._graphs = None
+            self._flush_all()
             self._gpu_step()
         return self.multi.ensure_valid(again)
 
@@ -413,23 +491,57 @@ class ClosedLoopRenderer:
         (synchronises)."""
         return sum(lane.stats().overflow_frames for lane in self.multi.lanes)
 
+    @property
+    def captured(self) -> bool:
+        """A step is replayed from a hipGraph (one graph, or one per ring slot with the host values staged inside)."""
+        return self._graph is not None or self._graphs is not None
+
+    def _flush_all(self):
+        """(after staged graphs: the eager path stages what is dirty only -- everything the host holds is, once)"""
+        self._dirty.update(n for n in ["poses"] + self.names if n not in self._stale)
+
     def capture(self):
-        """Captures the GPU side of a step into one hipGraph (call after :meth:`reset`)."""
+        """Captures the GPU side of a step into a hipGraph (call after :meth:`reset`).
+
+        When every per-step value comes from the host (poses and cameras handed over as host tensors: a CPU simulator, the
+        rollouts of the tests and of ``bench.py``), the step's host values are staged INSIDE the graph: one graph per pinned
+        ring slot, each starting with the ``gsr_stage_step`` launch that reads its slot -- :meth:`step` then writes the
+        host mirror into the next slot and replays that slot's graph: nothing is enqueued between two replays (round 5: an
+        H2D copy and the pack kernel; an eager launch between two graph replays costs ~14 us of idle device per step by the
+        kernel trace).  Values handed over as device tensors are never staged over: such a loop captures ONE graph of the
+        frames, and whatever the host still provides goes up in front of each replay."""
         dev = self.device
-        self._graph = None
+        self._graph = self._graphs = None
         self._gpu_step()
         self.multi.ensure_valid(self._gpu_step)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        staged = self._table is not None and self._ring_dev is not None and not self._stale and self.fuse_transform
+        n_all = int(self._stage.numel())
+
+        def one(k):
+            if k is not None:
+                self._launch_stage(k, n_all)
             self._gpu_step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            self._gpu_step()
-        self._graph = g
+
+        graphs = []
+        for k in (range(len(self._ring)) if staged else [None]):
+            if k is not None:
+                self._ring[k].copy_(self._host)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                one(k)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                one(k)
+            graphs.append(g)
+        if staged:
+            self._graphs = graphs
+            self._dirty.clear()
+        else:
+            self._graph = graphs[0]
         self._overflows_acknowledged()
-        return g
+        return graphs[0]
 
 
 class PipelinedClosedLoop:

@@ -54,7 +54,13 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream) {
 extern "C" {
 
 const char *gsr_last_error(void) { return g_err; }
-const char *gsr_version(void) { return "gsworld_amd-gsr 0.3 (gfx950)"; }
+// (0.4: GsrFrameStats grew by `truncated` / `coop_timeouts`, gsr_debug_sort_state writes out[8], gsr_plan_query /
+//  gsr_stage_step are new -- callers compiled against 0.3's header must be rebuilt)
+const char *gsr_version(void) {
+    static char v[96] = "";
+    if (v[0] == 0) snprintf(v, sizeof(v), "gsworld_amd-gsr 0.4 (gfx950; %s)", gsr_render_build_flags());
+    return v;
+}
 void gsr_abi_sizes(int32_t out[6]) {
     out[0] = (int32_t)sizeof(GsrSettings);
     out[1] = (int32_t)sizeof(GsrInputs);
@@ -87,8 +93,12 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
         gsr_set_error("gsr_forward: negative P");
         return GSR_E_INVALID;
     }
-    if (!out->out_color || !out->out_invdepth || !in->background) {
-        gsr_set_error("gsr_forward: out_color, out_invdepth and background are required");
+    // (out_color / out_invdepth may be NULL together for an inference frame that hands over out_rgb8: make_plan checks the
+    //  frame really takes the compositor that honours that)
+    const bool no_float = !out->out_color && !out->out_invdepth && st->forward_only && out->out_rgb8;
+    if (((!out->out_color || !out->out_invdepth) && !no_float) || !in->background) {
+        gsr_set_error("gsr_forward: out_color, out_invdepth and background are required (the two images may be NULL "
+                      "together for a forward_only frame with out_rgb8)");
         return GSR_E_INVALID;
     }
     if (in->P > 0) {
@@ -161,7 +171,7 @@ struct Plan {
     GsrSettings st_bin;  // the settings with the super-tile grid as image (inference frames on the default path)
 };
 
-int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Plan &p) {
+int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Plan &p, const GsrOutputs *out = nullptr) {
     p.W = st->image_width;
     p.H = st->image_height;
     p.tiles_x = gsr_div_up(p.W, GSR_TILE);
@@ -203,6 +213,11 @@ int make_plan(const GsrSettings *st, const GsrInputs *in, int64_t r_capacity, Pl
     if (in->orig_index != nullptr && !(p.infer && p.mode == 1)) {
         gsr_set_error("gsr_forward: orig_index (a permuted model) needs a forward_only frame on the default sort / "
                       "placement path");
+        return GSR_E_INVALID;
+    }
+    if (out && !out->out_color && !p.super) {
+        gsr_set_error("gsr_forward: out_color / out_invdepth may only be NULL for an inference frame on the default path "
+                      "(super-tile lists, stream compositor)");
         return GSR_E_INVALID;
     }
     // the compositor's quadrant order depends on the previous frame only: a second workgroup of the depth sort's prepare
@@ -278,8 +293,11 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
         if (int e = gsr_launch_chunk_count(p.st_bin, in[0].P, g, debug, stream)) return e;
         if (int e = gsr_launch_tile_starts(1, fr, p.order_early, debug, stream)) return e;
     } else if (band) {
-        if (int e = gsr_launch_band_count(B, fr, !p.radix_depth, debug, stream)) return e;
-        if (int e = gsr_launch_tile_starts(B, fr, p.order_early, debug, stream)) return e;
+        // (the ranges come out of the counting launches themselves when nothing else is asked of tile_starts_kernel)
+        bool starts_done = false;
+        if (int e = gsr_launch_band_count(B, fr, !p.radix_depth, p.order_early, &starts_done, debug, stream)) return e;
+        if (!starts_done)
+            if (int e = gsr_launch_tile_starts(B, fr, p.order_early, debug, stream)) return e;
     } else if (mode == 1) {
         if (int e = gsr_launch_tile_count(st[0], in[0].P, g, img, fr[0].cap32, debug, stream)) return e;
     } else {
@@ -334,8 +352,8 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
 int zero_outputs(const GsrSettings *st, const GsrOutputs *out, hipStream_t stream) {
     // upstream launches nothing for P == 0: the outputs keep their zero fill (NOT the background)
     const size_t n = (size_t)st->image_width * st->image_height;
-    if (hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess ||
-        hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess ||
+    if ((out->out_color && hipMemsetAsync(out->out_color, 0, 3 * n * sizeof(float), stream) != hipSuccess) ||
+        (out->out_invdepth && hipMemsetAsync(out->out_invdepth, 0, n * sizeof(float), stream) != hipSuccess) ||
         (out->out_rgb8 && hipMemsetAsync(out->out_rgb8, 0, 3 * n, stream) != hipSuccess)) {
         gsr_set_error("gsr_forward: hipMemsetAsync(outputs) failed");
         return GSR_E_HIP;
@@ -354,7 +372,7 @@ int gsr_forward(const GsrSettings *st, const GsrInputs *in, const GsrOutputs *ou
     if (stats) memset(stats, 0, sizeof(*stats));
     if (in->P == 0) return zero_outputs(st, out, stream);
     Plan p;
-    if (int e = make_plan(st, in, r_capacity, p)) return e;
+    if (int e = make_plan(st, in, r_capacity, p, out)) return e;
     return run_frames(1, st, in, out, buf, &r_capacity, &p, stats, stream);
 }
 
@@ -387,20 +405,45 @@ int gsr_forward_batch(int32_t B, const GsrSettings *st, const GsrInputs *in, con
             k++;
             continue;
         }
-        if (int e = make_plan(&st[k], &in[k], r_capacity[k], plans[0])) return e;
+        if (int e = make_plan(&st[k], &in[k], r_capacity[k], plans[0], &out[k])) return e;
         int n = 1;
         // (what can share launches: the default path -- sample sort, band placement, stream compositor -- with a
         //  capacity; an exact-mode frame reads its instance count back in the middle of the frame)
         const bool batchable = plans[0].mode == 1 && plans[0].band && !plans[0].radix_depth && !plans[0].exact &&
                                st[k].render_variant == 0;
         while (batchable && n < GSR_MAX_BATCH && k + n < B && in[k + n].P != 0 && r_capacity[k + n] > 0) {
-            if (int e = make_plan(&st[k + n], &in[k + n], r_capacity[k + n], plans[n])) return e;
+            if (int e = make_plan(&st[k + n], &in[k + n], r_capacity[k + n], plans[n], &out[k + n])) return e;
             if (!shares(k, k + n, plans[0], plans[n])) break;
             n++;
         }
         if (int e = run_frames(n, st + k, in + k, out + k, buf + k, r_capacity + k, plans, nullptr, stream)) return e;
         k += n;
     }
+    return GSR_OK;
+}
+
+// How gsr_forward would run a frame: make_plan's answer without touching the device (tests; the Python side asks it
+// whether a frame takes a permuted model instead of mirroring the rules).
+int gsr_plan_query(const GsrSettings *st, int32_t P, int32_t permuted, int64_t r_capacity, int32_t out[8]) {
+    if (!st || !out || P < 0 || st->image_width <= 0 || st->image_height <= 0) {
+        gsr_set_error("gsr_plan_query: null argument, negative P or empty image");
+        return GSR_E_INVALID;
+    }
+    GsrInputs in;
+    memset(&in, 0, sizeof(in));
+    in.P = P;
+    static const int32_t one = 0;
+    in.orig_index = permuted ? &one : nullptr;  // (only ever compared with NULL)
+    Plan p;
+    if (int e = make_plan(st, &in, r_capacity, p)) return e;
+    out[0] = p.mode;
+    out[1] = p.band ? 1 : (p.chunk ? 2 : 0);
+    out[2] = p.infer ? 1 : 0;
+    out[3] = p.super ? 1 : 0;
+    out[4] = p.lean ? 1 : 0;
+    out[5] = p.radix_depth ? 1 : 0;
+    out[6] = p.order_early ? 1 : 0;
+    out[7] = p.exact ? 1 : 0;
     return GSR_OK;
 }
 
@@ -507,7 +550,9 @@ int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream_) {
     stats->num_rendered = h.R_raw;
     stats->overflow = (int32_t)h.overflow;
     stats->overflow_frames = h.of_magic == GSR_OF_MAGIC ? (int32_t)h.overflow_frames : 0;
-    return h.overflow ? GSR_E_OVERFLOW : GSR_OK;
+    stats->truncated = h.coop_timeout_now != 0u ? 1 : 0;
+    stats->coop_timeouts = h.of_magic == GSR_OF_MAGIC ? (int32_t)h.coop_timeouts : 0;
+    return h.overflow ? GSR_E_OVERFLOW : (stats->truncated ? GSR_E_TRUNCATED : GSR_OK);
 }
 
 int gsr_state_view(int32_t P, int32_t width, int32_t height, int64_t r_capacity, const void *geom, const void *binning,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, const float4 *__restrict__ splat,
     int W, int H, int gx, const float *__restrict__ bg, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
-    const float *__restrict__ dL_dinvdepth_pix, float *__restrict__ grad_rec /*(P,12): the kGrad sums + 2 unused*/) {
+    const float *__restrict__ dL_dinvdepth_pix, GsrGradWord *__restrict__ grad_rec /*(P,12): the kGrad sums + 2 unused*/) {
     __shared__ float4 s_rec0[GSR_BLOCK];
     __shared__ float4 s_rec1[GSR_BLOCK];
     __shared__ float4 s_rec2[GSR_BLOCK];
@@ -238,7 +238,8 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             const int j = e / kGradRec, c = e - j * kGradRec;
             if (j < cnt && c < kGrad) {
                 const float v = s_grad[e];
-                if (v != 0.f) atomicAdd(&grad_rec[(size_t)kGradRec * s_id[j] + c], v);
+                // (binary64 from here on: what a Gaussian collects from its tiles no longer depends on their order)
+                if (v != 0.f) atomicAdd(&grad_rec[(size_t)kGradRec * s_id[j] + c], (GsrGradWord)v);
             }
         }
     }
@@ -261,7 +262,7 @@ struct BwdArgs {
     const int32_t *radii;
     const float *cov3D;        // precomputed input or the forward's stored copy
     const uint32_t *clamped;
-    const float *grad_rec;     // (P,12) the compositor's sums (render_backward_kernel)
+    const GsrGradWord *grad_rec;  // (P,12) the compositor's sums (render_backward_kernel)
     float *dL_dmean2D, *dL_dcolors;  // written from the record (API outputs)
     float *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
     float *dL_dsh_rest;        // with shs_rest: dL_dsh is the dc part
@@ -273,8 +274,20 @@ struct BwdArgs {
 __global__ __launch_bounds__(GSR_BLOCK) void geometry_backward_kernel(const BwdArgs a) {
     const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
     if (i >= a.P || a.radii[i] <= 0) return;
-    const float4 *rec = reinterpret_cast<const float4 *>(a.grad_rec) + 3 * (size_t)i;
-    const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2];  // (mx, my, cxx, cxy) (cyy, opacity, r, g) (b, 1/depth, -, -)
+    // (mx, my, cxx, cxy) (cyy, opacity, r, g) (b, 1/depth, -, -): the sums, rounded to binary32 once
+    float4 g0, g1, g2;
+    {
+#if GSR_GRAD_F64
+        const double2 *rec = reinterpret_cast<const double2 *>(a.grad_rec + 12 * (size_t)i);
+        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+        g0 = make_float4((float)r0.x, (float)r0.y, (float)r1.x, (float)r1.y);
+        g1 = make_float4((float)r2.x, (float)r2.y, (float)r3.x, (float)r3.y);
+        g2 = make_float4((float)r4.x, (float)r4.y, 0.f, 0.f);
+#else
+        const float4 *rec = reinterpret_cast<const float4 *>(a.grad_rec) + 3 * (size_t)i;
+        g0 = rec[0]; g1 = rec[1]; g2 = rec[2];
+#endif
+    }
     const float *m = a.view;
     const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
     const float *c6 = a.cov3D + 6 * (size_t)i;
@@ -575,11 +588,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void sh_backward_kernel(const BwdArgs a)
         const float len = sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
         const float x = ox / len, y = oy / len, z = oz / len;
         const uint32_t cl = a.clamped[i];
-        const float *rec = a.grad_rec + 12 * (size_t)i;
+        const GsrGradWord *rec = a.grad_rec + 12 * (size_t)i;
         float dRGB[3];
-        dRGB[0] = (cl & 0xffu) ? 0.f : rec[6];
-        dRGB[1] = (cl & 0xff00u) ? 0.f : rec[7];
-        dRGB[2] = (cl & 0xff0000u) ? 0.f : rec[8];
+        dRGB[0] = (cl & 0xffu) ? 0.f : (float)rec[6];
+        dRGB[1] = (cl & 0xff00u) ? 0.f : (float)rec[7];
+        dRGB[2] = (cl & 0xff0000u) ? 0.f : (float)rec[8];
         ShBasis b;
         sh_basis(a.D, x, y, z, b);
         const int nb = (a.D + 1) * (a.D + 1);
@@ -773,7 +786,7 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
     const BinningState b = BinningState::carve((char *)bw->binning, bw->num_rendered);
     const ImageState img = ImageState::carve((char *)bw->image, W, H);
     const int gx = gsr_div_up(W, GSR_TILE), gy = gsr_div_up(H, GSR_TILE);
-    if (hipMemsetAsync(g.grad_rec, 0, (size_t)P * kGradRec * sizeof(float), stream) != hipSuccess) {
+    if (hipMemsetAsync(g.grad_rec, 0, (size_t)P * kGradRec * sizeof(GsrGradWord), stream) != hipSuccess) {
         gsr_set_error("gsr_backward: hipMemsetAsync failed");
         return GSR_E_HIP;
     }

@@ -44,45 +44,138 @@ constexpr int kMaxSegments = 4;
 // instances, and the nearest splats (first in depth order) are the largest on screen: at config 5 the 5000 near-band
 // splats cover the whole image and all sat in the first three waves of every row (290 us).  With the running sums the
 // depth sort leaves (tiles per bucket, running sum inside each bucket) the order is cut at equal cumulative INSTANCE
-// counts: wave j starts at the first rank whose inclusive running sum exceeds j R / waves.  One workgroup.
-// While the camera rests (the depth sort took its splitters unchecked: hdr->ss_blind) the cuts of the last exact
-// computation are kept, rescaled to this frame's V, for up to kCutsMaxAge frames: the searches below are a chain of
-// dependent global round trips on the frame's critical path, and any monotone cut gives the same point list.
+// counts: wave j starts at the first rank whose inclusive running sum exceeds j R / waves.
 constexpr uint32_t kCutsMagic = 0x43555453u;  // 'CUTS'
-constexpr uint32_t kCutsMaxAge = 15u;
 
-__device__ __forceinline__ void band_ranges_body(GsrHeader *__restrict__ hdr, int bmax,
-                                                          const uint32_t *__restrict__ bucket_start,
-                                                          const uint32_t *__restrict__ bucket_tiles,
-                                                          const uint32_t *__restrict__ tile_cum, int waves,
-                                                          uint32_t *__restrict__ wave_lo,
-                                                          uint32_t *__restrict__ wave_lo_base, uint32_t sig) {
+// Since round 6 the cuts have no launch of their own and, from the second frame on a state, no place on the frame's
+// critical path: any ascending cuts give the same point list, only the balance of the placement waves depends on them, and
+// consecutive frames of a state -- a sensor camera, a wrist camera riding on the arm -- have nearly the same depth order.
+// So every counting workgroup (rank range r, tile row y) takes the five cuts of its four waves from the table the
+// PREVIOUS frame left (wave_lo_base: exact equal-cost cuts of that frame's order), rescaled to this frame's V -- one load
+// per thread for the check, one rescale per cut -- and the workgroups of tile row 0 leave them in wave_lo for the
+// placement; the exact cuts of THIS frame's order are computed beside the scan that follows the counting pass
+// (band_cuts_next: a workgroup of its own, nobody waits for it) for the next frame.  A state without a valid table (first
+// frame, another model) computes its cuts on the spot, in every counting workgroup, from the 256 .. 2048 bucket totals
+// (block scan in LDS, the bucket of a cut found by its owner).  Round 5: band_ranges_kernel, one workgroup per frame
+// between the depth sort and the counting pass, 5.2 us of launch floor per closed-loop step -- kept tables were only
+// trusted while camera and scene stood still.  First version of the fold (every workgroup computing every frame):
+// +4.5 us on the counting kernel, whose 3 840 workgroups are two rounds of the chip and paid the prologue twice.
+// -> route: 0 = equal rank shares (no running sums), 1 = the previous frame's cuts rescaled, 2 = cuts computed on the
+// spot.  Nothing the routes are decided by is written while the counting kernel runs -- not the header, not wave_lo_base.
+__device__ __forceinline__ uint32_t band_cuts_block(const GsrHeader *__restrict__ hdr, int bmax,
+                                                    const uint32_t *__restrict__ bucket_start,
+                                                    const uint32_t *__restrict__ bucket_tiles,
+                                                    const uint32_t *__restrict__ tile_cum,
+                                                    const uint32_t *__restrict__ wave_lo_base, uint32_t sig, uint32_t r,
+                                                    uint32_t *s_cut /*[kBW + 1]*/, uint32_t *s_pre /*[2048 + 1]*/,
+                                                    uint32_t *s_bs /*[2048 + 1]*/, uint32_t *s_w /*[4]*/) {
+    constexpr int waves = GSR_BAND_RANGES * kBW;
+    static_assert(waves == kBT, "a thread per kept cut");
+    const int tid = (int)threadIdx.x;
+    // ONE round trip for what the usual route needs: the header words, this thread's pair of the kept cuts (the check) and
+    // the cut this thread may rescale
+    const uint32_t V = hdr->V, base_V = hdr->br_V, magic = hdr->br_magic, hP = hdr->br_P;
+    const int B = (int)hdr->ss_B;  // (the frame's bucket count: depthsort.hip ss_prepare)
+    const uint32_t wb0 = wave_lo_base[tid], wb1 = wave_lo_base[tid + 1];
+    const uint32_t wbj = tid <= kBW ? wave_lo_base[r * (uint32_t)kBW + (uint32_t)tid] : 0u;
+    if (tile_cum == nullptr || V == 0u) {  // no running sums (LSD radix variant of the depth sort): equal rank shares
+        const uint32_t per = (((V + (uint32_t)waves - 1u) / (uint32_t)waves) + 63u) & ~63u;
+        if (tid <= kBW) s_cut[tid] = min(V, (r * (uint32_t)kBW + (uint32_t)tid) * per);
+        __syncthreads();
+        return 0u;
+    }
+    bool keep = magic == kCutsMagic && hP == sig && base_V != 0u;
+    if (keep) {
+        // (the kept table is checked before it is used -- ascending from 0 to base_V -- see ss_prepare_body)
+        uint32_t bad = wb0 > wb1 ? 1u : 0u;
+        if (tid == 0) bad |= wb0 != 0u ? 1u : 0u;
+        if (tid == waves - 1) bad |= wb1 != base_V ? 1u : 0u;
+        keep = __syncthreads_or((int)bad) == 0;
+    }
+    if (keep) {
+        if (tid <= kBW) {
+            const uint32_t j = r * (uint32_t)kBW + (uint32_t)tid;
+            // (monotone in wbj, 0 -> 0 and base_V -> V: every operation of the chain is; no 64-bit division)
+            s_cut[tid] = j == (uint32_t)waves ? V : min(V, (uint32_t)((double)wbj * ((double)V / (double)base_V)));
+        }
+        __syncthreads();
+        return 1u;
+    }
+    // ---- no valid table (first frame on this state, another model): the cuts of THIS frame's order, on the spot
+    const int PER = B / kBT;  // 1, 2, 4 or 8 buckets per thread
+    uint32_t bt[8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        bt[k] = k < PER ? bucket_tiles[tid + k * kBT] : 0u;
+        bs[k] = k < PER ? bucket_start[tid + k * kBT] : 0u;
+    }
+    const uint32_t bs_B = tid == 0 ? bucket_start[B] : 0u;
+    // the rows arrive strided (entry tid + 256 k); a thread scans PER consecutive entries: through the LDS
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (k < PER) {
+            s_pre[tid + k * kBT] = bt[k];
+            s_bs[tid + k * kBT] = bs[k];
+        }
+    if (tid == 0) s_bs[B] = bs_B;
+    __syncthreads();
+    uint32_t t[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        t[k] = k < PER ? s_pre[tid * PER + k] : 0u;
+        sum += t[k];
+    }
+    uint32_t total;
+    uint32_t run = gsr_block_incl_scan(sum, s_w, total) - sum;
+    // the bucket that holds a cut's crossing finds it itself: target in [exclusive sum, + the bucket's total) -- one
+    // non-empty bucket per target below the grand total (a binary search was nine dependent LDS round trips)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < PER && t[k] != 0u) {
+            const int b = tid * PER + k;
+#pragma unroll
+            for (int c = 0; c <= kBW; c++) {
+                const uint32_t j = r * (uint32_t)kBW + (uint32_t)c;
+                const uint32_t target = (uint32_t)(((uint64_t)total * j) / (uint32_t)waves);
+                if (j != (uint32_t)waves && target >= run && target - run < t[k]) {
+                    // inside the bucket the cut is placed by proportion (its records are ~V / B consecutive depth ranks
+                    // of similar size)
+                    const uint32_t s0 = s_bs[b], n = s_bs[b + 1] - s0, rest = target - run;
+                    s_cut[c] = s0 + min(n, (uint32_t)((float)n * ((float)rest / (float)t[k])));
+                }
+            }
+        }
+        run += t[k];
+    }
+    if (tid <= kBW) {
+        const uint32_t j = r * (uint32_t)kBW + (uint32_t)tid;
+        if (j == (uint32_t)waves || total == 0u) s_cut[tid] = j == (uint32_t)waves ? V : 0u;
+    }
+    __syncthreads();
+    return 2u;
+}
+
+// The exact equal-cost cuts of THIS frame's depth order, for the NEXT frame on the state (band_cuts_block route 1): one
+// workgroup of 256 threads beside the scan that follows the counting pass -- nobody in this frame waits for it.  With the
+// running sums the depth sort leaves (tiles per bucket) the order is cut at equal cumulative placement cost: cut j is
+// where the running cost crosses j / 256 of the total; the bucket of the crossing by a search over the scanned bucket
+// totals, the place inside the bucket by proportion (round 5 measured the exact place -- a binary search over the
+// bucket's running sums, ten dependent global round trips -- against the proportion: same balance).
+__device__ __forceinline__ void band_cuts_next(GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ bucket_start,
+                                               const uint32_t *__restrict__ bucket_tiles,
+                                               const uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ wave_lo_base,
+                                               uint32_t sig) {
+    constexpr int waves = GSR_BAND_RANGES * kBW;
     __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
     __shared__ uint32_t s_w[4];
     const int tid = (int)threadIdx.x;
     const uint32_t V = hdr->V;
-    if (tile_cum == nullptr || V == 0u) {  // no running sums (LSD radix variant of the depth sort): equal rank shares
-        const uint32_t per = (((V + (uint32_t)waves - 1u) / (uint32_t)waves) + 63u) & ~63u;
-        for (int j = tid; j <= waves; j += kBT) wave_lo[j] = min(V, (uint32_t)j * per);
+    if (tile_cum == nullptr) return;  // (LSD radix variant of the depth sort: no running sums, equal rank shares)
+    if (V == 0u) {
+        if (tid == 0) hdr->br_magic = 0u;
         return;
     }
-    const uint32_t base_V = hdr->br_V, age = hdr->br_age;
-    bool keep = hdr->ss_blind != 0u && hdr->br_magic == kCutsMagic && hdr->br_P == sig && age < kCutsMaxAge &&
-                base_V != 0u;
-    if (keep) {
-        // (the kept table is checked before it is used -- ascending from 0 to base_V -- see ss_compact_kernel)
-        uint32_t bad = 0u;
-        for (int j = tid; j < waves; j += kBT) bad |= wave_lo_base[j] > wave_lo_base[j + 1] ? 1u : 0u;
-        if (tid == 0) bad |= (wave_lo_base[0] != 0u || wave_lo_base[waves] != base_V) ? 1u : 0u;
-        keep = __syncthreads_or((int)bad) == 0;
-    }
-    if (keep) {
-        for (int j = tid; j <= waves; j += kBT)
-            wave_lo[j] = j == waves ? V : (uint32_t)(((uint64_t)wave_lo_base[j] * V) / base_V);
-        if (tid == 0) hdr->br_age = age + 1u;
-        return;
-    }
-    const int B = (int)hdr->ss_B;  // (the frame's bucket count: depthsort.hip ss_prepare)
+    const int B = (int)hdr->ss_B;
     const int PER = B / kBT;
     uint32_t t[8], sum = 0;
 #pragma unroll
@@ -102,14 +195,9 @@ __device__ __forceinline__ void band_ranges_body(GsrHeader *__restrict__ hdr, in
     __syncthreads();
     for (int j = tid; j <= waves; j += kBT) {
         const uint32_t target = (uint32_t)(((uint64_t)total * (uint32_t)j) / (uint32_t)waves);
-        // bucket that holds the crossing: the last one whose exclusive sum is <= target
-        int b = 0;
+        int b = 0;  // the last bucket whose exclusive sum is <= target
         for (int step = B >> 1; step > 0; step >>= 1)
             if (s_pre[b + step] <= target) b += step;
-        // inside that bucket the cut is placed by proportion (the bucket's records are ~V / B consecutive depth ranks of
-        // similar size): any ascending cut gives the same point list, and the exact one -- a binary search over the
-        // bucket's running sums -- was ten dependent global round trips on the critical path of every frame whose
-        // camera or scene moves (band_ranges 10 -> 5 us there)
         const uint32_t s0 = bucket_start[b], n = bucket_start[b + 1] - s0, rest = target - s_pre[b];
         const uint32_t tb = s_pre[b + 1] - s_pre[b];
 #if GSR_BAND_EXACT_CUTS
@@ -119,11 +207,9 @@ __device__ __forceinline__ void band_ranges_body(GsrHeader *__restrict__ hdr, in
             if (tile_cum[s0 + mid] <= rest) lo = mid + 1u; else hi = mid;
         }
 #else
-        const uint32_t lo = tb != 0u ? (uint32_t)min((uint64_t)n, ((uint64_t)n * rest) / tb) : 0u;
+        const uint32_t lo = tb != 0u ? min(n, (uint32_t)((float)n * ((float)rest / (float)tb))) : 0u;
 #endif
-        const uint32_t cut = j == waves ? V : s0 + lo;
-        wave_lo[j] = cut;
-        wave_lo_base[j] = cut;
+        wave_lo_base[j] = j == waves ? V : s0 + lo;
     }
     if (tid == 0) {
         hdr->br_magic = kCutsMagic;
@@ -138,15 +224,31 @@ constexpr int kBatch = 12;  // 64-rank rows of the stream requested together (70
 // Counting needs no order at all: a pair adds +1 at its first column and -1 behind its last one; the running sum over
 // the columns is the number of pairs covering each.  Two LDS atomics per pair, per-wave difference arrays.
 template <int NC>
-__device__ __forceinline__ void band_count_body(const uint2 *__restrict__ rect_sorted,
-                                                         const uint32_t *__restrict__ wave_lo, int gx, int NR,
+__device__ __forceinline__ void band_count_body(const uint2 *__restrict__ rect_sorted, GsrHeader *__restrict__ hdr,
+                                                         int bmax, const uint32_t *__restrict__ bucket_start,
+                                                         const uint32_t *__restrict__ bucket_tiles,
+                                                         const uint32_t *__restrict__ tile_cum, int waves,
+                                                         uint32_t *__restrict__ wave_lo,
+                                                         uint32_t *__restrict__ wave_lo_base, uint32_t sig, int gx, int NR,
                                                          uint32_t *__restrict__ table, uint32_t *__restrict__ wtable,
                                                          uint32_t *__restrict__ nseg_tab) {
     __shared__ int s_diff[kBW][NC * 64 + 1];
     __shared__ uint32_t s_tot[kBW][NC * 64];
+    __shared__ uint32_t s_pre[2048 + 1];  // exclusive running sum of the bucket totals
+    __shared__ uint32_t s_bs[2048 + 1];   // the bucket starts
+    __shared__ uint32_t s_cut[kBW + 1], s_w[4];
     const int lane = gsr_lane(), wave = gsr_wave();
     const uint32_t r = blockIdx.x, y = blockIdx.y;
-    const uint32_t lo = wave_lo[r * kBW + (uint32_t)wave], hi = wave_lo[r * kBW + (uint32_t)wave + 1u];
+    const uint32_t route = band_cuts_block(hdr, bmax, bucket_start, bucket_tiles, tile_cum, wave_lo_base, sig, r, s_cut,
+                                           s_pre, s_bs, s_w);
+    const uint32_t lo = s_cut[wave], hi = s_cut[wave + 1];
+    if (y == 0u) {  // tile row 0 leaves the cuts for the placement (and, freshly computed ones, for the frames to come)
+        const int tid = (int)threadIdx.x;
+        if (tid < kBW || (tid == kBW && r + 1u == gridDim.x)) {
+            wave_lo[r * kBW + (uint32_t)tid] = s_cut[tid];
+        }
+        if (r == 0u && tid == 0) hdr->br_route = route;  // (tools: which route the frame took)
+    }
     int *diff = s_diff[wave];
 #pragma unroll
     for (int k = 0; k < NC; k++) diff[k * 64 + lane] = 0;
@@ -197,7 +299,7 @@ __device__ __forceinline__ void band_scan_body(uint32_t *__restrict__ table, int
                                                         uint32_t *__restrict__ totals) {
     constexpr int PL = (GSR_BAND_RANGES + GSR_WAVE - 1) / GSR_WAVE;  // consecutive entries per lane
     const int t = (int)blockIdx.x * kBW + gsr_wave();
-    if (t >= T) return;
+    if (t >= T) return;  // (inlined: the caller goes on)
     const int lane = gsr_lane();
     uint32_t *row = table + (size_t)t * GSR_BAND_RANGES;
     uint32_t v[PL], sum = 0;
@@ -428,19 +530,23 @@ struct BandArgs {
     const uint32_t *order;
     const uint2 *ranges;
     uint32_t *point_list;
+    uint32_t r_capacity;  // (the merged scan + starts kernel: what tile_starts_kernel checks R against)
+    uint2 *ranges_w;
 };
 
-__global__ __launch_bounds__(kBT) void band_ranges_kernel(const GsrBatch<BandArgs> bt) {
-    const BandArgs &a = bt.f[blockIdx.y];
-    band_ranges_body(a.hdr, a.bmax, a.bucket_start, a.bucket_tiles, a.tile_cum, a.waves, a.wave_lo, a.wave_lo_base, a.sig);
-}
 template <int NC>
 __global__ __launch_bounds__(kBT) void band_count_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.z];
-    band_count_body<NC>(a.rect_sorted, a.wave_lo, a.gx, a.NR, a.table, a.wtable, a.nseg);
+    band_count_body<NC>(a.rect_sorted, a.hdr, a.bmax, a.bucket_start, a.bucket_tiles, a.tile_cum, a.waves, a.wave_lo, a.wave_lo_base,
+                        a.sig, a.gx, a.NR, a.table, a.wtable, a.nseg);
 }
+// (grid.x = workgroups of the scan + 1: the last one computes the next frame's cuts)
 __global__ __launch_bounds__(kBT) void band_scan_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.y];
+    if (blockIdx.x == gridDim.x - 1) {
+        band_cuts_next(a.hdr, a.bucket_start, a.bucket_tiles, a.tile_cum, a.wave_lo_base, a.sig);
+        return;
+    }
     band_scan_body(a.table, a.T, a.totals);
 }
 template <int NC>
@@ -448,6 +554,121 @@ __global__ __launch_bounds__(kBT, 8) void band_place_kernel(const GsrBatch<BandA
     const BandArgs &a = bt.f[blockIdx.z / (uint32_t)kMaxSegments];
     band_place_body<NC>(blockIdx.z % (uint32_t)kMaxSegments, a.rect_sorted, a.order, a.hdr, a.wave_lo, a.gx, a.NR, a.table,
                         a.wtable, a.ranges, a.point_list, a.nseg);
+}
+
+// ---- band_scan + tile_starts in ONE launch (round 6) --------------------------------------------------------------
+// Between the counting pass and the placement the frame needs (a) the exclusive scan of every tile's NR entries and the
+// tile totals, (b) the exclusive scan of the totals = the ranges, R and the capacity check.  Until round 5 those were two
+// launches at the launch floor (150 workgroups of four waves, then one workgroup: 5.0 + 4.9 us per closed-loop step).
+// GSR_SCAN_MODE 1 (default): ONE workgroup of sixteen waves per frame does both -- a wave takes every sixteenth tile,
+// sixteen rows in flight per lane, the totals stay in LDS for the second scan.  GSR_SCAN_MODE 2 (measured against it:
+// DESIGN.md section 7): the 150 workgroups of (a) as before, and the LAST of them to finish -- a ticket from a
+// device-scope atomic behind an agent-scope release, an acquire in front of the reads -- does (b).  0: the two launches.
+#ifndef GSR_SCAN_MODE
+#define GSR_SCAN_MODE 1
+#endif
+constexpr int kSST = 1024, kSSW = kSST / GSR_WAVE;  // the merged kernel's workgroup
+constexpr int kSSMaxTiles = 8 * kSST;               // totals kept in LDS (32 KiB); larger grids keep the two launches
+static_assert(GSR_BAND_RANGES == GSR_WAVE, "a tile's row of the band table is one entry per lane");
+
+// totals[T] (LDS or global) -> ranges, R, capacity check: THREADS threads, each owns `per` consecutive tiles
+template <int THREADS, int MAXPER>
+__device__ __forceinline__ void band_starts_block(const uint32_t *totals, int T, GsrHeader *__restrict__ hdr,
+                                                  uint32_t r_capacity, uint2 *__restrict__ ranges, uint32_t *s_wv) {
+    constexpr int NWV = THREADS / GSR_WAVE;
+    const int tid = (int)threadIdx.x, lane = gsr_lane(), wave = tid >> 6;
+    const int per = (T + THREADS - 1) / THREADS, t0 = tid * per;
+    uint32_t v[MAXPER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < MAXPER; k++) {
+        v[k] = (k < per && t0 + k < T) ? totals[t0 + k] : 0u;
+        sum += v[k];
+    }
+    const uint32_t incl = gsr_wave_incl_scan(sum);
+    if (lane == 63) s_wv[wave] = incl;
+    __syncthreads();
+    uint32_t add = 0, grand = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+        const uint32_t x = s_wv[w];
+        add += w < wave ? x : 0u;
+        grand += x;
+    }
+    uint32_t run = incl - sum + add;
+    const bool overflow = grand > r_capacity;
+#pragma unroll
+    for (int k = 0; k < MAXPER; k++) {
+        const int t = t0 + k;
+        if (k < per && t < T) ranges[t] = (v[k] == 0u || overflow) ? make_uint2(0u, 0u) : make_uint2(run, run + v[k]);
+        run += v[k];
+    }
+    if (tid == 0) {
+        hdr->R_raw = grand;
+        hdr->r_capacity = r_capacity;
+        gsr_set_overflow(hdr, overflow);
+        hdr->R = overflow ? 0u : grand;
+    }
+}
+
+__device__ __forceinline__ void band_scan_starts_body(uint32_t *__restrict__ table, int T, GsrHeader *__restrict__ hdr,
+                                                      uint32_t r_capacity, uint2 *__restrict__ ranges) {
+    __shared__ uint32_t s_tot[kSSMaxTiles];
+    __shared__ uint32_t s_wv[kSSW];
+    // A wave takes every sixteenth tile, sixteen rows in flight per lane (lane = rank range: one coalesced 256-byte row per
+    // load), a six-instruction DPP scan per row.  (Measured on the way: the same with ds_bpermute scans -- 38 rows per wave,
+    // six dependent LDS-crossbar round trips each -- 15.4 us; a THREAD per tile scanning its row in registers -- every
+    // load a quarter-used 64-byte request per lane, 20 k requests through one CU's L1 -- 13.6 us.)
+    const int lane = gsr_lane(), wave = (int)(threadIdx.x >> 6);
+    constexpr int kU = 16;
+    for (int t0 = wave; t0 < T; t0 += kSSW * kU) {
+        uint32_t v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int t = t0 + u * kSSW;
+            v[u] = t < T ? table[(size_t)t * GSR_BAND_RANGES + lane] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int t = t0 + u * kSSW;
+            const uint32_t incl = gsr_wave_incl_scan(v[u]);
+            if (t < T) {
+                table[(size_t)t * GSR_BAND_RANGES + lane] = incl - v[u];
+                if (lane == 63) s_tot[t] = incl;
+            }
+        }
+    }
+    __syncthreads();
+    band_starts_block<kSST, kSSMaxTiles / kSST>(s_tot, T, hdr, r_capacity, ranges, s_wv);
+}
+
+// (grid.x = 2: workgroup 1 -- its first four waves -- computes the next frame's cuts)
+__global__ __launch_bounds__(kSST) void band_scan_starts_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.y];
+    if (blockIdx.x == 1) {
+        if (threadIdx.x >= kBT) return;  // (the waves that stay meet at their own barriers: finished waves do not count)
+        band_cuts_next(a.hdr, a.bucket_start, a.bucket_tiles, a.tile_cum, a.wave_lo_base, a.sig);
+        return;
+    }
+    band_scan_starts_body(a.table, a.T, a.hdr, a.r_capacity, a.ranges_w);
+}
+// GSR_SCAN_MODE 2: band_scan's grid (+ the workgroup of the cuts); the last scanning workgroup of a frame to finish turns
+// the totals into ranges
+__global__ __launch_bounds__(kBT) void band_scan_tail_kernel(const GsrBatch<BandArgs> bt) {
+    const BandArgs &a = bt.f[blockIdx.y];
+    __shared__ uint32_t s_last, s_wv[kBW];
+    if (blockIdx.x == gridDim.x - 1) {
+        band_cuts_next(a.hdr, a.bucket_start, a.bucket_tiles, a.tile_cum, a.wave_lo_base, a.sig);
+        return;
+    }
+    band_scan_body(a.table, a.T, a.totals);
+    __threadfence();  // release: this workgroup's totals are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&a.hdr->tile_queue, 1u) == gridDim.x - 2u ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u) return;
+    __threadfence();  // acquire: the other workgroups' totals, not what this CU's caches held before
+    if (threadIdx.x == 0) a.hdr->tile_queue = 0u;
+    band_starts_block<kBT, kSSMaxTiles / kBT>(a.totals, a.T, a.hdr, a.r_capacity, a.ranges_w, s_wv);
 }
 
 // depth-ordered rects for depth sorts that do not write them themselves (the LSD radix variant)
@@ -496,19 +717,20 @@ static void band_args(int B, const GsrFrame *fr, bool balanced, bool place, GsrB
         a.nseg = g.band_nseg;
         a.order = g.order;
         a.ranges = fr[k].img.ranges;
+        a.ranges_w = fr[k].img.ranges;
+        a.r_capacity = fr[k].cap32;
         a.point_list = place ? fr[k].b.gidx[0] : (uint32_t *)nullptr;
     }
 }
 
 // counts -> ranges, R (tile_starts_kernel lives in binning.hip)
-int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, hipStream_t stream) {
+int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool merge_starts, bool *starts_done, bool debug,
+                          hipStream_t stream) {
     const GsrSettings &st = *fr[0].st_bin;
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    GsrBatch<BandArgs> bt;
+    GsrBatch<BandArgs> bt{};  // (entries beyond B stay zero: nothing uninitialised travels in the kernarg)
     band_args(B, fr, balanced, false, bt);
     const dim3 grid(GSR_BAND_RANGES, gy, B);
-    hipLaunchKernelGGL(band_ranges_kernel, dim3(1, B), dim3(kBT), 0, stream, bt);
-    if (int e = gsr_check_launch("band_ranges", debug, stream)) return e;
     if (gx <= 64)
         hipLaunchKernelGGL(band_count_kernel<1>, grid, dim3(kBT), 0, stream, bt);
     else if (gx <= 128)
@@ -517,14 +739,27 @@ int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, 
         hipLaunchKernelGGL(band_count_kernel<4>, grid, dim3(kBT), 0, stream, bt);
     if (int e = gsr_check_launch("band_count", debug, stream)) return e;
     const int T = gx * gy;
-    hipLaunchKernelGGL(band_scan_kernel, dim3(gsr_div_up(T, kBW), B), dim3(kBT), 0, stream, bt);
+    // (merged: nothing but the ranges is asked of tile_starts_kernel -- the compositing order was dealt earlier in the frame
+    //  (merge_starts) and there are no quadrants to split: the default path)
+    const bool merged = GSR_SCAN_MODE != 0 && merge_starts && T <= kSSMaxTiles &&
+                        (T > 2048 || gsr_render_split_blocks(st, T) == 0);
+    if (starts_done) *starts_done = merged;
+    if (merged && GSR_SCAN_MODE == 1) {
+        hipLaunchKernelGGL(band_scan_starts_kernel, dim3(2, B), dim3(kSST), 0, stream, bt);
+        return gsr_check_launch("band_scan_starts", debug, stream);
+    }
+    if (merged) {
+        hipLaunchKernelGGL(band_scan_tail_kernel, dim3(gsr_div_up(T, kBW) + 1, B), dim3(kBT), 0, stream, bt);
+        return gsr_check_launch("band_scan_tail", debug, stream);
+    }
+    hipLaunchKernelGGL(band_scan_kernel, dim3(gsr_div_up(T, kBW) + 1, B), dim3(kBT), 0, stream, bt);
     return gsr_check_launch("band_scan", debug, stream);
 }
 
 int gsr_launch_band_place(int B, const GsrFrame *fr, bool debug, hipStream_t stream) {
     const GsrSettings &st = *fr[0].st_bin;
     const int gx = gsr_div_up(st.image_width, GSR_TILE), gy = gsr_div_up(st.image_height, GSR_TILE);
-    GsrBatch<BandArgs> bt;
+    GsrBatch<BandArgs> bt{};  // (entries beyond B stay zero: nothing uninitialised travels in the kernarg)
     band_args(B, fr, true, true, bt);
     const dim3 grid(GSR_BAND_RANGES, gy, kMaxSegments * B);
     if (gx <= 64)

@@ -632,7 +632,7 @@ int gsr_launch_tile_starts(int B, const GsrFrame *fr, bool order_done, bool debu
     const GsrSettings &st = *fr[0].st_bin;
     const int T = gsr_div_up(st.image_width, GSR_TILE) * gsr_div_up(st.image_height, GSR_TILE);
     const int split_blocks = T <= 2048 ? gsr_render_split_blocks(st, T) : 0;
-    GsrBatch<TileStartsArgs> bt;
+    GsrBatch<TileStartsArgs> bt{};  // (entries beyond B stay zero: nothing uninitialised travels in the kernarg)
     for (int k = 0; k < B; k++) {
         const GeomState &g = fr[k].g;
         const ImageState &img = fr[k].img;

@@ -376,7 +376,7 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     const unsigned dbg_wg = 0; (void)dbg_wg;
     SS_STAMP(dbg, 0);
     __shared__ uint32_t s_key[2 * kMaxSamples];
-    __shared__ uint32_t s_cur[kPW * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cur[kPW * 256];
     __shared__ uint32_t s_split[2048], s_hist[2048];  // (bmax <= 2048)
     __shared__ uint32_t s_pex[kPT + 8];               // visible Gaussians before every thread's slice
     __shared__ __attribute__((aligned(16))) uint16_t s_cnt16[kPrepBlocks];  // running sums inside every slice
@@ -437,6 +437,7 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
         hdr->V = V;
         hdr->R = 0u;
         hdr->overflow = 0u;
+        hdr->coop_timeout_now = 0u;
         hdr->r_capacity = 0u;
         hdr->R_raw = 0u;
         hdr->tile_queue = 0u;
@@ -684,17 +685,59 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
             mx = max(mx, s_mm[kPW + w]);
         }
         const uint32_t range = mx - mn;
-        const int shift = range < 65536u ? 0 : (32 - __builtin_clz(range)) - 16;
-        for (int i = tid; i < (int)S; i += kPT) s_key[i] = (s_key[i] - mn) >> shift;
-        __syncthreads();
-        ss_radix_pass16(s_key, s_key + kMaxSamples, (int)S, 0, s_cur, s_w16);
-        ss_radix_pass16(s_key + kMaxSamples, s_key, (int)S, 8, s_cur, s_w16);
-        const uint32_t *sorted = s_key;
-        // NOT into the table a later frame's validation reads before ss_buckets rewrites it: the drawn table goes to its
-        // own array, which this frame's compaction and partition passes read; `splitters` is written by ss_buckets alone
-        for (int i = tid; i < B; i += kPT) {
-            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
-            splitters_new[i] = (i < B - 1 && q < S) ? (((sorted[q] << shift) + mn) & kKeyMask) : 0xFFFFFFFFu;
+        // Round 6: the quantiles from a HISTOGRAM of 12-bit codes first -- 4096 bins over the samples' range (s_cur, one
+        // word per bin), one LDS atomic per sample, one scan of the bins, and every bin names the splitters whose rank falls
+        // into it (S / B is a power of two: rank (i + 1) S / B): five barriers instead of the two LSD passes' fourteen and
+        // their ranking rounds (a wrist camera draws a new table nearly every step: ss_prepare 17.3 -> us per closed-loop
+        // step).  A splitter is then the lower edge of its bin: no finer than 1 / 4096 of the range, so a
+        // bin that draws more than four shares of the samples (a clump of depths beside far outliers: its records could
+        // not be cut apart and would outgrow a bucket's LDS) sends the frame down the exact route below.
+#ifndef GSR_SS_HIST_SPLITTERS
+#define GSR_SS_HIST_SPLITTERS 1
+#endif
+        bool drawn = false;
+        if (GSR_SS_HIST_SPLITTERS) {
+            static_assert(kPW * 256 == 4 * kPT, "a thread owns four of the 4096 bins");
+            const int hshift = range < 4096u ? 0 : (32 - __builtin_clz(range)) - 12;
+            const int lg = ss_log2((int)S) - ss_log2(B);  // samples per splitter: S / B = 2, 4 or 8
+            for (int i = tid; i < 4 * kPT; i += kPT) s_cur[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < (int)S; i += kPT) atomicAdd(&s_cur[(s_key[i] - mn) >> hshift], 1u);
+            __syncthreads();
+            const uint4 c = *reinterpret_cast<const uint4 *>(s_cur + 4 * tid);
+            const uint32_t cnt[4] = {c.x, c.y, c.z, c.w};
+            const uint32_t mine4 = c.x + c.y + c.z + c.w, lim = 4u << lg;
+            uint32_t tot4;
+            uint32_t run = ss_scan1024(mine4, s_w16, tot4) - mine4;
+            const bool heavy = __syncthreads_or((c.x > lim || c.y > lim || c.z > lim || c.w > lim) ? 1 : 0) != 0;
+            if (!heavy) {
+                // NOT into the table a later frame's validation reads before ss_buckets rewrites it: the drawn table goes to
+                // its own array, which this frame's compaction and partition passes read
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (cnt[k] != 0u) {
+                        // ranks [run, run + cnt) hold the samples of this bin: splitter i has rank (i + 1) << lg
+                        const uint32_t i1 = (run + (1u << lg) - 1u) >> lg, i2 = (run + cnt[k] + (1u << lg) - 1u) >> lg;
+                        const uint32_t edge = ((((uint32_t)(4 * tid + k)) << hshift) + mn) & kKeyMask;
+                        for (uint32_t j = max(i1, 1u); j < i2 && j < (uint32_t)B; j++) splitters_new[j - 1u] = edge;
+                    }
+                    run += cnt[k];
+                }
+                if (tid == 0) splitters_new[B - 1] = 0xFFFFFFFFu;
+                drawn = true;
+            }
+        }
+        if (!drawn) {
+            const int shift = range < 65536u ? 0 : (32 - __builtin_clz(range)) - 16;
+            for (int i = tid; i < (int)S; i += kPT) s_key[i] = (s_key[i] - mn) >> shift;
+            __syncthreads();
+            ss_radix_pass16(s_key, s_key + kMaxSamples, (int)S, 0, s_cur, s_w16);
+            ss_radix_pass16(s_key + kMaxSamples, s_key, (int)S, 8, s_cur, s_w16);
+            const uint32_t *sorted = s_key;
+            for (int i = tid; i < B; i += kPT) {
+                const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * S) / (uint32_t)B);
+                splitters_new[i] = (i < B - 1 && q < S) ? (((sorted[q] << shift) + mn) & kKeyMask) : 0xFFFFFFFFu;
+            }
         }
     }
     if (tid == 0) hdr->ss_fresh = reuse ? 0u : 1u;
@@ -1396,7 +1439,7 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
     const int32_t P = fr[0].in->P;
     const int nb1 = GeomState::prep_blocks(P);
     const int nbc = gsr_ss_nbc(P), bpw = gsr_div_up(nb1, nbc), bmax = gsr_ss_bmax(P);
-    GsrBatch<SsArgs> bt;
+    GsrBatch<SsArgs> bt{};  // (entries beyond B stay zero: nothing uninitialised travels in the kernarg)
     for (int k = 0; k < B; k++) {
         const GeomState &g = fr[k].g;
         SsArgs &a = bt.f[k];

@@ -70,7 +70,11 @@ struct GsrHeader {
     uint32_t ss_B;        // depth buckets of THIS frame (chosen by ss_prepare: every later kernel of the frame reads it)
     uint32_t ss_stride;   // 2: this (blind) frame takes every second entry of a kept table of 2 ss_B quantiles; else 1
     uint32_t coop_quads;  // quadrants the compositor of this frame hands to cooperative workgroups (render.hip)
-    uint32_t pad[25];
+    uint32_t br_route;    // band placement: how this frame's counting pass came by its cuts (bandplace.hip band_cuts_block)
+    uint32_t coop_timeouts;  // cooperative quadrants whose hand-off timed out in the frames on this state (render.hip;
+                          //   never cleared by a frame: reported like overflow_frames -- such a quadrant is truncated)
+    uint32_t coop_timeout_now;  // ... and in THIS frame (cleared by the frame's first kernel: gsr_frame_stats -> GSR_E_TRUNCATED)
+    uint32_t pad[22];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)
@@ -85,9 +89,23 @@ __device__ inline void gsr_set_overflow(GsrHeader *hdr, bool overflow) {
         if (hdr->of_magic != GSR_OF_MAGIC) {
             hdr->of_magic = GSR_OF_MAGIC;
             hdr->overflow_frames = 0u;
+            hdr->coop_timeouts = 0u;
         }
         hdr->overflow_frames += 1u;
     }
+}
+// A cooperative quadrant of the compositor gave up waiting for a hand-off (render.hip render_coop_quadrant): its pixels are
+// truncated.  Counted under the same validity word as the overflow count (a header that never held a count reads as 0);
+// several workgroups may report at once.
+__device__ inline void gsr_note_coop_timeout(GsrHeader *hdr) {
+    if (hdr->of_magic != GSR_OF_MAGIC) {
+        hdr->overflow_frames = 0u;
+        hdr->coop_timeouts = 0u;
+        __threadfence();
+        hdr->of_magic = GSR_OF_MAGIC;
+    }
+    atomicAdd(&hdr->coop_timeouts, 1u);
+    hdr->coop_timeout_now = 1u;
 }
 static_assert(sizeof(GsrHeader) == 256, "header is one 256-byte line");
 
@@ -99,6 +117,15 @@ int gsr_ss_nbc(int32_t P);
 int gsr_ss_bmax(int32_t P);
 bool gsr_ss_supported(int32_t P);
 
+#ifndef GSR_GRAD_F64
+#define GSR_GRAD_F64 1  // (A/B: 0 = the per-Gaussian gradient sums of the backward accumulate in binary32, rounds 1-5)
+#endif
+#if GSR_GRAD_F64
+typedef double GsrGradWord;
+#else
+typedef float GsrGradWord;
+#endif
+
 // ---- geometry state (per Gaussian) -------------------------------------------------------------------
 struct GeomState {
     GsrHeader *hdr;
@@ -109,8 +136,11 @@ struct GeomState {
                               //       rec2 = (r, g, b, radius as float)
     float *cov3D;             // [6P]
     uint32_t *clamped;        // [P]   byte c = SH clamp flag of channel c
-    float *grad_rec;          // [12P] backward only: the compositor's ten per-Gaussian sums as ONE 48-byte record
-                              //       (mean2D.xy, conic xx xy yy, opacity, rgb, 1/depth, 2 unused) -- see backward.hip
+    GsrGradWord *grad_rec;    // [12P] backward only: the compositor's ten per-Gaussian sums as ONE record (mean2D.xy,
+                              //       conic xx xy yy, opacity, rgb, 1/depth, 2 unused) -- see backward.hip.  binary64 words
+                              //       (round 6): a Gaussian's sums arrive tile by tile, by device-scope atomics in whatever
+                              //       order the workgroups retire -- in binary32 that order was worth up to 1.7e-3 of a
+                              //       gradient's scale from run to run at configs[4] size
     uint32_t *tiles_touched;  // [P]
     uint2 *rects;             // [P]   x = min.x | min.y<<16, y = max.x | max.y<<16
     uint32_t *block_counts;   // [ceil(P/256)+1]  visible per preprocess block -> exclusive offsets
@@ -174,7 +204,7 @@ struct GeomState {
         g.splat = take<float4>(p, 3 * n);
         g.cov3D = take<float>(p, 6 * nf);
         g.clamped = take<uint32_t>(p, nf);
-        g.grad_rec = take<float>(p, 12 * nf);
+        g.grad_rec = take<GsrGradWord>(p, 12 * nf);
         g.tiles_touched = take<uint32_t>(p, nf);
         g.rects = take<uint2>(p, n);
         g.block_counts = take<uint32_t>(p, (size_t)prep_blocks(P) + 1);
@@ -383,6 +413,9 @@ __device__ __forceinline__ float sigmoid_canonical(float x) { return 1.0f / (1.0
 template <typename A>
 struct GsrBatch {
     A f[GSR_MAX_BATCH];
+    // (the kernarg segment of a launch is 4 KiB: a table that outgrows it fails at run time only -- hipErrorInvalidValue
+    //  on the first launch -- so the limit is checked where an argument block gains a field)
+    static_assert(sizeof(A) * GSR_MAX_BATCH <= 4096 - 128, "per-frame argument blocks must fit the 4 KiB kernarg segment");
 };
 
 // One frame of a (batched) set of launches as api.hip resolved it: the caller's structs and the carved state.
@@ -417,7 +450,10 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
                                  int coop_blocks, bool debug, hipStream_t stream);
 bool gsr_band_supported(int gx);
 int gsr_launch_gather_rects(int32_t P, const GeomState &g, bool debug, hipStream_t stream);
-int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool debug, hipStream_t stream);
+// (merge_starts: the caller wants nothing of tile_starts_kernel but ranges / R / the capacity check; *starts_done = true
+//  when the counting launches have produced them -- gsr_launch_tile_starts is then not needed)
+int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool merge_starts, bool *starts_done, bool debug,
+                          hipStream_t stream);
 int gsr_launch_band_place(int B, const GsrFrame *fr, bool debug, hipStream_t stream);
 // placement by chunks of the depth order (chunkplace.hip)
 bool gsr_chunk_supported(int gx, int gy);
@@ -431,6 +467,7 @@ int gsr_launch_tile_offsets(int32_t P, const GeomState &g, uint32_t r_capacity, 
 int gsr_launch_emit_and_tile_sort(const GsrSettings &st, int32_t P, const GeomState &g, const BinningState &b,
                                   const ImageState &img, int64_t r_capacity, bool debug, hipStream_t stream);
 bool gsr_render_wants_tile_order(const GsrSettings &st, int num_tiles);
+const char *gsr_render_build_flags();  // what render.hip was compiled with (csrc/Makefile may fall back): in gsr_version()
 int gsr_render_split_blocks(const GsrSettings &st, int num_tiles);
 bool gsr_render_uses_quad_order(const GsrSettings &st, int num_tiles);
 int gsr_render_cus_per_xcd();  // CUs of one XCD (the quadrant deal of gsr_quad_order_block)
@@ -455,7 +492,25 @@ __device__ __forceinline__ int gsr_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int gsr_wave() { return (int)(threadIdx.x >> 6); }
 __device__ __forceinline__ uint64_t gsr_lanemask_lt() { return (1ull << gsr_lane()) - 1ull; }
 
+// Inclusive running sum over the 64 lanes of the wave, in DPP moves: four shifted adds inside every row of 16 lanes
+// (row_shr 1 / 2 / 4 / 8, out-of-row sources read as 0), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15),
+// then lane 31 into the upper half (row_bcast:31): six VALU instructions.  (Rounds 1-5: six __shfl_up = ds_bpermute_b32
+// round trips through the LDS crossbar, ~100 cycles each in a dependent chain -- every block scan of the frame's
+// latency-bound kernels paid them.)
+#ifndef GSR_DPP_SCAN
+#define GSR_DPP_SCAN 1
+#endif
 __device__ __forceinline__ uint32_t gsr_wave_incl_scan(uint32_t v) {
+#if GSR_DPP_SCAN
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
+#else
     const int lane = gsr_lane();
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -463,6 +518,7 @@ __device__ __forceinline__ uint32_t gsr_wave_incl_scan(uint32_t v) {
         if (lane >= o) v += t;
     }
     return v;
+#endif
 }
 
 // Inclusive scan over the 256 threads of a block.  s_w must hold 4 uint32 in LDS.  Two barriers.

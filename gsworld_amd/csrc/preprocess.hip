@@ -7,6 +7,8 @@
 //
 // HBM traffic per Gaussian: 12 B xyz always; +28 B scale/quat, +4 B opacity once the near cull passed;
 // +192 B of SH and 88 B of state written only for Gaussians that survive to a non-empty tile rect.
+#include <string.h>
+
 #include "gsr_internal.h"
 
 #ifndef GSR_TIGHT_RECT
@@ -122,35 +124,26 @@ struct GeomOut {
     int radius;
 };
 
-// The exact per-Gaussian geometry: cull, projection, covariances, conic, radius, rect.
-// Writes rec0 / rec1 / cov3D / rects of a visible Gaussian; the caller writes radii, tiles_touched and the block-local sort record.
-__device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i) {
-    bool visible = false;
-    float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 my_rect = make_uint2(0u, 0u);
+// What a Gaussian is in the WORLD under one pose table and scale modifier -- everything of the per-Gaussian pass that no
+// camera enters: position after the part transform, 3D covariance, raw opacity.  The frames of a step that share the
+// model (gsr_forward_batch: cameras x environments) compute it once per Gaussian and pose table (round 6; until then
+// every frame's workgroup read and transformed the model for itself).  The covariance half is filled in when the first
+// frame needs it (a Gaussian behind every camera's near plane never loads its scales / rotation / opacity).
+struct WorldGauss {
     float px, py, pz;
-    const float *xf;
-    int part;
-    prep_position(a, i, px, py, pz, xf, part);
-    const float *m = a.view;
-    // transformPoint4x3: M[r][c] = m[c*4+r]
-    const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
-    const float vy = fma_(m[9], pz, fma_(m[5], py, m[1] * px)) + m[13];
-    const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
-    int radius = 0;
-    uint32_t touched = 0;
-    if (vz > a.near_plane) {  // in_frustum with GSWorld's near plane
-        const float *q = a.proj;
-        const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
-        const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
-        const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
-        const float p_w = 1.0f / (hw + 0.0000001f);
-        const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+    int part;           // moving part of the Gaussian (-1: none): what the pose table can change
+    bool have_cov;
+    float c0, c1, c2, c3, c4, c5, opacity_raw;
+};
 
+__device__ __forceinline__ void prep_world_cov(const PreprocessArgs &a, int i, WorldGauss &w) {
+    {
         // ---- 3D covariance: Sigma = R diag((mod*s)^2) R^T ------------------------------------------------
         // (requested with the covariance inputs: one round trip, not two.  Requesting all of them together with the
         //  POSITION in blocks that passed the frustum test -- nearly every Gaussian of such a block is in front of the
         //  camera -- was measured in round 4: no gain, 6 468 against 6 481 frames/s one at a time)
+        const int part = w.part;
+        const float *xf = (part >= 0 && part < a.part_count && a.part_labels != nullptr) ? a.part_transforms + (size_t)part * 17 : nullptr;
         const float opacity_raw = a.opacities[i];
         float c0, c1, c2, c3, c4, c5;
         if (a.cov3D_precomp) {
@@ -213,6 +206,36 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i)
             c4 = fma_(M21, M22, fma_(M11, M12, M01 * M02));
             c5 = fma_(M22, M22, fma_(M12, M12, M02 * M02));
         }
+        w.c0 = c0; w.c1 = c1; w.c2 = c2; w.c3 = c3; w.c4 = c4; w.c5 = c5;
+        w.opacity_raw = opacity_raw;
+        w.have_cov = true;
+    }
+}
+
+// The exact per-Gaussian geometry of ONE frame: cull, projection, covariances, conic, radius,
+// rect.  Writes rec0 / rec1 / cov3D / rects of a visible Gaussian; the caller writes radii, tiles_touched and the
+// block-local sort record.
+__device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i, WorldGauss &w) {
+    bool visible = false;
+    float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 my_rect = make_uint2(0u, 0u);
+    const float px = w.px, py = w.py, pz = w.pz;
+    const float *m = a.view;
+    // transformPoint4x3: M[r][c] = m[c*4+r]
+    const float vx = fma_(m[8], pz, fma_(m[4], py, m[0] * px)) + m[12];
+    const float vy = fma_(m[9], pz, fma_(m[5], py, m[1] * px)) + m[13];
+    const float vz = fma_(m[10], pz, fma_(m[6], py, m[2] * px)) + m[14];
+    int radius = 0;
+    uint32_t touched = 0;
+    if (vz > a.near_plane) {  // in_frustum with GSWorld's near plane
+        const float *q = a.proj;
+        const float hx = fma_(q[8], pz, fma_(q[4], py, q[0] * px)) + q[12];
+        const float hy = fma_(q[9], pz, fma_(q[5], py, q[1] * px)) + q[13];
+        const float hw = fma_(q[11], pz, fma_(q[7], py, q[3] * px)) + q[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+        if (!w.have_cov) prep_world_cov(a, i, w);
+        const float c0 = w.c0, c1 = w.c1, c2 = w.c2, c3 = w.c3, c4 = w.c4, c5 = w.c5, opacity_raw = w.opacity_raw;
 
         // ---- EWA 2D covariance: (J W) Sigma (J W)^T ---------------------------------------------------------
         const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
@@ -512,46 +535,84 @@ __device__ __forceinline__ bool prep_block_culled(const PreprocessArgs &a, int b
     return xhi + rb < -1.0f || xlo - rb > xend || yhi + rb < -1.0f || ylo - rb > yend;
 }
 
-// grid = (blocks of 256 Gaussians, frames): blockIdx.y picks the frame's argument block (gsr_internal.h GsrBatch).
-// (Measured in round 5 and not kept: the workgroups that read one block of the model for the B frames of a step as
-// neighbours on one XCD, so that the model comes out of that L2 after the first frame: 57.3 -> 55.0 us for four identical
-// frames, but 38.7 -> 42.3 us for the two different cameras of a closed-loop step.)
-template <bool FAST_SH16, bool COUNT_TILES>
-__global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const GsrBatch<PreprocessArgs> bt) {
-    const PreprocessArgs a = bt.f[blockIdx.y];  // (by value: every field is requested at the top, not at its first use)
-    const uint32_t blk = blockIdx.x;
-    extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
-    const int i = (int)blk * GSR_BLOCK + (int)threadIdx.x;
+// ---------------------------------------------------------------------------------------------------------
+// The kernel.  grid = (blocks of 256 Gaussians, GROUPS of frames): the frames of one launch (gsr_forward_batch) that read
+// the SAME model -- the cameras x environments of a simulation step, gs_world_wrapper.py:238-242 -- form a group, and one
+// workgroup takes a block of the model through all of them (round 6; SURVEY.md 8f-4 "shares the preprocess work"):
+//   * the block's view-frustum test for every frame of the group up front (wave w: frames w, w + 4); a block no frame
+//     sees costs one short workgroup per GROUP instead of one per frame (seven blocks in ten from a sensor camera);
+//   * a Gaussian's position after the part transform, its 3D covariance and opacity are computed once per pose table
+//     (WorldGauss: the two cameras of a closed-loop step share them; with E environments a Gaussian of the static scene is
+//     transformed once for all of them) and its parameters are read once -- the first frame brings them, the others find
+//     them in registers or, the SH coefficients of a Gaussian several cameras see, in this CU's cache;
+//   * per frame: projection, EWA covariance, conic, radius, rect, block compaction, SH -> RGB, in exactly the operations of
+//     the single-frame kernel: every frame's state is bit-identical to a launch of its own (tests/test_batch_gpu.py).
+// A single frame is a group of one.  (Measured in round 5 and not kept: one workgroup per frame and block, the workgroups
+// of a block neighbours on one XCD so that the model comes out of that L2: -4 % for four identical frames, +9 % for the
+// two cameras of a closed-loop step.)
+// ---------------------------------------------------------------------------------------------------------
+struct PrepLaunch {
+    GsrBatch<PreprocessArgs> bt;        // the frames, those of a group next to each other
+    uint8_t first[GSR_MAX_BATCH];       // per group: its first frame in bt ...
+    uint8_t count[GSR_MAX_BATCH];       // ... and how many
+};
+static_assert(sizeof(PrepLaunch) <= 4096, "kernel arguments travel in the 4 KiB kernarg segment");
+
+// LDS of a workgroup: the block-compacted survivors of the frame in hand, and what is kept from frame to frame
+struct PrepShared {
+    uint32_t w[4];
+    float4 pos[GSR_BLOCK];
+    int idx[GSR_BLOCK];
+    int culled[GSR_MAX_BATCH];
+};
+typedef float PrepWorld[11][GSR_BLOCK];  // (multi-frame groups only: WorldGauss in LDS, each thread its own slots)
+
+// One frame of the group on this workgroup's block.  have_world: an earlier frame of the group left the block's WorldGauss
+// in LDS (computed under pose table w_table and scale modifier w_mod); more: a later frame will want it.
+template <bool FAST_SH16, bool COUNT_TILES, bool MULTI>
+__device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i, const uint32_t blk, const bool have_world,
+                                           const float *w_table, const float w_mod, const bool more, PrepShared &sh,
+                                           PrepWorld *world, uint32_t *s_tcnt) {
     bool visible = false;
     float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);  // xyz + radius, handed to the colour phase
     uint32_t my_tiles = 0, my_key = 0;
     uint2 my_rect = make_uint2(0u, 0u);
-    if (COUNT_TILES) {
-        for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
-    }
-    // the Gaussian's number in the caller's arrays (radii)
-    const int oi = (a.orig_index != nullptr && a.radii != nullptr && i < a.P) ? a.orig_index[i] : i;
-    if (a.cull_blocks != nullptr) {
-        // (the first wave evaluates the block's test, ~100 instructions; the other three wait for its verdict at a
-        // barrier instead of repeating it: a skipped workgroup costs ~150 wave-instructions instead of ~400, and seven
-        // in ten are skipped)
-        __shared__ int s_culled;
-        if (threadIdx.x < GSR_WAVE) {
-            const bool c = prep_block_culled(a, (int)blk);
-            if (threadIdx.x == 0) s_culled = c ? 1 : 0;
-        }
-        __syncthreads();
-        if (s_culled != 0) {
-            if (i < a.P) {
-                if (a.radii != nullptr) a.radii[oi] = 0;
-                if (!a.infer) a.tiles_touched[i] = 0u;
-            }
-            if (threadIdx.x == 0) a.block_counts[blk] = 0u;
-            return;
-        }
-    }
     if (i < a.P) {
-        const GeomOut o = prep_geometry(a, i);
+        // the Gaussian's number in the caller's arrays (radii)
+        const int oi = (a.orig_index != nullptr && a.radii != nullptr) ? a.orig_index[i] : i;
+        WorldGauss w;
+        const int tid = (int)threadIdx.x;
+        if (MULTI && have_world) {
+            w.px = (*world)[0][tid]; w.py = (*world)[1][tid]; w.pz = (*world)[2][tid];
+            const int pf = __float_as_int((*world)[3][tid]);
+            w.part = pf >> 1;
+            w.have_cov = (pf & 1) != 0;
+            w.c0 = (*world)[4][tid]; w.c1 = (*world)[5][tid]; w.c2 = (*world)[6][tid];
+            w.c3 = (*world)[7][tid]; w.c4 = (*world)[8][tid]; w.c5 = (*world)[9][tid];
+            w.opacity_raw = (*world)[10][tid];
+        } else {
+            w.px = w.py = w.pz = 0.f;
+            w.part = -1;
+            w.have_cov = false;
+            w.c0 = w.c1 = w.c2 = w.c3 = w.c4 = w.c5 = w.opacity_raw = 0.f;
+        }
+        const bool same_mod = MULTI && have_world && a.scale_modifier == w_mod;
+        if (!same_mod || (a.part_transforms != w_table && w.part >= 0)) {
+            // (first frame of the block, or a Gaussian of a moving part under another environment's poses)
+            const float *xf;
+            int part;
+            prep_position(a, i, w.px, w.py, w.pz, xf, part);
+            w.part = xf != nullptr ? part : -1;
+            w.have_cov = false;
+        }
+        const GeomOut o = prep_geometry(a, i, w);
+        if (MULTI && more) {  // (another frame of the group looks at this block)
+            (*world)[0][tid] = w.px; (*world)[1][tid] = w.py; (*world)[2][tid] = w.pz;
+            (*world)[3][tid] = __int_as_float((int)((uint32_t)w.part << 1) | (w.have_cov ? 1 : 0));
+            (*world)[4][tid] = w.c0; (*world)[5][tid] = w.c1; (*world)[6][tid] = w.c2;
+            (*world)[7][tid] = w.c3; (*world)[8][tid] = w.c4; (*world)[9][tid] = w.c5;
+            (*world)[10][tid] = w.opacity_raw;
+        }
         visible = o.visible;
         mypos = o.pos;
         my_tiles = o.tiles;
@@ -560,18 +621,14 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const GsrBatch<Pr
         if (!a.infer) a.tiles_touched[i] = o.tiles;
         my_key = o.key;
     }
-
     // ---- phase 2: colour, on the block-compacted list of survivors ------------------------------------------
     // Typically only a fraction of the 256 lanes survive cull + rect; evaluating the SH (48 loads + ~110 VALU per
     // Gaussian) in place would run all 4 waves at that fraction of their lanes.  Dense lanes instead.
-    __shared__ uint32_t s_w[4];
-    __shared__ float4 s_pos[GSR_BLOCK];
-    __shared__ int s_idx[GSR_BLOCK];
     uint32_t cnt;
-    const uint32_t incl = gsr_block_incl_scan(visible ? 1u : 0u, s_w, cnt);
+    const uint32_t incl = gsr_block_incl_scan(visible ? 1u : 0u, sh.w, cnt);
     if (visible) {
-        s_pos[incl - 1u] = mypos;
-        s_idx[incl - 1u] = i;
+        sh.pos[incl - 1u] = mypos;
+        sh.idx[incl - 1u] = i;
         a.block_recs[(size_t)blk * GSR_BLOCK + (incl - 1u)] = make_uint2((uint32_t)i, my_key);
     }
     if (threadIdx.x == 0) {
@@ -591,7 +648,98 @@ __global__ __launch_bounds__(GSR_BLOCK) void preprocess_kernel(const GsrBatch<Pr
         }
     }
     if (threadIdx.x < cnt) {
-        prep_colour<FAST_SH16>(a, s_idx[threadIdx.x], s_pos[threadIdx.x]);
+        prep_colour<FAST_SH16>(a, sh.idx[threadIdx.x], sh.pos[threadIdx.x]);
+    }
+}
+
+// the block's view-frustum test for every frame of the group -> the frames that have to look at it; the others get their
+// zero count (and, where a caller reads them, zero radii) on the spot
+__device__ __forceinline__ uint32_t prep_live_frames(const PrepLaunch &L, const int f0, const int nf, const uint32_t blk,
+                                                     const int i, PrepShared &sh) {
+    uint32_t live = (1u << nf) - 1u;
+    if (L.bt.f[f0].cull_blocks == nullptr) return live;  // (the group shares the model: frame f0's block names it)
+    // (a wave evaluates the block's test for its frames, ~100 instructions each; the verdicts meet at a barrier)
+    for (int k = gsr_wave(); k < nf; k += GSR_BLOCK / GSR_WAVE) {
+        const PreprocessArgs a = L.bt.f[f0 + k];
+        const bool c = prep_block_culled(a, (int)blk);
+        if (gsr_lane() == 0) sh.culled[k] = c ? 1 : 0;
+    }
+    __syncthreads();
+    for (int k = 0; k < nf; k++) {
+        if (sh.culled[k] == 0) continue;
+        live &= ~(1u << k);
+        const PreprocessArgs &a = L.bt.f[f0 + k];
+        if (i < a.P) {
+            if (a.radii != nullptr) a.radii[a.orig_index != nullptr ? a.orig_index[i] : i] = 0;
+            if (!a.infer) a.tiles_touched[i] = 0u;
+        }
+        if (threadIdx.x == 0) a.block_counts[blk] = 0u;
+    }
+    return live;
+}
+
+// groups of ONE frame (a single gsr_forward, frames of a batch that share nothing): no loop around the frame -- the loop
+// alone costs the compiler 40 VGPRs (hoisted constants, lane predicates, addresses), 113 against 72
+#ifndef GSR_PREP_MAX_WAVES
+#define GSR_PREP_MAX_WAVES 0  // (A/B probe: cap the single-frame kernel's waves per SIMD -- what does occupancy buy it?)
+#endif
+template <bool FAST_SH16, bool COUNT_TILES>
+__global__ __launch_bounds__(GSR_BLOCK)
+#if GSR_PREP_MAX_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(1, GSR_PREP_MAX_WAVES)))
+#endif
+void preprocess_kernel(const PrepLaunch L) {
+    const int f0 = (int)L.first[blockIdx.y];
+    const uint32_t blk = blockIdx.x;
+    extern __shared__ uint32_t s_tcnt[];  // [num_tiles] when COUNT_TILES
+    __shared__ PrepShared sh;
+    const int i = (int)blk * GSR_BLOCK + (int)threadIdx.x;
+    const PreprocessArgs a = L.bt.f[f0];  // (by value: every field is requested at the top, not at its first use)
+    if (COUNT_TILES) {
+        for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
+    }
+    if (prep_live_frames(L, f0, 1, blk, i, sh) == 0u) return;
+    prep_frame<FAST_SH16, COUNT_TILES, false>(a, i, blk, false, nullptr, 0.f, false, sh, nullptr, s_tcnt);
+}
+
+// groups of several frames
+#ifndef GSR_PREP_GROUP_WAVES
+#define GSR_PREP_GROUP_WAVES 0  // A/B: minimum waves per SIMD asked of the compiler for the multi-frame kernel (0: none)
+#endif
+template <bool FAST_SH16>
+__global__
+#if GSR_PREP_GROUP_WAVES > 0
+__launch_bounds__(GSR_BLOCK, GSR_PREP_GROUP_WAVES)
+#else
+__launch_bounds__(GSR_BLOCK)
+#endif
+void preprocess_group_kernel(const PrepLaunch L) {
+    const int f0 = (int)L.first[blockIdx.y], nf = (int)L.count[blockIdx.y];
+    const uint32_t blk = blockIdx.x;
+    __shared__ PrepShared sh;
+    __shared__ PrepWorld s_world;
+    const int i0 = (int)blk * GSR_BLOCK + (int)threadIdx.x;
+    const uint32_t live = prep_live_frames(L, f0, nf, blk, i0, sh);
+    if (live == 0u) return;
+    // ---- the frames that see the block, one after the other; what no camera enters is kept between them -- in LDS, each
+    // thread its own slots (in registers the eleven words would stay live across the colour phase, whose 48 SH
+    // coefficients in flight set the kernel's register count)
+    bool have_world = false;            // (wave-uniform)
+    const float *w_table = nullptr;     // pose table and scale modifier the kept values were computed under
+    float w_mod = 0.f;
+#pragma nounroll
+    for (int k = 0; k < nf; k++) {
+        if (!((live >> k) & 1u)) continue;
+        const PreprocessArgs a = L.bt.f[f0 + k];  // (by value: every field is requested at the top, not at its first use)
+        // (the Gaussian's number is made opaque per frame: otherwise every address of the body is hoisted out of the loop)
+        int i = i0;
+        asm volatile("" : "+v"(i));
+        prep_frame<FAST_SH16, false, true>(a, i, blk, have_world, w_table, w_mod, (live >> (k + 1)) != 0u, sh, &s_world,
+                                           nullptr);
+        have_world = true;
+        w_table = a.part_transforms;
+        w_mod = a.scale_modifier;
+        __syncthreads();  // (the next frame's survivors take the same LDS slots)
     }
 }
 
@@ -606,14 +754,35 @@ __global__ __launch_bounds__(GSR_BLOCK) void mark_visible_kernel(int P, const fl
 
 }  // namespace
 
+#ifndef GSR_PREP_GROUPS
+#define GSR_PREP_GROUPS 1  // (A/B: 0 = every frame of a launch its own group, workgroups per (block, frame) as in round 5)
+#endif
+// Frames that share a model form a group only from this many on.  The group kernel carries a loop over the frames, which
+// costs the compiler 40 VGPRs (113 against the single-frame kernel's 72: four workgroups per CU instead of seven), and in a
+// latency-bound launch residency is what counts: the two cameras of a closed-loop step are FASTER as 2 x 5 738 single-frame
+// workgroups (39.5 us) than as 5 738 two-frame ones (44.4 us; the single-frame kernel capped at four waves per SIMD: 46.6 us,
+// i.e. the sharing itself is worth 5 % at equal residency); eight frames per launch are faster shared.
+#ifndef GSR_PREP_GROUP_MIN
+#define GSR_PREP_GROUP_MIN 3
+#endif
+// two frames share a workgroup when everything but the camera, the pose TABLE and the outputs is the same
+static bool prep_same_model(const PreprocessArgs &x, const PreprocessArgs &y) {
+    return x.P == y.P && x.D == y.D && x.M == y.M && x.W == y.W && x.H == y.H && x.param_space == y.param_space &&
+           x.infer == y.infer && x.means3D == y.means3D && x.shs == y.shs && x.shs_rest == y.shs_rest &&
+           x.colors_precomp == y.colors_precomp && x.opacities == y.opacities && x.scales == y.scales &&
+           x.rotations == y.rotations && x.cov3D_precomp == y.cov3D_precomp && x.part_labels == y.part_labels &&
+           x.part_lut == y.part_lut && x.part_lut_size == y.part_lut_size && x.part_count == y.part_count &&
+           x.part_rescale == y.part_rescale && x.cull_blocks == y.cull_blocks && x.orig_index == y.orig_index;
+}
+
 int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream) {
-    GsrBatch<PreprocessArgs> bt;
+    PreprocessArgs args[GSR_MAX_BATCH];
     bool fast = true;
     for (int k = 0; k < B; k++) {
         const GsrSettings &st = *fr[k].st;
         const GsrInputs &in = *fr[k].in;
         const GeomState &g = fr[k].g;
-        PreprocessArgs &a = bt.f[k];
+        PreprocessArgs &a = args[k];
         a.infer = infer ? 1 : 0;
         a.P = in.P;
         a.D = st.sh_degree;
@@ -666,19 +835,44 @@ int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infe
         fast = fast && (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
                ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
     }
-    const PreprocessArgs &a0 = bt.f[0];
-    const dim3 grid(GeomState::prep_blocks(a0.P), B);
+    // groups: the frames that read the same model, next to each other in the kernel's table (a frame's place in the table
+    // means nothing: its argument block carries its own state and outputs)
+    PrepLaunch L;
+    memset(&L, 0, sizeof(L));
+    int groups = 0, filled = 0;
+    bool taken[GSR_MAX_BATCH] = {false};
+    for (int k = 0; k < B; k++) {
+        if (taken[k]) continue;
+        int same = 0;
+        for (int j = k; j < B; j++) same += (!taken[j] && prep_same_model(args[k], args[j])) ? 1 : 0;
+        const bool share = GSR_PREP_GROUPS && !count_tiles && same >= GSR_PREP_GROUP_MIN;
+        L.first[groups] = (uint8_t)filled;
+        for (int j = k; j < B; j++)
+            if (!taken[j] && (j == k || (share && prep_same_model(args[k], args[j])))) {
+                taken[j] = true;
+                L.bt.f[filled++] = args[j];
+            }
+        L.count[groups] = (uint8_t)(filled - (int)L.first[groups]);
+        groups++;
+    }
+    const PreprocessArgs &a0 = args[0];
+    const dim3 grid(GeomState::prep_blocks(a0.P), groups);
     const size_t lds = count_tiles ? (size_t)a0.num_tiles * sizeof(uint32_t) : 0;
-    if (count_tiles) {
+    if (groups < B) {  // (some frames share a model; count_tiles frames never do)
         if (fast)
-            hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, dim3(GSR_BLOCK), lds, stream, bt);
+            hipLaunchKernelGGL((preprocess_group_kernel<true>), grid, dim3(GSR_BLOCK), 0, stream, L);
         else
-            hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, dim3(GSR_BLOCK), lds, stream, bt);
+            hipLaunchKernelGGL((preprocess_group_kernel<false>), grid, dim3(GSR_BLOCK), 0, stream, L);
+    } else if (count_tiles) {
+        if (fast)
+            hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, dim3(GSR_BLOCK), lds, stream, L);
+        else
+            hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, dim3(GSR_BLOCK), lds, stream, L);
     } else {
         if (fast)
-            hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, dim3(GSR_BLOCK), 0, stream, bt);
+            hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
         else
-            hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, dim3(GSR_BLOCK), 0, stream, bt);
+            hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
     }
     return GSR_OK;
 }

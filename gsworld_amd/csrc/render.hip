@@ -527,7 +527,10 @@ __device__ __forceinline__ void stream_list_put(float4 (*list)[6], int rank, flo
 // is complete when the counter is seen; workgroup-scope fences keep the compiler from moving accesses across them.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCoopCullers = GSR_BLOCK / GSR_WAVE - 1;  // 3
-constexpr uint32_t kCoopSpinLimit = 1u << 20;           // polls of 64+ cycles each: ~50 ms
+#ifndef GSR_COOP_SPIN_LIMIT
+#define GSR_COOP_SPIN_LIMIT (1u << 20)                  // polls of 64+ cycles each: ~50 ms
+#endif
+constexpr uint32_t kCoopSpinLimit = GSR_COOP_SPIN_LIMIT;  // (the test library libgsr_hip_coopspin.so is built with 1)
 
 struct CoopFlags {
     uint32_t ready[4], done[4], n_surv[4], unsafe_lo[4], unsafe_hi[4], stop;
@@ -535,8 +538,10 @@ struct CoopFlags {
 
 __device__ __forceinline__ uint32_t coop_load(volatile uint32_t *p) { return *p; }
 
+// -> true (replaying wave only): a hand-off timed out and the quadrant was written TRUNCATED -- the caller reports it in the
+// frame header (GsrHeader::coop_timeouts; gsr_frame_stats), the way a binning overflow is reported.
 template <bool SUPER>
-__device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamList / 2][6], CoopFlags *fl, const uint32_t q,
+__device__ __forceinline__ bool render_coop_quadrant(float4 (*s_list)[kStreamList / 2][6], CoopFlags *fl, const uint32_t q,
                                                      const uint2 *__restrict__ ranges,
                                                      const uint32_t *__restrict__ point_list,
                                                      const float4 *__restrict__ splat, int W, int H, int gx,
@@ -613,7 +618,7 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
             }
             if (pn + kCoopCullers * GSR_WAVE < n_inst) g_next = src[pn + kCoopCullers * GSR_WAVE];
         }
-        return;
+        return false;
     }
     // ---- the replaying wave
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -624,6 +629,7 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
     float T = inside ? 1.0f : -1.0f;
     v2f acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};
     uint32_t work = 0;
+    bool timed_out = false;
     for (int rd = 0; rd < rounds; rd++) {
         if (__builtin_amdgcn_ballot_w64(T > 0.0f) == 0ull) break;
         const int w = 1 + rd % kCoopCullers;
@@ -635,7 +641,10 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
             __builtin_amdgcn_s_sleep(1);
             spin++;
         }
-        if (spin >= kCoopSpinLimit) break;
+        if (spin >= kCoopSpinLimit) {
+            timed_out = true;
+            break;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // (plain loads behind the acquire fence, one wait for the three: as volatile ones they were three LDS round trips in a
         //  row per round -- dense view alone -2 %)
@@ -701,10 +710,12 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
         const size_t plane = (size_t)H * W;
         T = fabsf(T);
         const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
-        out_color[pid] = r;
-        out_color[plane + pid] = g;
-        out_color[2 * plane + pid] = b;
-        out_invdepth[pid] = acc_bd.y;
+        if (out_color != nullptr) {
+            out_color[pid] = r;
+            out_color[plane + pid] = g;
+            out_color[2 * plane + pid] = b;
+            out_invdepth[pid] = acc_bd.y;
+        }
         if (rgb8) {
             uint8_t *o = rgb8 + 3 * pid;
             o[0] = (uint8_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
@@ -712,6 +723,7 @@ __device__ __forceinline__ void render_coop_quadrant(float4 (*s_list)[kStreamLis
             o[2] = (uint8_t)fminf(fmaxf(b * 255.0f, 0.0f), 255.0f);
         }
     }
+    return timed_out;
 }
 
 // SUPER (GsrSettings.forward_only): `ranges` / `point_list` are the lists of SUPER-TILES (2 x 1 tiles: 0.58 of the
@@ -738,7 +750,7 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                                                                   uint32_t *__restrict__ quad_work_b,
                                                                   const uint32_t *__restrict__ quad_order,
                                                                   const uint32_t *__restrict__ coop_list,
-                                                                  int coop_blocks) {
+                                                                  int coop_blocks, GsrHeader *__restrict__ hdr) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
@@ -757,8 +769,10 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
             __syncthreads();
             const uint32_t q = coop_list[blockIdx.x];
             if (q >= 4u * (uint32_t)num_tiles) return;  // (no quadrant for this workgroup: 0xFFFFFFFF)
-            render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg, out_color, out_invdepth,
-                                       rgb8, quad_work, final_T);
+            const bool timed_out = render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg,
+                                                              out_color, out_invdepth, rgb8, quad_work, final_T);
+            // (cannot happen by the counters' construction; if it ever does the quadrant is truncated, and the frame says so)
+            if (timed_out && lane == 0) gsr_note_coop_timeout(hdr);
             return;
         }
     }
@@ -980,10 +994,12 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                 n_contrib[pid] = last_contributor;
             }
             const float r = fma_(T, bg0, acc_rg.x), g = fma_(T, bg1, acc_rg.y), b = fma_(T, bg2, acc_bd.x);
-            out_color[pid] = r;
-            out_color[plane + pid] = g;
-            out_color[2 * plane + pid] = b;
-            out_invdepth[pid] = acc_bd.y;
+            if (out_color != nullptr) {  // (NULL: an inference frame whose caller keeps the uint8 frame only, include/gsr.h)
+                out_color[pid] = r;
+                out_color[plane + pid] = g;
+                out_color[2 * plane + pid] = b;
+                out_invdepth[pid] = acc_bd.y;
+            }
             if (rgb8) {  // GSWorld's frame conversion, same arithmetic as pack_rgb8_kernel
                 uint8_t *o = rgb8 + 3 * pid;
                 o[0] = (uint8_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
@@ -1017,6 +1033,7 @@ struct RenderStreamArgs {
     const uint32_t *quad_order;
     const uint32_t *coop_list;  // cooperative quadrants (null: none): the quadrant of each of the first coop_blocks workgroups
     int coop_blocks;
+    GsrHeader *hdr;             // (a cooperative quadrant whose hand-off timed out is counted there)
 };
 template <bool SUPER>
 __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(
@@ -1026,7 +1043,7 @@ __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) 
     render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
                               a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
                               a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order,
-                              a.coop_list, a.coop_blocks);
+                              a.coop_list, a.coop_blocks, a.hdr);
 }
 
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
@@ -1090,6 +1107,17 @@ static int render_num_cus() {
             num_cus = 256;
     }
     return num_cus;
+}
+
+// (csrc/Makefile compiles this file with the hand-scheduled blend -- inline asm that pins v[92:95] under
+//  amdgpu_waves_per_eu(5) -- and, should a compiler ever refuse it, again with -DGSR_STREAM_ALIVE_BLEND=0: the plain
+//  masked blend, bit-identical frames; gsr_version() tells which one the library holds)
+const char *gsr_render_build_flags() {
+#if GSR_STREAM_MASKED_BLEND && GSR_STREAM_ALIVE_BLEND
+    return "alive_blend=1";
+#else
+    return "alive_blend=0";
+#endif
 }
 
 int gsr_render_cus_per_xcd() { return render_num_cus() / GSR_XCDS > 0 ? render_num_cus() / GSR_XCDS : 1; }
@@ -1169,7 +1197,7 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
             const int coop = super_tiles && split_ready ? coop_blocks : 0;
             const int extra = coop > 0 ? coop : (split_ready && T <= 2048 ? gsr_render_split_blocks(st, T) : 0);
             const bool use_qorder = split_ready && gsr_render_uses_quad_order(st, T);
-            GsrBatch<RenderStreamArgs> bt;
+            GsrBatch<RenderStreamArgs> bt{};  // (entries beyond B stay zero: nothing uninitialised travels in the kernarg)
             for (int k = 0; k < B; k++) {
                 const ImageState &im = fr[k].img;
                 RenderStreamArgs &a = bt.f[k];
@@ -1191,6 +1219,7 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
                 a.split_flag = extra > 0 && coop == 0 ? im.split_flag : (const uint32_t *)nullptr;
                 a.coop_list = coop > 0 ? im.split_list : (const uint32_t *)nullptr;  // (the split list, reused)
                 a.coop_blocks = coop;
+                a.hdr = fr[k].g.hdr;
                 a.split_list = im.split_list;
                 a.split_count = im.split_count;
                 a.quad_work_b = im.quad_work_b;

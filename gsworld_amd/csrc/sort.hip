@@ -76,6 +76,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void compact_kernel(int P, const uint32_
         hdr->V = offset + total;
         hdr->R = 0u;
         hdr->overflow = 0u;
+        hdr->coop_timeout_now = 0u;
         hdr->r_capacity = 0u;
         hdr->R_raw = 0u;
         hdr->tile_queue = 0u;

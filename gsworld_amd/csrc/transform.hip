@@ -80,13 +80,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void transform_kernel(int P, const float
 // The quaternion is ManiSkill's / PyTorch3D's matrix_to_quaternion in its exact float32 order (mirror:
 // gsworld_amd/transform.py): 4 candidate rows scaled by 1 / (2 max(q_abs, 0.1)), the row of the largest q_abs (first
 // on ties), sign standardised to a non-negative real part.
-__global__ void pack_transforms_kernel(int K, const float *__restrict__ matrices, const float *__restrict__ scales,
-                                       float *__restrict__ table) {
-    const int k = blockIdx.x * blockDim.x + (int)threadIdx.x;
-    if (k >= K) return;
-    const float *M = matrices + 16 * (size_t)k;
+__device__ __forceinline__ void pack_one_transform(const float *__restrict__ M, const float scale, float *__restrict__ T) {
     const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[4], m11 = M[5], m12 = M[6], m20 = M[8], m21 = M[9],
                 m22 = M[10];
+    const float t0 = M[3], t1 = M[7], t2 = M[11];
     const float d[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
     float qa[4];
     int best = 0;
@@ -107,11 +104,33 @@ __global__ void pack_transforms_kernel(int K, const float *__restrict__ matrices
 #pragma unroll
         for (int j = 0; j < 4; j++) q[j] = -q[j];
     }
-    float *T = table + (size_t)k * kXf;
     T[0] = m00; T[1] = m01; T[2] = m02; T[3] = m10; T[4] = m11; T[5] = m12; T[6] = m20; T[7] = m21; T[8] = m22;
-    T[9] = M[3]; T[10] = M[7]; T[11] = M[11];
-    T[12] = scales ? scales[k] : 1.0f;
+    T[9] = t0; T[10] = t1; T[11] = t2;
+    T[12] = scale;
     T[13] = q[0]; T[14] = q[1]; T[15] = q[2]; T[16] = q[3];
+}
+
+__global__ void pack_transforms_kernel(int K, const float *__restrict__ matrices, const float *__restrict__ scales,
+                                       float *__restrict__ table) {
+    const int k = blockIdx.x * blockDim.x + (int)threadIdx.x;
+    if (k >= K) return;
+    pack_one_transform(matrices + 16 * (size_t)k, scales ? scales[k] : 1.0f, table + (size_t)k * kXf);
+}
+
+// One step's host values -> the device, in ONE launch: `src` is a pinned host buffer the device reads directly (n floats:
+// part matrices, uniform scales, camera matrices -- gsworld_amd/closed_loop.py keeps them in one staging vector), `dst`
+// its device-resident twin the step's kernels read; the K part matrices at src + mat_off (scales at src + scale_off, or
+// none) are packed into the 17-float pose table on the way.  Replaces an H2D copy + pack_transforms_kernel per
+// closed-loop step (4.2 + 4.4 us on the step's stream) by one kernel whose loads cross PCIe.
+__global__ __launch_bounds__(GSR_BLOCK) void stage_step_kernel(int n, const float *__restrict__ src,
+                                                               float *__restrict__ dst, int K, int mat_off,
+                                                               int scale_off, float *__restrict__ table) {
+    const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
+    // (both requests go out before either is used)
+    const float v = i < n ? src[i] : 0.0f;
+    if (i < K) pack_one_transform(src + mat_off + 16 * (size_t)i, scale_off >= 0 ? src[scale_off + i] : 1.0f,
+                                  table + (size_t)i * kXf);
+    if (i < n) dst[i] = v;
 }
 
 }  // namespace
@@ -126,6 +145,36 @@ extern "C" int gsr_pack_part_transforms(int32_t K, const float *matrices, const 
     hipLaunchKernelGGL(pack_transforms_kernel, dim3(gsr_div_up(K, 64)), dim3(64), 0, (hipStream_t)stream, K, matrices,
                        scales, table);
     return gsr_check_launch("pack_part_transforms", false, (hipStream_t)stream);
+}
+
+extern "C" int gsr_pinned_device_address(const void *host, void **device) {
+    if (!host || !device) {
+        gsr_set_error("gsr_pinned_device_address: null argument");
+        return GSR_E_INVALID;
+    }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void *>(host), 0) != hipSuccess || d == nullptr) {
+        (void)hipGetLastError();
+        gsr_set_error("gsr_pinned_device_address: not pinned host memory the device can read");
+        return GSR_E_INVALID;
+    }
+    *device = d;
+    return GSR_OK;
+}
+
+extern "C" int gsr_stage_step(int32_t n, const float *src, float *dst, int32_t K, int32_t mat_off, int32_t scale_off,
+                              float *table, void *stream) {
+    if (n < 0 || K < 0 || (n > 0 && (!src || !dst)) || (K > 0 && (!table || mat_off < 0 || mat_off + 16 * (int64_t)K > n ||
+                                                                  (scale_off >= 0 && scale_off + (int64_t)K > n)))) {
+        gsr_set_error("gsr_stage_step: negative size, null pointer or part matrices outside the staged floats");
+        return GSR_E_INVALID;
+    }
+    const int m = n > K ? n : K;
+    if (m == 0) return GSR_OK;
+    // (nothing but the launch: the call is capturable into a hipGraph -- the address was resolved by the caller, once)
+    hipLaunchKernelGGL(stage_step_kernel, dim3(gsr_div_up(m, GSR_BLOCK)), dim3(GSR_BLOCK), 0, (hipStream_t)stream, n, src, dst, K,
+                       mat_off, scale_off, table);
+    return gsr_check_launch("stage_step", false, (hipStream_t)stream);
 }
 
 extern "C" int gsr_transform_gaussians_batch(int32_t P, int32_t E, const float *xyz, const float *rot,

@@ -153,7 +153,8 @@ void fill_frame(FrameCall &f, int H, int W, double tanfovx, double tanfovy, doub
         in.orig_index = orig_index.data_ptr<int32_t>();
     }
     f.in = in;
-    f.out = GsrOutputs{out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(),
+    f.out = GsrOutputs{out_color.numel() ? out_color.data_ptr<float>() : nullptr,
+                       out_invdepth.numel() ? out_invdepth.data_ptr<float>() : nullptr,
                        radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
                        rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
     f.geom = geom;
@@ -225,7 +226,7 @@ std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(geom.device());
     GsrFrameStats s{};
     const int rc = gsr_frame_stats(geom.data_ptr(), &s, current_stream(geom.device()));
-    TORCH_CHECK(rc == GSR_OK || rc == GSR_E_OVERFLOW, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    TORCH_CHECK(rc == GSR_OK || rc == GSR_E_OVERFLOW, "libgsr_hip error ", rc, ": ", gsr_last_error());  // (a truncated frame: loud)
     return {s.num_visible, s.num_rendered, (int64_t)s.overflow};
 }
 

@@ -152,6 +152,17 @@ class SceneLayout:
         P = means3D.shape[0]
         dev = means3D.device
         if reorder:
+            from ._lib import plan_query
+
+            # a permuted model is only taken by inference frames on the default sort / placement path; a model beyond the
+            # sample sort (8 388 608 Gaussians) never gets one, whatever the camera: keep its order, hand over bounds only
+            if plan_query(640, 480, P, permuted=True, forward_only=True, tuned=False) is None:
+                import warnings
+
+                warnings.warn(f"SceneLayout: a model of {P} Gaussians is rendered through the LSD radix depth sort, which "
+                              "takes no permuted model: the layout keeps the caller's order (block bounds only)", stacklevel=2)
+                reorder = False
+        if reorder:
             s = scales.detach().to(torch.float32)
             perm = morton_order(means3D, labels, (torch.exp(s) if param_space & RAW_SCALES else s).abs().amax(1))
         else:

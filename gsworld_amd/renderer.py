@@ -25,6 +25,8 @@ class FrameStats:
     num_rendered: int
     overflow: bool
     overflow_frames: int = 0  # frames on this renderer's state that overflowed since its buffers were allocated
+    truncated: bool = False   # a cooperative quadrant of this frame's compositor timed out (GSR_E_TRUNCATED): pixels are wrong
+    coop_timeouts: int = 0    # such quadrants in all frames on this state
 
     def algorithmic_bytes(self, width: int, height: int) -> int:
         """B_alg of SURVEY.md 8d: 48 N + 280 V + 64 R + 16 W H."""
@@ -34,7 +36,7 @@ class FrameStats:
 class FrameRenderer:
     def __init__(self, device="cuda", growth: float = 1.25, near_plane: float | None = None,
                  forward_only: bool = False, want_radii: bool = True, min_capacity: int = 1 << 16,
-                 bound_capacity: bool = False, overflow_mirror: bool = False):
+                 bound_capacity: bool = False, overflow_mirror: bool = False, want_float: bool = True):
         """``forward_only``: inference frames (GsrSettings.forward_only, include/gsr.h): the image is bit-identical, but
         nothing a backward would read is written and the instances are binned per super-tile of 2 x 1 tiles -- the state buffers
         are then no input for ``gsr_backward`` and :meth:`stats` counts super-tile instances.  ``want_radii=False``
@@ -46,6 +48,9 @@ class FrameRenderer:
         Gaussians, 640 x 480): no exact-mode first frame, no overflow, hence no flag to read back --
         :attr:`bounded` then says that :meth:`ensure_valid` (a host synchronisation) is not needed.  For a single
         renderer that serves call after call (the drop-in ``render()``); not for dozens of lanes.
+        ``want_float=False`` (forward_only only; every call must then pass ``rgb8_out``): the float colour / inverse-depth
+        images are not written at all -- a caller that keeps GSWorld's uint8 frame only (gs_world_wrapper.py:266-270) saves
+        16 bytes per pixel of stores nobody reads; :meth:`render` returns ``None`` for both.
         ``overflow_mirror``: after every frame the header's overflow count is copied (8 bytes, asynchronously, also
         inside a captured graph) into pinned host memory: :meth:`overflows_seen` then tells WITHOUT a synchronisation
         how many frames on this state have exceeded their capacity so far, as of the last copy that has landed --
@@ -57,6 +62,7 @@ class FrameRenderer:
             self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self.forward_only = bool(forward_only)
         self.want_radii = bool(want_radii) or not self.forward_only
+        self.want_float = bool(want_float) or not self.forward_only
         self.growth = growth
         self.min_capacity = int(min_capacity)
         self.bound_capacity = bool(bound_capacity)
@@ -165,6 +171,13 @@ class FrameRenderer:
                     or color.device != dev or invd.device != dev or rad.device != dev):
                 raise ValueError("outputs must be dense (3,H,W) float32, (1,H,W) float32, (P,) int32 tensors on the "
                                  "renderer's device")
+        elif not self.want_float:
+            if rgb8_out is None:
+                raise ValueError("a renderer built with want_float=False writes the uint8 frame only: pass rgb8_out")
+            if self._out is None or self._out[2].shape[0] != P:
+                none = torch.empty(0, dtype=torch.float32, device=dev)
+                self._out = (none, none, torch.zeros((P if self.want_radii else 0,), dtype=torch.int32, device=dev))
+            color, invd, radii = self._out
         else:
             color, invd, radii = self._outputs(P, H, W)
         if not self.want_radii:
@@ -193,6 +206,8 @@ class FrameRenderer:
             sh=shs if shs is not None else empty, campos=campos, out_color=color, out_invdepth=invd, radii=radii,
             geomBuffer=self.geom, binningBuffer=self.binning, imgBuffer=self.image, r_capacity=cap, sh_rest=shs_rest,
             param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout)
+        if not self.want_float and outputs is None:
+            color = invd = None  # (what the caller gets back; the call holds the empty tensors = NULL images)
         return call, color, radii, invd
 
     def _finish(self, cap: int, stats=None):
@@ -229,19 +244,32 @@ class FrameRenderer:
         with torch.cuda.device(self.device):
             code = lib().gsr_frame_stats(C.c_void_p(self.geom.data_ptr()), C.byref(s),
                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        if code not in (0, -4):
+        if code not in (0, -4, -5):
             check(code)
-        return FrameStats(self._P, int(s.num_visible), int(s.num_rendered), bool(s.overflow), int(s.overflow_frames))
+        return FrameStats(self._P, int(s.num_visible), int(s.num_rendered), bool(s.overflow), int(s.overflow_frames),
+                          bool(s.truncated), int(s.coop_timeouts))
 
     def ensure_valid(self, rerender) -> FrameStats:
         """Checks the last frame for capacity overflow; if it overflowed, grows the capacity and calls
         ``rerender()`` (which must call :meth:`render` again with the same arguments)."""
         s = self.stats()
-        if s.overflow:
-            self.r_capacity = self._capacity_for(s.num_rendered)
+        if s.overflow or s.truncated:
+            if s.overflow:
+                self.r_capacity = self._capacity_for(s.num_rendered)
             rerender()
             s = self.stats()
+            _raise_if_truncated([s])
         return s
+
+
+def _raise_if_truncated(stats) -> None:
+    """A frame whose compositor reported a timed-out cooperative quadrant (``GsrFrameStats.truncated``) shows wrong pixels;
+    the validity checks re-render it once -- the hand-off cannot time out by construction, so a second time is a fault of the
+    library or the device, never something to render on with."""
+    if any(s.truncated for s in stats):
+        raise RuntimeError("libgsr_hip: a cooperative quadrant of the compositor timed out again on the re-rendered frame "
+                           f"(GSR_E_TRUNCATED; {sum(s.coop_timeouts for s in stats)} such quadrants on these states): the "
+                           "frame is invalid.  GSWORLD_AMD_TUNING=render_split=3 renders without cooperative quadrants")
 
 
 class MultiCameraRenderer:
@@ -320,10 +348,11 @@ class MultiCameraRenderer:
         """Overflow check of every lane's last frame (synchronises); ``rerender()`` must repeat the step's
         :meth:`render` call.  Returns the per-camera :class:`FrameStats`."""
         stats = [lane.stats() for lane in self.lanes]
-        if any(s.overflow for s in stats):
+        if any(s.overflow or s.truncated for s in stats):
             for lane, s in zip(self.lanes, stats):
                 if s.overflow:
                     lane.r_capacity = lane._capacity_for(s.num_rendered)
             rerender()
             stats = [lane.stats() for lane in self.lanes]
+            _raise_if_truncated(stats)
         return stats

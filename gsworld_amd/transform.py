@@ -151,6 +151,10 @@ class FusedPartTransform:
         one tuple per environment).  The pose table lives in a persistent buffer (capturable)."""
         table = self.pack_on_device(matrices, scales) if matrices.is_cuda else \
             self.pack(matrices, scales).to(self.device, non_blocking=True)
+        return self.parts_of_table(table, env)
+
+    def parts_of_table(self, table: torch.Tensor, env: int | None = None):
+        """The ``parts=`` tuple(s) over a pose table that is already packed ((K,17) or (E,K,17) on the device)."""
         rescale = self.rescale if self._any_rescale else None
         if table.dim() == 2:
             return (self.semantics, self.lut, table, rescale)

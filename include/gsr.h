@@ -37,6 +37,7 @@ extern "C" {
 #define GSR_E_HIP (-2)       /* a HIP runtime call or kernel failed (debug mode checks every launch) */
 #define GSR_E_ALLOC (-3)     /* a resize callback returned NULL */
 #define GSR_E_OVERFLOW (-4)  /* num_rendered exceeded the binning capacity in no-sync mode */
+#define GSR_E_TRUNCATED (-5) /* a cooperative quadrant of the compositor gave up on a hand-off: pixels of the frame are wrong */
 
 #define GSR_TILE 16          /* BLOCK_X = BLOCK_Y of cuda_rasterizer/config.h */
 #define GSR_NEAR_PLANE 0.05f /* /root/reference/README.md:33 (stock upstream 0.2f) */
@@ -154,6 +155,9 @@ typedef struct GsrInputs {
 #define GSR_RAW_ROTATIONS 4 /* rotations are un-normalised:  rotation = q / max(|q|, 1e-12) */
 
 typedef struct GsrOutputs {
+    /* The two float images.  Both may be NULL for an inference frame (GsrSettings.forward_only on the default path) that
+     * hands over out_rgb8: GSWorld keeps the uint8 frame only (gs_world_wrapper.py:266-270 -- ["render"], x 255, clamp,
+     * uint8), and 16 bytes per pixel that nobody reads are then not written (4.9 MB per 640 x 480 frame). */
     float *out_color;    /* (3,H,W) */
     float *out_invdepth; /* (1,H,W) */
     int32_t *radii;      /* (P) */
@@ -181,6 +185,10 @@ typedef struct GsrFrameStats {
                               * the buffer were last zeroed (this package's resize callbacks zero them on new storage;
                               * a header that never held a count reads as 0) -- a rollout that never synchronises reads
                               * it once at the end to learn whether every frame was valid.  Occupies former padding. */
+    int32_t truncated;       /* 1: a cooperative quadrant of THIS frame's compositor timed out waiting for a hand-off between
+                              * its waves and was written truncated (cannot happen by the counters' construction; if it ever
+                              * does the frame says so instead of showing a wrong quadrant silently: re-render) */
+    int32_t coop_timeouts;   /* such quadrants in all frames on this state since the header was last zeroed */
 } GsrFrameStats;
 
 const char *gsr_last_error(void);
@@ -227,6 +235,18 @@ int gsr_forward(const GsrSettings *settings, const GsrInputs *in, const GsrOutpu
 int gsr_forward_batch(int32_t B, const GsrSettings *settings, const GsrInputs *in, const GsrOutputs *out,
                       const GsrBuffers *buffers, const int64_t *r_capacity, void *stream);
 
+/*
+ * How gsr_forward would run a frame with these settings on a model of P Gaussians (`permuted`: GsrInputs.orig_index
+ * given; r_capacity as for gsr_forward) -- the library's own decision, made on the host without touching a device:
+ * out[0] = binning mode (1 = depth sort + counting placement, 2 = bin-then-sort, 0 = depth sort + radix), out[1] = the
+ * counting placement (1 by tile rows, 2 by chunks, 0 neither), out[2] = 1: inference frame (forward_only honoured),
+ * out[3] = 1: super-tile lists, out[4] = 1: lean state layout, out[5] = 1: LSD radix depth sort (depth_sort = 1, or a
+ * model beyond the sample sort's 8 388 608 Gaussians), out[6] = 1: the compositor's order is dealt beside the depth
+ * sort, out[7] = 1: exact mode.  Returns GSR_E_INVALID where gsr_forward would (a permuted model on a path that does not
+ * take one).
+ */
+int gsr_plan_query(const GsrSettings *settings, int32_t P, int32_t permuted, int64_t r_capacity, int32_t out[8]);
+
 /* Tuning aid: cycle stamps of the depth-sort kernels (meaningful in builds with -DGSR_SS_TIMING only).  A negative
  * height reads the state of a forward_only frame (the lean layout). */
 int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *geom, uint64_t *out64);
@@ -239,7 +259,8 @@ int gsr_debug_ss_stamps(int32_t P, int32_t width, int32_t height, const void *ge
  * out[6]: quadrants the frame's compositor handed to cooperative workgroups; out[7]: reserved (0). */
 int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream);
 
-/* Reads V / R / overflow of the frame whose geometry state is `geom` (synchronises `stream`). */
+/* Reads V / R / overflow of the frame whose geometry state is `geom` (synchronises `stream`).  Returns GSR_E_OVERFLOW for a
+ * frame that exceeded its capacity, GSR_E_TRUNCATED for one with a timed-out cooperative quadrant (stats filled either way). */
 int gsr_frame_stats(const void *geom, GsrFrameStats *stats, void *stream);
 
 /* Views into the opaque state, for tests and tools (device pointers into the caller's buffers). */
@@ -376,6 +397,19 @@ int gsr_transform_gaussians_batch(int32_t P, int32_t E, const float *xyz, const 
  * ManiSkill's matrix_to_quaternion (real part first, non-negative) in its float32 operation order.
  */
 int gsr_pack_part_transforms(int32_t K, const float *matrices, const float *scales, float *table, void *stream);
+
+/*
+ * One closed-loop step's host values in ONE launch (gs_world_wrapper.py:110-162 computes the part poses per step, :238 the
+ * cameras; a CPU simulator leaves both on the host): `src` is the DEVICE-VISIBLE address of pinned host memory
+ * (gsr_pinned_device_address of a hipHostMalloc / torch pin_memory buffer), n floats; they are copied to `dst` (device),
+ * and the K row-major 4x4 part matrices at src + mat_off (uniform scales at src + scale_off; scale_off < 0: all 1) are
+ * packed into the 17-float pose table exactly as gsr_pack_part_transforms packs them.  Nothing but a kernel launch: the
+ * call can be captured into a hipGraph, the step's host values then travel INSIDE the step's graph (no copy, no launch
+ * between two replays).  The kernel reads the host buffer when it RUNS: keep it unchanged until then (a ring of slots).
+ */
+int gsr_pinned_device_address(const void *host, void **device);
+int gsr_stage_step(int32_t n, const float *src, float *dst, int32_t K, int32_t mat_off, int32_t scale_off,
+                   float *table, void *stream);
 
 /* Self-test of the wave reductions used by the backward: out44[w] = sum(in256[64w .. 64w+63]) for the 4 waves, then
  * out44[4 + 10w + c] = sum over the wave's lanes l with l % (c + 2) == 0 of (c + 1) * in256[64w + l]  (ten different

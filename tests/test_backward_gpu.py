@@ -159,22 +159,19 @@ def test_config5_full_size_gradients_against_the_oracle(cuda_device, capsys):
     """BASELINE.json configs[4] at FULL size -- 500 k Gaussians, 800x800 -- all eight gradients against the backward
     oracle (float64 sums; ~20 s of host time).  render_backward_kernel takes one hardware reciprocal of (1 - alpha) per
     hit instead of two correctly rounded divisions (backward.hip, round 3): this is the assertion of what that costs at
-    the size the step is benchmarked at -- the suite's bounds (99.95 % of the elements within 2e-3 relative, worst
-    normalised error 5e-3) must hold here too, and the worst figure is printed for the record."""
+    the size the step is benchmarked at -- EVERY element within 2e-3 of its output's scale, in every run."""
     raw = scenes.random_scene_camera_frame(500_000, seed=5, near_fraction=0.0)
-    # The worst element is summation noise -- the kernels add a Gaussian's contributions with float atomics in whatever
-    # order the waves retire, the oracle in binary64 -- so it moves from run to run (3.0e-4 .. 1.7e-3 observed on one
-    # build).  The bar is 2e-3 on EVERY element; a run above it gets one repeat, and both figures are printed.
-    worsts = []
-    for attempt in range(2):
-        rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw, **hb.SUITE_TOLERANCES)
-        worsts.append(max(v["max_norm_err"] for v in rep.values()))
-        with capsys.disabled():
-            print(f"\n[configs[4] full size] worst normalised gradient error {worsts[-1]:.3e}; per output: " +
-                  ", ".join(f"{k} {v['max_norm_err']:.1e} ({100 * v['frac_within']:.3f} % within 2e-3)" for k, v in rep.items()))
-        if worsts[-1] <= 2e-3:
-            break
-    assert min(worsts) <= 2e-3, f"worst normalised gradient error {worsts} > 2e-3 at configs[4] size"
+    # ONE run, no repeat (rounds 3-5 allowed a second try: the worst element moved between 1.9e-4 and 1.7e-3 from run to
+    # run).  That was the ORDER in which a Gaussian's per-tile sums reached its record -- device-scope binary32 atomics in
+    # whatever order the tiles' workgroups retire; the record is binary64 since round 6 (backward.hip, GsrGradWord) and the
+    # figure is the same in every run: 9.3e-4 on this build (profiles/round6/config5_gradient_bound.txt: four runs each
+    # way, same box).  What is left is float arithmetic inside a tile against the oracle's binary64: a bound, not noise.
+    rep = hb.run_case(500_000, 800, 800, seed=5, scale_boost=0.0, raw=raw, **hb.SUITE_TOLERANCES)
+    worst = max(v["max_norm_err"] for v in rep.values())
+    with capsys.disabled():
+        print(f"\n[configs[4] full size] worst normalised gradient error {worst:.3e}; per output: " +
+              ", ".join(f"{k} {v['max_norm_err']:.1e} ({100 * v['frac_within']:.3f} % within 2e-3)" for k, v in rep.items()))
+    assert worst <= 2e-3, f"worst normalised gradient error {worst} > 2e-3 at configs[4] size"
     assert set(rep) >= {"dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"}
 
 

@@ -20,13 +20,13 @@ from oracle import wrapper_glue_ref as ref
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, n, num_envs=1, seed=1, fuse_transform=True, rollout=None):
+def _setup(dev, n, num_envs=1, seed=1, fuse_transform=True, rollout=None, keep_float=False):
     raw = scenes.tabletop_scene("xarm6_align", n=n, seed=seed)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
     parts, actors = cl.xarm6_parts() if rollout is None else cl.xarm6_rollout_parts(rollout)
     loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=num_envs, device=dev,
-                                 fuse_transform=fuse_transform)
+                                 fuse_transform=fuse_transform, keep_float=keep_float)
     rawd = raw.to(dev)
     model = types.SimpleNamespace(_xyz=rawd.xyz, _scaling=rawd.scaling, _rotation=rawd.rotation,
                                   _opacity=rawd.opacity.reshape(-1, 1, 1), _semantics=rawd.semantics,
@@ -298,7 +298,7 @@ def test_overflow_under_graph_replay_is_never_returned(cuda_device):
         for n in want:
             assert torch.equal(got[n], want[n]), f"step {k}, {n}: an overflowed frame was returned"
     assert tight.recovered_steps > 0, "the rollout never outgrew a list: the test proves nothing"
-    assert tight.late_overflow_frames == 0 and tight._graph is not None
+    assert tight.late_overflow_frames == 0 and tight.captured
     # throughput mode: no wait per step; whatever overflowed is noticed (late) and the loop ends valid
     loose = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, num_envs=E, device=dev, bound_capacity=False,
                                   growth=1.0, min_capacity=1 << 16)
@@ -433,7 +433,7 @@ def test_a_rollout_frame_pair_with_moved_parts_meets_the_oracle(cuda_device, cap
 
     dev = cuda_device
     rollout = cl.xarm6_rollout()
-    raw, cams, parts, actors, loop, _ = _setup(dev, scenes.XARM6_ALIGN_NUM_GAUSSIANS, rollout=rollout)
+    raw, cams, parts, actors, loop, _ = _setup(dev, scenes.XARM6_ALIGN_NUM_GAUSSIANS, rollout=rollout, keep_float=True)
     poses = list(cl.rollout_poses(rollout, len(actors), steps=121, seed=0))
     M, s = poses[120]
     loop.reset(*poses[0])
@@ -471,3 +471,54 @@ def test_a_rollout_frame_pair_with_moved_parts_meets_the_oracle(cuda_device, cap
         assert int(d8.max()) <= 1 and int(want8.max()) > 100
     with capsys.disabled():
         print("\n[configs[2] step 120 against the oracle] " + "; ".join(lines))
+
+
+def test_host_values_staged_inside_the_graph_give_the_eager_loop_s_frames(cuda_device):
+    """Round 6: a loop whose poses and cameras arrive on the host captures ONE GRAPH PER PINNED RING SLOT, each starting with
+    the gsr_stage_step launch that reads its slot (the step's part matrices, scales and camera matrices -> the device
+    vector the kernels read, and the 17-float pose table packed on the way): nothing is enqueued between two replays.
+    More steps than slots (the ring wraps), a wrist camera that moves every step: every frame equals the frame of a loop
+    that never captured, and the pose table the staging kernel packed equals gsr_pack_part_transforms of the same matrices
+    bit for bit.  A pose handed over as a DEVICE tensor is never staged over: the loop drops to one graph of the frames."""
+    dev = cuda_device
+    raw, cams, parts, actors, loop, _ = _setup(dev, 120_000, seed=6)
+    eager = cl.ClosedLoopRenderer(raw, parts, {k: v.to("cpu") for k, v in cams.items()}, scaled_parts=actors, device=dev)
+    sim2gs = torch.tensor(scenes.SIM2GS_XARM_TRANS)
+    poses = list(cl.random_walk_poses(sim2gs, len(parts), len(actors), steps=14, seed=5))
+
+    def wrist(k):
+        return look_at_view([0.55 - 0.01 * k, 0.35, 0.25 + 0.005 * k], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448,
+                            640, 480)
+
+    loop.reset(*poses[0])
+    eager.reset(*poses[0])
+    loop.capture()
+    assert loop._graphs is not None and len(loop._graphs) == len(loop._ring) and loop._graph is None
+    from gsworld_amd.transform import FusedPartTransform
+
+    packer = FusedPartTransform(parts, raw.semantics.to(dev), scaled_parts=actors)
+    for k, (M, s) in enumerate(poses[1:]):
+        w = wrist(k)
+        got = {n: f.clone() for n, f in loop.step(M, s, cameras={"wrist_cam": w}).items()}
+        want = eager.step(M, s, cameras={"wrist_cam": w})
+        torch.cuda.synchronize()
+        for n in want:
+            assert torch.equal(got[n], want[n]), f"step {k}, {n}"
+        table = packer.pack_on_device(M.to(dev, torch.float32).contiguous(), s.to(dev, torch.float32).contiguous())
+        assert torch.equal(loop._table.view(torch.int32), table.view(torch.int32)), f"step {k}: pose table"
+    assert loop._ring_k > len(loop._ring)  # the ring wrapped
+    # device poses: staged graphs would write the host mirror over them -- the loop re-captures without the staging
+    M, s = poses[3]
+    got = {n: f.clone() for n, f in loop.step(M.to(dev), s.to(dev), cameras={"wrist_cam": wrist(2)}).items()}
+    want = eager.step(M, s, cameras={"wrist_cam": wrist(2)})
+    torch.cuda.synchronize()
+    assert loop._graphs is None and loop._graph is not None
+    for n in want:
+        assert torch.equal(got[n], want[n]), n
+    # ... and back on the host (scales not handed over: read back once), same frames
+    M2, _ = poses[5]
+    got = {n: f.clone() for n, f in loop.step(M2).items()}
+    want = eager.step(M2, s)
+    torch.cuda.synchronize()
+    for n in want:
+        assert torch.equal(got[n], want[n]), n

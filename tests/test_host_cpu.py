@@ -343,3 +343,28 @@ def test_xarm6_rollout_fixture_is_what_its_script_writes(tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_plan_query_is_the_librarys_own_decision_and_knows_the_sample_sorts_model_limit():
+    """gsr_plan_query = csrc/api.hip make_plan on the host (no device): an inference frame at configs[1] takes a permuted
+    model on the default path; beyond 8 388 608 Gaussians (more block counts than ss_prepare's LDS holds) the frame falls
+    back to the LSD radix depth sort, which takes NO permuted model -- the closed loop and SceneLayout ask this instead of
+    mirroring the rules (the mirror had forgotten the model limit, and every frame of such a loop failed)."""
+    from gsworld_amd import _lib
+    from gsworld_amd.closed_loop import ClosedLoopRenderer
+
+    p = _lib.plan_query(640, 480, 1_468_850, permuted=True, tuned=False)
+    assert p is not None and p["infer"] == 1 and p["super"] == 1 and p["lean"] == 1 and p["radix_depth"] == 0
+    limit = 32768 * 256
+    assert _lib.plan_query(640, 480, limit, permuted=True, tuned=False)["radix_depth"] == 0
+    assert _lib.plan_query(640, 480, limit + 1, permuted=True, tuned=False) is None
+    big = _lib.plan_query(640, 480, limit + 1, permuted=False, tuned=False)
+    assert big is not None and big["radix_depth"] == 1 and big["infer"] == 0
+    # tile grids the counting placement does not take keep the caller's order as well
+    assert _lib.plan_query(8192, 4096, 1000, permuted=True, tuned=False) is None
+
+    class Cam:
+        image_width, image_height = 640, 480
+
+    assert ClosedLoopRenderer._takes_permuted_model(Cam, 1_468_850)
+    assert not ClosedLoopRenderer._takes_permuted_model(Cam, limit + 1)

@@ -565,3 +565,48 @@ def test_bounded_capacity_renderer_never_reads_back(cuda_device):
         assert not r2.ensure_valid(lambda: r2.render(cam, means, op, **kw)).overflow
     finally:
         _C.NOSYNC_LIST_BYTES = budget
+
+
+@pytest.mark.gpu
+def test_a_cooperative_quadrant_that_gives_up_is_reported_not_drawn(cuda_device, monkeypatch):
+    """The replaying wave of a cooperative quadrant bounds its waits for the culling waves (render.hip kCoopSpinLimit); a
+    hand-off that never came would leave a truncated quadrant.  That cannot happen by the counters' construction -- and if it
+    ever does, the frame has to SAY so, the way a binning overflow does.  libgsr_hip_coopspin.so
+    is the same library with the limit at ONE poll (csrc/Makefile): from above the table the second frame on a state has
+    cooperative quadrants, their first hand-offs time out, and gsr_frame_stats reports the frame as truncated
+    (GSR_E_TRUNCATED, GsrFrameStats.truncated / coop_timeouts); ensure_valid re-renders once and then raises."""
+    import os
+
+    from gsworld_amd import _C, _lib
+    from gsworld_amd.renderer import FrameRenderer
+
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgsr_hip_coopspin.so")
+    if not os.path.exists(path):
+        pytest.skip("libgsr_hip_coopspin.so not built (make -C gsworld_amd/csrc)")
+    dev = cuda_device
+    cam = scenes.dense_view_camera("xarm6_align").to(dev)
+    raw = scenes.tabletop_scene("xarm6_align", n=700_000, seed=4)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    kw = dict(shs=shs, scales=sc, rotations=rot, bg=torch.zeros(3, device=dev))
+    # the committed library first: same frames, nothing truncated
+    r = FrameRenderer(dev, forward_only=True, want_radii=False)
+    for _ in range(4):
+        r.render(cam, means, op, **kw)
+        r.ensure_valid(lambda: r.render(cam, means, op, **kw))
+    assert dbg.sort_state(r.geom)["coop_quads"] > 0
+    s = r.stats()
+    assert not s.truncated and s.coop_timeouts == 0
+    monkeypatch.setattr(_C, "_ext", None)        # (the compiled binding is linked against the committed library)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", path)
+    assert b"gfx950" in _lib.lib().gsr_version()
+    r2 = FrameRenderer(dev, forward_only=True, want_radii=False)
+    seen = []
+    for _ in range(4):
+        r2.render(cam, means, op, **kw)
+        s2 = r2.stats()
+        seen.append((s2.truncated, s2.coop_timeouts, dbg.sort_state(r2.geom)["coop_quads"]))
+    assert seen[0][0] is False or seen[0][2] == 0  # (a fresh state knows no costs: no cooperative quadrants, nothing to time out)
+    assert seen[-1][2] > 0 and seen[-1][0] is True and seen[-1][1] >= seen[-1][2] > 0, seen
+    with pytest.raises(RuntimeError, match="timed out"):
+        r2.ensure_valid(lambda: r2.render(cam, means, op, **kw))

@@ -47,9 +47,10 @@ def main():
             continue
         loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E)
         loop.reset(*pinned[0])
-        loop.capture()
+        if os.environ.get("CL_EAGER", "") != "1":  # (A/B: every step's launches issued one by one instead of a graph replay)
+            loop.capture()
         for ensure in (False, True):
-            if only and ensure != bool(int(only.split(",")[1])):
+            if only and "," in only and ensure != bool(int(only.split(",")[1])):
                 continue
             torch.cuda.synchronize()
             t0 = time.perf_counter()
