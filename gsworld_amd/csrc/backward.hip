@@ -271,9 +271,28 @@ struct BwdArgs {
 // Per-Gaussian chain rule, one thread per Gaussian, in two kernels: the geometry (2D mean, EWA covariance, 3D
 // covariance -> scale / quaternion, opacity) here, the SH colour below.  As one kernel it held 180 VGPRs (two waves per
 // SIMD) and moved every Gaussian's 2 x 180 bytes of SH through per-lane strided accesses.
+// The kernel writes EVERY element of its outputs -- zeros for the Gaussians the forward culled (round 6): gsr_backward used
+// to clear the seven arrays with a memset in front of every backward, 46 MB per step at configs[4] size for a kernel that
+// then rewrote nearly all of it.  (Measured with it and not kept: the record array cleared the same way -- by the
+// forward for the Gaussians it makes visible, by this kernel behind its read -- instead of by its memset: preprocess
+// 42 -> 52 us and this kernel 24 -> 45 us for the 25 us the two memsets took.)
 __global__ __launch_bounds__(GSR_BLOCK) void geometry_backward_kernel(const BwdArgs a) {
     const int i = blockIdx.x * GSR_BLOCK + (int)threadIdx.x;
-    if (i >= a.P || a.radii[i] <= 0) return;
+    if (i >= a.P) return;
+    if (a.radii[i] <= 0) {
+        a.dL_dopacity[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            a.dL_dmean2D[3 * (size_t)i + k] = 0.f;
+            a.dL_dcolors[3 * (size_t)i + k] = 0.f;
+            a.dL_dmeans3D[3 * (size_t)i + k] = 0.f;
+            if (!a.cov_precomp) a.dL_dscales[3 * (size_t)i + k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
+        if (!a.cov_precomp) *reinterpret_cast<float4 *>(a.dL_drots + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     // (mx, my, cxx, cxy) (cyy, opacity, r, g) (b, 1/depth, -, -): the sums, rounded to binary32 once
     float4 g0, g1, g2;
     {
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(GSR_BLOCK) void geometry_backward_kernel(const BwdA
     a.dL_dopacity[i] = dL_dop_out;
     a.dL_dmean2D[3 * (size_t)i] = g0.x;
     a.dL_dmean2D[3 * (size_t)i + 1] = g0.y;
+    a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
     a.dL_dcolors[3 * (size_t)i] = g1.z;
     a.dL_dcolors[3 * (size_t)i + 1] = g1.w;
     a.dL_dcolors[3 * (size_t)i + 2] = g2.x;
@@ -588,11 +608,13 @@ __global__ __launch_bounds__(GSR_BLOCK) void sh_backward_kernel(const BwdArgs a)
         const float len = sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
         const float x = ox / len, y = oy / len, z = oz / len;
         const uint32_t cl = a.clamped[i];
-        const GsrGradWord *rec = a.grad_rec + 12 * (size_t)i;
+        // (the three colour sums, as geometry_backward_kernel -- the record's only reader, launched in front of this
+        //  kernel -- left them in dL_dcolors)
+        const float *rec = a.dL_dcolors + 3 * (size_t)i;
         float dRGB[3];
-        dRGB[0] = (cl & 0xffu) ? 0.f : (float)rec[6];
-        dRGB[1] = (cl & 0xff00u) ? 0.f : (float)rec[7];
-        dRGB[2] = (cl & 0xff0000u) ? 0.f : (float)rec[8];
+        dRGB[0] = (cl & 0xffu) ? 0.f : rec[0];
+        dRGB[1] = (cl & 0xff00u) ? 0.f : rec[1];
+        dRGB[2] = (cl & 0xff0000u) ? 0.f : rec[2];
         ShBasis b;
         sh_basis(a.D, x, y, z, b);
         const int nb = (a.D + 1) * (a.D + 1);
@@ -753,11 +775,14 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
         const size_t n = (size_t)(P > 0 ? P : 0);
         const size_t m_dc = in->shs_rest ? 1u : (size_t)M, m_rest = in->shs_rest ? (size_t)M - 1u : 0u;
         constexpr int NR = 9;
+        // (with work to do, geometry_backward_kernel writes every element of the seven per-Gaussian arrays itself)
+        const bool geo = !work;
         struct Range { char *p; size_t bytes; } r[NR] = {
-            {(char *)gr->dL_dmeans2D, 3 * n * 4}, {(char *)gr->dL_dcolors, 3 * n * 4}, {(char *)gr->dL_dopacity, n * 4},
-            {(char *)gr->dL_dmeans3D, 3 * n * 4}, {(char *)gr->dL_dcov3D, 6 * n * 4},
-            {(char *)(sh_self_clearing ? nullptr : gr->dL_dsh), 3 * n * m_dc * 4}, {(char *)gr->dL_dscales, 3 * n * 4},
-            {(char *)gr->dL_drots, 4 * n * 4},
+            {(char *)(geo ? gr->dL_dmeans2D : nullptr), 3 * n * 4}, {(char *)(geo ? gr->dL_dcolors : nullptr), 3 * n * 4},
+            {(char *)(geo ? gr->dL_dopacity : nullptr), n * 4}, {(char *)(geo ? gr->dL_dmeans3D : nullptr), 3 * n * 4},
+            {(char *)(geo ? gr->dL_dcov3D : nullptr), 6 * n * 4},
+            {(char *)(sh_self_clearing ? nullptr : gr->dL_dsh), 3 * n * m_dc * 4},
+            {(char *)(geo ? gr->dL_dscales : nullptr), 3 * n * 4}, {(char *)(geo ? gr->dL_drots : nullptr), 4 * n * 4},
             {(char *)(in->shs_rest && !sh_self_clearing ? gr->dL_dsh_rest : nullptr), 3 * n * m_rest * 4}};
         for (int i = 1; i < NR; i++)  // insertion sort by address
             for (int j = i; j > 0 && r[j].p < r[j - 1].p; j--) {
@@ -769,7 +794,7 @@ extern "C" int gsr_backward(const GsrSettings *st, const GsrInputs *in, const Gs
             char *p = r[i].p;
             size_t bytes = r[i].bytes;
             int j = i + 1;
-            while (j < NR && p && r[j].p == p + bytes) bytes += r[j++].bytes;
+            while (j < NR && p && r[j].p == p + bytes && r[j].p) bytes += r[j++].bytes;
             if (p && bytes && hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) {
                 gsr_set_error("gsr_backward: hipMemsetAsync failed");
                 return GSR_E_HIP;

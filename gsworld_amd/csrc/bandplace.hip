@@ -532,6 +532,8 @@ struct BandArgs {
     uint32_t *point_list;
     uint32_t r_capacity;  // (the merged scan + starts kernel: what tile_starts_kernel checks R against)
     uint2 *ranges_w;
+    const uint32_t *quad_work;  // (... and its tile-order workgroup: the tiles' costs in the previous frame -> tile_order)
+    uint32_t *tile_order;
 };
 
 template <int NC>
@@ -568,7 +570,11 @@ __global__ __launch_bounds__(kBT, 8) void band_place_kernel(const GsrBatch<BandA
 #define GSR_SCAN_MODE 1
 #endif
 constexpr int kSST = 1024, kSSW = kSST / GSR_WAVE;  // the merged kernel's workgroup
-constexpr int kSSMaxTiles = 8 * kSST;               // totals kept in LDS (32 KiB); larger grids keep the two launches
+constexpr int kSSMaxTiles = 8 * kSST;               // (what the merged kernel's LDS and registers are sized for)
+// ... but ONE workgroup scanning every tile's row is only worth it while the rows are few: 600 super-tiles (640 x 480
+// inference frames) 8.4 us against 5.0 + 4.9 for the two launches; 2 500 tiles (800 x 800 training frames) 24 us against
+// 5.1 + 9.3 -- larger grids keep the two launches
+constexpr int kSSMergeTiles = 1024;
 static_assert(GSR_BAND_RANGES == GSR_WAVE, "a tile's row of the band table is one entry per lane");
 
 // totals[T] (LDS or global) -> ranges, R, capacity check: THREADS threads, each owns `per` consecutive tiles
@@ -641,12 +647,26 @@ __device__ __forceinline__ void band_scan_starts_body(uint32_t *__restrict__ tab
     band_starts_block<kSST, kSSMaxTiles / kSST>(s_tot, T, hdr, r_capacity, ranges, s_wv);
 }
 
-// (grid.x = 2: workgroup 1 -- its first four waves -- computes the next frame's cuts)
+// (grid.x = 2 or 3: workgroup 1 -- its first four waves -- computes the next frame's cuts; workgroup 2, where the frame's
+//  compositor takes its tiles in the order of their cost in the previous frame and nobody dealt them earlier -- training
+//  frames, grids above 2048 tiles -- sorts the tiles by that cost: tile_starts_kernel's second workgroup)
 __global__ __launch_bounds__(kSST) void band_scan_starts_kernel(const GsrBatch<BandArgs> bt) {
     const BandArgs &a = bt.f[blockIdx.y];
     if (blockIdx.x == 1) {
         if (threadIdx.x >= kBT) return;  // (the waves that stay meet at their own barriers: finished waves do not count)
         band_cuts_next(a.hdr, a.bucket_start, a.bucket_tiles, a.tile_cum, a.wave_lo_base, a.sig);
+        return;
+    }
+    if (blockIdx.x == 2) {
+        if (threadIdx.x >= kBT) return;
+        __shared__ uint32_t s_bins[64], s_red[4];
+        uint32_t key[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int t = (int)threadIdx.x + i * kBT;
+            key[i] = t < a.T ? gsr_tile_order_key(nullptr, a.quad_work, t) : 0u;
+        }
+        gsr_tile_order_block_keys<32>(key, a.T, a.tile_order, s_bins, s_red);
         return;
     }
     band_scan_starts_body(a.table, a.T, a.hdr, a.r_capacity, a.ranges_w);
@@ -719,6 +739,8 @@ static void band_args(int B, const GsrFrame *fr, bool balanced, bool place, GsrB
         a.ranges = fr[k].img.ranges;
         a.ranges_w = fr[k].img.ranges;
         a.r_capacity = fr[k].cap32;
+        a.quad_work = fr[k].img.quad_work;
+        a.tile_order = fr[k].img.tile_order;
         a.point_list = place ? fr[k].b.gidx[0] : (uint32_t *)nullptr;
     }
 }
@@ -741,11 +763,14 @@ int gsr_launch_band_count(int B, const GsrFrame *fr, bool balanced, bool merge_s
     const int T = gx * gy;
     // (merged: nothing but the ranges is asked of tile_starts_kernel -- the compositing order was dealt earlier in the frame
     //  (merge_starts) and there are no quadrants to split: the default path)
-    const bool merged = GSR_SCAN_MODE != 0 && merge_starts && T <= kSSMaxTiles &&
-                        (T > 2048 || gsr_render_split_blocks(st, T) == 0);
+    // what else tile_starts_kernel would do for this frame: nothing (the quadrants were dealt beside the depth sort:
+    // merge_starts), or the tile order by last frame's costs (a compositor that wants one and has no quadrant deal)
+    const bool by_tiles = !merge_starts && gsr_render_wants_tile_order(st, T) && !gsr_render_uses_quad_order(st, T);
+    const bool merged = GSR_SCAN_MODE != 0 && (merge_starts || (by_tiles && GSR_SCAN_MODE == 1)) && T <= kSSMergeTiles &&
+                        gsr_render_split_blocks(st, T) == 0;
     if (starts_done) *starts_done = merged;
     if (merged && GSR_SCAN_MODE == 1) {
-        hipLaunchKernelGGL(band_scan_starts_kernel, dim3(2, B), dim3(kSST), 0, stream, bt);
+        hipLaunchKernelGGL(band_scan_starts_kernel, dim3(by_tiles ? 3 : 2, B), dim3(kSST), 0, stream, bt);
         return gsr_check_launch("band_scan_starts", debug, stream);
     }
     if (merged) {

@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
                                                         uint32_t *__restrict__ tile_cum, uint32_t *__restrict__ bucket_tiles,
                                                         GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0,
                                                         const float *__restrict__ view, uint32_t sig, int sshift,
-                                                        const int32_t *__restrict__ orig) {
+                                                        const int32_t *__restrict__ orig, const int bucket) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
@@ -1072,20 +1072,20 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     const uint32_t V = hdr->V;
     if (V == 0u) return;
     const int B = (int)hdr->ss_B;
-    if ((int)blockIdx.x >= B) return;
-    if (blockIdx.x == 0 && tid == 0) {
+    if (bucket >= B) return;
+    if (bucket == 0 && tid == 0) {
         hdr->ss_magic = kSplitMagic;
         hdr->ss_buckets = (uint32_t)B;
         hdr->ss_P = sig;
     }
-    if (blockIdx.x == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
-    const uint32_t s = bucket_start[blockIdx.x];
-    const int n = (int)(bucket_start[blockIdx.x + 1] - s);
+    if (bucket == 0 && tid < 16) hdr->ss_view[tid] = __float_as_uint(view[tid]);
+    const uint32_t s = bucket_start[bucket];
+    const int n = (int)(bucket_start[bucket + 1] - s);
     // above what the exact quantiles of the last frame give when nothing moved (share V / B, plus depth ties): the scene
     // is changing under the camera, the next frames check the kept table against samples (ss_compact_kernel)
     if (tid == 0 && (uint32_t)n > (V / (uint32_t)B) + (V / (uint32_t)B) / 4u + 64u) hdr->ss_bad = 1u;
     if (n == 0) {
-        if (tid == 0) bucket_tiles[blockIdx.x] = 0u;
+        if (tid == 0) bucket_tiles[bucket] = 0u;
         return;
     }
     uint2 *seg = recs + s;
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
             }
             __syncthreads();  // the LDS halves are free for the next piece
         }
-        if (tid == 0) bucket_tiles[blockIdx.x] = carry;
+        if (tid == 0) bucket_tiles[bucket] = carry;
         return;
     }
     SS_STAMP(dbg, 1);
@@ -1355,8 +1355,191 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     fix_ties(src, n);
     const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
     const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i] + kbase); }, s, n, 0u);
-    if (tid == 0) bucket_tiles[blockIdx.x] = carry;
+    if (tid == 0) bucket_tiles[bucket] = carry;
     SS_STAMP(dbg, 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ss_buckets, a WAVE per bucket (round 6).  A frame that samples cuts the depth order into buckets of <= 512 records on
+// average (290 at configs[2]'s closed loop): for a workgroup of four waves that is one record per thread and some twenty
+// workgroup barriers -- two LSD passes of (zero, count, scan, rank), the tie fix-up, the emit's scans -- on a launch that
+// does not fill the chip: the kernel lasted as long as one such chain (21 us for the two frames of a closed-loop step;
+// 1 024 workgroups of 862 records in the dense view: 38 us, "four workgroups per CU stand in each other's way").  Here a
+// wave takes a bucket by itself: its records live in wave-private LDS (lane l, round r = record 64 r + l), the LSD passes
+// rank with wave-wide match masks, scans are DPP scans, and nothing waits at a workgroup barrier; four buckets per
+// workgroup.  Buckets above kWaveCap records (an unlucky sampled table, depth ties, a scene that jumped) are left to the
+// workgroup path, which the four waves then run together, one such bucket after the other.  Same order, same outputs.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kWaveCap = 512;
+constexpr int kWaveLds = 4 * kWaveCap + 256;  // words per wave: keys and values, two halves each, + 256 digit cursors
+
+// one stable LSD pass (8-bit digit at `shift`) over the wave's n records
+__device__ __forceinline__ void ss_wave_radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+                                                   int n, int shift, uint32_t *cur) {
+    const int lane = gsr_lane();
+    const uint64_t lt = gsr_lanemask_lt();
+    const int rounds = (n + GSR_WAVE - 1) >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[4 * lane + k] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < rounds; r++) {
+        const int i = (r << 6) + lane;
+        if (i < n) atomicAdd(&cur[(kin[i] >> shift) & 255u], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t c0 = cur[4 * lane], c1 = cur[4 * lane + 1], c2 = cur[4 * lane + 2], c3 = cur[4 * lane + 3];
+        const uint32_t sum = c0 + c1 + c2 + c3;
+        const uint32_t excl = gsr_wave_incl_scan(sum) - sum;
+        cur[4 * lane] = excl;
+        cur[4 * lane + 1] = excl + c0;
+        cur[4 * lane + 2] = excl + c0 + c1;
+        cur[4 * lane + 3] = excl + c0 + c1 + c2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < rounds; r++) {
+        const int i = (r << 6) + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? kin[i] : 0u;
+        const uint32_t val = valid ? vin[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        const uint64_t same = ss_match(d, 8, valid);
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        if (valid) {
+            const uint32_t pos = cur[d] + rank;
+            kout[pos] = key;
+            vout[pos] = val;
+        }
+        __builtin_amdgcn_wave_barrier();  // every lane has read its cursor before the group leader moves it
+        if (valid && rank == 0u) cur[d] += (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the whole of ss_buckets_body for one bucket of n <= kWaveCap records, by ONE wave; lds: this wave's kWaveLds words
+__device__ __forceinline__ void ss_bucket_wave(const int bucket, const int B, const uint32_t V, const uint32_t s, const int n,
+                                               const uint2 *__restrict__ recs, uint32_t *__restrict__ order,
+                                               uint32_t *__restrict__ splitters, const uint2 *__restrict__ rects,
+                                               uint2 *__restrict__ rect_sorted, uint32_t *__restrict__ tile_cum,
+                                               uint32_t *__restrict__ bucket_tiles, const int sshift,
+                                               const int32_t *__restrict__ orig, uint32_t *lds) {
+    const int lane = gsr_lane();
+    uint32_t *s_k = lds, *s_v = lds + 2 * kWaveCap, *cur = lds + 4 * kWaveCap;
+    if (n == 0) {
+        if (lane == 0) bucket_tiles[bucket] = 0u;
+        return;
+    }
+    constexpr int kR = kWaveCap / GSR_WAVE;
+    const int rounds = (n + GSR_WAVE - 1) >> 6;
+    // ---- the records, every load in flight at once; keys go to the LDS as offsets from the bucket's smallest
+    uint2 r[kR];
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+    for (int e = 0; e < kR; e++) {
+        const int i = (e << 6) + lane;
+        r[e] = i < n ? recs[s + (uint32_t)i] : make_uint2(0u, 0xFFFFFFFFu);
+        if (i < n) {
+            kmn = min(kmn, r[e].y);
+            kmx = max(kmx, r[e].y);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, o, 64));
+        kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o, 64));
+    }
+#pragma unroll
+    for (int e = 0; e < kR; e++) {
+        const int i = (e << 6) + lane;
+        if (i < n) {
+            s_k[i] = r[e].y - kmn;
+            s_v[i] = r[e].x;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t range = kmx - kmn;
+    const int bits = range == 0u ? 0 : 32 - __builtin_clz(range);
+    int src = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        ss_wave_radix_pass(s_k + src * kWaveCap, s_v + src * kWaveCap, s_k + (src ^ 1) * kWaveCap, s_v + (src ^ 1) * kWaveCap, n,
+                           shift, cur);
+        src ^= 1;
+    }
+    uint32_t *kk = s_k + src * kWaveCap, *vv = s_v + src * kWaveCap;
+    // ---- a permuted model: runs of equal depth in the order of the ORIGINAL numbers (ss_buckets_body fix_ties, wave form:
+    // odd-even transposition over the pairs of equal keys, a ballot per round instead of a workgroup barrier)
+    if (orig != nullptr) {
+        uint32_t *oo = s_v + (src ^ 1) * kWaveCap;  // (the free half: original numbers of the run members)
+        bool eq[kR];
+        int any = 0;
+#pragma unroll
+        for (int e = 0; e < kR; e++) {
+            const int i = (e << 6) + lane;
+            eq[e] = e < rounds && i + 1 < n && kk[i] == kk[i + 1];
+            const bool prev = e < rounds && i > 0 && i < n && kk[i - 1] == kk[i];
+            if (eq[e] || prev) {
+                oo[i] = (uint32_t)orig[vv[i]];
+                any = 1;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any != 0) != 0ull) {
+            __builtin_amdgcn_wave_barrier();
+            int quiet = 0;
+            for (int round = 0; quiet < 2; round++) {
+                int moved = 0;
+#pragma unroll
+                for (int e = 0; e < kR; e++) {
+                    const int i = (e << 6) + lane;
+                    if (eq[e] && ((i ^ round) & 1) == 0) {
+                        const uint32_t o0 = oo[i], o1 = oo[i + 1];
+                        if (o0 > o1) {
+                            const uint32_t v0 = vv[i], v1 = vv[i + 1];
+                            oo[i] = o1; oo[i + 1] = o0;
+                            vv[i] = v1; vv[i + 1] = v0;
+                            moved = 1;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                quiet = __builtin_amdgcn_ballot_w64(moved != 0) != 0ull ? 0 : quiet + 1;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- what leaves the kernel: next frame's splitters (the exact B-quantiles of this frame's order: rank
+    // floor((i + 1) V / B) for splitter i, written by whoever holds it), depth order, rects in that order, running cost
+    {
+        const uint64_t lo = ((uint64_t)s * (uint32_t)B + V - 1u) / V, hi = ((uint64_t)(s + (uint32_t)n) * (uint32_t)B + V - 1u) / V;
+        for (uint64_t j = max(lo, (uint64_t)1) + (uint32_t)lane; j < hi && j < (uint64_t)B; j += GSR_WAVE) {
+            const uint32_t q = (uint32_t)((j * V) >> ss_log2(B));  // rank of splitter j - 1 (B is a power of two)
+            if (q >= s && q < s + (uint32_t)n) splitters[j - 1u] = (kk[q - s] + kmn) & kKeyMask;
+        }
+    }
+    uint32_t gi[kR];
+    uint2 rc[kR];
+#pragma unroll
+    for (int e = 0; e < kR; e++) {
+        const int i = (e << 6) + lane;
+        gi[e] = (e < rounds && i < n) ? vv[i] : 0u;
+        rc[e] = (e < rounds && i < n) ? rects[gi[e]] : make_uint2(0u, 0u);
+    }
+    uint32_t carry = 0u;
+#pragma unroll
+    for (int e = 0; e < kR; e++) {
+        if (e >= rounds) break;
+        const int i = (e << 6) + lane;
+        uint32_t t = 0u;
+        if (i < n) {
+            const uint2 r2 = ss_super_rect(rc[e], sshift);
+            order[s + (uint32_t)i] = gi[e];
+            rect_sorted[s + (uint32_t)i] = r2;
+            t = ((r2.y & 0xffffu) - (r2.x & 0xffffu)) * ((r2.y >> 16) - (r2.x >> 16)) + kRankCost;
+        }
+        const uint32_t incl = gsr_wave_incl_scan(t);
+        if (i < n) tile_cum[s + (uint32_t)i] = carry + incl;
+        carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    if (lane == 0) bucket_tiles[bucket] = carry;
 }
 
 // ---- the four kernels: grid = (workgroups of one frame, frames); blockIdx.y picks the frame's argument block ----------
@@ -1406,10 +1589,56 @@ __global__ __launch_bounds__(kT) void ss_partition_kernel(const GsrBatch<SsArgs>
     ss_partition_body(a.bmax, a.pair0, a.pair1, a.table, a.totals, a.splitters, a.splitters_new, a.seg, a.bucket_start,
                       a.hdr, a.dbg);
 }
+#ifndef GSR_SS_WAVE_BUCKETS
+#define GSR_SS_WAVE_BUCKETS 0  // MEASURED AND NOT KEPT (1 = on): at configs[2]'s closed loop -- 2 x 512 buckets of ~290
+                               // records -- ss_buckets lasted 47 us with a wave per bucket against 21 us with a workgroup
+                               // per bucket (closed loop 7.5 against 8.4 k frames/s; every test green either way): a
+                               // bucket's ten ranking rounds are a chain of dependent LDS round trips, and four waves
+                               // walk a quarter of it each -- the barriers between them were never the price
+#endif
 __global__ __launch_bounds__(kT) void ss_buckets_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
-    ss_buckets_body(a.bmax, a.pair1, a.pair0, a.bucket_start, a.order, a.splitters, a.rects, a.rect_sorted, a.tile_cum,
-                    a.bucket_tiles, a.hdr, a.dbg, a.view, a.sig, a.sshift, a.orig);
+    const uint32_t V = a.hdr->V;
+    if (V == 0u) return;
+    const int B = (int)a.hdr->ss_B;
+    // a frame that took its kept quantiles blind has buckets of up to 1024 records: a workgroup each, as before; a frame
+    // that sampled (buckets of <= 512 on average): a wave each, four buckets per workgroup
+    const bool by_wave = GSR_SS_WAVE_BUCKETS && a.hdr->ss_blind == 0u;
+    if (!by_wave) {
+        ss_buckets_body(a.bmax, a.pair1, a.pair0, a.bucket_start, a.order, a.splitters, a.rects, a.rect_sorted, a.tile_cum,
+                        a.bucket_tiles, a.hdr, a.dbg, a.view, a.sig, a.sshift, a.orig, (int)blockIdx.x);
+        return;
+    }
+    constexpr int NW = kT / GSR_WAVE;
+    if ((int)blockIdx.x * NW >= B) return;
+    extern __shared__ uint32_t smem[];
+    static_assert(NW * kWaveLds <= 4 * kBucketCap + 4 * 256, "the waves' LDS fits the workgroup path's");
+    __shared__ uint32_t s_big[NW];
+    const int tid = (int)threadIdx.x, wave = gsr_wave();
+    const int bucket = (int)blockIdx.x * NW + wave;
+    if (blockIdx.x == 0 && tid == 0) {
+        a.hdr->ss_magic = kSplitMagic;
+        a.hdr->ss_buckets = (uint32_t)B;
+        a.hdr->ss_P = a.sig;
+    }
+    if (blockIdx.x == 0 && tid < 16) a.hdr->ss_view[tid] = __float_as_uint(a.view[tid]);
+    const uint32_t s0 = a.bucket_start[bucket];
+    const int n = (int)(a.bucket_start[bucket + 1] - s0);
+    // (above what the exact quantiles of the last frame give when nothing moved: see ss_buckets_body)
+    if (gsr_lane() == 0) {
+        if ((uint32_t)n > (V / (uint32_t)B) + (V / (uint32_t)B) / 4u + 64u) a.hdr->ss_bad = 1u;
+        s_big[wave] = n > kWaveCap ? 1u : 0u;
+    }
+    if (n <= kWaveCap)
+        ss_bucket_wave(bucket, B, V, s0, n, a.pair1, a.order, a.splitters, a.rects, a.rect_sorted, a.tile_cum, a.bucket_tiles,
+                       a.sshift, a.orig, smem + wave * kWaveLds);
+    __syncthreads();
+    for (int w = 0; w < NW; w++) {  // (rare: the buckets a wave could not hold, by the four waves together)
+        if (s_big[w] == 0u) continue;
+        ss_buckets_body(a.bmax, a.pair1, a.pair0, a.bucket_start, a.order, a.splitters, a.rects, a.rect_sorted, a.tile_cum,
+                        a.bucket_tiles, a.hdr, a.dbg, a.view, a.sig, a.sshift, a.orig, (int)blockIdx.x * NW + w);
+        __syncthreads();
+    }
 }
 
 }  // namespace

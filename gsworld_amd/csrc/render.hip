@@ -750,7 +750,8 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                                                                   uint32_t *__restrict__ quad_work_b,
                                                                   const uint32_t *__restrict__ quad_order,
                                                                   const uint32_t *__restrict__ coop_list,
-                                                                  int coop_blocks, GsrHeader *__restrict__ hdr) {
+                                                                  int coop_blocks, GsrHeader *__restrict__ hdr,
+                                                                  const uint32_t wgx /* workgroup of this frame */) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
@@ -763,11 +764,11 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
         // dispatcher cannot place waits for another to retire -- behind the grid a few of the longest chains of the frame
         // started 35 us late (sensor view 6.7 -> 6.1 k frames/s); in front, what may wait is the main grid's tail, which the
         // deal fills with the cheapest quadrants
-        if (coop_list != nullptr && (int)blockIdx.x < coop_blocks) {
+        if (coop_list != nullptr && (int)wgx < coop_blocks) {
             __shared__ CoopFlags s_coop;
             if (threadIdx.x < sizeof(CoopFlags) / sizeof(uint32_t)) reinterpret_cast<uint32_t *>(&s_coop)[threadIdx.x] = 0u;
             __syncthreads();
-            const uint32_t q = coop_list[blockIdx.x];
+            const uint32_t q = coop_list[wgx];
             if (q >= 4u * (uint32_t)num_tiles) return;  // (no quadrant for this workgroup: 0xFFFFFFFF)
             const bool timed_out = render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg,
                                                               out_color, out_invdepth, rgb8, quad_work, final_T);
@@ -794,7 +795,7 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
     // frame on this state (tile_starts_kernel, workgroup 2) are therefore cut in two 8 x 4 halves: the quadrant's own
     // wave keeps rows 0-3 (its lanes 0-31), a wave of the EXTRA workgroups behind the main grid takes rows 4-7, each
     // with its own, tighter cull rectangle.  Pixels are independent, so the image state does not change by a bit.
-    const uint32_t bx = blockIdx.x - (uint32_t)coop_blocks;  // (coop_blocks is a multiple of 8: workgroup bx on XCD bx mod 8)
+    const uint32_t bx = wgx - (uint32_t)coop_blocks;  // (coop_blocks is a multiple of 8: workgroup bx on XCD bx mod 8)
     const bool extra = (int)bx >= main_blocks;
     uint32_t extra_q = 0;
     if (extra) {
@@ -820,7 +821,7 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
         int tile = extra ? (int)(extra_q >> 2) : (tile_order ? (int)tile_order[unit] : (int)unit);
         int quad = extra ? (int)(extra_q & 3u) : (int)(ticket & 3u);
         if (!extra && quad_order != nullptr && main_blocks >= num_tiles) {
-            // Everything resident: workgroup `unit` (= blockIdx.x) takes the four quadrants the deal of
+            // Everything resident: workgroup `unit` (= wgx) takes the four quadrants the deal of
             // gsr_quad_order_block assigned to it -- four of (nearly) equal cost in the previous frame, from tiles of
             // this workgroup's XCD.  The four waves of a workgroup go to the four SIMDs of its CU, so every SIMD of the CU
             // carries the same load; dealing tiles (four quadrants of unequal cost) left the SIMD loads a sum of five
@@ -1034,16 +1035,24 @@ struct RenderStreamArgs {
     const uint32_t *coop_list;  // cooperative quadrants (null: none): the quadrant of each of the first coop_blocks workgroups
     int coop_blocks;
     GsrHeader *hdr;             // (a cooperative quadrant whose hand-off timed out is counted there)
+    int frames;                 // frames of the launch (the interleaved grid: render_stream_kernel)
 };
 template <bool SUPER>
 __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(
     const GsrBatch<RenderStreamArgs> bt) {
-    const RenderStreamArgs &a = bt.f[blockIdx.y];
-    if ((int)blockIdx.x >= a.total_blocks) return;  // (padding of the row to a multiple of 8)
+    // (grid = (row, frames): the frames' rows one behind the other.  A one-row grid is the A/B variant that interleaves the
+    //  frames eight workgroups at a time, so that every frame's costliest quadrants start at once -- measured slower, see
+    //  GSR_RENDER_INTERLEAVE)
+    const uint32_t frames = gridDim.y == 1u ? (uint32_t)bt.f[0].frames : 1u;
+    const uint32_t grp = blockIdx.x >> 3;
+    const uint32_t frame = gridDim.y == 1u ? grp % frames : blockIdx.y;
+    const uint32_t wgx = gridDim.y == 1u ? (grp / frames) * 8u + (blockIdx.x & 7u) : blockIdx.x;
+    const RenderStreamArgs &a = bt.f[frame];
+    if ((int)wgx >= a.total_blocks) return;  // (padding of the row to a multiple of 8)
     render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
                               a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
                               a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order,
-                              a.coop_list, a.coop_blocks, a.hdr);
+                              a.coop_list, a.coop_blocks, a.hdr, wgx);
 }
 
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
@@ -1220,16 +1229,24 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
                 a.coop_list = coop > 0 ? im.split_list : (const uint32_t *)nullptr;  // (the split list, reused)
                 a.coop_blocks = coop;
                 a.hdr = fr[k].g.hdr;
+                a.frames = B;
                 a.split_list = im.split_list;
                 a.split_count = im.split_count;
                 a.quad_work_b = im.quad_work_b;
                 a.quad_order = use_qorder ? im.quad_order : (const uint32_t *)nullptr;
             }
             const int row = B > 1 ? (blocks + extra + GSR_XCDS - 1) / GSR_XCDS * GSR_XCDS : blocks + extra;
+#ifndef GSR_RENDER_INTERLEAVE
+#define GSR_RENDER_INTERLEAVE 0  // MEASURED AND NOT KEPT (1 = on): the two cameras of a closed-loop step 80.7 -> 93.1 us,
+                                 // four environments 12.6 -> 11.2 k frames/s, the headline 14.7 -> 14.5 k -- a frame's
+                                 // workgroups next to each other in the grid share its lists in the L2s
+#endif
+            const dim3 grid = (GSR_RENDER_INTERLEAVE && B > 1) ? dim3(row * B, 1) : dim3(row, B > 1 ? B : 1);
+            if (B == 1) bt.f[0].frames = 1;
             if (super_tiles)
-                hipLaunchKernelGGL(render_stream_kernel<true>, dim3(row, B), dim3(GSR_BLOCK), 0, stream, bt);
+                hipLaunchKernelGGL(render_stream_kernel<true>, grid, dim3(GSR_BLOCK), 0, stream, bt);
             else
-                hipLaunchKernelGGL(render_stream_kernel<false>, dim3(row, B), dim3(GSR_BLOCK), 0, stream, bt);
+                hipLaunchKernelGGL(render_stream_kernel<false>, grid, dim3(GSR_BLOCK), 0, stream, bt);
         }
         else if (rc.variant == 3)
             hipLaunchKernelGGL(render_queue_kernel<true>, dim3(blocks), dim3(GSR_BLOCK), 0, stream, img.ranges,

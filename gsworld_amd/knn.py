@@ -20,8 +20,14 @@ def _bind():
     return L
 
 
-def distCUDA2(points: torch.Tensor) -> torch.Tensor:
-    """points: (P,3) float32 on a HIP device -> (P,) mean squared distance to the 3 nearest other points."""
+_WORKSPACES: dict = {}  # (device, bytes) -> the last workspace of that size (callers that ask again: no allocation)
+
+
+def distCUDA2(points: torch.Tensor, workspace: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """points: (P,3) float32 on a HIP device -> (P,) mean squared distance to the 3 nearest other points.
+    ``workspace`` / ``out``: optional caller-owned uint8 workspace of ``gsr_knn_workspace_bytes(P)`` bytes and (P,) float32
+    result (a timing loop, a caller that runs the op repeatedly); by default the last workspace of the same size on the
+    device is reused and the result is a fresh tensor, as upstream's."""
     if not points.is_cuda:
         raise RuntimeError(f"distCUDA2: points are on {points.device}; the MI355X op has no CPU path")
     if points.ndim != 2 or points.size(1) != 3:
@@ -29,11 +35,22 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     L = _bind()
     pts = points.detach().to(torch.float32).contiguous()
     P = pts.size(0)
-    out = torch.zeros((P,), dtype=torch.float32, device=pts.device)
+    if out is None:
+        out = torch.zeros((P,), dtype=torch.float32, device=pts.device)
+    elif tuple(out.shape) != (P,) or out.dtype != torch.float32 or out.device != pts.device or not out.is_contiguous():
+        raise RuntimeError("distCUDA2: out must be a dense (P,) float32 tensor on the points' device")
     if P == 0:
         return out
     nbytes = int(L.gsr_knn_workspace_bytes(P))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    ws = workspace
+    if ws is None:
+        key = (pts.device, nbytes)
+        ws = _WORKSPACES.get(key)
+        if ws is None:
+            _WORKSPACES.clear()  # (one size at a time: create_from_pcd calls this once per model)
+            ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    elif ws.numel() < nbytes or ws.dtype != torch.uint8 or ws.device != pts.device:
+        raise RuntimeError(f"distCUDA2: workspace must hold {nbytes} bytes (uint8) on the points' device")
     with torch.cuda.device(pts.device):
         check(L.gsr_knn_dist2(P, C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
                               nbytes, C.c_void_p(torch.cuda.current_stream(pts.device).cuda_stream)))

@@ -296,6 +296,7 @@ class MultiCameraRenderer:
         self.batched = bool(batched)
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)] if not self.batched else []
+        self._set_streams: list = []  # (batched: one per image size beyond the first, created when a step has several)
 
     def render(self, views, means3D, opacities, rgb8_out=None, per_lane=None, **render_kw):
         """``views``: one :class:`gsworld_amd.camera.ViewParams` per camera.  Returns ``[(color, radii, invdepth)]``
@@ -338,8 +339,26 @@ class MultiCameraRenderer:
                 calls.append(call)
                 caps.append((lane, cap))
         if calls:
+            # frames of ONE image size share their launches; a rig with cameras of several sizes (a wrist camera beside a
+            # sensor camera) is several such sets, which have nothing to wait for in each other: each set on a stream of its
+            # own, forked from and joined to the caller's (rounds 2-4 overlapped such frames lane by lane; round 5's batched
+            # path ran them one after the other on the caller's stream)
+            sets: dict = {}
+            for call in calls:
+                sets.setdefault((call["settings"].image_height, call["settings"].image_width), []).append(call)
             with torch.cuda.device(self.device):
-                _C.forward_batch_raw(calls, device=self.device)
+                if len(sets) == 1:
+                    _C.forward_batch_raw(calls, device=self.device)
+                else:
+                    cur = torch.cuda.current_stream(self.device)
+                    while len(self._set_streams) < len(sets):
+                        self._set_streams.append(torch.cuda.Stream(self.device))
+                    for st, group in zip(self._set_streams, sets.values()):
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st):
+                            _C.forward_batch_raw(group, device=self.device)
+                    for st, _ in zip(self._set_streams, sets):
+                        cur.wait_stream(st)
             for lane, cap in caps:
                 lane._finish(cap)
         return outs

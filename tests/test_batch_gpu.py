@@ -272,3 +272,48 @@ def test_the_timed_arrangement_meets_the_oracle_after_many_replays(cuda_device):
             want8 = (color.permute(1, 2, 0) * 255).clamp(0, 255).to(torch.uint8)
             assert torch.equal(rgb8[g][b], want8), f"stream {g} frame {b}: uint8 frame"
     print(f"timed arrangement vs oracle: worst pixel of 24 frames {worst:.3e}")
+
+
+def test_cameras_of_two_image_sizes_overlap_as_two_sets_and_stay_bit_identical(cuda_device):
+    """A rig with a wrist camera of another resolution than the sensor cameras: the batched
+    MultiCameraRenderer sends the frames of each image size through gsr_forward_batch as one set, each set on a stream of
+    its own, forked from and joined to the caller's stream -- also under hipGraph capture.  Every frame equals the frame of
+    a FrameRenderer that renders it alone."""
+    from gsworld_amd.renderer import FrameRenderer, MultiCameraRenderer
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=150_000, seed=12)
+    means, shs, op, sc, rot = (t.to(dev) for t in raw.activated())
+    big = _cams(dev, 3)
+    small = _cams(dev, 2, W=320, H=240)
+    cams = [big[0], small[0], big[1], small[1], big[2]]
+    kw = dict(shs=shs, scales=sc, rotations=rot, bg=torch.tensor([0.2, 0.1, 0.0], device=dev))
+    want = []
+    for cam in cams:
+        r = FrameRenderer(dev, forward_only=True, want_radii=False)
+        for _ in range(2):
+            color, _, invd = r.render(cam, means, op, **kw)
+        assert not r.ensure_valid(lambda: None).overflow
+        want.append((color.clone(), invd.clone()))
+    mc = MultiCameraRenderer(len(cams), dev, batched=True, forward_only=True, want_radii=False)
+    for _ in range(3):
+        outs = mc.render(cams, means, op, **kw)
+        mc.ensure_valid(lambda: mc.render(cams, means, op, **kw))
+    assert len(mc._set_streams) >= 2
+    torch.cuda.synchronize()
+    for (color, _, invd), (wc, wi) in zip(outs, want):
+        assert torch.equal(color, wc) and torch.equal(invd, wi)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mc.render(cams, means, op, **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        outs = mc.render(cams, means, op, **kw)
+    for color, _, invd in outs:
+        color.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for (color, _, invd), (wc, wi) in zip(outs, want):
+        assert torch.equal(color, wc) and torch.equal(invd, wi)

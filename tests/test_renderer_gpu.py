@@ -606,7 +606,9 @@ def test_a_cooperative_quadrant_that_gives_up_is_reported_not_drawn(cuda_device,
         r2.render(cam, means, op, **kw)
         s2 = r2.stats()
         seen.append((s2.truncated, s2.coop_timeouts, dbg.sort_state(r2.geom)["coop_quads"]))
-    assert seen[0][0] is False or seen[0][2] == 0  # (a fresh state knows no costs: no cooperative quadrants, nothing to time out)
+    # (a state without cooperative quadrants has nothing to time out; the first frame of THIS renderer may well have some --
+    #  the allocator hands it the image state of the renderer above, last frame's costs included)
+    assert all(q > 0 for t, _, q in seen if t), seen
     assert seen[-1][2] > 0 and seen[-1][0] is True and seen[-1][1] >= seen[-1][2] > 0, seen
     with pytest.raises(RuntimeError, match="timed out"):
         r2.ensure_valid(lambda: r2.render(cam, means, op, **kw))

@@ -2,7 +2,7 @@
 """exp() at the compositing thresholds: for the 8 scenes of BASELINE configs[3] at 200 k
 Gaussians and the two headline configurations, how far is the HIP image from the oracle's on EVERY pixel (borderline
 ones included), how many pixels exceed 1e-4, how many pixels does the oracle flag as borderline.  Run once per library
-build (-DGSR_EXP_ACCURATE=0 / 1).  GPU.  usage: exp_parity.py [--json out]"""
+build (-DGSR_EXP_ACCURATE=0 / 1).  GPU.  usage: exp_parity.py [--full | --full-size] [--json out]"""
 import json
 import os
 import sys
@@ -15,8 +15,14 @@ from gsworld_amd import scenes  # noqa: E402
 from tests import helpers as hp  # noqa: E402
 
 rows = {}
-cases = [(n, scenes.tabletop_scene(n, n=200_000, seed=1 + i), scenes.sensor_camera(n)) for i, n in enumerate(scenes.SCENE_NAMES)]
-cases.append(("configs[0]", scenes.random_scene_camera_frame(100_000, seed=0), scenes.identity_camera(256, 256, 60.0)))
+# --full-size (round 6): the eight scenes at 1 468 850 Gaussians, as tests/test_forward_gpu.py::test_all_eight_scenes_of_config4
+# and bench.py's parity record run them (seed = 1 + index: gsworld_amd.distributed.scene_for_rank) -- the two scenes whose
+# worst pixel is a flipped threshold decision (fr3_pour 6.1e-4, xarm6_rot_banana 3.9e-4) with and without -DGSR_EXP_ACCURATE
+full_size = "--full-size" in sys.argv
+cases = [(n, scenes.tabletop_scene(n, n=(scenes.XARM6_ALIGN_NUM_GAUSSIANS if full_size else 200_000), seed=1 + i),
+          scenes.sensor_camera(n)) for i, n in enumerate(scenes.SCENE_NAMES)]
+if not full_size:
+    cases.append(("configs[0]", scenes.random_scene_camera_frame(100_000, seed=0), scenes.identity_camera(256, 256, 60.0)))
 if "--full" in sys.argv:
     cases.append(("configs[1]", scenes.tabletop_scene("xarm6_align"), scenes.sensor_camera("xarm6_align")))
 for name, raw, cam in cases:

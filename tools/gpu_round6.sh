@@ -34,7 +34,7 @@ PY
 for target in "$@"; do
 case $target in
 suite)
-  timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -15
+  timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -v "Warning\|warnings.warn\|^$" | tail -${SUITE_TAIL:-40}
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | cut -c1-200
   ;;
 cl)
@@ -71,13 +71,26 @@ cl_vstats)  # kernel stats of the closed-loop surrogate for every variant librar
   done
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
+test)  # some tests, with their output: TEST_K='expr' (pytest -k)
+  timeout 1200 python -m pytest tests/ -x -q -m gpu -k "${TEST_K:-config}" 2>&1 | tail -${TEST_TAIL:-70}
+  ;;
+cl_env)  # the closed loop under HIP runtime knobs (what does the boundary between two graph replays cost, and why)
+  for e in "X=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" "DEBUG_HIP_GRAPH_BATCH_SIZE=64" "DEBUG_HIP_FORCE_GRAPH_QUEUES=1" \
+           "ROC_SYSTEM_SCOPE_SIGNAL=0" "GPU_STREAMOPS_CP_WAIT=1" "DEBUG_HIP_DYNAMIC_QUEUES=0" "ROC_ACTIVE_WAIT_TIMEOUT=0" "GPU_MAX_HW_QUEUES=1"; do
+    env $e CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 1 > $OUT/cl_env.txt 2> $OUT/cl_env.err
+    cl_line $OUT/cl_env.txt "$e"
+  done
+  ;;
 cl_eager)  # the closed loop without hipGraph replay: what the graph boundary costs against eleven eager launches
   CL_EAGER=1 CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 1 > $OUT/cl_eager.txt 2> $OUT/cl_eager.err
   cl_line $OUT/cl_eager.txt "eager E=1"
   CL_EAGER=1 CL_ONLY=1,0 bash tools/gpu_trace_seq.sh cl6e render_stream tools/ab_closed_loop.py 2>&1 | tail -14
   ;;
 cl_seq)  # the kernel sequence of one closed-loop step with start offsets (gaps between launches)
-  CL_ONLY=1,0 bash tools/gpu_trace_seq.sh cl6 render_stream tools/ab_closed_loop.py 2>&1 | tail -20
+  for E in ${CL_SEQ_ENVS:-1}; do
+    echo "-- one step, $E environment(s)"
+    CL_ONLY=1,0 bash tools/gpu_trace_seq.sh cl6 render_stream tools/ab_closed_loop.py 1468850 $E 2>&1 | tail -20
+  done
   ;;
 headline_v)  # the headline on every variant library
   cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so

@@ -43,7 +43,11 @@ for k, (M, s) in enumerate(poses[1:]):
             print(f"step {k} {name}: V {st.num_visible} R {st.num_rendered} sort {dbg.sort_state(lane.geom)}")
             print(f"   prepare (1024 threads): counts+sums {d(0, 1)} | scan {d(1, 22)} | table + blind decision {d(22, 23)} | "
                   f"ranges + sample search {d(23, 24)} | sample keys {d(24, 2)} | validate / new splitters {d(2, 3)} | total {d(0, 3)}")
+            # (slots 10-13 -- the slowest compaction workgroup, kept by an atomicMax -- start from whatever the allocator
+            #  left in a fresh state buffer: a "maximum" beyond a second of cycles was never written by a workgroup)
+            slow = (f"slowest wg {v[10]} clk (wg {v[11]}, {v[12]} blocks, {v[13]} records)"
+                    if 0 < v[10] < 2_000_000_000 and v[11] < 65536 else "slowest wg: not recorded")
             print(f"   compact wg64: plan {d(8, 9)} | offsets {d(9, 4)} | walk {d(4, 5)} | classify {d(5, 6)} | table {d(6, 7)} | total {d(8, 7)}; "
-                  f"slowest wg {v[10]} clk (wg {v[11]}, {v[12]} blocks, {v[13]} records)")
+                  f"{slow}")
             print(f"   partition wg64: setup {int(v[17] - v[16])} move {int(v[18] - v[17])} | buckets wg100: hdr {int(v[33] - v[32])} "
                   f"sort {int(v[35] - v[33])} emit {int(v[36] - v[35])} bits {v[40]} n {v[41]}")
