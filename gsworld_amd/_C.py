@@ -178,7 +178,16 @@ def forward_batch_raw(frames, device=None):
     if not frames:
         return
     dev = frames[0]["means3D"].device if device is None else device
+    run_packed_batch(pack_batch(frames), dev)
+
+
+def pack_batch(frames):
+    """The argument pack of :func:`forward_batch_raw` for these frames, built once: a caller that renders the SAME frames
+    again and again -- same tensors, same settings, same state buffers: a closed loop whose per-step values live in device
+    buffers the kernels read -- keeps it and calls :func:`run_packed_batch` per step (the per-frame Python that builds it
+    costs more host time than the step's eleven launches)."""
     B = len(frames)
+    dev = frames[0]["means3D"].device
     if _ext is not None and hasattr(_ext, "forward_batch"):
         e = torch.empty(0, device=dev)
         ei = torch.empty(0, dtype=torch.int32, device=dev)
@@ -199,8 +208,7 @@ def forward_batch_raw(frames, device=None):
                 parts[3] if (parts is not None and parts[3] is not None) else eb,
                 layout[0] if layout is not None else e,
                 layout[1] if (layout is not None and layout[1] is not None) else ei))
-        _ext.forward_batch(packed)
-        return
+        return ("ext", packed)
     built, caps = [], (C.c_int64 * B)()
     for k, f in enumerate(frames):
         f = dict(f)
@@ -211,9 +219,18 @@ def forward_batch_raw(frames, device=None):
     In = (GsrInputs * B)(*[b[1] for b in built])
     Out = (GsrOutputs * B)(*[b[2] for b in built])
     Buf = (GsrBuffers * B)(*[b[3] for b in built])
-    with torch.cuda.device(dev):
-        check(lib().gsr_forward_batch(B, St, In, Out, Buf, caps, _stream(dev)))
-    del built  # (the resize callbacks had to outlive the call)
+    return ("ctypes", (B, St, In, Out, Buf, caps, built, frames))  # (built / frames: keep callbacks and tensors alive)
+
+
+def run_packed_batch(pack, device):
+    """Enqueues the frames of :func:`pack_batch` on the current stream of ``device``."""
+    kind, p = pack
+    if kind == "ext":
+        _ext.forward_batch(p)
+        return
+    B, St, In, Out, Buf, caps = p[:6]
+    with torch.cuda.device(device):
+        check(lib().gsr_forward_batch(B, St, In, Out, Buf, caps, _stream(device)))
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,

@@ -1703,7 +1703,11 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
     const size_t lds2 = (size_t)(6 * bmax) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_partition_kernel, dim3(nbc, B), dim3(kT), lds2, stream, bt);
     if (int e = gsr_check_launch("ss_partition", debug, stream)) return e;
-    const size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
+#ifndef GSR_SS_BUCKETS_LDS_KB
+#define GSR_SS_BUCKETS_LDS_KB 0  // (A/B: ask for this much LDS per bucket workgroup instead of the 36 KB it needs -- caps the
+#endif                           //  workgroups resident per CU: 160 KB / this)
+    size_t lds3 = (size_t)(4 * kBucketCap + 4 * 256) * sizeof(uint32_t);
+    if ((size_t)GSR_SS_BUCKETS_LDS_KB * 1024 > lds3) lds3 = (size_t)GSR_SS_BUCKETS_LDS_KB * 1024;
     hipLaunchKernelGGL(ss_buckets_kernel, dim3(bmax, B), dim3(kT), lds3, stream, bt);
     return gsr_check_launch("ss_buckets", debug, stream);
 }

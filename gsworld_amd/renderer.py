@@ -297,6 +297,17 @@ class MultiCameraRenderer:
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)] if not self.batched else []
         self._set_streams: list = []  # (batched: one per image size beyond the first, created when a step has several)
+        self.last_pack = None
+
+    def rerun(self, pack_caps) -> None:
+        """Enqueues a step again from the argument pack :meth:`render` left in ``last_pack`` -- same tensors, same settings,
+        same state: what a loop whose per-step values live in device buffers does every step, without the per-frame Python
+        of :meth:`render` (normalising tensors, building settings) in front of the launches."""
+        pack, caps = pack_caps
+        with torch.cuda.device(self.device):
+            _C.run_packed_batch(pack, self.device)
+        for lane, cap in caps:
+            lane._finish(cap)
 
     def render(self, views, means3D, opacities, rgb8_out=None, per_lane=None, **render_kw):
         """``views``: one :class:`gsworld_amd.camera.ViewParams` per camera.  Returns ``[(color, radii, invdepth)]``
@@ -324,6 +335,7 @@ class MultiCameraRenderer:
         return outs
 
     def _render_batched(self, views, means3D, opacities, rgb8_out, per_lane, render_kw):
+        self.last_pack = None  # (the argument pack of this step, when ALL its frames went through one gsr_forward_batch call)
         outs, calls, caps = [], [], []
         for k, (lane, view) in enumerate(zip(self.lanes, views)):
             kw = render_kw if per_lane is None else {**render_kw, **per_lane[k]}
@@ -348,7 +360,10 @@ class MultiCameraRenderer:
                 sets.setdefault((call["settings"].image_height, call["settings"].image_width), []).append(call)
             with torch.cuda.device(self.device):
                 if len(sets) == 1:
-                    _C.forward_batch_raw(calls, device=self.device)
+                    pack = _C.pack_batch(calls)
+                    _C.run_packed_batch(pack, self.device)
+                    if len(calls) == len(self.lanes):
+                        self.last_pack = (pack, caps)
                 else:
                     cur = torch.cuda.current_stream(self.device)
                     while len(self._set_streams) < len(sets):

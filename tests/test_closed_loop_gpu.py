@@ -167,6 +167,7 @@ def test_moving_wrist_camera_follows_through_eager_steps_and_graph_replay(cuda_d
 
     loop.reset(*poses[0])
     loop.capture()
+    loop.eager_when_ahead = False  # (this test is about the REPLAYED step; step(ensure=False) would issue eager launches)
     seen = []
     for k, (M, s) in enumerate(poses[1:]):
         w = wrist(k)
@@ -499,7 +500,9 @@ def test_host_values_staged_inside_the_graph_give_the_eager_loop_s_frames(cuda_d
     packer = FusedPartTransform(parts, raw.semantics.to(dev), scaled_parts=actors)
     for k, (M, s) in enumerate(poses[1:]):
         w = wrist(k)
-        got = {n: f.clone() for n, f in loop.step(M, s, cameras={"wrist_cam": w}).items()}
+        # (odd steps: waited for -> the slot's graph is replayed; even steps: enqueued ahead -> the same launches one by one
+        #  from the argument pack, the host values staged by the same kernel -- both walk the one ring of slots)
+        got = {n: f.clone() for n, f in loop.step(M, s, cameras={"wrist_cam": w}, ensure=bool(k & 1)).items()}
         want = eager.step(M, s, cameras={"wrist_cam": w})
         torch.cuda.synchronize()
         for n in want:

@@ -92,6 +92,20 @@ cl_seq)  # the kernel sequence of one closed-loop step with start offsets (gaps 
     CL_ONLY=1,0 bash tools/gpu_trace_seq.sh cl6 render_stream tools/ab_closed_loop.py 1468850 $E 2>&1 | tail -20
   done
   ;;
+ab_v)  # tools/ab_batch.py on the committed library and every variant: AB_VIEW=dense|sensor AB_CONFIGS=batch1,batch8,3x8
+  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
+  for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
+    [ -f "$lib" ] || continue
+    name=$(basename $lib .so); name=${name#libgsr_hip.}
+    cp $lib gsworld_amd/libgsr_hip.so
+    for view in ${AB_VIEW:-dense}; do
+      echo "$name $view: $(timeout 600 python tools/ab_batch.py --view $view --steps ${AB_STEPS:-400} --configs ${AB_CONFIGS:-batch1,batch8,3x8} 2>/dev/null | python -c "
+import json,sys
+print(' '.join(f\"{r['config']}={r['frames_per_s']:.0f}\" for r in map(json.loads, (l for l in sys.stdin if l.startswith('{')))))")"
+    done
+  done
+  cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
+  ;;
 headline_v)  # the headline on every variant library
   cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
   for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
