@@ -381,7 +381,13 @@ __device__ __forceinline__ GeomOut prep_geometry(const PreprocessArgs &a, int i,
 }
 
 // SH -> RGB (or the precomputed colour) of visible Gaussian g at position pp.xyz; writes rec2 and the clamp flags.
-template <bool FAST_SH16>
+#ifndef GSR_PREP_GROUP_HALVES
+#define GSR_PREP_GROUP_HALVES 1  // (A/B: the multi-frame kernel's SH coefficients in two batches; see prep_colour)
+#endif
+// (HALVES: the coefficients are requested in two batches instead of one -- half the registers in flight, one more round
+//  trip.  The multi-frame kernel takes it: its loop over the frames costs the compiler registers, and the second and
+//  later frames of a group find the coefficients in this CU's cache.  Same products, same order: same colours.)
+template <bool FAST_SH16, bool HALVES = false>
 __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g, const float4 pp) {
     float cr, cg, cb;
     uint32_t clamp_bits = 0;
@@ -401,7 +407,26 @@ __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g
             const float *rest = a.shs_rest + (size_t)g * (a.M - 1) * 3;
             const int nb = (a.D + 1) * (a.D + 1);
             cr = b[0] * dc[0]; cg = b[0] * dc[1]; cb = b[0] * dc[2];
-            if (a.D == 3) {
+            if (a.D == 3 && HALVES) {
+                float f[24];
+#pragma unroll
+                for (int k = 0; k < 24; k++) f[k] = rest[k];
+#pragma unroll
+                for (int k = 1; k < 9; k++) {
+                    cr = fma_(b[k], f[3 * k - 3], cr);
+                    cg = fma_(b[k], f[3 * k - 2], cg);
+                    cb = fma_(b[k], f[3 * k - 1], cb);
+                }
+                asm volatile("" : "+v"(cr), "+v"(cg), "+v"(cb));  // (the second batch is requested behind the first's use)
+#pragma unroll
+                for (int k = 0; k < 21; k++) f[k] = rest[24 + k];
+#pragma unroll
+                for (int k = 9; k < 16; k++) {
+                    cr = fma_(b[k], f[3 * k - 27], cr);
+                    cg = fma_(b[k], f[3 * k - 26], cg);
+                    cb = fma_(b[k], f[3 * k - 25], cb);
+                }
+            } else if (a.D == 3) {
                 float f[45];
 #pragma unroll
                 for (int k = 0; k < 45; k++) f[k] = rest[k];  // 15 x dwordx3, all in flight together
@@ -421,6 +446,30 @@ __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g
         } else if (FAST_SH16) {
             // D == 3, M == 16: 48 contiguous floats, 16-byte aligned -> 12 x dwordx4
             const float4 *sh4 = reinterpret_cast<const float4 *>(a.shs + (size_t)g * 48);
+            if (HALVES) {
+                float4 v[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = sh4[k];
+                const float *f = reinterpret_cast<const float *>(v);
+                cr = b[0] * f[0]; cg = b[0] * f[1]; cb = b[0] * f[2];
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    cr = fma_(b[k], f[3 * k], cr);
+                    cg = fma_(b[k], f[3 * k + 1], cg);
+                    cb = fma_(b[k], f[3 * k + 2], cb);
+                }
+                asm volatile("" : "+v"(cr), "+v"(cg), "+v"(cb));  // (the second batch is requested behind the first's use)
+                float4 u[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) u[k] = sh4[6 + k];
+                const float *h = reinterpret_cast<const float *>(u);
+#pragma unroll
+                for (int k = 8; k < 16; k++) {
+                    cr = fma_(b[k], h[3 * k - 24], cr);
+                    cg = fma_(b[k], h[3 * k - 23], cg);
+                    cb = fma_(b[k], h[3 * k - 22], cb);
+                }
+            } else {
             float4 v[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) v[k] = sh4[k];
@@ -431,6 +480,7 @@ __device__ __forceinline__ void prep_colour(const PreprocessArgs &a, const int g
                 cr = fma_(b[k], f[3 * k], cr);
                 cg = fma_(b[k], f[3 * k + 1], cg);
                 cb = fma_(b[k], f[3 * k + 2], cb);
+            }
             }
         } else {
             const float *sh = a.shs + (size_t)g * a.M * 3;
@@ -648,7 +698,7 @@ __device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i,
         }
     }
     if (threadIdx.x < cnt) {
-        prep_colour<FAST_SH16>(a, sh.idx[threadIdx.x], sh.pos[threadIdx.x]);
+        prep_colour<FAST_SH16, MULTI && GSR_PREP_GROUP_HALVES>(a, sh.idx[threadIdx.x], sh.pos[threadIdx.x]);
     }
 }
 
@@ -704,7 +754,7 @@ void preprocess_kernel(const PrepLaunch L) {
 
 // groups of several frames
 #ifndef GSR_PREP_GROUP_WAVES
-#define GSR_PREP_GROUP_WAVES 0  // A/B: minimum waves per SIMD asked of the compiler for the multi-frame kernel (0: none)
+#define GSR_PREP_GROUP_WAVES 6  // minimum waves per SIMD asked of the compiler for the multi-frame kernel: 80 VGPRs, no scratch (0: no limit -- 84; 7: 72 + 28 B of scratch)
 #endif
 template <bool FAST_SH16>
 __global__
