@@ -854,7 +854,10 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
             out.setdefault("train_step", {})[label] = {
                 "ms_per_step": rec["ms_per_step"], "it_per_s": rec["value"],
                 "algorithmic_bytes_per_step": rec["roofline"]["algorithmic_bytes_per_step"],
-                "frac_of_8TBs": rec["roofline"]["frac"], "num_visible": rec["config"]["num_visible"],
+                "frac_of_8TBs": rec["roofline"]["frac"],
+                "real_hbm_GBs": (rec["roofline"].get("counters") or {}).get("real_hbm_GBs"),
+                "real_hbm_source": (rec["roofline"].get("counters") or {}).get("source"),
+                "num_visible": rec["config"]["num_visible"],
                 "num_rendered": rec["config"]["num_rendered"], "grads_finite": rec["config"]["grads_finite"],
                 "variant": rec["config"]["parameter_packing"], "loss": rec["config"]["loss"]}
         out["train_step"]["workload"] = rec["config"]["workload"]

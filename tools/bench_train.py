@@ -99,13 +99,27 @@ def run(steps=50, warmup=5, num_gaussians=500_000, size=800, fused=False, device
     b_alg = (48 * N + 280 * V + 64 * R + 16 * S * S) + (128 * R + 284 * V + 16 * S * S)
     finite = all(torch.isfinite(p.grad).all().item() for p in (raw.xyz, raw.features_dc, raw.features_rest,
                                                                raw.opacity, raw.scaling, raw.rotation))
+    # the step's REAL HBM traffic, from the committed counter run of this very command (profiles/round*/pmc_train_step.json:
+    # 2 x FETCH_SIZE + WRITE_SIZE per kernel + the memsets; tools/pmc_train_summary.py) -- beside the byte model's figure
+    real = None
+    if fused:
+        import glob
+        import json as _json
+
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "pmc_train_step.json"))):
+            rec_ = _json.load(open(path))
+            real = {"hbm_bytes_per_step": rec_["hbm_bytes_per_step"], "real_hbm_GBs": rec_["hbm_bytes_per_step"] / dt / 1e9,
+                    "frac_of_8TBs": rec_["hbm_bytes_per_step"] / dt / 1e9 / 8000.0,
+                    "source": os.path.relpath(path, ROOT) + f" (collected {rec_['collected']}; counters of another run of this "
+                                                            "command, this run's step time)"}
     return {
         "metric": "training iterations/sec (forward + backward, fused-ssim loss)", "value": 1.0 / dt,
         "unit": "it/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
         "data": "synthetic",
         "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(b_alg), "achieved": b_alg / dt / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": b_alg / dt / 1e9 / 8000.0,
-                     "note": "whole step (forward + backward + loss) against the HBM peak; SURVEY.md 8d byte model"},
+                     "note": "whole step (forward + backward + loss) against the HBM peak; SURVEY.md 8d byte model",
+                     "counters": real},
         "config": {"workload": f"{num_gaussians} Gaussians (config-1 distribution, seed 5), {S}x{S}, "
                                "loss 0.8*L1 + 0.2*(1-ssim), forward+backward, no optimizer step, another of 8 nearby views every "
                                "step as a training loop would draw them "

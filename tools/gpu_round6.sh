@@ -38,7 +38,7 @@ suite)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | cut -c1-200
   ;;
 cl)
-  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
+  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so; : > $OUT/closed_loop_same_box.txt
   for rep in $(seq 1 ${CL_REPS:-2}); do
     for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
       [ -f "$lib" ] || continue
@@ -46,14 +46,14 @@ cl)
       cp $lib gsworld_amd/libgsr_hip.so
       for E in ${CL_ENVS:-1}; do
         CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E > $OUT/cl_${name}_E$E.txt 2> $OUT/cl_${name}_E$E.err
-        cl_line $OUT/cl_${name}_E$E.txt "$name E=$E"
+        cl_line $OUT/cl_${name}_E$E.txt "$name E=$E" | tee -a $OUT/closed_loop_same_box.txt
       done
     done
     cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
     if [ -d .r5ref ]; then
       for E in ${CL_ENVS:-1}; do
         (cd .r5ref && CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E > $OUT/cl_r5_E$E.txt 2> $OUT/cl_r5_E$E.err)
-        cl_line $OUT/cl_r5_E$E.txt "round5 E=$E"
+        cl_line $OUT/cl_r5_E$E.txt "round5 E=$E" | tee -a $OUT/closed_loop_same_box.txt
       done
     fi
   done
@@ -90,7 +90,7 @@ cl_seq)  # the kernel sequence of one closed-loop step with start offsets (gaps 
   for E in ${CL_SEQ_ENVS:-1}; do
     echo "-- one step, $E environment(s)"
     CL_ONLY=1,0 bash tools/gpu_trace_seq.sh cl6 render_stream tools/ab_closed_loop.py 1468850 $E 2>&1 | tail -20
-  done
+  done | tee $OUT/closed_loop_step_sequence.txt
   ;;
 ab_v)  # tools/ab_batch.py on the committed library and every variant: AB_VIEW=dense|sensor AB_CONFIGS=batch1,batch8,3x8
   cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
@@ -107,7 +107,7 @@ print(' '.join(f\"{r['config']}={r['frames_per_s']:.0f}\" for r in map(json.load
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
 headline_v)  # the headline on every variant library
-  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
+  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so; : > $OUT/headline_variants.txt
   for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
     [ -f "$lib" ] || continue
     name=$(basename $lib .so); name=${name#libgsr_hip.}
@@ -115,7 +115,7 @@ headline_v)  # the headline on every variant library
     timeout 600 python bench.py --no-extras --no-cpu-baseline 2> /dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
-print('$name', 'value', round(d['value']), 'one frame', round(c.get('one_frame_in_flight_frames_per_s') or 0), 'one stream', round(c.get('one_stream_frames_per_s') or 0), 'p50', d['frame_roofline'].get('frame_ms_p50'))"
+print('$name', 'value', round(d['value']), 'one frame', round(c.get('one_frame_in_flight_frames_per_s') or 0), 'one stream', round(c.get('one_stream_frames_per_s') or 0), 'p50', d['frame_roofline'].get('frame_ms_p50'), 'compositor us per 8-frame launch', round(1e3 * d['roofline']['kernel_ms'], 1), 'one frame', round(1e3 * d['roofline']['one_frame_per_launch']['kernel_ms'], 1))" | tee -a $OUT/headline_variants.txt
   done
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
@@ -168,7 +168,10 @@ train_v)  # the fused training step on the committed library and the variants
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
 trainpmc)
-  bash tools/gpu_pmc_train.sh round6/pmc_train_raw > $OUT/pmc/train_step.txt 2>&1; tail -30 $OUT/pmc/train_step.txt | cut -c1-300
+  bash tools/gpu_pmc_train.sh round6/pmc_train_raw > $OUT/pmc/train_step.txt 2>&1; grep -c "grid" $OUT/pmc/train_step.txt
+  # (+ the one memset gsr_backward still issues: 500 k Gaussians x 12 binary64 words of the gradient records)
+  python tools/pmc_train_summary.py $OUT/pmc/train_step.txt $OUT/pmc_train_step.json 48000000
+  rm -rf gpurun_out/round6/pmc_train_raw/p*/
   ;;
 pmc)
   echo "== pmc (the step's launches: 8 frames per launch)"
