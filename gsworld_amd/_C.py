@@ -91,8 +91,9 @@ def _require_gpu(t: torch.Tensor, what: str):
 def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                 viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                 imgBuffer, r_capacity: int = 0, want_stats: bool = True, sh_rest=None, param_space: int = 0,
-                rgb8_out=None, parts=None, forward_only: bool | None = False, layout=None):
+                rgb8_out=None, parts=None, forward_only: bool | None = False, layout=None, overflow_mirror: int = 0):
     """Thin call into gsr_forward with caller-owned output and state tensors (no allocation here).
+    ``overflow_mirror``: GsrOutputs.overflow_mirror as an address (0 = not wanted).
     ``sh_rest``: optional features_rest (P,M-1,3); ``sh`` is then features_dc (P,1,3) -- no per-frame concatenation.
     ``param_space``: OR of ``_lib.RAW_*`` -- opacity logits / log scales / un-normalised rotations are activated
     inside preprocess instead of by three torch passes.
@@ -121,14 +122,16 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
             parts[2] if parts is not None else e,
             parts[3] if (parts is not None and parts[3] is not None) else torch.empty(0, dtype=torch.uint8, device=dev),
             layout[0] if layout is not None else e,
-            layout[1] if (layout is not None and layout[1] is not None) else torch.empty(0, dtype=torch.int32, device=dev))
+            layout[1] if (layout is not None and layout[1] is not None) else torch.empty(0, dtype=torch.int32, device=dev),
+            int(overflow_mirror or 0))
         stats = GsrFrameStats()
         stats.num_visible, stats.num_rendered, stats.overflow = nv, nr, ov
         return stats
     settings, inp, out, buf, _keep = _frame_structs(
         settings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh,
         campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer, imgBuffer, sh_rest=sh_rest,
-        param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=forward_only, layout=layout)
+        param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=forward_only, layout=layout,
+        overflow_mirror=overflow_mirror)
     stats = GsrFrameStats()
     with torch.cuda.device(dev):
         check(lib().gsr_forward(C.byref(settings), C.byref(inp), C.byref(out), C.byref(buf), C.c_int64(r_capacity),
@@ -139,7 +142,7 @@ def forward_raw(settings: GsrSettings, background, means3D, colors, opacity, sca
 def _frame_structs(settings: GsrSettings, background, means3D, colors, opacity, scales, rotations, cov3D_precomp,
                    viewmatrix, projmatrix, sh, campos, out_color, out_invdepth, radii, geomBuffer, binningBuffer,
                    imgBuffer, sh_rest=None, param_space: int = 0, rgb8_out=None, parts=None,
-                   forward_only: bool | None = False, layout=None):
+                   forward_only: bool | None = False, layout=None, overflow_mirror: int = 0):
     """The four argument structs of one frame (include/gsr.h) from tensors; the fifth value keeps the resize callbacks
     alive while the structs are in use."""
     settings.forward_only = int(bool(forward_only))
@@ -163,7 +166,7 @@ def _frame_structs(settings: GsrSettings, background, means3D, colors, opacity, 
         inp.cull_blocks = _ptr(blocks)
         inp.orig_index = _ptr(orig) if orig is not None else None
     out = GsrOutputs(_ptr(out_color), _ptr(out_invdepth), _ptr(radii),
-                     _ptr(rgb8_out) if rgb8_out is not None else None)
+                     _ptr(rgb8_out) if rgb8_out is not None else None, int(overflow_mirror) if overflow_mirror else None)
     cbs = (_resizer(geomBuffer, header=True), _resizer(binningBuffer), _resizer(imgBuffer))
     buf = GsrBuffers(cbs[0], None, cbs[1], None, cbs[2], None)
     return settings, inp, out, buf, cbs
@@ -207,7 +210,8 @@ def pack_batch(frames):
                 parts[2] if parts is not None else e,
                 parts[3] if (parts is not None and parts[3] is not None) else eb,
                 layout[0] if layout is not None else e,
-                layout[1] if (layout is not None and layout[1] is not None) else ei))
+                layout[1] if (layout is not None and layout[1] is not None) else ei,
+                int(f.get("overflow_mirror") or 0)))
         return ("ext", packed)
     built, caps = [], (C.c_int64 * B)()
     for k, f in enumerate(frames):

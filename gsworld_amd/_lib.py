@@ -85,7 +85,8 @@ RAW_OPACITY, RAW_SCALES, RAW_ROTATIONS = 1, 2, 4  # include/gsr.h GSR_RAW_*
 
 class GsrOutputs(C.Structure):
     _fields_ = [("out_color", C.c_void_p), ("out_invdepth", C.c_void_p), ("radii", C.c_void_p),
-                ("out_rgb8", C.c_void_p)]  # optional (H,W,3) uint8 frame written by the compositor
+                ("out_rgb8", C.c_void_p),  # optional (H,W,3) uint8 frame written by the compositor
+                ("overflow_mirror", C.c_void_p)]  # optional: two host-readable words for the state's overflow count
 
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

@@ -20,11 +20,22 @@ random-action rollout from forward kinematics of the reference's xarm6 URDF, pus
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import transform as tf
 from ._lib import RAW_ROTATIONS, RAW_SCALES
 from .renderer import MultiCameraRenderer
+
+
+def _to_mirror(dst: torch.Tensor, dst_np, src: torch.Tensor) -> None:
+    """``dst.copy_(src.to(float32).reshape(dst.shape))`` for the host mirror; a float32 host tensor that needs no
+    conversion goes through numpy (same memory, a fraction of a torch op's dispatch)."""
+    if src.dtype == torch.float32 and src.device.type == "cpu" and not src.requires_grad and src.is_contiguous() and \
+            src.numel() == dst_np.size:
+        np.copyto(dst_np, src.numpy().reshape(dst_np.shape))
+    else:
+        dst.copy_(src.detach().to("cpu", torch.float32).reshape(dst.shape))
 
 
 class ClosedLoopRenderer:
@@ -175,6 +186,12 @@ class ClosedLoopRenderer:
             return v
 
         self._hv, dv = views(self._host), views(self._stage)
+        # (the same host memory as numpy arrays: what a step writes into the mirror and the ring are a dozen copies of a
+        #  few hundred bytes, ~0.4 us each through numpy against 1.5-2 us through a torch op -- with the policy in the loop
+        #  the host's share of a step is on the critical path: round 6, tools/host_step_profile.py)
+        self._hv_np = {k: (tuple(x.numpy() for x in v) if isinstance(v, tuple) else v.numpy()) for k, v in self._hv.items()}
+        self._host_np = self._host.numpy()
+        self._ring_np = [r.numpy() for r in self._ring]
         self._hv["matrices"].copy_(torch.eye(4).expand(*lead, 4, 4))
         self._hv["scales"].fill_(1.0)
         from .camera import ViewParams
@@ -347,9 +364,9 @@ class ClosedLoopRenderer:
             # synchronisation on the change from device to host poses only -- a GPU simulator that falls back to host
             # poses in mid-rollout keeps going)
             self._hv["scales"].copy_(self.scales.detach().to("cpu"))
-        self._hv["matrices"].copy_(matrices.to(torch.float32))
+        _to_mirror(self._hv["matrices"], self._hv_np["matrices"], matrices)
         if scales is not None:
-            self._hv["scales"].copy_(scales.to(torch.float32).reshape(self.scales.shape))
+            _to_mirror(self._hv["scales"], self._hv_np["scales"], scales)
         self._dirty.add("poses")
 
     def set_cameras(self, cameras: dict):
@@ -372,8 +389,8 @@ class ClosedLoopRenderer:
                     dst.copy_(t.to(torch.float32), non_blocking=True)
                 self._stale.add(name)
             else:
-                for dst, t in zip(self._hv[name], src):
-                    dst.copy_(t.to(torch.float32))
+                for dst, dst_np, t in zip(self._hv[name], self._hv_np[name], src):
+                    _to_mirror(dst, dst_np, t)
                 self._dirty.add(name)
 
     def step(self, matrices: torch.Tensor | None = None, scales: torch.Tensor | None = None,
@@ -411,7 +428,7 @@ class ClosedLoopRenderer:
             self._ring_k += 1
             if self._ring_ev[k] is not None:
                 self._ring_ev[k].synchronize()
-            self._ring[k].copy_(self._host)
+            np.copyto(self._ring_np[k], self._host_np)
             self._dirty.clear()
             self._launch_stage(k, int(self._stage.numel()))
             self.multi.rerun(self._pack)
@@ -425,12 +442,16 @@ class ClosedLoopRenderer:
             self._ring_k += 1
             if self._ring_ev[k] is not None:
                 self._ring_ev[k].synchronize()  # (eight steps ago: long done)
-            self._ring[k].copy_(self._host)
+            np.copyto(self._ring_np[k], self._host_np)
             self._dirty.clear()
             self._graphs[k].replay()
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._ring_ev[k] = ev
+            if ensure:
+                # (the wait below covers the slot: no event to create and record in front of it)
+                self._ring_ev[k] = None
+            else:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._ring_ev[k] = ev
         elif self._graph is not None:
             self._flush()  # this step's host values: one copy / launch on the step's stream, ahead of the replay
             self._graph.replay()

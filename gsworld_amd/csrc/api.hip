@@ -304,6 +304,15 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
         if (int e = gsr_launch_tile_offsets(in[0].P, g, fr[0].cap32, debug, stream)) return e;
     }
     prof_mark(3, stream);
+    // GsrOutputs.overflow_mirror: the capacity check of the counting placements (band, chunk) writes it itself; the A/B
+    // paths take the 8-byte copy their callers used to make
+    if (!(band || chunk))
+        for (int k = 0; k < B; k++)
+            if (out[k].overflow_mirror &&
+                hipMemcpyAsync(out[k].overflow_mirror, &fr[k].g.hdr->of_magic, 8, hipMemcpyDefault, stream) != hipSuccess) {
+                gsr_set_error("gsr_forward: overflow mirror copy failed: %s", hipGetErrorString(hipGetLastError()));
+                return GSR_E_HIP;
+            }
     int64_t cap0 = r_capacity[0];
     if (exact) {
         GsrHeader h;

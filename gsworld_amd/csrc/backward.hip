@@ -37,6 +37,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 #endif
 }
 
+#ifndef GSR_BWD_DIAG
+#define GSR_BWD_DIAG 0
+#endif
 constexpr int kGradRec = 12;  // words of a Gaussian's record in GeomState::grad_rec (kGrad sums + 2 unused)
 constexpr int kGrad = 10;  // mean2D.x, mean2D.y, conic.xx, conic.xy(half), conic.yy, opacity, r, g, b, invdepth
 
@@ -91,6 +94,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
     __shared__ float s_grad[GSR_BLOCK * kGradRec];  // [staged instance][component]
     __shared__ uint32_t s_max[4];
 
+    // (Measured in round 6 and not kept: the workgroups in the forward's compositing order, longest lists first -- 107.1
+    //  against 107.4 us at configs[4]: the kernel is not bound by its tail.  What it is bound by, from builds that leave
+    //  parts out (GSR_BWD_DIAG, profiles/round6/README.md): staging + cull + flush loop 12.6 us, the walk's evaluations
+    //  42 us, the wave sums + LDS atomics 50 us, the global atomics 5 us.)
     const int tile = (int)blockIdx.x;
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int lane = gsr_lane(), wave = gsr_wave();
@@ -162,6 +169,9 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
                 may = quadrant_may_hit(c0.x, c0.y, s_rec1[jj], qxf, qyf);
             }
             todo = __builtin_amdgcn_ballot_w64(may);
+#if GSR_BWD_DIAG == 3  // (timing diagnostics only: staging, cull and flush without the walk)
+            todo = todo == 0x123456789abcull ? 1ull : 0ull;
+#endif
         }
         while (todo != 0ull) {
             const int j = j0 + (int)__builtin_ctzll(todo);
@@ -223,6 +233,10 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             }
             if (__ballot(hit) == 0ull) continue;  // nothing in this wave touches the instance
             const float gv[kGrad] = {g_mx, g_my, g_cxx, g_cxy, g_cyy, g_op, g_r, g_g, g_b, g_d};
+#if GSR_BWD_DIAG == 2  // (timing diagnostics only -- wrong gradients: no wave sums)
+            if (my_comp >= 0) s_grad[j * kGradRec + my_comp] = g_mx + g_op + g_r + g_d + g_cxy;
+            continue;
+#endif
             const float total = wave_reduce10(gv);
             if (my_comp >= 0) atomicAdd(&s_grad[j * kGradRec + my_comp], total);  // LDS: at most 4 waves per address
         }
@@ -239,7 +253,11 @@ __global__ __launch_bounds__(GSR_BLOCK) void render_backward_kernel(
             if (j < cnt && c < kGrad) {
                 const float v = s_grad[e];
                 // (binary64 from here on: what a Gaussian collects from its tiles no longer depends on their order)
+#if GSR_BWD_DIAG == 1 || GSR_BWD_DIAG == 2  // (timing diagnostics only: the sums stay in the LDS)
+                if (v == 12345.678f) grad_rec[0] = (GsrGradWord)v;
+#else
                 if (v != 0.f) atomicAdd(&grad_rec[(size_t)kGradRec * s_id[j] + c], (GsrGradWord)v);
+#endif
             }
         }
     }

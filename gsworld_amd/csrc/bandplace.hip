@@ -534,6 +534,7 @@ struct BandArgs {
     uint2 *ranges_w;
     const uint32_t *quad_work;  // (... and its tile-order workgroup: the tiles' costs in the previous frame -> tile_order)
     uint32_t *tile_order;
+    uint32_t *mirror;  // (GsrOutputs.overflow_mirror: where the capacity check leaves the state's overflow count for the host)
 };
 
 template <int NC>
@@ -580,7 +581,8 @@ static_assert(GSR_BAND_RANGES == GSR_WAVE, "a tile's row of the band table is on
 // totals[T] (LDS or global) -> ranges, R, capacity check: THREADS threads, each owns `per` consecutive tiles
 template <int THREADS, int MAXPER>
 __device__ __forceinline__ void band_starts_block(const uint32_t *totals, int T, GsrHeader *__restrict__ hdr,
-                                                  uint32_t r_capacity, uint2 *__restrict__ ranges, uint32_t *s_wv) {
+                                                  uint32_t r_capacity, uint2 *__restrict__ ranges, uint32_t *s_wv,
+                                                  uint32_t *__restrict__ mirror) {
     constexpr int NWV = THREADS / GSR_WAVE;
     const int tid = (int)threadIdx.x, lane = gsr_lane(), wave = tid >> 6;
     const int per = (T + THREADS - 1) / THREADS, t0 = tid * per;
@@ -611,13 +613,14 @@ __device__ __forceinline__ void band_starts_block(const uint32_t *totals, int T,
     if (tid == 0) {
         hdr->R_raw = grand;
         hdr->r_capacity = r_capacity;
-        gsr_set_overflow(hdr, overflow);
+        gsr_set_overflow(hdr, overflow, mirror);
         hdr->R = overflow ? 0u : grand;
     }
 }
 
 __device__ __forceinline__ void band_scan_starts_body(uint32_t *__restrict__ table, int T, GsrHeader *__restrict__ hdr,
-                                                      uint32_t r_capacity, uint2 *__restrict__ ranges) {
+                                                      uint32_t r_capacity, uint2 *__restrict__ ranges,
+                                                      uint32_t *__restrict__ mirror) {
     __shared__ uint32_t s_tot[kSSMaxTiles];
     __shared__ uint32_t s_wv[kSSW];
     // A wave takes every sixteenth tile, sixteen rows in flight per lane (lane = rank range: one coalesced 256-byte row per
@@ -644,7 +647,7 @@ __device__ __forceinline__ void band_scan_starts_body(uint32_t *__restrict__ tab
         }
     }
     __syncthreads();
-    band_starts_block<kSST, kSSMaxTiles / kSST>(s_tot, T, hdr, r_capacity, ranges, s_wv);
+    band_starts_block<kSST, kSSMaxTiles / kSST>(s_tot, T, hdr, r_capacity, ranges, s_wv, mirror);
 }
 
 // (grid.x = 2 or 3: workgroup 1 -- its first four waves -- computes the next frame's cuts; workgroup 2, where the frame's
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(kSST) void band_scan_starts_kernel(const GsrBatch<B
         gsr_tile_order_block_keys<32>(key, a.T, a.tile_order, s_bins, s_red);
         return;
     }
-    band_scan_starts_body(a.table, a.T, a.hdr, a.r_capacity, a.ranges_w);
+    band_scan_starts_body(a.table, a.T, a.hdr, a.r_capacity, a.ranges_w, a.mirror);
 }
 // GSR_SCAN_MODE 2: band_scan's grid (+ the workgroup of the cuts); the last scanning workgroup of a frame to finish turns
 // the totals into ranges
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(kBT) void band_scan_tail_kernel(const GsrBatch<Band
     if (s_last == 0u) return;
     __threadfence();  // acquire: the other workgroups' totals, not what this CU's caches held before
     if (threadIdx.x == 0) a.hdr->tile_queue = 0u;
-    band_starts_block<kBT, kSSMaxTiles / kBT>(a.totals, a.T, a.hdr, a.r_capacity, a.ranges_w, s_wv);
+    band_starts_block<kBT, kSSMaxTiles / kBT>(a.totals, a.T, a.hdr, a.r_capacity, a.ranges_w, s_wv, a.mirror);
 }
 
 // depth-ordered rects for depth sorts that do not write them themselves (the LSD radix variant)
@@ -741,6 +744,7 @@ static void band_args(int B, const GsrFrame *fr, bool balanced, bool place, GsrB
         a.r_capacity = fr[k].cap32;
         a.quad_work = fr[k].img.quad_work;
         a.tile_order = fr[k].img.tile_order;
+        a.mirror = fr[k].out ? fr[k].out->overflow_mirror : (uint32_t *)nullptr;
         a.point_list = place ? fr[k].b.gidx[0] : (uint32_t *)nullptr;
     }
 }

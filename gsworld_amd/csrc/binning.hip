@@ -245,7 +245,8 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ to
                                                                 uint32_t *__restrict__ split_flag,
                                                                 uint32_t *__restrict__ split_list,
                                                                 uint32_t *__restrict__ split_count, int split_cap,
-                                                                uint32_t *__restrict__ quad_order, int cus_per_xcd) {
+                                                                uint32_t *__restrict__ quad_order, int cus_per_xcd,
+                                                                uint32_t *__restrict__ mirror) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bins[64];
     const bool keyed = tile_order != nullptr && quad_work != nullptr && T <= 32 * GSR_BLOCK;
@@ -361,7 +362,7 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ to
         if (threadIdx.x == 0) {
             hdr->R_raw = grand;
             hdr->r_capacity = r_capacity;
-            gsr_set_overflow(hdr, overflow);
+            gsr_set_overflow(hdr, overflow, mirror);
             hdr->R = overflow ? 0u : grand;
         }
         if (tile_order == nullptr || keyed) return;
@@ -389,7 +390,7 @@ __device__ __forceinline__ void tile_starts_body(const uint32_t *__restrict__ to
     if (threadIdx.x == 0) {
         hdr->R_raw = grand;
         hdr->r_capacity = r_capacity;
-        gsr_set_overflow(hdr, overflow);
+        gsr_set_overflow(hdr, overflow, mirror);
         hdr->R = overflow ? 0u : grand;
     }
     if (tile_order == nullptr || keyed) return;
@@ -410,11 +411,13 @@ struct TileStartsArgs {
     int split_cap;
     uint32_t *quad_order;
     int cus_per_xcd;
+    uint32_t *mirror;  // (GsrOutputs.overflow_mirror or nullptr)
 };
 __global__ __launch_bounds__(GSR_BLOCK) void tile_starts_kernel(const GsrBatch<TileStartsArgs> bt) {
     const TileStartsArgs &a = bt.f[blockIdx.y];
     tile_starts_body(a.totals, a.T, a.hdr, a.r_capacity, a.ranges, a.tile_order, a.cursor_to_zero, a.quad_work,
-                     a.quad_work_b, a.split_flag, a.split_list, a.split_count, a.split_cap, a.quad_order, a.cus_per_xcd);
+                     a.quad_work_b, a.split_flag, a.split_list, a.split_count, a.split_cap, a.quad_order, a.cus_per_xcd,
+                     a.mirror);
 }
 
 template <int NW>
@@ -652,6 +655,7 @@ int gsr_launch_tile_starts(int B, const GsrFrame *fr, bool order_done, bool debu
         a.split_cap = split_blocks * (GSR_BLOCK / GSR_WAVE);
         a.quad_order = !order_done && gsr_render_uses_quad_order(st, T) ? img.quad_order : (uint32_t *)nullptr;
         a.cus_per_xcd = gsr_render_cus_per_xcd();
+        a.mirror = fr[k].out ? fr[k].out->overflow_mirror : (uint32_t *)nullptr;
     }
     // (order_done: the compositing order was computed earlier in the frame, beside the depth sort's partition pass)
     hipLaunchKernelGGL(tile_starts_kernel, dim3(split_blocks > 0 ? 3 : (order_done ? 1 : 2), B), dim3(GSR_BLOCK), 0, stream,

@@ -82,16 +82,23 @@ struct GsrHeader {
 #define GSR_OF_MAGIC 0x0F10F10Fu
 // The one thread that compared R with the capacity.  Every frame clears hdr->overflow before its first such check, and a
 // path with two checks per frame (bin-then-sort) must count the frame once: only the 0 -> 1 edge counts.
-__device__ inline void gsr_set_overflow(GsrHeader *hdr, bool overflow) {
+// `mirror` (GsrOutputs.overflow_mirror: two words the HOST can read, or nullptr) receives (of_magic, overflow_frames) as
+// they stand after this frame's check -- what callers used to fetch with an 8-byte copy behind every frame.
+__device__ inline void gsr_set_overflow(GsrHeader *hdr, bool overflow, uint32_t *mirror = nullptr) {
     const bool was = hdr->overflow != 0u;
     hdr->overflow = overflow ? 1u : 0u;
+    uint32_t magic = hdr->of_magic, count = hdr->overflow_frames;
     if (overflow && !was) {
-        if (hdr->of_magic != GSR_OF_MAGIC) {
-            hdr->of_magic = GSR_OF_MAGIC;
-            hdr->overflow_frames = 0u;
+        if (magic != GSR_OF_MAGIC) {
+            hdr->of_magic = magic = GSR_OF_MAGIC;
+            count = 0u;
             hdr->coop_timeouts = 0u;
         }
-        hdr->overflow_frames += 1u;
+        hdr->overflow_frames = ++count;
+    }
+    if (mirror != nullptr) {
+        mirror[1] = magic == GSR_OF_MAGIC ? count : 0u;
+        mirror[0] = magic;
     }
 }
 // A cooperative quadrant of the compositor gave up waiting for a hand-off (render.hip render_coop_quadrant): its pixels are

@@ -118,7 +118,7 @@ void fill_frame(FrameCall &f, int H, int W, double tanfovx, double tanfovy, doub
                 const torch::Tensor &image, const torch::Tensor &rgb8_out, int param_space,
                 const std::vector<int> &tuning, const torch::Tensor &part_labels, const torch::Tensor &part_lut,
                 const torch::Tensor &part_table, const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks,
-                const torch::Tensor &orig_index) {
+                const torch::Tensor &orig_index, int64_t overflow_mirror) {
     f.st = settings(H, W, (float)tanfovx, (float)tanfovy, (float)scale_modifier, degree, M, false, antialiasing, debug,
                     (float)near_plane, tuning_from(tuning));
     GsrInputs in{};
@@ -156,7 +156,8 @@ void fill_frame(FrameCall &f, int H, int W, double tanfovx, double tanfovy, doub
     f.out = GsrOutputs{out_color.numel() ? out_color.data_ptr<float>() : nullptr,
                        out_invdepth.numel() ? out_invdepth.data_ptr<float>() : nullptr,
                        radii.numel() ? radii.data_ptr<int32_t>() : nullptr,
-                       rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr};
+                       rgb8_out.numel() ? rgb8_out.data_ptr<uint8_t>() : nullptr,
+                       reinterpret_cast<uint32_t *>((uintptr_t)overflow_mirror)};
     f.geom = geom;
     f.binning = binning;
     f.image = image;
@@ -172,14 +173,15 @@ std::tuple<int64_t, int64_t, int64_t> forward_frame(
     torch::Tensor out_invdepth, torch::Tensor radii, torch::Tensor geom, torch::Tensor binning, torch::Tensor image,
     const torch::Tensor &rgb8_out, int64_t r_capacity, bool want_stats, int param_space, std::vector<int> tuning,
     const torch::Tensor &part_labels, const torch::Tensor &part_lut, const torch::Tensor &part_table,
-    const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks, const torch::Tensor &orig_index) {
+    const torch::Tensor &part_rescale, const torch::Tensor &cull_blocks, const torch::Tensor &orig_index,
+    int64_t overflow_mirror) {
     const auto dev = means3D.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     FrameCall f;
     fill_frame(f, H, W, tanfovx, tanfovy, scale_modifier, degree, M, antialiasing, debug, near_plane, bg, means3D, colors,
                opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, sh, sh_rest, campos, out_color,
                out_invdepth, radii, geom, binning, image, rgb8_out, param_space, tuning, part_labels, part_lut, part_table,
-               part_rescale, cull_blocks, orig_index);
+               part_rescale, cull_blocks, orig_index, overflow_mirror);
     GsrFrameStats stats{};
     const int rc = gsr_forward(&f.st, &f.in, &f.out, &f.buf, r_capacity, want_stats ? &stats : nullptr, current_stream(dev));
     TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
@@ -196,7 +198,7 @@ void forward_batch(const py::list &frames) {
     torch::Device dev(torch::kCPU);
     for (size_t k = 0; k < B; k++) {
         const py::tuple t = frames[k].cast<py::tuple>();
-        TORCH_CHECK(t.size() == 38, "forward_batch: a frame is a tuple of 38 values, got ", t.size());
+        TORCH_CHECK(t.size() == 39, "forward_batch: a frame is a tuple of 39 values, got ", t.size());
         auto T = [&](int i) { return t[i].cast<torch::Tensor>(); };
         if (k == 0) dev = T(11).device();
         caps[k] = t[29].cast<int64_t>();
@@ -204,7 +206,7 @@ void forward_batch(const py::list &frames) {
                    t[4].cast<double>(), t[5].cast<int>(), t[6].cast<int>(), t[7].cast<bool>(), t[8].cast<bool>(),
                    t[9].cast<double>(), T(10), T(11), T(12), T(13), T(14), T(15), T(16), T(17), T(18), T(19), T(20), T(21),
                    T(22), T(23), T(24), T(25), T(26), T(27), T(28), t[30].cast<int>(), t[31].cast<std::vector<int>>(),
-                   T(32), T(33), T(34), T(35), T(36), T(37));
+                   T(32), T(33), T(34), T(35), T(36), T(37), t[38].cast<int64_t>());
     }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     std::vector<GsrSettings> st(B);
@@ -276,7 +278,7 @@ rasterize_gaussians(const torch::Tensor &background, const torch::Tensor &means3
                                    param_space, tuning, torch::empty({0}, fopt),
                                    torch::empty({0}, means3D.options().dtype(torch::kInt32)), torch::empty({0}, fopt),
                                    torch::empty({0}, bopt), torch::empty({0}, fopt),
-                                   torch::empty({0}, means3D.options().dtype(torch::kInt32)));
+                                   torch::empty({0}, means3D.options().dtype(torch::kInt32)), 0);
         (void)prefiltered;
         rendered = (int)std::get<1>(stats);
     }

@@ -77,6 +77,18 @@ class FrameRenderer:
         self._out = None
         self._P = 0
         self._mirror = torch.zeros(2, dtype=torch.int32).pin_memory() if overflow_mirror and torch.cuda.is_available() else None
+        # The frame's capacity check writes the mirror itself (GsrOutputs.overflow_mirror: the pinned words' device-visible
+        # address); round 5 copied the header's last 8 bytes behind every frame -- two copies per closed-loop step, ~6 us of
+        # its stream by the kernel trace.  (No device-visible address: the copy it is.)
+        self._mirror_np = self._mirror.numpy() if self._mirror is not None else None
+        self._mirror_dev = None
+        if self._mirror is not None:
+            import ctypes as C
+
+            from ._lib import lib
+            d = C.c_void_p()
+            if lib().gsr_pinned_device_address(C.c_void_p(self._mirror.data_ptr()), C.byref(d)) == 0 and d.value:
+                self._mirror_dev = int(d.value)
         self.overflows_handled = 0  # (callers that re-render on overflow keep their own tally against overflows_seen)
 
     def _capacity_for(self, num_rendered: int) -> int:
@@ -205,7 +217,8 @@ class FrameRenderer:
             cov3D_precomp=cov3D_precomp if cov3D_precomp is not None else empty, viewmatrix=view_m, projmatrix=proj_m,
             sh=shs if shs is not None else empty, campos=campos, out_color=color, out_invdepth=invd, radii=radii,
             geomBuffer=self.geom, binningBuffer=self.binning, imgBuffer=self.image, r_capacity=cap, sh_rest=shs_rest,
-            param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout)
+            param_space=param_space, rgb8_out=rgb8_out, parts=parts, forward_only=self.forward_only, layout=layout,
+            overflow_mirror=(self._mirror_dev or 0) if not self.bounded else 0)
         if not self.want_float and outputs is None:
             color = invd = None  # (what the caller gets back; the call holds the empty tensors = NULL images)
         return call, color, radii, invd
@@ -214,7 +227,7 @@ class FrameRenderer:
         """Bookkeeping behind a frame: capacity from an exact frame's count, the overflow mirror copy."""
         if cap == 0:
             self.r_capacity = self._capacity_for(stats.num_rendered)
-        if self._mirror is not None and not self.bounded and self.geom.numel() >= 256:
+        if self._mirror is not None and self._mirror_dev is None and not self.bounded and self.geom.numel() >= 256:
             # (of_magic, overflow_frames): the last two words of the 256-byte frame header (csrc/gsr_internal.h GsrHeader)
             self._mirror.copy_(self.geom[248:256].view(torch.int32), non_blocking=True)
 
@@ -224,7 +237,7 @@ class FrameRenderer:
         mirror copy that has COMPLETED was taken."""
         if self._mirror is None:
             raise RuntimeError("FrameRenderer was built without overflow_mirror=True")
-        magic, count = int(self._mirror[0]), int(self._mirror[1])
+        magic, count = int(self._mirror_np[0]), int(self._mirror_np[1])
         return count if (magic & 0xFFFFFFFF) == 0x0F10F10F else 0
 
     def pack_rgb8(self, color: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

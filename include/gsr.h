@@ -165,6 +165,12 @@ typedef struct GsrOutputs {
      * (uint8)clamp(255 * out_color, 0, 255), written by the compositor itself instead of a second pass over the
      * image (gsr_pack_rgb8 remains for callers that convert later).  NULL = not wanted. */
     uint8_t *out_rgb8;
+    /* Optional: two words the HOST can read and the device can write -- the device-visible address of pinned host memory
+     * (gsr_pinned_device_address) or plain device memory.  The frame's capacity check leaves there what GsrFrameStats
+     * reports as overflow_frames, as (0x0F10F10F, count) -- (anything else, -) while the state has never overflowed:
+     * a caller that runs ahead of the device learns of an overflowed frame without a copy behind every frame (8 bytes,
+     * but a copy: ~3 us of the stream per frame) and without a wait.  NULL = not wanted. */
+    uint32_t *overflow_mirror;
 } GsrOutputs;
 
 /* resize callback: must return a device pointer to at least `bytes` bytes (256-byte aligned), or NULL. */

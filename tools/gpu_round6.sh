@@ -145,6 +145,16 @@ stats)
 train)
   stats train_step_fused tools/bench_train.py --fused --steps 30
   ;;
+hostprof)  # the host's share of a policy-in-the-loop step
+  timeout 600 python tools/host_step_profile.py 2>&1 | cut -c1-200 | tee $OUT/host_step_profile.txt | head -70
+  ;;
+train_host)  # the fused training step: device-bound or host-bound?  (tiny problem = the host's floor)
+  echo "configs[4]: $(timeout 600 python tools/bench_train.py --fused --steps 60 2>&1 | tail -1 | cut -c1-200)"
+  echo "tiny: $(timeout 600 python tools/bench_train.py --fused --steps 200 --num-gaussians 2000 --size 64 2>&1 | tail -1 | cut -c1-200)"
+  ;;
+train_seq)  # the kernel sequence of one training step with start offsets
+  bash tools/gpu_trace_seq.sh tr6 render_backward tools/bench_train.py --fused --steps 12 2>&1 | tail -40 | tee $OUT/train_step_sequence.txt
+  ;;
 gradbound)  # the configs[4]-size gradient comparison against the oracle, several runs per library: what the atomics' order is worth
   cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
   for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.gradf32.so; do
@@ -157,13 +167,20 @@ gradbound)  # the configs[4]-size gradient comparison against the oracle, severa
   done | tee $OUT/config5_gradient_bound.txt
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
-train_v)  # the fused training step on the committed library and the variants
+train_v)  # the fused training step on the committed library and every variant present (TRAIN_STATS=1: + per-kernel times)
   cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
-  for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.gradf32.so; do
+  for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
     [ -f "$lib" ] || continue
     name=$(basename $lib .so); name=${name#libgsr_hip.}
     cp $lib gsworld_amd/libgsr_hip.so
-    echo "$name: $(timeout 600 python tools/bench_train.py --fused --steps 60 2>&1 | tail -1 | cut -c1-300)"
+    for rep in $(seq 1 ${TRAIN_REPS:-2}); do
+      echo "$name: $(timeout 600 python tools/bench_train.py --fused --steps 100 2>&1 | tail -1 | python -c "
+import json,sys
+r=json.loads(sys.stdin.readline()); print('ms_per_step %.4f host %.3f' % (r['ms_per_step'], r['host_issue_ms_per_step']))")"
+    done
+    if [ "${TRAIN_STATS:-0}" = 1 ]; then
+      stats train_step_$name tools/bench_train.py --fused --steps 30 2>/dev/null | grep -E "render_backward|geometry_backward|sh_backward|band_place|preprocess" | cut -c1-110
+    fi
   done
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
   ;;
