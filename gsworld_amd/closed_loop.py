@@ -175,7 +175,8 @@ class ClosedLoopRenderer:
         self._host = torch.zeros(off)
         pin = dev.type == "cuda" and torch.cuda.is_available()
         self._ring = [torch.zeros(off).pin_memory() if pin else torch.zeros(off) for _ in range(8)]
-        self._ring_ev, self._ring_k = [None] * len(self._ring), 0
+        self._ring_ev, self._ring_k, self._ring_waited = [None] * len(self._ring), 0, -1
+        self._on_gpu = pin
         self._dirty, self._stale = set(), set()  # segments changed on the host / last written from a device tensor
 
         def views(buf):
@@ -308,18 +309,12 @@ class ClosedLoopRenderer:
             else:
                 cur[1] = hi
         for lo, hi in runs:
-            k = self._ring_k % len(self._ring)
-            self._ring_k += 1
-            if self._ring_ev[k] is not None:
-                self._ring_ev[k].synchronize()  # (eight copies ago: long done)
+            k = self._slot_acquire()
             slot = self._ring[k]
             slot[lo:hi].copy_(self._host[lo:hi])
             if not self._stage_poses(k, lo, hi):
                 self._stage[lo:hi].copy_(slot[lo:hi], non_blocking=True)
-            if self.device.type == "cuda" and torch.cuda.is_available():
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self._ring_ev[k] = ev
+            self._slot_release(k, False)
         self._stale -= self._dirty
         self._dirty.clear()
 
@@ -424,34 +419,20 @@ class ClosedLoopRenderer:
             # ahead the host is); launches queue back to back.  8.58 k against 8.36 k frames/s on the configs[2] surrogate.
             # With the policy in the loop the graph wins -- one submission instead of eleven in front of every wait: 7.67 k
             # against 7.25 k -- and `ensure=True` takes it.
-            k = self._ring_k % len(self._ring)
-            self._ring_k += 1
-            if self._ring_ev[k] is not None:
-                self._ring_ev[k].synchronize()
+            k = self._slot_acquire()
             np.copyto(self._ring_np[k], self._host_np)
             self._dirty.clear()
             self._launch_stage(k, int(self._stage.numel()))
             self.multi.rerun(self._pack)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._ring_ev[k] = ev
+            self._slot_release(k, False)
         elif self._graphs is not None:
             # this step's host values travel INSIDE its graph: the whole mirror into the next pinned slot (a host copy of a
             # kilobyte), then the replay of the graph that was captured reading that slot
-            k = self._ring_k % len(self._ring)
-            self._ring_k += 1
-            if self._ring_ev[k] is not None:
-                self._ring_ev[k].synchronize()  # (eight steps ago: long done)
+            k = self._slot_acquire()
             np.copyto(self._ring_np[k], self._host_np)
             self._dirty.clear()
             self._graphs[k].replay()
-            if ensure:
-                # (the wait below covers the slot: no event to create and record in front of it)
-                self._ring_ev[k] = None
-            else:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self._ring_ev[k] = ev
+            self._slot_release(k, ensure)
         elif self._graph is not None:
             self._flush()  # this step's host values: one copy / launch on the step's stream, ahead of the replay
             self._graph.replay()
@@ -465,6 +446,38 @@ class ClosedLoopRenderer:
             torch.cuda.current_stream(self.device).synchronize()
         self._check_overflow(late=not ensure)
         return self.frames
+
+    # The pinned ring: slot k is read by the device during the step that staged it, and written again eight steps later.
+    # An event behind EVERY step is a marker the queue stops at: ~6 us between a step's last kernel and the next step's
+    # first by the kernel trace (round 6).  So only every fourth step records one, and a slot's writer waits for the first
+    # event at or after the step that last read the slot -- at most three steps later, still five steps back.
+    _EV_EVERY = 4
+
+    def _slot_acquire(self) -> int:
+        n = len(self._ring)
+        s = self._ring_k
+        self._ring_k += 1
+        last_reader = s - n
+        if last_reader >= 0 and self._on_gpu:
+            e = last_reader + ((self._EV_EVERY - 1 - last_reader) % self._EV_EVERY)  # first recording step >= last_reader
+            ev = self._ring_ev[e % n]
+            if ev is not None and ev[0] == e:
+                ev[1].synchronize()
+            elif ev is None or ev[0] < last_reader:
+                # (no marker covers the slot's last reader -- e.g. that step ended in a wait of its own: ensure=True)
+                if self._ring_waited < last_reader:
+                    torch.cuda.current_stream(self.device).synchronize()
+                    self._ring_waited = s - 1
+        return s % n
+
+    def _slot_release(self, k: int, waited: bool):
+        s = self._ring_k - 1
+        if waited:
+            self._ring_waited = s  # (the caller waits for this step's frames: every slot up to here is free after that)
+        elif s % self._EV_EVERY == self._EV_EVERY - 1 and self._on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._ring_ev[s % len(self._ring)] = (s, ev)
 
     def _check_overflow(self, late: bool):
         pending = 0

@@ -556,6 +556,10 @@ __device__ __forceinline__ void sh_basis(int D, float x, float y, float z, ShBas
 // each thread works on its own row.  The kernel writes EVERY coefficient gradient of its 256 Gaussians -- zeros for
 // culled ones and for coefficients above the active degree -- so the caller does not clear those arrays.
 // CNT = 0: any other SH layout, per-thread accesses, arrays cleared by the caller.
+// (Measured in round 6 and not kept: the forward of the fused training path leaving d colour / d direction -- 9 floats per
+// visible Gaussian, computed while the coefficients are in preprocess' registers -- so that this kernel need not read the
+// coefficients again: 56.5 -> 32.4 us here, but preprocess 39.7 -> 61.4 us at configs[4] size (the sums alone +9 us, the
+// nine stores alone +12 us, planar or as records, 73 or 104 VGPRs): the step stayed at 0.505 ms.)
 template <int CNT>
 __global__ __launch_bounds__(GSR_BLOCK) void sh_backward_kernel(const BwdArgs a) {
     constexpr int STRIDE = CNT | 1;                                      // odd: a wave's rows start in 32 distinct banks

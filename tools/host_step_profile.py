@@ -84,5 +84,58 @@ def main():
     st.sort_stats("cumulative").print_stats(28)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "parts"):
     main()
+
+
+def parts():
+    """Every host-side piece of a policy-in-the-loop step timed by itself (us per call)."""
+    import numpy as np
+
+    dev = torch.device("cuda:0")
+    W, H = 640, 480
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=1)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align", W, H),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
+    rollout = cl.xarm6_rollout()
+    parts_, actors = cl.xarm6_rollout_parts(rollout)
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=4, seed=0, num_envs=1))
+    M, s = poses[1][0].pin_memory(), poses[1][1].pin_memory()
+    w = look_at_view([0.5, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)
+    loop = cl.ClosedLoopRenderer(raw, parts_, cams, scaled_parts=actors, device=dev, batched=True, num_envs=1)
+    loop.reset(M, s)
+    loop.capture()
+    loop.step(M, s, cameras={"wrist_cam": w}, ensure=True)
+
+    def t(name, fn, n=2000):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        print(f"{name:34s} {(time.perf_counter() - t0) / n * 1e6:7.2f} us", flush=True)
+
+    stream = torch.cuda.current_stream(dev)
+    t("set_poses", lambda: loop.set_poses(M, s))
+    t("set_cameras (one camera)", lambda: loop.set_cameras({"wrist_cam": w}))
+    t("ring copy (numpy)", lambda: np.copyto(loop._ring_np[0], loop._host_np))
+    t("torch.cuda.current_stream", lambda: torch.cuda.current_stream(dev))
+    t("stream.synchronize (idle)", lambda: stream.synchronize())
+    t("_check_overflow", lambda: loop._check_overflow(late=False))
+    t("_slot_acquire + release(waited)", lambda: loop._slot_release(loop._slot_acquire(), True))
+    g = loop._graphs[0]
+
+    def replay_and_wait():
+        g.replay()
+        stream.synchronize()
+    t("graph replay + wait (a whole step's device time inside)", replay_and_wait, 300)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        g.replay()
+    t1 = time.perf_counter()
+    stream.synchronize()
+    print(f"{'graph.replay() alone (issue)':34s} {(t1 - t0) / 300 * 1e6:7.2f} us")
+    t("step(ensure=True) whole", lambda: loop.step(M, s, cameras={"wrist_cam": w}, ensure=True), 300)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "parts":
+    parts()
