@@ -539,7 +539,7 @@ int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream_) {
     out[4] = (int32_t)h.ss_B;
     out[5] = (int32_t)h.ss_stride;
     out[6] = (int32_t)h.coop_quads;
-    out[7] = 0;
+    out[7] = (int32_t)h.ss_near;  // (this frame took the kept table unchecked under a view that moved a little)
     return GSR_OK;
 }
 

@@ -30,6 +30,7 @@
 // kept splitters, depth ties) is cut once more by the same workgroup and sorted in LDS pieces; only a piece of equal
 // keys goes through a bitonic network over the (key << 32 | index) composites in global memory (ss_buckets_kernel).
 #include "gsr_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -81,6 +82,39 @@ __device__ __forceinline__ int ss_num_buckets(uint32_t V, int bmax, uint32_t per
     return B;
 }
 __device__ __forceinline__ int ss_log2(int B) { return 31 - __builtin_clz((unsigned)B); }
+// minimum / maximum over the 64 lanes, in every lane (DPP row shifts and row broadcasts: six adds' worth of VALU instead of
+// six ds_bpermute round trips per value)
+__device__ __forceinline__ uint32_t ss_wave_min(uint32_t v) {
+    int x = (int)v;
+#define SS_STEP(ctrl, rmask) x = (int)min((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false))
+    SS_STEP(0x111, 0xf); SS_STEP(0x112, 0xf); SS_STEP(0x114, 0xf); SS_STEP(0x118, 0xf); SS_STEP(0x142, 0xa); SS_STEP(0x143, 0xc);
+#undef SS_STEP
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ uint32_t ss_wave_max(uint32_t v) {
+    int x = (int)v;
+#define SS_STEP(ctrl, rmask) x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false))
+    SS_STEP(0x111, 0xf); SS_STEP(0x112, 0xf); SS_STEP(0x114, 0xf); SS_STEP(0x118, 0xf); SS_STEP(0x142, 0xa); SS_STEP(0x143, 0xc);
+#undef SS_STEP
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+// a bucket above this many records makes its frame "unbalanced" (ss_bad): 1.25 shares under the view the table was built
+// under, 2 under another one
+__device__ __forceinline__ uint32_t ss_share_limit(uint32_t V, int B, bool moved) {
+    const uint32_t share = V / (uint32_t)B;
+    return (moved ? 2u * share : share + share / 4u) + 64u;
+}
+#ifndef GSR_SS_PROBE_EVERY
+#define GSR_SS_PROBE_EVERY 4  // (A/B: 0 = every frame with a kept table checks it against its samples, as until round 6)
+#endif
+#ifndef GSR_SS_NEAR
+#define GSR_SS_NEAR 1  // (A/B: 0 = only a bit-identical view matrix takes the kept table unchecked, as until round 6)
+#endif
+#ifndef GSR_SS_NEAR_TOL
+#define GSR_SS_NEAR_TOL 0.015625f
+#endif
+// "a little": every element of the view matrix within this of the table's -- 1 / 64: under a degree, 1.6 cm of a metric scene
+constexpr float kNearTol = GSR_SS_NEAR_TOL;
 
 // tile rect -> rect in super-tile units (min rounds down, the exclusive max rounds up); s = 0: unchanged
 __device__ __forceinline__ uint2 ss_super_rect(uint2 rc, int s) {
@@ -372,7 +406,11 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
                                                 uint32_t *__restrict__ splitters_new, uint32_t *__restrict__ seg_off,
                                                 uint32_t *__restrict__ seg_first, GsrHeader *__restrict__ hdr,
                                                 uint64_t *__restrict__ dbg, const float *__restrict__ view,
-                                                uint32_t sig) {
+                                                uint32_t sig, const int role) {
+    // role 0: the frame's plan -- V, bucket count, which table classifies, samples, new splitters; role 1: the runs of blocks
+    // of the compaction workgroups.  Two workgroups since round 6: both start from the same sums of the block counts
+    // (summed twice: 23 KB from the L2), neither reads what the other writes, and the frame's sort waits for the longer of
+    // the two chains instead of their sum (31-35 k cycles as one workgroup by the stamps, of which the ranges ~4 k).
     const unsigned dbg_wg = 0; (void)dbg_wg;
     SS_STAMP(dbg, 0);
     __shared__ uint32_t s_key[2 * kMaxSamples];
@@ -391,10 +429,14 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // What decides whether the splitters in the state are taken as they are is requested NOW, with the table itself: by
     // the time the counts are summed it has all arrived.
     const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_trust = hdr->ss_trust,
-                   h_P = hdr->ss_P;
-    bool same_view = true;
+                   h_P = hdr->ss_P, h_near = hdr->ss_near, h_near_fail = hdr->ss_near_fail, h_vfail = hdr->ss_vfail;
+    bool same_view = true, near_view = true;
 #pragma unroll
-    for (int k = 0; k < 16; k++) same_view = same_view && __float_as_uint(view[k]) == hdr->ss_view[k];
+    for (int k = 0; k < 16; k++) {
+        const uint32_t was = hdr->ss_view[k];
+        same_view = same_view && __float_as_uint(view[k]) == was;
+        near_view = near_view && fabsf(view[k] - __uint_as_float(was)) <= kNearTol;  // (false on a NaN)
+    }
     uint32_t pre_sp[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) pre_sp[k] = tid + k * kPT < bmax - 1 ? splitters[tid + k * kPT] : 0xFFFFFFFFu;
@@ -433,7 +475,7 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     (void)p_incl;
     s_pex[tid] = p_excl;
     if (tid == 0) s_pex[kPT] = V;
-    if (tid == 0) {  // first kernel of the frame that touches the header
+    if (tid == 0 && role == 0) {  // first kernel of the frame that touches the header
         hdr->V = V;
         hdr->R = 0u;
         hdr->overflow = 0u;
@@ -443,19 +485,58 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
         hdr->tile_queue = 0u;
     }
     if (V == 0u) {
-        for (int j = tid; j <= nbc; j += kPT) {
-            seg_off[j] = 0u;
-            seg_first[j] = (uint32_t)nb1;
-        }
-        if (tid == 0) {
+        if (role == 1)
+            for (int j = tid; j <= nbc; j += kPT) {
+                seg_off[j] = 0u;
+                seg_first[j] = (uint32_t)nb1;
+            }
+        if (tid == 0 && role == 0) {
             hdr->ss_fresh = 0u;
             hdr->ss_B = 256u;
             hdr->ss_stride = 1u;
+            hdr->ss_near = 0u;
+            hdr->ss_moved = 1u;
         }
         return;
     }
     __syncthreads();
     SS_STAMP(dbg, 22);
+    if (role == 1) {
+    // ---- the run of blocks of every compaction workgroup.  Ownership follows a COST: a block costs its visible Gaussians
+    // (records to classify and move) + kBlockCost (its 256 keys have to be fetched and tested whatever they hold) -- equal
+    // record shares alone hand a workgroup in an empty stretch of the model a thousand blocks to sweep.  The cost before
+    // block j is (records before j) + kBlockCost j; workgroup b's run starts at the block in which that crosses b's
+    // share boundary: thread b finds boundary b.
+    if (tid <= nbc) {
+        uint32_t j = 0u, before_j = 0u;
+        if (tid == nbc) {
+            j = (uint32_t)nb1;
+            before_j = V;
+        } else if (tid > 0) {
+            const uint32_t W = V + kBlockCost * (uint32_t)nb1;
+            const uint32_t t = (uint32_t)((double)W * (double)tid / (double)nbc);
+            uint32_t us = 0u;  // last slice whose cost-before is <= t
+#pragma unroll
+            for (int st = kPT / 2; st > 0; st >>= 1)
+                if (s_pex[us + (uint32_t)st] + kBlockCost * min((uint32_t)nb1, (us + (uint32_t)st) * (uint32_t)per) <= t)
+                    us += (uint32_t)st;
+            const uint32_t jb = min((uint32_t)nb1, us * (uint32_t)per), je = min((uint32_t)nb1, jb + (uint32_t)per);
+            uint32_t pos = 0u;  // last block of the slice whose cost-before is <= t (the slice's first one qualifies)
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {
+                const uint32_t k = jb + pos + (uint32_t)st;
+                if (pos + (uint32_t)st < (uint32_t)per && k < je &&
+                    s_pex[us] + (uint32_t)s_cnt16[k - 1u] + kBlockCost * k <= t)
+                    pos += (uint32_t)st;
+            }
+            j = jb + pos;
+            before_j = s_pex[us] + (pos > 0u ? (uint32_t)s_cnt16[j - 1u] : 0u);
+        }
+        seg_off[tid] = before_j;
+        seg_first[tid] = j;
+    }
+        return;
+    }
     // A fixed sensor camera (GSWorld's right_cam and the like) over a scene that stands still: the view matrix is bit
     // for bit the one the splitters in the state were built under and the last frames that classified with the kept
     // table came out as balanced as exact quantiles of an unchanged scene do (ss_trust, kept by ss_partition /
@@ -475,21 +556,56 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // -5.5 %).  The first blind frame after sampling ones finds a table of twice its count and takes every second entry
     // (the 2i-th of 2B quantiles is the i-th of B): `stride`.  A frame that samples again finds a table of half its count,
     // which fails `reuse` below: one drawn table per change from resting to moving.
-    const int B0 = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET);
+    int B0 = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET);
+    // (hysteresis: a camera whose visible count hovers around a power-of-two multiple of the bucket size -- the surrogate's
+    //  wrist camera sees 263 k Gaussians, 512 x 512 = 262 144 -- would flip between two bucket counts from frame to frame,
+    //  and a kept table of the other count is no table: a new one drawn nearly every step.  The kept count stays while its
+    //  buckets average 192 .. 640 records.)
+    if (GSR_SS_NEAR != 0 && h_magic == kSplitMagic && h_P == sig && h_buckets >= 256u && h_buckets <= (uint32_t)bmax &&
+        (h_buckets & (h_buckets - 1u)) == 0u && V >= h_buckets * 192u && V <= h_buckets * 640u)
+        B0 = (int)h_buckets;
     const int Bf = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET_FULL);  // (B0 or B0 / 2)
-    bool blind = same_view && h_magic == kSplitMagic && (h_buckets == (uint32_t)Bf || h_buckets == 2u * (uint32_t)Bf) &&
-                 h_buckets <= (uint32_t)bmax && (GSR_SS_IGNORE_BAD || h_bad == 0u) &&
-                 h_trust >= (uint32_t)GSR_SS_TRUST_MIN && h_trust <= 255u && h_P == sig;
-    const int B = blind ? Bf : B0;
-    const uint32_t stride = blind ? h_buckets / (uint32_t)Bf : 1u;
+    const bool table_ok = h_magic == kSplitMagic && h_buckets <= (uint32_t)bmax && (GSR_SS_IGNORE_BAD || h_bad == 0u) &&
+                          h_trust <= 255u && h_P == sig;
+    const bool blind_same = same_view && table_ok && (h_buckets == (uint32_t)Bf || h_buckets == 2u * (uint32_t)Bf) &&
+                            h_trust >= (uint32_t)GSR_SS_TRUST_MIN;
+    // Round 6: a camera that MOVES A LITTLE (a wrist camera riding on the arm: millimetres and a fraction of a degree per
+    // step) over the table its previous frame left -- the exact quantiles of THAT frame's depth order, one step old.  Depths
+    // shift smoothly under such a move, so the buckets stay near their shares; drawing samples to confirm it (two binary
+    // searches per sample, a gather, a classification: 14.2 against 8.3 us on this one workgroup) is most of what the frame's
+    // sort waits for.  Such a frame goes blind as well once the kept table has been earning its trust under the moving
+    // camera -- the frames before it classified with it and no bucket came out above TWICE its share (ss_buckets: the
+    // bound for frames whose view differs from the table's; a static camera keeps 1.25) -- with the full bucket count (a
+    // bucket of twice its share still fits the LDS), and a near-blind frame that does come out unbalanced doubles the
+    // trust the next one has to show (ss_near_fail): a rig whose small moves do unbalance its tables ends up sampling.
+    uint32_t near_fail = h_near_fail > 6u ? 0u : h_near_fail;  // (a fresh state holds garbage)
+    if (h_magic == kSplitMagic && h_near == 1u && h_bad != 0u && near_fail < 6u) near_fail++;
+    const bool blind_near = GSR_SS_NEAR != 0 && !same_view && near_view && table_ok && h_buckets == (uint32_t)B0 &&
+                            h_trust >= (2u << near_fail);
+    bool blind = blind_same || blind_near;
+    const int B = blind_same ? Bf : B0;
+    const uint32_t stride = blind_same ? h_buckets / (uint32_t)Bf : 1u;
     if (tid == 0) {
         hdr->ss_B = (uint32_t)B;
         hdr->ss_stride = stride;
+        hdr->ss_moved = same_view ? 0u : 1u;
+        hdr->ss_near_fail = near_fail;
     }
     // (at least kMinSamples: with few buckets the splitters would otherwise be cut from two samples each, and one bucket
     // in a few hundred frames outgrows the LDS)
     const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
     const int logS = ss_log2((int)S);  // (S is a power of two)
+    // Round 6: the kept table is CHECKED against this frame's samples only when the last check passed, or every fourth
+    // frame after one that failed (ss_vfail: frames since).  While a scene changes from step to step (the arm of a
+    // random-action rollout: the visible count of either camera moves by 10-20 % per step) the check fails three frames out of
+    // four, and since the new-table route is a histogram (7 k cycles) the check (6.4 k + 3.7 k for the table) no longer buys
+    // what it cost against the two LSD passes it used to save.
+    const bool table_there = h_magic == kSplitMagic && h_buckets == (uint32_t)B && h_P == sig;
+    const uint32_t vfail = (h_magic == kSplitMagic && h_vfail <= 255u) ? h_vfail : 0u;
+    const bool attempt = table_there && (GSR_SS_PROBE_EVERY == 0 || vfail == 0u || vfail >= (uint32_t)GSR_SS_PROBE_EVERY);
+    const bool need_table = blind || attempt;
+    bool ascending = false;
+    if (need_table) {
     // the kept table into LDS (used blind, or validated below)
     if (stride == 1u) {
 #pragma unroll
@@ -526,45 +642,19 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // between: what is taken for BALANCE must still be an ascending table, or the order breaks)
     uint32_t unsorted = 0u;
     for (int i = tid; i + 1 < B - 1; i += kPT) unsorted |= s_split[i + 1] < s_split[i] ? 1u : 0u;
-    const bool ascending = __syncthreads_or((int)unsorted) == 0;
-    blind = blind && ascending;
-    if (tid == 0) hdr->ss_blind = blind ? 1u : 0u;  // (the placement keeps its cuts on the same condition)
-    SS_STAMP(dbg, 23);
-    // ---- the run of blocks of every compaction workgroup.  Ownership follows a COST: a block costs its visible Gaussians
-    // (records to classify and move) + kBlockCost (its 256 keys have to be fetched and tested whatever they hold) -- equal
-    // record shares alone hand a workgroup in an empty stretch of the model a thousand blocks to sweep.  The cost before
-    // block j is (records before j) + kBlockCost j; workgroup b's run starts at the block in which that crosses b's
-    // share boundary: thread b finds boundary b.
-    if (tid <= nbc) {
-        uint32_t j = 0u, before_j = 0u;
-        if (tid == nbc) {
-            j = (uint32_t)nb1;
-            before_j = V;
-        } else if (tid > 0) {
-            const uint32_t W = V + kBlockCost * (uint32_t)nb1;
-            const uint32_t t = (uint32_t)((double)W * (double)tid / (double)nbc);
-            uint32_t us = 0u;  // last slice whose cost-before is <= t
-#pragma unroll
-            for (int st = kPT / 2; st > 0; st >>= 1)
-                if (s_pex[us + (uint32_t)st] + kBlockCost * min((uint32_t)nb1, (us + (uint32_t)st) * (uint32_t)per) <= t)
-                    us += (uint32_t)st;
-            const uint32_t jb = min((uint32_t)nb1, us * (uint32_t)per), je = min((uint32_t)nb1, jb + (uint32_t)per);
-            uint32_t pos = 0u;  // last block of the slice whose cost-before is <= t (the slice's first one qualifies)
-#pragma unroll
-            for (int st = 16; st > 0; st >>= 1) {
-                const uint32_t k = jb + pos + (uint32_t)st;
-                if (pos + (uint32_t)st < (uint32_t)per && k < je &&
-                    s_pex[us] + (uint32_t)s_cnt16[k - 1u] + kBlockCost * k <= t)
-                    pos += (uint32_t)st;
-            }
-            j = jb + pos;
-            before_j = s_pex[us] + (pos > 0u ? (uint32_t)s_cnt16[j - 1u] : 0u);
-        }
-        seg_off[tid] = before_j;
-        seg_first[tid] = j;
+    ascending = __syncthreads_or((int)unsorted) == 0;
     }
+    blind = blind && ascending;
+    if (tid == 0) {
+        hdr->ss_blind = blind ? 1u : 0u;
+        hdr->ss_near = (blind && !blind_same) ? 1u : 0u;
+    }
+    SS_STAMP(dbg, 23);
     if (blind) {
-        if (tid == 0) hdr->ss_fresh = 0u;
+        if (tid == 0) {
+            hdr->ss_fresh = 0u;
+            hdr->ss_vfail = 0u;
+        }
         return;
     }
     // ---- samples.  Sample s belongs to the preprocess block that holds visible Gaussian floor(s V / S) of the index
@@ -578,8 +668,11 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // visible records -- one or two cache lines of the block's compacted records instead of a line per sample; inside a
     // block of 256 consecutive Gaussians -- neighbours in space for a laid-out model, a random subset otherwise -- any n
     // records are as good a sample of the block's depths as any other.
-    {
-        constexpr int SW = kMaxSamples / kPT;  // 4
+    // (S = 2048 or 4096: two or four samples per thread -- sixteen waves' dependent LDS reads on one CU are what this phase
+    //  costs, 7.5 k cycles with four chains per thread whatever S was; with S = 2048 the other two only repeated the last
+    //  sample)
+    auto draw = [&](auto swc) {
+        constexpr int SW = decltype(swc)::value;
         const double s_per_rank = (double)S / (double)V;
         uint32_t tgt[SW], u[SW];
 #pragma unroll
@@ -630,7 +723,9 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
 #pragma unroll
         for (int q = 0; q < SW; q++)
             if ((uint32_t)(tid + q * kPT) < S) s_key[tid + q * kPT] = k[q] & kKeyMask;
-    }
+    };
+    if (S <= 2u * (uint32_t)kPT) draw(std::integral_constant<int, 2>{});
+    else draw(std::integral_constant<int, kMaxSamples / kPT>{});
     __syncthreads();
     SS_STAMP(dbg, 2);
     // ---- splitters.  A closed-loop camera hardly moves: the exact quantiles ss_buckets left in the state after the
@@ -639,11 +734,12 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // sort when it holds.
     // (the largest of B Poisson(2) sample counts grows with B: 8 passes for 512 buckets 9 times out of 10, 12 for 2048)
     const uint32_t reuse_max = 4u * (S / (uint32_t)B) + (B > 512 ? 2u * (uint32_t)(ss_log2(B) - 9) : 0u);
-    bool reuse = h_magic == kSplitMagic && h_buckets == (uint32_t)B && S >= (uint32_t)B && h_P == sig && ascending;
+    const bool checked = attempt && S >= (uint32_t)B && ascending;
+    bool reuse = checked;
     if (reuse) {
         uint32_t bad = 0;
-        {
-            constexpr int SW = kMaxSamples / kPT;
+        auto classify = [&](auto swc) {
+            constexpr int SW = decltype(swc)::value;
             uint32_t tk[SW], bk[SW];
 #pragma unroll
             for (int q = 0; q < SW; q++) tk[q] = (uint32_t)(tid + q * kPT) < S ? s_key[tid + q * kPT] : kNoKey;
@@ -651,7 +747,9 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
 #pragma unroll
             for (int q = 0; q < SW; q++)
                 if (tk[q] != kNoKey) atomicAdd(&s_hist[bk[q]], 1u);
-        }
+        };
+        if (S <= 2u * (uint32_t)kPT) classify(std::integral_constant<int, 2>{});
+        else classify(std::integral_constant<int, kMaxSamples / kPT>{});
         __syncthreads();
         for (int i = tid; i < B; i += kPT)
             if (s_hist[i] > reuse_max) bad = 1u;
@@ -668,11 +766,8 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
             mn = min(mn, s_key[i]);
             mx = max(mx, s_key[i]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-        }
+        mn = ss_wave_min(mn);
+        mx = ss_wave_max(mx);
         __shared__ uint32_t s_mm[2 * kPW];
         if (lane == 0) {
             s_mm[wave] = mn;
@@ -740,7 +835,11 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
             }
         }
     }
-    if (tid == 0) hdr->ss_fresh = reuse ? 0u : 1u;
+    if (tid == 0) {
+        hdr->ss_fresh = reuse ? 0u : 1u;
+        // (frames since a check of the kept table failed; 0: the last check passed, or there was nothing to check)
+        hdr->ss_vfail = checked ? (reuse ? 0u : 1u) : (table_there ? min(vfail + 1u, 255u) : 0u);
+    }
     SS_STAMP(dbg, 3);
 }
 
@@ -1083,7 +1182,8 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     const int n = (int)(bucket_start[bucket + 1] - s);
     // above what the exact quantiles of the last frame give when nothing moved (share V / B, plus depth ties): the scene
     // is changing under the camera, the next frames check the kept table against samples (ss_compact_kernel)
-    if (tid == 0 && (uint32_t)n > (V / (uint32_t)B) + (V / (uint32_t)B) / 4u + 64u) hdr->ss_bad = 1u;
+    // (a frame whose view is not the table's -- hdr->ss_moved, ss_prepare -- is held to twice its share instead)
+    if (tid == 0 && (uint32_t)n > ss_share_limit(V, B, hdr->ss_moved != 0u)) hdr->ss_bad = 1u;
     if (n == 0) {
         if (tid == 0) bucket_tiles[bucket] = 0u;
         return;
@@ -1568,12 +1668,12 @@ struct SsArgs {
 
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
-    if (blockIdx.x == 1) {  // (only launched with a deal to make)
+    if (blockIdx.x == 2) {  // (only launched with a deal to make)
         ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_list, a.coop_cap, a.hdr);
         return;
     }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
-                    a.hdr, a.dbg, a.view, a.sig);
+                    a.hdr, a.dbg, a.view, a.sig, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(kT) void ss_compact_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
@@ -1626,7 +1726,7 @@ __global__ __launch_bounds__(kT) void ss_buckets_kernel(const GsrBatch<SsArgs> b
     const int n = (int)(a.bucket_start[bucket + 1] - s0);
     // (above what the exact quantiles of the last frame give when nothing moved: see ss_buckets_body)
     if (gsr_lane() == 0) {
-        if ((uint32_t)n > (V / (uint32_t)B) + (V / (uint32_t)B) / 4u + 64u) a.hdr->ss_bad = 1u;
+        if ((uint32_t)n > ss_share_limit(V, B, a.hdr->ss_moved != 0u)) a.hdr->ss_bad = 1u;
         s_big[wave] = n > kWaveCap ? 1u : 0u;
     }
     if (n <= kWaveCap)
@@ -1693,7 +1793,7 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
     }
-    hipLaunchKernelGGL(ss_prepare_kernel, dim3(order_early ? 2 : 1, B), dim3(kPT), 0, stream, bt);
+    hipLaunchKernelGGL(ss_prepare_kernel, dim3(order_early ? 3 : 2, B), dim3(kPT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_prepare", debug, stream)) return e;
     const size_t lds1 = (size_t)(2 * bmax + 4 * kT + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(ss_compact_kernel, dim3(nbc, B), dim3(kT), lds1, stream, bt);

@@ -74,7 +74,11 @@ struct GsrHeader {
     uint32_t coop_timeouts;  // cooperative quadrants whose hand-off timed out in the frames on this state (render.hip;
                           //   never cleared by a frame: reported like overflow_frames -- such a quadrant is truncated)
     uint32_t coop_timeout_now;  // ... and in THIS frame (cleared by the frame's first kernel: gsr_frame_stats -> GSR_E_TRUNCATED)
-    uint32_t pad[22];
+    uint32_t ss_moved;    // this frame's view matrix is not the one the kept splitters were built under (depthsort.hip)
+    uint32_t ss_near;     // ... and the frame took them unchecked all the same (a camera that moves a little)
+    uint32_t ss_near_fail;  // such frames that came out unbalanced (each doubles the trust the next one has to show)
+    uint32_t ss_vfail;    // frames since a check of the kept table against samples failed (0: the last one passed)
+    uint32_t pad[18];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)

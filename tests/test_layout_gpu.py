@@ -200,7 +200,7 @@ def test_tie_order_survives_trusted_splitters_and_a_moving_arm(cuda_device):
     for k in (12, 20, 27, 28, 29, 31):
         a = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, bound_capacity=True)
         a.reset(*poses[k - 1])
-        for _ in range(3):
+        for _ in range(6):
             a.step(*poses[k - 1])
         got = a.step(*poses[k])["right_cam"].clone()
         torch.cuda.synchronize()
