@@ -104,6 +104,9 @@ __device__ __forceinline__ uint32_t ss_share_limit(uint32_t V, int B, bool moved
     const uint32_t share = V / (uint32_t)B;
     return (moved ? 2u * share : share + share / 4u) + 64u;
 }
+#ifndef GSR_SS_DIAG
+#define GSR_SS_DIAG 0
+#endif
 #ifndef GSR_SS_PROBE_EVERY
 #define GSR_SS_PROBE_EVERY 4  // (A/B: 0 = every frame with a kept table checks it against its samples, as until round 6)
 #endif
@@ -413,6 +416,9 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // the two chains instead of their sum (31-35 k cycles as one workgroup by the stamps, of which the ranges ~4 k).
     const unsigned dbg_wg = 0; (void)dbg_wg;
     SS_STAMP(dbg, 0);
+#ifdef GSR_SS_TIMING
+    if (role == 0 && threadIdx.x < 8) dbg[48 + threadIdx.x] = 0ull;
+#endif
     __shared__ uint32_t s_key[2 * kMaxSamples];
     __shared__ __attribute__((aligned(16))) uint32_t s_cur[kPW * 256];
     __shared__ uint32_t s_split[2048], s_hist[2048];  // (bmax <= 2048)
@@ -1163,6 +1169,21 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0 + 32; const unsigned dbg_wg = 100; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 0);
+#ifdef GSR_SS_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    auto note_time = [&](int nrec) {  // the slowest bucket workgroup of the frame (slots 48..50) and the sum of all (51, 52)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long el = __builtin_amdgcn_s_memtime() - t_start;
+            const unsigned long long old = atomicMax((unsigned long long *)&dbg0[48], el);
+            if (el > old) { dbg0[49] = (uint64_t)nrec; dbg0[50] = (uint64_t)bucket; }
+            atomicAdd((unsigned long long *)&dbg0[51], el);
+            atomicAdd((unsigned long long *)&dbg0[52], 1ull);
+        }
+    };
+#else
+    auto note_time = [&](int) {};
+#endif
     uint32_t *s_k = smem;                      // [2][kBucketCap]
     uint32_t *s_v = s_k + 2 * kBucketCap;      // [2][kBucketCap]
     uint32_t *s_cur = s_v + 2 * kBucketCap;    // [4][256]
@@ -1194,10 +1215,21 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
     // inside the bucket (the placement cuts the depth order into shares of equal INSTANCE count with it), and next
     // frame's splitters -- the exact B-quantiles of this frame's depth order, each written by whoever holds its rank
     auto emit = [&](auto at, uint32_t abs, int cnt, uint32_t carry) -> uint32_t {
-        for (int i = tid; i < B - 1; i += kT) {
-            const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) / (uint32_t)B);
-            if (q >= abs && q < abs + (uint32_t)cnt) splitters[i] = at((int)(q - abs)).y & kKeyMask;
+        // Quantile i is rank q(i) = (i + 1) V / B, B a power of two.  Until round 6 every thread walked all B - 1 of them
+        // with a 64-bit division each -- 5 k of a bucket workgroup's ~25 k cycles by the stamps -- to find the one or two
+        // that fall into its records; now the walk starts two short of a float estimate of the first that can (q is
+        // monotone; the estimate is off by far less than one) and ends at the first beyond.
+        {
+            const int lg = ss_log2(B);
+            const float est = (float)abs * ((float)B / (float)V);
+            const int i0 = max((int)est - 2, 0);
+            for (int i = i0 + tid; i < B - 1; i += kT) {
+                const uint32_t q = (uint32_t)(((uint64_t)(i + 1) * V) >> lg);
+                if (q >= abs + (uint32_t)cnt) break;
+                if (q >= abs) splitters[i] = at((int)(q - abs)).y & kKeyMask;
+            }
         }
+        SS_STAMP(dbg, 5);
         // (every rect gather of the thread goes out before the first is used: kBucketCap / kT per thread and chunk; a
         //  piece of equal keys that went through the global-memory network can be longer than one chunk)
         constexpr int kPerE = kBucketCap / kT;
@@ -1208,7 +1240,11 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
             for (int e = 0; e < kPerE; e++) {
                 const int i = c0 + e * kT + tid;
                 gi[e] = i < cnt ? at(i).x : 0u;
+#if GSR_SS_DIAG == 1  // (timing diagnostics only -- wrong rects: the gather as a coalesced read)
+                rc[e] = i < cnt ? rects[abs + (uint32_t)i] : make_uint2(0u, 0u);
+#else
                 rc[e] = i < cnt ? rects[gi[e]] : make_uint2(0u, 0u);
+#endif
             }
 #pragma unroll
             for (int e = 0; e < kPerE; e++) {
@@ -1225,6 +1261,7 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
                 const uint32_t incl = gsr_block_incl_scan(t, s_w, tot);
                 if (i < cnt) tile_cum[abs + i] = carry + incl;
                 carry += tot;
+                if (e == 0 && c0 == 0) SS_STAMP(dbg, 6);
             }
         }
         return carry;
@@ -1346,7 +1383,10 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
         // round in a row moved nothing.  A run of L equal keys takes at most L rounds; thousands of equal depths (a plane
         // facing the camera) cost a barrier each and stay exact.  (Measured against it in round 4: ranking every member
         // inside a +-6 window with straight-line code and falling back to the rounds for longer runs -- slower on both
-        // views: the window is probed whether or not a run is long.)
+        // views: the window is probed whether or not a run is long.  Round 6, after the stamps showed fix-ups of 10-38 k
+        // cycles in the slowest bucket workgroup of a closed-loop frame: every member of a run of up to 192 finding the ends
+        // of its run and counting the smaller original numbers, two barriers per bucket -- ss_buckets 21.3 -> 23.8 us: the
+        // usual run is three to six members, for which a handful of rounds is the shorter chain.)
         int quiet = 0;
         for (int round = 0; quiet < 2; round++) {
             int moved = 0;
@@ -1447,16 +1487,29 @@ __device__ __forceinline__ void ss_buckets_body(int bmax, uint2 *__restrict__ re
             __syncthreads();  // the LDS halves are free for the next piece
         }
         if (tid == 0) bucket_tiles[bucket] = carry;
+        note_time(n);
         return;
     }
     SS_STAMP(dbg, 1);
     const int src = sort_in_lds(seg, n, false);
     SS_STAMP(dbg, 3);
+#ifdef GSR_SS_TIMING
+    const unsigned long long t_fix0 = __builtin_amdgcn_s_memtime();
+#endif
     fix_ties(src, n);
+#ifdef GSR_SS_TIMING
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long el = __builtin_amdgcn_s_memtime() - t_fix0;
+        const unsigned long long old = atomicMax((unsigned long long *)&dbg0[53], el);
+        if (el > old) dbg0[54] = (uint64_t)n;
+    }
+#endif
     const uint32_t *kk = s_k + src * kBucketCap, *vv = s_v + src * kBucketCap;
     const uint32_t carry = emit([&](int i) { return make_uint2(vv[i], kk[i] + kbase); }, s, n, 0u);
     if (tid == 0) bucket_tiles[bucket] = carry;
     SS_STAMP(dbg, 4);
+    note_time(n);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -49,5 +49,8 @@ for k, (M, s) in enumerate(poses[1:]):
                     if 0 < v[10] < 2_000_000_000 and v[11] < 65536 else "slowest wg: not recorded")
             print(f"   compact wg64: plan {d(8, 9)} | offsets {d(9, 4)} | walk {d(4, 5)} | classify {d(5, 6)} | table {d(6, 7)} | total {d(8, 7)}; "
                   f"{slow}")
+            if 0 < v[48] < 2_000_000_000 and v[52] > 0:
+                print(f"   buckets: slowest wg {v[48]} clk ({v[49]} records, bucket {v[50]}), mean {v[51] / v[52]:.0f} clk over {v[52]} workgroups; longest tie fix-up {v[53]} clk (bucket of {v[54]})")
             print(f"   partition wg64: setup {int(v[17] - v[16])} move {int(v[18] - v[17])} | buckets wg100: hdr {int(v[33] - v[32])} "
-                  f"sort {int(v[35] - v[33])} emit {int(v[36] - v[35])} bits {v[40]} n {v[41]}")
+                  f"sort {int(v[35] - v[33])} emit {int(v[36] - v[35])} (quantiles {int(v[37] - v[35])}, gather + first scan {int(v[38] - v[37])}) "
+                  f"bits {v[40]} n {v[41]}")
