@@ -566,9 +566,9 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // (hysteresis: a camera whose visible count hovers around a power-of-two multiple of the bucket size -- the surrogate's
     //  wrist camera sees 263 k Gaussians, 512 x 512 = 262 144 -- would flip between two bucket counts from frame to frame,
     //  and a kept table of the other count is no table: a new one drawn nearly every step.  The kept count stays while its
-    //  buckets average 192 .. 640 records.)
+    //  buckets average 224 .. 576 records: an eighth either side of the nominal 256 .. 512.)
     if (GSR_SS_NEAR != 0 && h_magic == kSplitMagic && h_P == sig && h_buckets >= 256u && h_buckets <= (uint32_t)bmax &&
-        (h_buckets & (h_buckets - 1u)) == 0u && V >= h_buckets * 192u && V <= h_buckets * 640u)
+        (h_buckets & (h_buckets - 1u)) == 0u && V >= h_buckets * 224u && V <= h_buckets * 576u)
         B0 = (int)h_buckets;
     const int Bf = ss_num_buckets(V, bmax, (uint32_t)GSR_SS_PER_BUCKET_FULL);  // (B0 or B0 / 2)
     const bool table_ok = h_magic == kSplitMagic && h_buckets <= (uint32_t)bmax && (GSR_SS_IGNORE_BAD || h_bad == 0u) &&

@@ -142,6 +142,19 @@ stats)
   stats moving_camera tools/prof_scene.py --view sensor --moving
   stats default_mode_frame tools/prof_scene.py --view sensor --default-mode
   ;;
+dense_v)  # the dense view, one frame per launch, per kernel: the committed library and every variant present
+  # (NOT for the timing-diagnostics builds -- GSR_SS_DIAG, GSR_BWD_DIAG: their frames are wrong on purpose, and a wrong rect
+  #  can keep a later kernel busy for good; session of round 6: 15 GPU-minutes until the limit)
+  cp gsworld_amd/libgsr_hip.so /tmp/libgsr_hip.base.so
+  for lib in /tmp/libgsr_hip.base.so tools/variants/libgsr_hip.*.so; do
+    [ -f "$lib" ] || continue
+    name=$(basename $lib .so); name=${name#libgsr_hip.}
+    cp $lib gsworld_amd/libgsr_hip.so
+    STATS_ROWS=10 stats dense_view_$name tools/prof_scene.py --view dense
+    echo "$name: $(python tools/ab_batch.py --view dense --steps 300 --configs batch1 2>/dev/null | tail -1 | cut -c1-120)"
+  done
+  cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
+  ;;
 train)
   stats train_step_fused tools/bench_train.py --fused --steps 30
   ;;
