@@ -48,8 +48,8 @@ constexpr int kT = GSR_BLOCK;        // 256 threads, 4 waves
 #define GSR_SS_IGNORE_BAD 0
 #endif
 #ifndef GSR_SS_SPB
-#define GSR_SS_SPB 2
-#endif
+#define GSR_SS_SPB 4  // (2 until round 6: frames of 1 024 buckets -- 262 k to 524 k visible Gaussians -- drew 2 048 samples;
+#endif                //  with 4 096 the training step's ss_buckets is 4 us shorter, the closed loop the same)
 constexpr int kSamplesPerBucket = GSR_SS_SPB;
 constexpr int kMinSamples = 2048;
 constexpr int kMaxSamples = 4096;
@@ -108,7 +108,11 @@ __device__ __forceinline__ uint32_t ss_share_limit(uint32_t V, int B, bool moved
 #define GSR_SS_DIAG 0
 #endif
 #ifndef GSR_SS_PROBE_EVERY
-#define GSR_SS_PROBE_EVERY 4  // (A/B: 0 = every frame with a kept table checks it against its samples, as until round 6)
+#define GSR_SS_PROBE_EVERY 0  // MEASURED AND NOT KEPT (4 = after a failed check, check again only every fourth frame):
+                              // closed loop +0.4 % (8.74 against 8.70 k frames/s), but the training step 0.503 -> 0.52 ms --
+                              // its views change every step and a kept table that passes the check (exact quantiles of a
+                              // nearby view) balances 1 024 buckets far better than one drawn from two samples per bucket:
+                              // ss_buckets 23.7 -> 38.5 us
 #endif
 #ifndef GSR_SS_NEAR
 #define GSR_SS_NEAR 1  // (A/B: 0 = only a bit-identical view matrix takes the kept table unchecked, as until round 6)
@@ -601,11 +605,8 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // in a few hundred frames outgrows the LDS)
     const uint32_t S = (uint32_t)min(kMaxSamples, max(kSamplesPerBucket * B, kMinSamples));
     const int logS = ss_log2((int)S);  // (S is a power of two)
-    // Round 6: the kept table is CHECKED against this frame's samples only when the last check passed, or every fourth
-    // frame after one that failed (ss_vfail: frames since).  While a scene changes from step to step (the arm of a
-    // random-action rollout: the visible count of either camera moves by 10-20 % per step) the check fails three frames out of
-    // four, and since the new-table route is a histogram (7 k cycles) the check (6.4 k + 3.7 k for the table) no longer buys
-    // what it cost against the two LSD passes it used to save.
+    // (GSR_SS_PROBE_EVERY, an A/B switch: the kept table checked against this frame's samples only when the last check passed,
+    //  or every n-th frame after one that failed -- ss_vfail: frames since.  Off: see the macro.)
     const bool table_there = h_magic == kSplitMagic && h_buckets == (uint32_t)B && h_P == sig;
     const uint32_t vfail = (h_magic == kSplitMagic && h_vfail <= 255u) ? h_vfail : 0u;
     const bool attempt = table_there && (GSR_SS_PROBE_EVERY == 0 || vfail == 0u || vfail >= (uint32_t)GSR_SS_PROBE_EVERY);

@@ -60,23 +60,31 @@ __global__ __launch_bounds__(GSR_BLOCK, 5) void ssim_forward_kernel(int H, int W
     // horizontal pass: 26 rows x 8 groups of 4 columns
     if (tid < kHY * (kTX / 4)) {
         const int ly = tid / (kTX / 4), c0 = (tid - ly * (kTX / 4)) * 4;
-        float a[14], b[14];
+        float a[14], b[14], aa[14], bb[14], ab[14];
 #pragma unroll
         for (int j = 0; j < 14; j++) {
             a[j] = s1[ly][c0 + j];
             b[j] = s2[ly][c0 + j];
+        }
+        // (the three products once per loaded value, not once per tap that uses it: the same roundings, 42 multiplies for
+        //  the four outputs instead of 132)
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            aa[j] = a[j] * a[j];
+            bb[j] = b[j] * b[j];
+            ab[j] = a[j] * b[j];
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const float av = a[c + k], bv = b[c + k], w = g.w[k];
-                m1 = fmaf_(w, av, m1);
-                m2 = fmaf_(w, bv, m2);
-                e11 = fmaf_(w, av * av, e11);
-                e22 = fmaf_(w, bv * bv, e22);
-                e12 = fmaf_(w, av * bv, e12);
+                const float w = g.w[k];
+                m1 = fmaf_(w, a[c + k], m1);
+                m2 = fmaf_(w, b[c + k], m2);
+                e11 = fmaf_(w, aa[c + k], e11);
+                e22 = fmaf_(w, bb[c + k], e22);
+                e12 = fmaf_(w, ab[c + k], e12);
             }
             sh[0][ly][c0 + c] = m1; sh[1][ly][c0 + c] = m2; sh[2][ly][c0 + c] = e11; sh[3][ly][c0 + c] = e22;
             sh[4][ly][c0 + c] = e12;

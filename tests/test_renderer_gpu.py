@@ -374,16 +374,28 @@ def test_forward_only_capacity_overflow_is_recovered(cuda_device):
     # the default (training-capable) frames and the alternative binning paths count the same way
     from gsworld_amd import _lib
 
+    # ... and every path leaves the count where a host that does not wait can read it (GsrOutputs.overflow_mirror: two pinned
+    # words the frame's capacity check writes itself on the counting placements, an 8-byte copy on the A/B paths)
     for tune in ({}, {"binning_path": 2}, {"binning_path": 1}, {"binning_path": 3}, {"depth_sort": 1}):
         saved = dict(_lib.TUNING)
         _lib.TUNING.update(tune)
         try:
-            d = FrameRenderer(dev)
+            d = FrameRenderer(dev, overflow_mirror=True)
+            assert d._mirror_dev, "pinned host memory has a device-visible address on this platform"
             d.render(cam, means, op, **kw)
+            torch.cuda.synchronize()
+            assert d.overflows_seen() == 0, tune
             d.r_capacity = 1 << 10
             d.render(cam, means, op, **kw)
             d.render(cam, means, op, **kw)
             assert d.stats().overflow_frames == 2, tune
+            assert d.overflows_seen() == 2, tune  # (stats() has synchronised: the mirror is what the device wrote)
+            m = FrameRenderer(dev, forward_only=True, overflow_mirror=True)
+            m.render(cam, means, op, **kw)
+            m.r_capacity = 1 << 10
+            m.render(cam, means, op, **kw)
+            torch.cuda.synchronize()
+            assert m.overflows_seen() == 1 and m.stats().overflow_frames == 1, tune
         finally:
             _lib.TUNING.update(saved)
 
