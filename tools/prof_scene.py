@@ -3,6 +3,7 @@
 usage: prof_scene.py [--view sensor|dense] [--frames N] [--default-mode] [--moving]"""
 import argparse
 import math
+import time
 import os
 import sys
 
@@ -18,6 +19,7 @@ ap.add_argument("--view", default="sensor")
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--default-mode", action="store_true", help="forward_only = 0 (the training-capable frame)")
 ap.add_argument("--moving", action="store_true", help="turn the camera a little on every frame")
+ap.add_argument("--states", action="store_true", help="print what the depth sort did with its kept table, frame by frame (synchronises)")
 ap.add_argument("--sh-degree", type=int, default=3, help="ablation: evaluate fewer SH bands (0: the DC term only)")
 ap.add_argument("--no-layout", action="store_true", help="the model as given (no Morton order / block culling)")
 args = ap.parse_args()
@@ -47,5 +49,14 @@ for k in range(args.frames):
     r.render(cam, means, op, shs=shs, scales=sc, rotations=rot, rgb8_out=rgb8, sh_degree=args.sh_degree, layout=lay)
     if k == 1:
         r.ensure_valid(lambda: None)
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+    if args.states:
+        from gsworld_amd import debug as dbg
+        st = dbg.sort_state(r.geom)
+        print(k, "B", st["buckets"], "blind", int(st["blind"]), "near", int(st["near"]), "fresh", int(st["fresh"]), "bad", int(st["bad"]),
+              "trust", st["trust"])
 torch.cuda.synchronize()
+fps_line = f"{(args.frames - 2) / (time.perf_counter() - t_start):.0f} frames/s one at a time (eager launches)"
 print("stats", r.stats())
+print(fps_line)
