@@ -158,6 +158,18 @@ dense_v)  # the dense view, one frame per launch, per kernel: the committed libr
 train)
   stats train_step_fused tools/bench_train.py --fused --steps 30
   ;;
+fuzz)  # fuzz sweeps and soaks on the committed library -> $OUT/fuzz_and_soak.txt
+  {
+    timeout 600 python tools/fuzz_forward_only.py 500 61 2>&1 | tail -1
+    timeout 600 python tools/fuzz_batch.py 300 62 2>&1 | tail -1
+    timeout 600 python tools/fuzz_parity.py 100 63 2>&1 | tail -1
+    timeout 600 python tools/fuzz_fused_backward.py 20 64 2>&1 | tail -1
+    timeout 600 python tools/fuzz_backward.py 30 65 2>&1 | tail -1
+    timeout 900 python tools/soak_static_scene.py 9000 inference 2>&1 | tail -1
+    timeout 900 python tools/soak_moving_camera.py 600 400000 1 2>&1 | tail -1
+    timeout 900 python tools/soak_moving_camera.py 300 1468850 2 2>&1 | tail -1
+  } | cut -c1-400 | tee $OUT/fuzz_and_soak.txt
+  ;;
 hostprof)  # the host's share of a policy-in-the-loop step
   timeout 600 python tools/host_step_profile.py 2>&1 | cut -c1-200 | tee $OUT/host_step_profile.txt | head -70
   ;;
