@@ -83,6 +83,13 @@ class GsrInputs(C.Structure):
 RAW_OPACITY, RAW_SCALES, RAW_ROTATIONS = 1, 2, 4  # include/gsr.h GSR_RAW_*
 
 
+def model_version(v: int) -> int:
+    """include/gsr.h GSR_MODEL_VERSION: bits 8..31 of ``param_space`` -- the caller's promise that the model arrays, labels,
+    LUT and block bounds hold what they held in the previous frame on the state that carried the same (nonzero) version."""
+    x = (int(v) & 0xFFFFFF) << 8
+    return x - (1 << 32) if x >= (1 << 31) else x  # (param_space is an int32)
+
+
 class GsrOutputs(C.Structure):
     _fields_ = [("out_color", C.c_void_p), ("out_invdepth", C.c_void_p), ("radii", C.c_void_p),
                 ("out_rgb8", C.c_void_p),  # optional (H,W,3) uint8 frame written by the compositor

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import transform as tf
-from ._lib import RAW_ROTATIONS, RAW_SCALES
+from ._lib import RAW_ROTATIONS, RAW_SCALES, model_version
 from .renderer import MultiCameraRenderer
 
 
@@ -42,7 +42,7 @@ class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
                  layout: bool = True, min_capacity: int | None = None, share_model_of=None, batched: bool = True,
-                 keep_float: bool = False):
+                 keep_float: bool = False, block_cache: bool = True):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -226,6 +226,15 @@ class ClosedLoopRenderer:
                     break
                 addr.append(d.value)
             self._ring_dev = addr
+        # The model is this object's own copy (laid out at construction, never written afterwards): the frames may keep the
+        # blocks of 256 Gaussians whose camera and part pose are the previous frame's bit for bit (include/gsr.h
+        # GSR_MODEL_VERSION; csrc/preprocess.hip prep_block_cached) -- under a fixed sensor camera everything that is not a
+        # robot link or a tracked object.  A random version per object: a state buffer the allocator hands from one loop to
+        # another never vouches for the other's model.  ``block_cache=False``: every block recomputed every frame.
+        import random
+
+        self._model_version = model_version(random.getrandbits(24) | 1) if (block_cache and self.fuse_transform and
+                                                                            self.layout is not None) else 0
         self._graph = None    # the captured step (host values staged OUTSIDE it: a copy / a launch between two replays) ...
         self._graphs = None   # ... or one captured step per ring slot, each staging its slot itself (see capture())
         self._pack = None     # the step's argument pack (MultiCameraRenderer.last_pack): eager steps without the Python
@@ -262,7 +271,8 @@ class ClosedLoopRenderer:
                     per_lane.append(dict(parts=parts if E == 1 else parts[e]))
             self.multi.render(views, self.xyz, self.opacity, rgb8_out=outs, shs=self.features_dc,
                               shs_rest=self.features_rest, scales=self.scaling, rotations=self.rotation,
-                              param_space=RAW_SCALES | RAW_ROTATIONS, bg=self.bg, per_lane=per_lane, layout=self.layout)
+                              param_space=RAW_SCALES | RAW_ROTATIONS | self._model_version, bg=self.bg, per_lane=per_lane,
+                              layout=self.layout)
             return
         if self.rescaled:
             xyz, rot, scaling = self.op.apply(self.xyz, self.rotation, self.matrices, self.scales, scaling=self.scaling)

@@ -128,7 +128,7 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
             gsr_set_error("gsr_forward: binning_path must be 0..4, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
             return GSR_E_INVALID;
         }
-        if (in->param_space & ~(GSR_RAW_OPACITY | GSR_RAW_SCALES | GSR_RAW_ROTATIONS)) {
+        if (in->param_space & 0xF8) {  // (bits 0-2: GSR_RAW_*; bits 8-31: GSR_MODEL_VERSION)
             gsr_set_error("gsr_forward: unknown bits in param_space");
             return GSR_E_INVALID;
         }
@@ -256,6 +256,10 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
         f.img = ImageState::carve(img_mem, p.W, p.H);
         // exact mode first counts with an unlimited capacity, reads R back, then sizes the binning state exactly
         f.cap32 = exact ? 0xFFFFFFFFu : (uint32_t)r_capacity[k];
+        // block cache (preprocess.hip prep_block_cached): inference frames of the default path whose caller vouches for the model
+        f.pc = GSR_PREP_BLOCK_CACHE && infer && band && mode == 1 && !p.radix_depth && ((uint32_t)in[k].param_space >> 8) != 0u &&
+               in[k].part_labels != nullptr && in[k].cull_blocks != nullptr && out[k].radii == nullptr &&
+               in[k].part_count <= GSR_PC_MAX_PARTS;
     }
     const GeomState &g = fr[0].g;
     const ImageState &img = fr[0].img;
@@ -539,7 +543,9 @@ int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream_) {
     out[4] = (int32_t)h.ss_B;
     out[5] = (int32_t)h.ss_stride;
     out[6] = (int32_t)h.coop_quads;
-    out[7] = (int32_t)h.ss_near;  // (this frame took the kept table unchecked under a view that moved a little)
+    // (bit 0: this frame took the kept table unchecked under a view that moved a little; bit 1: its preprocess kept blocks of
+    //  the previous frame -- the block cache)
+    out[7] = (int32_t)((h.ss_near & 1u) | ((h.pc_hit_last & 1u) << 1));
     return GSR_OK;
 }
 

@@ -413,7 +413,7 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
                                                 uint32_t *__restrict__ splitters_new, uint32_t *__restrict__ seg_off,
                                                 uint32_t *__restrict__ seg_first, GsrHeader *__restrict__ hdr,
                                                 uint64_t *__restrict__ dbg, const float *__restrict__ view,
-                                                uint32_t sig, const int role) {
+                                                uint32_t sig, const int role, const bool pc_enabled) {
     // role 0: the frame's plan -- V, bucket count, which table classifies, samples, new splitters; role 1: the runs of blocks
     // of the compaction workgroups.  Two workgroups since round 6: both start from the same sums of the block counts
     // (summed twice: 23 KB from the L2), neither reads what the other writes, and the frame's sort waits for the longer of
@@ -440,6 +440,9 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     // the time the counts are summed it has all arrived.
     const uint32_t h_magic = hdr->ss_magic, h_buckets = hdr->ss_buckets, h_bad = hdr->ss_bad, h_trust = hdr->ss_trust,
                    h_P = hdr->ss_P, h_near = hdr->ss_near, h_near_fail = hdr->ss_near_fail, h_vfail = hdr->ss_vfail;
+    // (the block cache's words too: thread 0 turns them over below, in front of a barrier everybody waits at)
+    const uint32_t h_pc_pending = hdr->pc_pending, h_pc_parity = hdr->pc_parity, h_pc_sig_next = hdr->pc_sig_next,
+                   h_pc_hit = hdr->pc_hit;
     bool same_view = true, near_view = true;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -486,6 +489,17 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
     s_pex[tid] = p_excl;
     if (tid == 0) s_pex[kPT] = V;
     if (tid == 0 && role == 0) {  // first kernel of the frame that touches the header
+        // (block cache, preprocess.hip: the slot this frame's preprocess wrote its camera and poses to becomes the current one)
+        if (pc_enabled && h_pc_pending == GSR_PC_MAGIC) {
+            hdr->pc_parity = (h_pc_parity & 1u) ^ 1u;
+            hdr->pc_sig = h_pc_sig_next;
+            hdr->pc_magic = GSR_PC_MAGIC;
+        } else {
+            hdr->pc_magic = 0u;
+        }
+        hdr->pc_pending = 0u;
+        hdr->pc_hit_last = pc_enabled ? h_pc_hit : 0u;
+        hdr->pc_hit = 0u;
         hdr->V = V;
         hdr->R = 0u;
         hdr->overflow = 0u;
@@ -1718,6 +1732,8 @@ struct SsArgs {
     uint32_t *tile_cum, *bucket_tiles;
     int sshift;
     const int32_t *orig;
+    const uint2 *block_recs;  // preprocess' block-local records (GeomState::block_recs)
+    int pc_enabled;           // this frame's preprocess ran with the block cache: ss_prepare makes its slot current
 };
 
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
@@ -1726,12 +1742,12 @@ __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> 
         ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_list, a.coop_cap, a.hdr);
         return;
     }
-    ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.pair1, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
-                    a.hdr, a.dbg, a.view, a.sig, (int)blockIdx.x);
+    ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.block_recs, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
+                    a.hdr, a.dbg, a.view, a.sig, (int)blockIdx.x, a.pc_enabled != 0);
 }
 __global__ __launch_bounds__(kT) void ss_compact_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
-    ss_compact_body(a.bmax, a.pair1, a.block_counts, a.pair0, a.table, a.splitters, a.splitters_new, a.seg, a.first,
+    ss_compact_body(a.bmax, a.block_recs, a.block_counts, a.pair0, a.table, a.splitters, a.splitters_new, a.seg, a.first,
                     a.hdr, a.dbg);
 }
 __global__ __launch_bounds__(kColT) void ss_colscan_kernel(const GsrBatch<SsArgs> bt) {
@@ -1846,6 +1862,8 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.coop_cap = coop_blocks;
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
+        a.block_recs = g.block_recs;
+        a.pc_enabled = fr[k].pc ? 1 : 0;
     }
     hipLaunchKernelGGL(ss_prepare_kernel, dim3(order_early ? 3 : 2, B), dim3(kPT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_prepare", debug, stream)) return e;

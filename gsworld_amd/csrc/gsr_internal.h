@@ -78,12 +78,27 @@ struct GsrHeader {
     uint32_t ss_near;     // ... and the frame took them unchecked all the same (a camera that moves a little)
     uint32_t ss_near_fail;  // such frames that came out unbalanced (each doubles the trust the next one has to show)
     uint32_t ss_vfail;    // frames since a check of the kept table against samples failed (0: the last one passed)
-    uint32_t pad[18];
+    // block cache of preprocess (preprocess.hip prep_block_cached): the previous frame on this state left its camera and pose
+    // table in GeomState::pc_slots[pc_parity] and every per-Gaussian record it computed is still in place
+    uint32_t pc_magic;    // GSR_PC_MAGIC: ... and they are valid for pc_sig
+    uint32_t pc_parity;   // which slot holds them
+    uint32_t pc_pending;  // this frame's preprocess has written the other slot (ss_prepare flips)
+    uint32_t pc_sig;      // settings + model signature of the frame that left the valid slot
+    uint32_t pc_sig_next; // ... of the frame that wrote the pending one
+    uint32_t pc_hit;      // some workgroup of this frame's preprocess kept its block (plain stores of 1) ...
+    uint32_t pc_hit_last; // ... as ss_prepare found it: did the last frame on this state keep any block? (gsr_debug_sort_state)
+    uint32_t pad[11];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)
 };
 #define GSR_OF_MAGIC 0x0F10F10Fu
+#ifndef GSR_PREP_BLOCK_CACHE
+#define GSR_PREP_BLOCK_CACHE 1  // (A/B: 0 = every frame recomputes every block, whatever its caller promises)
+#endif
+#define GSR_PC_MAGIC 0x50434348u  // 'PCCH'
+#define GSR_PC_MAX_PARTS 64
+#define GSR_PC_SLOT (40 + 17 * GSR_PC_MAX_PARTS)  // floats of one slot: view 16 | proj 16 | campos 3 | pad 5 | pose table
 // The one thread that compared R with the capacity.  Every frame clears hdr->overflow before its first such check, and a
 // path with two checks per frame (bin-then-sort) must count the frame once: only the 0 -> 1 edge counts.
 // `mirror` (GsrOutputs.overflow_mirror: two words the HOST can read, or nullptr) receives (of_magic, overflow_frames) as
@@ -147,6 +162,11 @@ struct GeomState {
                               //       rec2 = (r, g, b, radius as float)
     float *cov3D;             // [6P]
     uint32_t *clamped;        // [P]   byte c = SH clamp flag of channel c
+    uint2 *block_recs;        // [P]   (index, depth bits) of every block's visible Gaussians, compacted to the head of the
+                              //       block's own 256 slots (preprocess -> the sample sort's compaction).  An array of its own
+                              //       since round 6 (it used to be pair[1], which the sort's partition pass overwrites): a block
+                              //       the next frame does not recompute keeps its records
+    float *pc_slots;          // [2][GSR_PC_SLOT] camera + pose table of the last two frames' preprocess (GsrHeader::pc_*)
     GsrGradWord *grad_rec;    // [12P] backward only: the compositor's ten per-Gaussian sums as ONE record (mean2D.xy,
                               //       conic xx xy yy, opacity, rgb, 1/depth, 2 unused) -- see backward.hip.  binary64 words
                               //       (round 6): a Gaussian's sums arrive tile by tile, by device-scope atomics in whatever
@@ -245,6 +265,8 @@ struct GeomState {
         g.ss_totals = take<uint32_t>(p, (size_t)gsr_ss_bmax(P));
         g.band_nseg = take<uint32_t>(p, (size_t)tiles * GSR_BAND_RANGES);  // (rows <= tiles: sized for the narrowest grid)
         g.ss_first = take<uint32_t>(p, (size_t)gsr_ss_nbc(P) + 1);
+        g.block_recs = take<uint2>(p, n);
+        g.pc_slots = take<float>(p, 2 * GSR_PC_SLOT);
         // LAST: the only array whose size depends on tiles_x, which the read-only carvers (gsr_backward,
         // gsr_state_view, gsr_debug_ss_stamps) do not pass -- nothing may follow it
         g.band_wtable = take<uint32_t>(p, band_wtable_words(tiles_x, tiles));
@@ -439,6 +461,7 @@ struct GsrFrame {
     ImageState img;
     BinningState b;             // (valid from the placement on)
     uint32_t cap32;             // binning capacity the range kernel checks R against
+    bool pc;                    // this frame's preprocess may keep last frame's blocks (preprocess.hip prep_block_cached)
 };
 
 // ---- error plumbing ------------------------------------------------------------------------------------
@@ -447,7 +470,7 @@ int gsr_check_launch(const char *what, bool debug, hipStream_t stream);
 
 // ---- launchers implemented in the kernel files -----------------------------------------------------------
 // (B frames of one model size and image size; every launcher below that takes `B, fr` spans them with one launch)
-int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream);
+int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream);
 // bin-then-sort path (default): unordered binning into tile segments, then a per-tile (depth, index) sort
 int gsr_launch_bin_starts(const GsrSettings &st, const GeomState &g, const ImageState &img, uint32_t r_capacity,
                           bool debug, hipStream_t stream);

@@ -52,6 +52,10 @@ struct PreprocessArgs {
     int num_tiles;
     uint32_t *tile_accum;
     GsrHeader *hdr;
+    // block cache (prep_block_cached): the two slots that hold the last two frames' camera + pose table, or nullptr = this
+    // frame recomputes every block; pc_sig: everything else the records depend on (settings, model identity, state layout)
+    float *pc_slots;
+    uint32_t pc_sig;
 };
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -614,6 +618,7 @@ struct PrepShared {
     float4 pos[GSR_BLOCK];
     int idx[GSR_BLOCK];
     int culled[GSR_MAX_BATCH];
+    int cached[GSR_MAX_BATCH];  // (the block keeps the previous frame's records for this frame -- prep_block_cached)
 };
 typedef float PrepWorld[11][GSR_BLOCK];  // (multi-frame groups only: WorldGauss in LDS, each thread its own slots)
 
@@ -702,20 +707,104 @@ __device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Block cache (round 6).  A closed loop renders the same model from a FIXED sensor camera step after step, and most of what
+// that camera sees -- table, walls, whatever is not a robot link or a tracked object -- has not moved: the records preprocess
+// would write for such a block (splat, rect, block-local depth records, block count) are bit for bit the ones it wrote a
+// step ago, and they are still in the state.  A block is therefore left as it is when (1) the caller vouches for the model
+// (a model version in GsrInputs.param_space: the arrays, labels, LUT and block bounds hold what they held in the previous
+// frame on this state that carried the same version), (2) settings, sizes and pointers are the previous frame's (pc_sig),
+// (3) view matrix, projection and camera centre are the previous frame's bit for bit, and (4) the block's Gaussians carry one
+// label (GsrInputs.cull_blocks names it) whose pose row is the previous frame's bit for bit, or no moving part at all.  The
+// previous frame's camera and pose table live in one of two slots of the state (GeomState::pc_slots); this frame's go to the
+// other one (workgroup 0), and the first kernel behind preprocess (ss_prepare) makes that one current -- nothing a workgroup
+// of this launch reads is written during it.  Every other preprocess launch on the state (several frames per workgroup,
+// training frames, the A/B paths) clears the mark.  What it saves on the configs[2] surrogate: the static right_cam's share of
+// the two-frame launch, 39 -> 27 us per step.  Frames are bit-identical by construction (tests/test_closed_loop_gpu.py).
+// ---------------------------------------------------------------------------------------------------------
+// (one WAVE asks, a lane per compared word -- 35 of the camera, 17 of the pose row: two loads per lane; the first version had
+//  every thread of every workgroup walk all 52 -- 39 -> 50 us instead of 39 -> 27)
+__device__ __forceinline__ bool prep_block_cached(const PreprocessArgs &a, const uint32_t blk) {
+    const GsrHeader *h = a.hdr;
+    const int lane = gsr_lane();
+    const uint32_t magic = h->pc_magic, sig = h->pc_sig, parity = h->pc_parity & 1u;
+    const uint32_t *prev = reinterpret_cast<const uint32_t *>(a.pc_slots + (size_t)parity * GSR_PC_SLOT);
+    const float lf = a.cull_blocks[8 * (size_t)blk + 7];
+    bool ok = magic == GSR_PC_MAGIC && sig == a.pc_sig && lf == lf;  // (NaN: members carry different labels)
+    const int label = ok ? (int)lf : -1;
+    const int part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
+    const bool moving = part >= 0 && part < a.part_count;
+    uint32_t cur = 0u, was = 0u;
+    if (lane < 16) {
+        cur = __float_as_uint(a.view[lane]);
+        was = prev[lane];
+    } else if (lane < 32) {
+        cur = __float_as_uint(a.proj[lane - 16]);
+        was = prev[lane];
+    } else if (lane < 35) {
+        cur = __float_as_uint(a.campos[lane - 32]);
+        was = prev[lane];
+    } else if (lane < 52 && moving) {
+        cur = __float_as_uint(a.part_transforms[(size_t)part * 17 + (lane - 35)]);
+        was = prev[40 + 17 * part + (lane - 35)];
+    }
+    return ok && __builtin_amdgcn_ballot_w64(cur != was) == 0ull;
+}
+// workgroup 0: this frame's camera and pose table into the slot that is NOT current
+__device__ __forceinline__ void prep_cache_publish(const PreprocessArgs &a) {
+    GsrHeader *h = a.hdr;
+    // (a state without a valid mark: which slot is "current" does not matter, nobody reads either)
+    const uint32_t parity = h->pc_magic == GSR_PC_MAGIC ? (h->pc_parity & 1u) : 0u;
+    float *cur = a.pc_slots + (size_t)(parity ^ 1u) * GSR_PC_SLOT;
+    const int tid = (int)threadIdx.x;
+    if (tid < 16) {
+        cur[tid] = a.view[tid];
+        cur[16 + tid] = a.proj[tid];
+    }
+    if (tid < 3) cur[32 + tid] = a.campos[tid];
+    for (int k = tid; k < 17 * a.part_count; k += GSR_BLOCK) cur[40 + k] = a.part_transforms[k];
+    if (tid == 0) {
+        h->pc_sig_next = a.pc_sig;
+        h->pc_pending = GSR_PC_MAGIC;
+        if (h->pc_magic != GSR_PC_MAGIC) h->pc_parity = 0u;
+    }
+}
+
 // the block's view-frustum test for every frame of the group -> the frames that have to look at it; the others get their
 // zero count (and, where a caller reads them, zero radii) on the spot
+template <bool CACHE = true>
 __device__ __forceinline__ uint32_t prep_live_frames(const PrepLaunch &L, const int f0, const int nf, const uint32_t blk,
                                                      const int i, PrepShared &sh) {
     uint32_t live = (1u << nf) - 1u;
     if (L.bt.f[f0].cull_blocks == nullptr) return live;  // (the group shares the model: frame f0's block names it)
-    // (a wave evaluates the block's test for its frames, ~100 instructions each; the verdicts meet at a barrier)
-    for (int k = gsr_wave(); k < nf; k += GSR_BLOCK / GSR_WAVE) {
+    // workgroup 0 leaves the camera and poses of the frames that take the block cache for their next frames
+    if (CACHE && blk == 0u)
+        for (int k = 0; k < nf; k++)
+            if (L.bt.f[f0 + k].pc_slots != nullptr) prep_cache_publish(L.bt.f[f0 + k]);
+    // (a wave evaluates the block's test for its frames, ~100 instructions each; the verdicts meet at a barrier.  A lone
+    //  frame's cache question is asked by the last wave meanwhile, a group's frames ask theirs behind their frustum test.)
+    constexpr int NW = GSR_BLOCK / GSR_WAVE;
+    for (int k = gsr_wave(); k < nf; k += NW) {
         const PreprocessArgs a = L.bt.f[f0 + k];
         const bool c = prep_block_culled(a, (int)blk);
-        if (gsr_lane() == 0) sh.culled[k] = c ? 1 : 0;
+        const bool h = CACHE && nf > 1 && a.pc_slots != nullptr && prep_block_cached(a, blk);
+        if (gsr_lane() == 0) {
+            sh.culled[k] = c ? 1 : 0;
+            if (nf > 1) sh.cached[k] = h ? 1 : 0;
+        }
+    }
+    if (CACHE && nf == 1 && gsr_wave() == NW - 1) {
+        const PreprocessArgs &a = L.bt.f[f0];
+        const bool h = a.pc_slots != nullptr && prep_block_cached(a, blk);
+        if (gsr_lane() == 0) sh.cached[0] = h ? 1 : 0;
     }
     __syncthreads();
     for (int k = 0; k < nf; k++) {
+        if (CACHE && sh.cached[k] != 0) {  // (everything this frame would write for the block is in place: the previous frame's)
+            live &= ~(1u << k);
+            if (threadIdx.x == 0) L.bt.f[f0 + k].hdr->pc_hit = 1u;
+            continue;
+        }
         if (sh.culled[k] == 0) continue;
         live &= ~(1u << k);
         const PreprocessArgs &a = L.bt.f[f0 + k];
@@ -748,7 +837,9 @@ void preprocess_kernel(const PrepLaunch L) {
     if (COUNT_TILES) {
         for (int t = (int)threadIdx.x; t < a.num_tiles; t += GSR_BLOCK) s_tcnt[t] = 0u;
     }
-    if (prep_live_frames(L, f0, 1, blk, i, sh) == 0u) return;
+    if (a.pc_slots == nullptr && blk == 0u && threadIdx.x == 0)
+        a.hdr->pc_magic = 0u;  // (this launch rewrites the records without leaving its camera: nothing to compare with next)
+    if (prep_live_frames(L, f0, 1, blk, i, sh) == 0u) return;  // (+ the block cache: cull_blocks is there whenever pc_slots is)
     prep_frame<FAST_SH16, COUNT_TILES, false>(a, i, blk, false, nullptr, 0.f, false, sh, nullptr, s_tcnt);
 }
 
@@ -756,10 +847,16 @@ void preprocess_kernel(const PrepLaunch L) {
 #ifndef GSR_PREP_GROUP_WAVES
 #define GSR_PREP_GROUP_WAVES 6  // minimum waves per SIMD asked of the compiler for the multi-frame kernel: 80 VGPRs, no scratch (0: no limit -- 84; 7: 72 + 28 B of scratch)
 #endif
-template <bool FAST_SH16>
+// (CACHE: some frame of the launch takes the block cache -- an instance of its own: the questions cost the frame loop five
+//  registers it does not have, 20 bytes of scratch per lane, which launches without the cache must not pay)
+#ifndef GSR_PREP_GROUP_CACHE_WAVES
+#define GSR_PREP_GROUP_CACHE_WAVES 5  // waves per SIMD asked for the CACHE instance: 85 VGPRs, no scratch (0 = the same six as
+                                      // the plain instance, with the scratch: four environments 13.12 against 13.23-13.33 k)
+#endif
+template <bool FAST_SH16, bool CACHE = false>
 __global__
 #if GSR_PREP_GROUP_WAVES > 0
-__launch_bounds__(GSR_BLOCK, GSR_PREP_GROUP_WAVES)
+__launch_bounds__(GSR_BLOCK, (CACHE && GSR_PREP_GROUP_CACHE_WAVES > 0) ? GSR_PREP_GROUP_CACHE_WAVES : GSR_PREP_GROUP_WAVES)
 #else
 __launch_bounds__(GSR_BLOCK)
 #endif
@@ -769,7 +866,9 @@ void preprocess_group_kernel(const PrepLaunch L) {
     __shared__ PrepShared sh;
     __shared__ PrepWorld s_world;
     const int i0 = (int)blk * GSR_BLOCK + (int)threadIdx.x;
-    const uint32_t live = prep_live_frames(L, f0, nf, blk, i0, sh);
+    if (blk == 0u && (int)threadIdx.x < nf && L.bt.f[f0 + (int)threadIdx.x].pc_slots == nullptr)
+        L.bt.f[f0 + (int)threadIdx.x].hdr->pc_magic = 0u;  // (a frame that rewrites its records without leaving its camera)
+    const uint32_t live = prep_live_frames<CACHE>(L, f0, nf, blk, i0, sh);
     if (live == 0u) return;
     // ---- the frames that see the block, one after the other; what no camera enters is kept between them -- in LDS, each
     // thread its own slots (in registers the eleven words would stay live across the colour phase, whose 48 SH
@@ -825,7 +924,7 @@ static bool prep_same_model(const PreprocessArgs &x, const PreprocessArgs &y) {
            x.part_rescale == y.part_rescale && x.cull_blocks == y.cull_blocks && x.orig_index == y.orig_index;
 }
 
-int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream) {
+int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hipStream_t stream) {
     PreprocessArgs args[GSR_MAX_BATCH];
     bool fast = true;
     for (int k = 0; k < B; k++) {
@@ -875,12 +974,34 @@ int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infe
         a.tiles_touched = g.tiles_touched;
         a.rects = g.rects;
         a.block_counts = g.block_counts;
-        a.block_recs = g.pair[1];  // (the sort's compaction gathers from here into pair[0]; its partition pass then
-                                   //  overwrites this array with the bucketed records)
+        a.block_recs = g.block_recs;  // (the sort's compaction gathers from here into pair[0])
 
         a.num_tiles = a.gx * a.gy;
         a.tile_accum = g.tile_accum;
         a.hdr = g.hdr;
+        a.pc_slots = nullptr;
+        a.pc_sig = 0u;
+        if (fr[k].pc) {
+            a.pc_slots = g.pc_slots;
+            // everything but camera and poses that the records depend on (FNV-1a over the values)
+            uint32_t hsh = 2166136261u;
+            auto mix = [&hsh](const void *p, size_t n) {
+                const unsigned char *c = (const unsigned char *)p;
+                for (size_t q = 0; q < n; q++) hsh = (hsh ^ c[q]) * 16777619u;
+            };
+            const uintptr_t ptrs[] = {(uintptr_t)in.means3D, (uintptr_t)in.shs, (uintptr_t)in.shs_rest, (uintptr_t)in.colors_precomp,
+                                      (uintptr_t)in.opacities, (uintptr_t)in.scales, (uintptr_t)in.rotations,
+                                      (uintptr_t)in.cov3D_precomp, (uintptr_t)in.part_labels, (uintptr_t)in.part_lut,
+                                      (uintptr_t)in.part_rescale, (uintptr_t)in.cull_blocks, (uintptr_t)in.orig_index,
+                                      (uintptr_t)((char *)g.block_recs - (char *)g.hdr)};
+            const int32_t ints[] = {in.P, st.sh_degree, st.sh_coeffs, st.image_width, st.image_height, st.antialiasing,
+                                    in.param_space, in.part_lut_size, in.part_count, infer ? 1 : 0};
+            const float flts[] = {st.tanfovx, st.tanfovy, st.scale_modifier, st.near_plane};
+            mix(ptrs, sizeof(ptrs));
+            mix(ints, sizeof(ints));
+            mix(flts, sizeof(flts));
+            a.pc_sig = hsh;
+        }
         // (the 12 x dwordx4 colour path needs every frame's SH array aligned)
         fast = fast && (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
                ((reinterpret_cast<uintptr_t>(in.shs) & 15u) == 0);
@@ -908,11 +1029,23 @@ int gsr_launch_preprocess(int B, const GsrFrame *fr, bool count_tiles, bool infe
     const PreprocessArgs &a0 = args[0];
     const dim3 grid(GeomState::prep_blocks(a0.P), groups);
     const size_t lds = count_tiles ? (size_t)a0.num_tiles * sizeof(uint32_t) : 0;
+    if (count_tiles) {  // (launches without the block cache: nobody publishes, so nobody may flip -- api.hip)
+        for (int k = 0; k < B; k++) {
+            L.bt.f[k].pc_slots = nullptr;
+            fr[k].pc = false;
+        }
+    }
     if (groups < B) {  // (some frames share a model; count_tiles frames never do)
-        if (fast)
-            hipLaunchKernelGGL((preprocess_group_kernel<true>), grid, dim3(GSR_BLOCK), 0, stream, L);
+        bool cache = false;
+        for (int k = 0; k < B; k++) cache = cache || L.bt.f[k].pc_slots != nullptr;
+        if (fast && cache)
+            hipLaunchKernelGGL((preprocess_group_kernel<true, true>), grid, dim3(GSR_BLOCK), 0, stream, L);
+        else if (fast)
+            hipLaunchKernelGGL((preprocess_group_kernel<true, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
+        else if (cache)
+            hipLaunchKernelGGL((preprocess_group_kernel<false, true>), grid, dim3(GSR_BLOCK), 0, stream, L);
         else
-            hipLaunchKernelGGL((preprocess_group_kernel<false>), grid, dim3(GSR_BLOCK), 0, stream, L);
+            hipLaunchKernelGGL((preprocess_group_kernel<false, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
     } else if (count_tiles) {
         if (fast)
             hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, dim3(GSR_BLOCK), lds, stream, L);

@@ -103,10 +103,11 @@ def sort_state(geomBuffer: torch.Tensor) -> dict:
     quantiles of an unchanged scene give; ``trust`` -- consecutive balanced frames on kept splitters before this one;
     ``buckets`` -- depth buckets of the frame; ``stride`` -- 2 when it took every second entry of a kept table;
     ``coop_quads`` -- quadrants the frame's compositor handed to cooperative workgroups; ``near`` -- ``blind`` under a view
-    matrix that differs a little from the one the kept table was built under (a camera that moves slowly)."""
+    matrix that differs a little from the one the kept table was built under (a camera that moves slowly); ``kept_blocks``
+    -- the frame's preprocess left blocks as the previous frame on the state had computed them (the block cache)."""
     out = (C.c_int32 * 8)()
     with torch.cuda.device(geomBuffer.device):
         check(lib().gsr_debug_sort_state(C.c_void_p(geomBuffer.data_ptr()), out,
                                          C.c_void_p(torch.cuda.current_stream(geomBuffer.device).cuda_stream)))
     return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]), buckets=int(out[4]),
-                stride=int(out[5]), coop_quads=int(out[6]), near=bool(out[7]))
+                stride=int(out[5]), coop_quads=int(out[6]), near=bool(out[7] & 1), kept_blocks=bool(out[7] & 2))

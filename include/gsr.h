@@ -153,6 +153,15 @@ typedef struct GsrInputs {
 #define GSR_RAW_OPACITY 1   /* opacities are logits:        opacity  = 1 / (1 + exp(-x)) */
 #define GSR_RAW_SCALES 2    /* scales are log-scales:        scale    = exp(x) */
 #define GSR_RAW_ROTATIONS 4 /* rotations are un-normalised:  rotation = q / max(|q|, 1e-12) */
+/* Bits 8..31 of param_space: a MODEL VERSION, or 0.  Nonzero is the caller's promise that the model arrays (means3D, shs, shs_rest,
+ * opacities, scales, rotations), part_labels, part_lut, part_rescale, cull_blocks and orig_index hold exactly what they held in the
+ * previous frame on this state that carried the same version -- pick a fresh random value whenever any of them is written.
+ * Inference frames (GsrSettings.forward_only, default path, radii == NULL) with part_labels and cull_blocks then leave a block of
+ * 256 Gaussians as the previous frame on the state computed it when nothing the block's records depend on has changed: settings,
+ * camera (view, projection, centre: bit for bit) and the pose row of the block's one part (csrc/preprocess.hip
+ * prep_block_cached).  A fixed sensor camera over a scene in which only the robot moves recomputes the robot.  Frames are the same
+ * bit for bit; the promise is the caller's: arrays changed under an unchanged version give stale blocks. */
+#define GSR_MODEL_VERSION(v) ((int32_t)(((uint32_t)(v) & 0xFFFFFFu) << 8))
 
 typedef struct GsrOutputs {
     /* The two float images.  Both may be NULL for an inference frame (GsrSettings.forward_only on the default path) that

@@ -7,12 +7,14 @@ actions (/root/reference/examples/maniskill/gsworld_rand_action_tabletop.py:99-1
 
 Bar: uint8 frames within 1 LSB (the two glues activate scales / rotations with different but <= 1 ulp exp / normalize,
 and the uint8 cast truncates), and only on a small fraction of the pixels."""
+import math
 import types
 
 import pytest
 import torch
 
 from gsworld_amd import closed_loop as cl
+from gsworld_amd import debug as dbg
 from gsworld_amd import scenes
 from gsworld_amd.camera import look_at_view
 from oracle import wrapper_glue_ref as ref
@@ -525,3 +527,47 @@ def test_host_values_staged_inside_the_graph_give_the_eager_loop_s_frames(cuda_d
     torch.cuda.synchronize()
     for n in want:
         assert torch.equal(got[n], want[n]), n
+
+
+def test_block_cache_keeps_what_did_not_move_and_every_frame_is_the_uncached_one(cuda_device):
+    """Inference frames whose caller vouches for the model (GSR_MODEL_VERSION in param_space: ClosedLoopRenderer owns its copy)
+    leave a block of 256 Gaussians as the previous frame on the state computed it when camera, settings and the block's pose
+    row are that frame's bit for bit (csrc/preprocess.hip prep_block_cached).  Under the fixed right_cam everything that is
+    no robot link and no tracked object keeps its records; under a wrist camera that moves nothing does.  Eager and under
+    graph replay, with a camera that rests, moves and rests again, and with poses that stand still for a step: every frame
+    is the frame of a loop built with ``block_cache=False``, byte for byte."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=300_000, seed=33)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    steps = 18
+    poses = list(cl.rollout_poses(rollout, len(actors), steps=steps, seed=4))
+
+    def wrist(k):  # rests for the first steps, then moves, then rests again
+        a = 0.05 * min(max(k - 5, 0), 6)
+        return look_at_view([0.55 - 0.10 * math.sin(a), 0.35, 0.25 + 0.05 * math.sin(2.0 * a)], [0.35, 0.05, 0.05], [0, 0, 1],
+                            0.9715089, 0.7551448, 640, 480)
+
+    for captured in (False, True):
+        cached = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
+        plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, block_cache=False)
+        assert cached._model_version != 0 and plain._model_version == 0
+        cached.reset(*poses[0])
+        plain.reset(*poses[0])
+        if captured:
+            cached.capture()
+            plain.capture()
+        kept = {n: 0 for n in cams}
+        for k in range(1, steps):
+            M, s = poses[k if k % 5 else k - 1]  # (every fifth step repeats the poses of the step before: nothing moved)
+            got = cached.step(M, s, cameras={"wrist_cam": wrist(k)}, ensure=True)
+            want = plain.step(M, s, cameras={"wrist_cam": wrist(k)}, ensure=True)
+            for n in cams:
+                assert torch.equal(got[n], want[n]), f"captured={captured} step {k} {n}"
+            for n, lane in zip(cached.names, cached.multi.lanes):
+                kept[n] += int(dbg.sort_state(lane.geom)["kept_blocks"])
+            assert not any(dbg.sort_state(lane.geom)["kept_blocks"] for lane in plain.multi.lanes)
+        assert kept["right_cam"] >= steps - 3, kept       # the fixed camera keeps its static blocks on (nearly) every step
+        assert 0 < kept["wrist_cam"] < steps - 1, kept    # the wrist camera only while it rests
