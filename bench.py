@@ -667,27 +667,32 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
     # ---- the same two measurements with every block recomputed every frame (block_cache=False): what the frames cost when
     # nothing is kept from the step before (csrc/preprocess.hip prep_block_cached keeps, under the fixed right_cam, the blocks of
     # Gaussians that belong to no moving part -- their camera and pose are the previous frame's bit for bit)
-    no_cache = None
-    try:
-        lp0 = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, block_cache=False)
-        lp0.reset(*pinned[0])
-        lp0.capture()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for (M, s), w in zip(pinned, wrists):
-            lp0.step(M, s, cameras={"wrist_cam": w})
-        torch.cuda.synchronize()
-        dt0 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for (M, s), w in zip(pinned, wrists):
-            lp0.step(M, s, cameras={"wrist_cam": w}, ensure=True)
-        dt0p = time.perf_counter() - t0
-        same = all(torch.equal(a_, b_) for a_, b_ in zip(lp0.frames.values(), loop.frames.values()))
-        no_cache = {"frames_per_s": (ep_len + 1) * len(cams) / dt0, "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt0p,
+    def loop_without(**kw):
+        try:
+            lp0 = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, **kw)
+            lp0.reset(*pinned[0])
+            lp0.capture()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for (M, s), w in zip(pinned, wrists):
+                lp0.step(M, s, cameras={"wrist_cam": w})
+            torch.cuda.synchronize()
+            dt0 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for (M, s), w in zip(pinned, wrists):
+                lp0.step(M, s, cameras={"wrist_cam": w}, ensure=True)
+            dt0p = time.perf_counter() - t0
+            same = all(torch.equal(a_, b_) for a_, b_ in zip(lp0.frames.values(), loop.frames.values()))
+            del lp0
+            return {"frames_per_s": (ep_len + 1) * len(cams) / dt0, "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt0p,
                     "last_frames_identical_to_the_cached_loop_s": bool(same)}
-        del lp0
-    except Exception as ex:  # noqa: BLE001
-        no_cache = {"error": f"{type(ex).__name__}: {ex}"}
+        except Exception as ex:  # noqa: BLE001
+            return {"error": f"{type(ex).__name__}: {ex}"}
+
+    no_cache = loop_without(block_cache=False)
+    # ... and with the block cache but every tile composited every frame (tile_reuse=False: csrc/render.hip leaves, under the
+    # fixed right_cam, the tiles no recomputed Gaussian touches as the previous step's frame holds them)
+    no_tile_reuse = loop_without(tile_reuse=False)
     # ---- SURVEY 8d's byte model for THIS loop: N, V, R of the reference's per-tile pipeline for both cameras at mid-episode
     # (step 100's poses and wrist camera; one default exact-mode frame per camera over the loop's own model and pose table)
     cl_alg = None
@@ -803,6 +808,9 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
                         "frame on the state computed it when settings, camera and the block's pose row are that frame's bit for "
                         "bit (GSR_MODEL_VERSION; the headline and every other figure of this line never pass a model version: "
                         "nothing is kept there)", "without": no_cache},
+        "tile_reuse": {"on": True, "what": "... and their compositor leaves a 16 x 16 tile of the loop's own uint8 frame as the "
+                       "previous step wrote it when camera and background are that step's and no recomputed Gaussian touches "
+                       "the tile now or touched it then (GSR_FRAME_KEPT)", "without": no_tile_reuse},
         "roofline": cl_alg,
         "frames_per_launch": len(cams),
         "frames": (ep_len + 1) * len(cams), "overflow": overflow,

@@ -81,6 +81,7 @@ class GsrInputs(C.Structure):
 
 
 RAW_OPACITY, RAW_SCALES, RAW_ROTATIONS = 1, 2, 4  # include/gsr.h GSR_RAW_*
+FRAME_KEPT = 8  # include/gsr.h GSR_FRAME_KEPT: out_rgb8 still holds the previous frame of this state (tile reuse)
 
 
 def model_version(v: int) -> int:

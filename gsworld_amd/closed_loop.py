@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import transform as tf
-from ._lib import RAW_ROTATIONS, RAW_SCALES, model_version
+from ._lib import FRAME_KEPT, RAW_ROTATIONS, RAW_SCALES, model_version
 from .renderer import MultiCameraRenderer
 
 
@@ -42,7 +42,7 @@ class ClosedLoopRenderer:
     def __init__(self, raw, part_labels: dict, cameras: dict, scaled_parts=(), num_envs: int = 1, device="cuda",
                  background=None, fuse_transform: bool = True, growth: float = 2.0, bound_capacity="auto",
                  layout: bool = True, min_capacity: int | None = None, share_model_of=None, batched: bool = True,
-                 keep_float: bool = False, block_cache: bool = True):
+                 keep_float: bool = False, block_cache: bool = True, tile_reuse: bool = True):
         """``raw``: :class:`gsworld_amd.scenes.RawGaussians` (or any object with the same raw parameter tensors, e.g. a
         merged semantic model's ``_xyz`` ... under those names); ``part_labels``: part name -> semantic label(s), in
         the order the pose matrices will arrive; ``cameras``: name -> :class:`gsworld_amd.camera.ViewParams`;
@@ -71,6 +71,11 @@ class ClosedLoopRenderer:
         ``keep_float``: the loop returns GSWorld's uint8 frames and, by default, writes nothing else -- the float colour /
         inverse-depth images of its lanes (16 bytes per pixel nobody reads) are left out (``GsrOutputs``: NULL images for an
         inference frame with ``out_rgb8``).  True keeps them in ``multi.lanes[k]._out`` (tests that compare float colour).
+        ``tile_reuse`` (with ``block_cache``; default): ``self.frames`` are the loop's own buffers and nobody else writes
+        them (READ the returned frames, copy them if you want to draw into them): a 16 x 16 tile that no recomputed Gaussian
+        touches under an unchanged camera and background is left as the previous step composited it (include/gsr.h
+        GSR_FRAME_KEPT; csrc/render.hip "tile reuse") -- from a fixed sensor camera everything but the tiles the robot and the
+        tracked objects cover, now or a step ago.  Same frames, bit for bit.  ``False`` for a caller that writes into them.
         ``batched`` (default): the E x C frames of a step go through ``gsr_forward_batch`` -- one set of launches on the
         step's stream whose grids span the frames -- instead of one pipeline per frame on its own stream
         (:class:`gsworld_amd.renderer.MultiCameraRenderer`); same frames bit for bit (tests/test_batch_gpu.py)."""
@@ -235,6 +240,8 @@ class ClosedLoopRenderer:
 
         self._model_version = model_version(random.getrandbits(24) | 1) if (block_cache and self.fuse_transform and
                                                                             self.layout is not None) else 0
+        if self._model_version != 0 and tile_reuse and not keep_float:
+            self._model_version |= FRAME_KEPT
         self._graph = None    # the captured step (host values staged OUTSIDE it: a copy / a launch between two replays) ...
         self._graphs = None   # ... or one captured step per ring slot, each staging its slot itself (see capture())
         self._pack = None     # the step's argument pack (MultiCameraRenderer.last_pack): eager steps without the Python

@@ -128,7 +128,7 @@ static int validate(const GsrSettings *st, const GsrInputs *in, const GsrOutputs
             gsr_set_error("gsr_forward: binning_path must be 0..4, render_variant 0..3, render_blocks_per_cu 0..8, depth_sort 0..1");
             return GSR_E_INVALID;
         }
-        if (in->param_space & 0xF8) {  // (bits 0-2: GSR_RAW_*; bits 8-31: GSR_MODEL_VERSION)
+        if (in->param_space & 0xF0) {  // (bits 0-2: GSR_RAW_*; bit 3: GSR_FRAME_KEPT; bits 8-31: GSR_MODEL_VERSION)
             gsr_set_error("gsr_forward: unknown bits in param_space");
             return GSR_E_INVALID;
         }
@@ -260,6 +260,9 @@ int run_frames(int B, const GsrSettings *st, const GsrInputs *in, const GsrOutpu
         f.pc = GSR_PREP_BLOCK_CACHE && infer && band && mode == 1 && !p.radix_depth && ((uint32_t)in[k].param_space >> 8) != 0u &&
                in[k].part_labels != nullptr && in[k].cull_blocks != nullptr && out[k].radii == nullptr &&
                in[k].part_count <= GSR_PC_MAX_PARTS;
+        // tile reuse (render.hip): ... whose only output is the uint8 frame, in a buffer the caller says nobody else writes
+        f.td = GSR_TILE_REUSE && f.pc && super && (in[k].param_space & GSR_FRAME_KEPT) != 0 && out[k].out_rgb8 != nullptr &&
+               out[k].out_color == nullptr && out[k].out_invdepth == nullptr;
     }
     const GeomState &g = fr[0].g;
     const ImageState &img = fr[0].img;
@@ -545,7 +548,7 @@ int gsr_debug_sort_state(const void *geom, int32_t out[8], void *stream_) {
     out[6] = (int32_t)h.coop_quads;
     // (bit 0: this frame took the kept table unchecked under a view that moved a little; bit 1: its preprocess kept blocks of
     //  the previous frame -- the block cache)
-    out[7] = (int32_t)((h.ss_near & 1u) | ((h.pc_hit_last & 1u) << 1));
+    out[7] = (int32_t)((h.ss_near & 1u) | ((h.pc_hit_last & 1u) << 1) | ((h.td_skipped & 1u) << 2));  // (bit 2: tiles skipped)
     return GSR_OK;
 }
 

@@ -319,7 +319,7 @@ __host__ __device__ inline int ss_prepare_per(int nb1) { return (((nb1 + kPT - 1
 __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ quad_work, int Q,
                                                    uint32_t *__restrict__ quad_order, int cus_per_xcd,
                                                    uint32_t *__restrict__ coop_list, int coop_cap,
-                                                   GsrHeader *__restrict__ hdr) {
+                                                   GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ tile_dirty) {
     __shared__ uint32_t s_qb[GSR_XCDS * 256];
     __shared__ uint32_t s_xbase[GSR_XCDS];
     __shared__ uint32_t s_w16[kPW], s_cs16[kPW];
@@ -328,11 +328,17 @@ __device__ __forceinline__ void ss_quad_order_1024(const uint32_t *__restrict__ 
     const int tid = (int)threadIdx.x;
     const int T = Q >> 2;
     if (tid == 0) s_coop_n = 0u;
+    const bool reuse = tile_dirty != nullptr && hdr->td_reuse != 0u;
+    const uint32_t tok = hdr->td_token + 1u;
     uint32_t c[KQ], cost[KQ], qmx = 0, csum = 0;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
         const int q = tid + k * kPT;
         c[k] = q < Q ? min(quad_work[q], (1u << 24) - 1u) : 0u;
+        // (tile reuse, render.hip: a tile nobody marked keeps the previous frame's pixels -- its quadrants cost nothing in this
+        //  frame, sort behind everything else and share workgroups that retire at once, instead of holding a residency slot
+        //  each beside one quadrant that does work.  The token is still the previous frame's here: ss_compact advances it.)
+        if (reuse && q < Q && tile_dirty[q >> 2] != tok) c[k] = 0u;
         cost[k] = c[k];
         qmx = max(qmx, c[k]);
         csum += c[k] >> 4;  // (in sixteenths: 8192 costs below 2^24 stay below 2^32)
@@ -500,6 +506,7 @@ __device__ __forceinline__ void ss_prepare_body(int P, int nb1, int bmax, int nb
         hdr->pc_pending = 0u;
         hdr->pc_hit_last = pc_enabled ? h_pc_hit : 0u;
         hdr->pc_hit = 0u;
+        hdr->td_skipped = 0u;  // (the tile token is advanced by ss_compact: the deal beside this workgroup still reads it)
         hdr->V = V;
         hdr->R = 0u;
         hdr->overflow = 0u;
@@ -875,10 +882,13 @@ __device__ __forceinline__ void ss_compact_body(int bmax, const uint2 *__restric
                                                 const uint32_t *__restrict__ splitters_new,
                                                 const uint32_t *__restrict__ seg_off,
                                                 const uint32_t *__restrict__ seg_first,
-                                                const GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0) {
+                                                GsrHeader *__restrict__ hdr, uint64_t *__restrict__ dbg0, const bool td_enabled) {
     extern __shared__ uint32_t smem[];
     uint64_t *dbg = dbg0; const unsigned dbg_wg = 64; (void)dbg_wg; (void)dbg;
     SS_STAMP(dbg, 8);
+    // (tile reuse: what this frame's preprocess marked carries the NEXT token; from here on it is the current one -- the deal in
+    //  the prepare launch has read the old one, the compositor compares with the new)
+    if (td_enabled && blockIdx.x == 0 && threadIdx.x == 0) hdr->td_token = hdr->td_token + 1u;
 #ifdef GSR_SS_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -1732,6 +1742,7 @@ struct SsArgs {
     uint32_t *tile_cum, *bucket_tiles;
     int sshift;
     const int32_t *orig;
+    const uint32_t *tile_dirty;  // (ImageState::tile_dirty: the deal of the compositor's quadrants reads it, bit 1 of pc_enabled)
     const uint2 *block_recs;  // preprocess' block-local records (GeomState::block_recs)
     int pc_enabled;           // this frame's preprocess ran with the block cache: ss_prepare makes its slot current
 };
@@ -1739,16 +1750,17 @@ struct SsArgs {
 __global__ __launch_bounds__(kPT) void ss_prepare_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     if (blockIdx.x == 2) {  // (only launched with a deal to make)
-        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_list, a.coop_cap, a.hdr);
+        ss_quad_order_1024(a.quad_work, a.num_quads, a.quad_order, a.cus_per_xcd, a.coop_list, a.coop_cap, a.hdr,
+                           (a.pc_enabled & 2) != 0 ? a.tile_dirty : (const uint32_t *)nullptr);
         return;
     }
     ss_prepare_body(a.P, a.nb1, a.bmax, a.nbc, a.block_recs, a.block_counts, a.splitters, a.splitters_new, a.seg, a.first,
-                    a.hdr, a.dbg, a.view, a.sig, (int)blockIdx.x, a.pc_enabled != 0);
+                    a.hdr, a.dbg, a.view, a.sig, (int)blockIdx.x, (a.pc_enabled & 1) != 0);
 }
 __global__ __launch_bounds__(kT) void ss_compact_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
     ss_compact_body(a.bmax, a.block_recs, a.block_counts, a.pair0, a.table, a.splitters, a.splitters_new, a.seg, a.first,
-                    a.hdr, a.dbg);
+                    a.hdr, a.dbg, (a.pc_enabled & 2) != 0);
 }
 __global__ __launch_bounds__(kColT) void ss_colscan_kernel(const GsrBatch<SsArgs> bt) {
     const SsArgs &a = bt.f[blockIdx.y];
@@ -1863,7 +1875,8 @@ int gsr_launch_sample_depth_sort(int B, const GsrFrame *fr, bool order_early, in
         a.order = g.order; a.rects = g.rects; a.rect_sorted = g.rect_sorted; a.tile_cum = g.tile_cum;
         a.bucket_tiles = g.bucket_tiles; a.sshift = super_shift; a.orig = fr[k].in->orig_index;
         a.block_recs = g.block_recs;
-        a.pc_enabled = fr[k].pc ? 1 : 0;
+        a.tile_dirty = fr[k].img.tile_dirty;
+        a.pc_enabled = (fr[k].pc ? 1 : 0) | (fr[k].pc && fr[k].td ? 2 : 0);
     }
     hipLaunchKernelGGL(ss_prepare_kernel, dim3(order_early ? 3 : 2, B), dim3(kPT), 0, stream, bt);
     if (int e = gsr_check_launch("ss_prepare", debug, stream)) return e;

@@ -87,12 +87,19 @@ struct GsrHeader {
     uint32_t pc_sig_next; // ... of the frame that wrote the pending one
     uint32_t pc_hit;      // some workgroup of this frame's preprocess kept its block (plain stores of 1) ...
     uint32_t pc_hit_last; // ... as ss_prepare found it: did the last frame on this state keep any block? (gsr_debug_sort_state)
-    uint32_t pad[11];
+    // tile reuse (render.hip): a tile no recomputed Gaussian touches -- now or in the previous frame -- keeps that frame's pixels
+    uint32_t td_token;    // ImageState::tile_dirty[t] == td_token: tile t has to be composited in this frame
+    uint32_t td_reuse;    // this frame may skip the others (same camera, background and output buffer; the previous frame complete)
+    uint32_t td_skipped;  // (diagnostics: some tile of the last frame was skipped)
+    uint32_t pad[8];
     uint32_t of_magic;    // overflow_frames below is a count (anything else: a fresh / recycled buffer, count = 0)
     uint32_t overflow_frames;  // frames rendered on this state whose R exceeded the capacity (never cleared by a frame:
                                //   a no-sync rollout learns at its end whether EVERY frame was valid)
 };
 #define GSR_OF_MAGIC 0x0F10F10Fu
+#ifndef GSR_TILE_REUSE
+#define GSR_TILE_REUSE 1  // (A/B: 0 = every tile composited in every frame)
+#endif
 #ifndef GSR_PREP_BLOCK_CACHE
 #define GSR_PREP_BLOCK_CACHE 1  // (A/B: 0 = every frame recomputes every block, whatever its caller promises)
 #endif
@@ -333,6 +340,8 @@ struct ImageState {
     uint32_t *split_list; // [4*tiles] quadrant ids (4 tile + quad) whose second half an extra wave takes
     uint32_t *split_count;// [1]
     uint32_t *quad_order; // [4*tiles] quadrant ids (4 tile + quad) sorted by descending cost in the last frame
+    uint32_t *tile_dirty; // [tiles] == GsrHeader::td_token: a Gaussian whose records this frame's preprocess recomputed touches the
+                          // tile now, or touched it in the previous frame (tile reuse: render.hip skips the others)
     static ImageState carve(char *base, int32_t W, int32_t H, size_t *bytes = nullptr) {
         ImageState s;
         char *p = base;
@@ -347,6 +356,7 @@ struct ImageState {
         s.quad_order = GeomState::take<uint32_t>(p, 4 * tiles);
         s.final_T = GeomState::take<float>(p, (size_t)W * H);
         s.n_contrib = GeomState::take<uint32_t>(p, (size_t)W * H);
+        s.tile_dirty = GeomState::take<uint32_t>(p, tiles);
         if (bytes) *bytes = (size_t)(p - base);
         return s;
     }
@@ -462,6 +472,7 @@ struct GsrFrame {
     BinningState b;             // (valid from the placement on)
     uint32_t cap32;             // binning capacity the range kernel checks R against
     bool pc;                    // this frame's preprocess may keep last frame's blocks (preprocess.hip prep_block_cached)
+    bool td;                    // ... and its compositor the tiles none of the recomputed Gaussians touches (render.hip)
 };
 
 // ---- error plumbing ------------------------------------------------------------------------------------

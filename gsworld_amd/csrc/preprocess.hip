@@ -56,6 +56,11 @@ struct PreprocessArgs {
     // frame recomputes every block; pc_sig: everything else the records depend on (settings, model identity, state layout)
     float *pc_slots;
     uint32_t pc_sig;
+    // tile reuse (render.hip): the tiles a recomputed Gaussian touches, now or in the previous frame, are marked here with the
+    // frame's token; nullptr = the frame composites every tile.  bg: the background colour is part of what a pixel depends on
+    uint32_t *tile_dirty;
+    const float *bg;
+    uint32_t td_sig;
 };
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -613,6 +618,30 @@ struct PrepLaunch {
 static_assert(sizeof(PrepLaunch) <= 4096, "kernel arguments travel in the 4 KiB kernarg segment");
 
 // LDS of a workgroup: the block-compacted survivors of the frame in hand, and what is kept from frame to frame
+// every tile of a rect (tile units, exclusive maxima; clamped to the grid: a Gaussian that has never been visible on this state
+// holds whatever the buffer held) gets the frame's token
+__device__ __forceinline__ void prep_mark_tiles(uint32_t *__restrict__ dirty, const uint2 rc, const int gx, const int gy,
+                                                const uint32_t tok) {
+    const int x0 = (int)(rc.x & 0xffffu), y0 = (int)(rc.x >> 16);
+    const int x1 = min((int)(rc.y & 0xffffu), gx), y1 = min((int)(rc.y >> 16), gy);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) dirty[y * gx + x] = tok;
+}
+
+// (tile reuse, blocks whose members carry different labels -- never kept, a few dozen per model, and the ones that hold the
+//  static scene's largest Gaussians where a size class of it borders on a part: has THIS Gaussian's own pose row changed
+//  against the previous frame's?  If not, its recomputed records are the previous frame's and it marks nothing.)
+__device__ __forceinline__ bool prep_gaussian_moved(const PreprocessArgs &a, const uint32_t idx) {
+    const int label = (int)a.part_labels[idx];
+    const int part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
+    if (part < 0 || part >= a.part_count) return false;
+    const uint32_t *prev = reinterpret_cast<const uint32_t *>(a.pc_slots + (size_t)(a.hdr->pc_parity & 1u) * GSR_PC_SLOT) + 40 + 17 * part;
+    const float *cur = a.part_transforms + (size_t)part * 17;
+    bool moved = false;
+    for (int j = 0; j < 17; j++) moved = moved || __float_as_uint(cur[j]) != prev[j];
+    return moved;
+}
+
 struct PrepShared {
     uint32_t w[4];
     float4 pos[GSR_BLOCK];
@@ -624,10 +653,10 @@ typedef float PrepWorld[11][GSR_BLOCK];  // (multi-frame groups only: WorldGauss
 
 // One frame of the group on this workgroup's block.  have_world: an earlier frame of the group left the block's WorldGauss
 // in LDS (computed under pose table w_table and scale modifier w_mod); more: a later frame will want it.
-template <bool FAST_SH16, bool COUNT_TILES, bool MULTI>
+template <bool FAST_SH16, bool COUNT_TILES, bool MULTI, bool MARK = false>
 __device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i, const uint32_t blk, const bool have_world,
                                            const float *w_table, const float w_mod, const bool more, PrepShared &sh,
-                                           PrepWorld *world, uint32_t *s_tcnt) {
+                                           PrepWorld *world, uint32_t *s_tcnt, const int mark = 0) {
     bool visible = false;
     float4 mypos = make_float4(0.f, 0.f, 0.f, 0.f);  // xyz + radius, handed to the colour phase
     uint32_t my_tiles = 0, my_key = 0;
@@ -672,6 +701,9 @@ __device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i,
         mypos = o.pos;
         my_tiles = o.tiles;
         my_rect = o.rect;
+        // (tile reuse: the tiles this recomputed Gaussian touches NOW; the ones it touched before: prep_live_frames)
+        if (MARK && mark != 0 && visible && (mark == 1 || prep_gaussian_moved(a, (uint32_t)i)))
+            prep_mark_tiles(a.tile_dirty, my_rect, a.gx, a.gy, a.hdr->td_token + 1u);
         if (a.radii != nullptr) a.radii[oi] = o.radius;
         if (!a.infer) a.tiles_touched[i] = o.tiles;
         my_key = o.key;
@@ -724,14 +756,18 @@ __device__ __forceinline__ void prep_frame(const PreprocessArgs &a, const int i,
 // ---------------------------------------------------------------------------------------------------------
 // (one WAVE asks, a lane per compared word -- 35 of the camera, 17 of the pose row: two loads per lane; the first version had
 //  every thread of every workgroup walk all 52 -- 39 -> 50 us instead of 39 -> 27)
-__device__ __forceinline__ bool prep_block_cached(const PreprocessArgs &a, const uint32_t blk) {
+// -> bit 0: the block keeps its records; bit 1: camera, background and everything in the signature are the previous frame's
+// (what the tile reuse asks: a recomputed block then marks the tiles it touches instead of every tile being composited);
+// bit 2: the block's members carry different labels
+__device__ __forceinline__ uint32_t prep_block_cached(const PreprocessArgs &a, const uint32_t blk) {
     const GsrHeader *h = a.hdr;
     const int lane = gsr_lane();
     const uint32_t magic = h->pc_magic, sig = h->pc_sig, parity = h->pc_parity & 1u;
     const uint32_t *prev = reinterpret_cast<const uint32_t *>(a.pc_slots + (size_t)parity * GSR_PC_SLOT);
     const float lf = a.cull_blocks[8 * (size_t)blk + 7];
-    bool ok = magic == GSR_PC_MAGIC && sig == a.pc_sig && lf == lf;  // (NaN: members carry different labels)
-    const int label = ok ? (int)lf : -1;
+    const bool valid = magic == GSR_PC_MAGIC && sig == a.pc_sig;
+    const bool one_label = lf == lf;  // (NaN: members carry different labels)
+    const int label = (valid && one_label) ? (int)lf : -1;
     const int part = (label >= 0 && label < a.part_lut_size) ? a.part_lut[label] : -1;
     const bool moving = part >= 0 && part < a.part_count;
     uint32_t cur = 0u, was = 0u;
@@ -744,11 +780,21 @@ __device__ __forceinline__ bool prep_block_cached(const PreprocessArgs &a, const
     } else if (lane < 35) {
         cur = __float_as_uint(a.campos[lane - 32]);
         was = prev[lane];
-    } else if (lane < 52 && moving) {
-        cur = __float_as_uint(a.part_transforms[(size_t)part * 17 + (lane - 35)]);
-        was = prev[40 + 17 * part + (lane - 35)];
+    } else if (lane < 38) {
+        cur = __float_as_uint(a.bg[lane - 35]);
+        was = prev[lane];
+    } else if (lane == 38) {
+        cur = a.td_sig;
+        was = prev[38];
+    } else if (lane < 56 && moving) {
+        cur = __float_as_uint(a.part_transforms[(size_t)part * 17 + (lane - 39)]);
+        was = prev[40 + 17 * part + (lane - 39)];
     }
-    return ok && __builtin_amdgcn_ballot_w64(cur != was) == 0ull;
+    const uint64_t differ = __builtin_amdgcn_ballot_w64(cur != was);
+    // (the records know nothing of background and output buffer -- lanes 35..38; the pixels nothing of the pose rows)
+    const bool kept = valid && one_label && (differ & ~(0xFull << 35)) == 0ull;
+    const bool frame_same = valid && (differ & ((1ull << 39) - 1ull)) == 0ull;
+    return (kept ? 1u : 0u) | (frame_same ? 2u : 0u) | (one_label ? 0u : 4u);
 }
 // workgroup 0: this frame's camera and pose table into the slot that is NOT current
 __device__ __forceinline__ void prep_cache_publish(const PreprocessArgs &a) {
@@ -761,7 +807,11 @@ __device__ __forceinline__ void prep_cache_publish(const PreprocessArgs &a) {
         cur[tid] = a.view[tid];
         cur[16 + tid] = a.proj[tid];
     }
-    if (tid < 3) cur[32 + tid] = a.campos[tid];
+    if (tid < 3) {
+        cur[32 + tid] = a.campos[tid];
+        cur[35 + tid] = a.bg[tid];
+    }
+    if (tid == 3) reinterpret_cast<uint32_t *>(cur)[38] = a.td_sig;
     for (int k = tid; k < 17 * a.part_count; k += GSR_BLOCK) cur[40 + k] = a.part_transforms[k];
     if (tid == 0) {
         h->pc_sig_next = a.pc_sig;
@@ -772,7 +822,7 @@ __device__ __forceinline__ void prep_cache_publish(const PreprocessArgs &a) {
 
 // the block's view-frustum test for every frame of the group -> the frames that have to look at it; the others get their
 // zero count (and, where a caller reads them, zero radii) on the spot
-template <bool CACHE = true>
+template <bool CACHE = true, bool TD = CACHE>
 __device__ __forceinline__ uint32_t prep_live_frames(const PrepLaunch &L, const int f0, const int nf, const uint32_t blk,
                                                      const int i, PrepShared &sh) {
     uint32_t live = (1u << nf) - 1u;
@@ -787,20 +837,46 @@ __device__ __forceinline__ uint32_t prep_live_frames(const PrepLaunch &L, const 
     for (int k = gsr_wave(); k < nf; k += NW) {
         const PreprocessArgs a = L.bt.f[f0 + k];
         const bool c = prep_block_culled(a, (int)blk);
-        const bool h = CACHE && nf > 1 && a.pc_slots != nullptr && prep_block_cached(a, blk);
+        const uint32_t h = (CACHE && nf > 1 && a.pc_slots != nullptr) ? prep_block_cached(a, blk) : 0u;
         if (gsr_lane() == 0) {
             sh.culled[k] = c ? 1 : 0;
-            if (nf > 1) sh.cached[k] = h ? 1 : 0;
+            if (nf > 1) {
+                sh.cached[k] = (int)h;
+                if (TD && blk == 0u && a.tile_dirty != nullptr)  // (may this frame's compositor skip what nobody marks?)
+                    a.hdr->td_reuse = ((h & 2u) != 0u && a.hdr->overflow == 0u && a.hdr->coop_timeout_now == 0u) ? 1u : 0u;
+            }
         }
     }
     if (CACHE && nf == 1 && gsr_wave() == NW - 1) {
         const PreprocessArgs &a = L.bt.f[f0];
-        const bool h = a.pc_slots != nullptr && prep_block_cached(a, blk);
-        if (gsr_lane() == 0) sh.cached[0] = h ? 1 : 0;
+        const uint32_t h = a.pc_slots != nullptr ? prep_block_cached(a, blk) : 0u;
+        if (gsr_lane() == 0) {
+            sh.cached[0] = (int)h;
+            if (TD && blk == 0u && a.tile_dirty != nullptr)
+                a.hdr->td_reuse = ((h & 2u) != 0u && a.hdr->overflow == 0u && a.hdr->coop_timeout_now == 0u) ? 1u : 0u;
+        }
     }
     __syncthreads();
+    if (TD) {
+        // Tile reuse: a block that IS recomputed under an unchanged camera first marks the tiles its Gaussians touched in the
+        // previous frame -- the block's visible records of that frame are still in place (count, block-local records, rects) --
+        // before anything of it is rewritten; the tiles they touch now are marked where the new rects appear (prep_frame).
+        bool any = false;
+        for (int k = 0; k < nf; k++) {
+            const PreprocessArgs &a = L.bt.f[f0 + k];
+            if ((sh.cached[k] & 3) != 2 || a.tile_dirty == nullptr) continue;  // (kept as it is, or every tile composited anyway)
+            any = true;
+            const uint32_t old_cnt = min(a.block_counts[blk], (uint32_t)GSR_BLOCK);
+            if (threadIdx.x < old_cnt) {
+                const uint32_t g = a.block_recs[(size_t)blk * GSR_BLOCK + threadIdx.x].x;
+                if ((g >> 8) == blk && ((sh.cached[k] & 4) == 0 || prep_gaussian_moved(a, g)))
+                    prep_mark_tiles(a.tile_dirty, a.rects[g], a.gx, a.gy, a.hdr->td_token + 1u);
+            }
+        }
+        if (any) __syncthreads();  // (the old records are read: they may be rewritten)
+    }
     for (int k = 0; k < nf; k++) {
-        if (CACHE && sh.cached[k] != 0) {  // (everything this frame would write for the block is in place: the previous frame's)
+        if (CACHE && (sh.cached[k] & 1) != 0) {  // (everything this frame would write for the block is in place: the previous frame's)
             live &= ~(1u << k);
             if (threadIdx.x == 0) L.bt.f[f0 + k].hdr->pc_hit = 1u;
             continue;
@@ -822,7 +898,9 @@ __device__ __forceinline__ uint32_t prep_live_frames(const PrepLaunch &L, const 
 #ifndef GSR_PREP_MAX_WAVES
 #define GSR_PREP_MAX_WAVES 0  // (A/B probe: cap the single-frame kernel's waves per SIMD -- what does occupancy buy it?)
 #endif
-template <bool FAST_SH16, bool COUNT_TILES>
+// (TD: some frame of the launch marks tiles for the compositor's tile reuse -- an instance of its own: the marking costs the
+//  single-frame kernel its 72nd register, i.e. a wave per SIMD, which frames without it must not pay)
+template <bool FAST_SH16, bool COUNT_TILES, bool TD = false>
 __global__ __launch_bounds__(GSR_BLOCK)
 #if GSR_PREP_MAX_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(1, GSR_PREP_MAX_WAVES)))
@@ -839,8 +917,10 @@ void preprocess_kernel(const PrepLaunch L) {
     }
     if (a.pc_slots == nullptr && blk == 0u && threadIdx.x == 0)
         a.hdr->pc_magic = 0u;  // (this launch rewrites the records without leaving its camera: nothing to compare with next)
-    if (prep_live_frames(L, f0, 1, blk, i, sh) == 0u) return;  // (+ the block cache: cull_blocks is there whenever pc_slots is)
-    prep_frame<FAST_SH16, COUNT_TILES, false>(a, i, blk, false, nullptr, 0.f, false, sh, nullptr, s_tcnt);
+    if (prep_live_frames<true, TD>(L, f0, 1, blk, i, sh) == 0u) return;  // (+ the block cache: cull_blocks is there whenever pc_slots is)
+    prep_frame<FAST_SH16, COUNT_TILES, false, TD>(a, i, blk, false, nullptr, 0.f, false, sh, nullptr, s_tcnt,
+                                                  (TD && a.tile_dirty != nullptr && (sh.cached[0] & 2) != 0)
+                                                      ? ((sh.cached[0] & 4) != 0 ? 2 : 1) : 0);
 }
 
 // groups of several frames
@@ -883,8 +963,9 @@ void preprocess_group_kernel(const PrepLaunch L) {
         // (the Gaussian's number is made opaque per frame: otherwise every address of the body is hoisted out of the loop)
         int i = i0;
         asm volatile("" : "+v"(i));
-        prep_frame<FAST_SH16, false, true>(a, i, blk, have_world, w_table, w_mod, (live >> (k + 1)) != 0u, sh, &s_world,
-                                           nullptr);
+        prep_frame<FAST_SH16, false, true, CACHE>(a, i, blk, have_world, w_table, w_mod, (live >> (k + 1)) != 0u, sh, &s_world,
+                                                  nullptr, (CACHE && a.tile_dirty != nullptr && (sh.cached[k] & 2) != 0)
+                                                               ? ((sh.cached[k] & 4) != 0 ? 2 : 1) : 0);
         have_world = true;
         w_table = a.part_transforms;
         w_mod = a.scale_modifier;
@@ -981,6 +1062,9 @@ int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hip
         a.hdr = g.hdr;
         a.pc_slots = nullptr;
         a.pc_sig = 0u;
+        a.td_sig = 0u;
+        a.tile_dirty = (fr[k].pc && fr[k].td) ? fr[k].img.tile_dirty : (uint32_t *)nullptr;
+        a.bg = in.background;
         if (fr[k].pc) {
             a.pc_slots = g.pc_slots;
             // everything but camera and poses that the records depend on (FNV-1a over the values)
@@ -1001,6 +1085,11 @@ int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hip
             mix(ints, sizeof(ints));
             mix(flts, sizeof(flts));
             a.pc_sig = hsh;
+            // ... and what the tile reuse depends on beyond camera and background: where the frame goes (a word of the slot
+            // by itself: a caller that rotates its output buffers keeps its blocks, it just composites every tile)
+            const uintptr_t outs[] = {(uintptr_t)fr[k].out->out_rgb8, (uintptr_t)fr[k].img.tile_dirty};
+            mix(outs, sizeof(outs));
+            a.td_sig = hsh;
         }
         // (the 12 x dwordx4 colour path needs every frame's SH array aligned)
         fast = fast && (in.colors_precomp == nullptr) && st.sh_degree == 3 && st.sh_coeffs == 16 &&
@@ -1032,7 +1121,8 @@ int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hip
     if (count_tiles) {  // (launches without the block cache: nobody publishes, so nobody may flip -- api.hip)
         for (int k = 0; k < B; k++) {
             L.bt.f[k].pc_slots = nullptr;
-            fr[k].pc = false;
+            L.bt.f[k].tile_dirty = nullptr;
+            fr[k].pc = fr[k].td = false;
         }
     }
     if (groups < B) {  // (some frames share a model; count_tiles frames never do)
@@ -1052,8 +1142,14 @@ int gsr_launch_preprocess(int B, GsrFrame *fr, bool count_tiles, bool infer, hip
         else
             hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, dim3(GSR_BLOCK), lds, stream, L);
     } else {
-        if (fast)
+        bool td = false;
+        for (int k = 0; k < B; k++) td = td || L.bt.f[k].tile_dirty != nullptr;
+        if (fast && td)
+            hipLaunchKernelGGL((preprocess_kernel<true, false, true>), grid, dim3(GSR_BLOCK), 0, stream, L);
+        else if (fast)
             hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
+        else if (td)
+            hipLaunchKernelGGL((preprocess_kernel<false, false, true>), grid, dim3(GSR_BLOCK), 0, stream, L);
         else
             hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, dim3(GSR_BLOCK), 0, stream, L);
     }

@@ -751,13 +751,28 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
                                                                   const uint32_t *__restrict__ quad_order,
                                                                   const uint32_t *__restrict__ coop_list,
                                                                   int coop_blocks, GsrHeader *__restrict__ hdr,
-                                                                  const uint32_t wgx /* workgroup of this frame */) {
+                                                                  const uint32_t wgx /* workgroup of this frame */,
+                                                                  const uint32_t *__restrict__ tile_dirty = nullptr) {
     // survivors are stored in PAIRS, component-interleaved, so that the replay reads register pairs it can feed to
     // the packed fp32 pipe (v_pk_mul/fma_f32: two survivors per instruction for the alpha evaluation, two
     // accumulators per instruction for the blend).  One pair = 6 x 16 B:
     //   [0] x0 x1 y0 y1   [1] A0 A1 C0 C1   [2] B0 B1 o0 o1   [3] r0 g0 b0 d0   [4] r1 g1 b1 d1   [5] pos0 pos1 - -
     __shared__ float4 s_list[GSR_BLOCK / GSR_WAVE][kStreamList / 2][6];
     const int lane = gsr_lane(), wave = gsr_wave();
+    // Tile reuse (round 6; inference frames whose only output is the uint8 frame, under the block cache of preprocess.hip): a
+    // tile's pixels depend on the splat records in its list, their order, the camera and the background.  When camera,
+    // background, settings and output buffer are the previous frame's on this state (td_reuse) and no Gaussian whose records
+    // this frame's preprocess recomputed touches the tile -- now, or in the previous frame -- the list holds the same records
+    // in the same order and the buffer already holds the pixels: the tile is not composited.  preprocess marks the tiles of
+    // every recomputed Gaussian (old and new rect) with the frame's token; every other tile is skipped here.
+    const uint32_t *dirty = nullptr;
+    uint32_t td_token = 0u;
+    if constexpr (SUPER) {
+        if (tile_dirty != nullptr && hdr->td_reuse != 0u) {
+            dirty = tile_dirty;
+            td_token = hdr->td_token;
+        }
+    }
     if constexpr (SUPER) {
         // the FIRST coop_blocks workgroups each take ONE of last frame's costliest quadrants (render_coop_quadrant).  First,
         // not last: the main grid fills the chip to a few workgroups short of what is resident at once, and a workgroup the
@@ -770,6 +785,10 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
             __syncthreads();
             const uint32_t q = coop_list[wgx];
             if (q >= 4u * (uint32_t)num_tiles) return;  // (no quadrant for this workgroup: 0xFFFFFFFF)
+            if (dirty != nullptr && dirty[q >> 2] != td_token) {  // (its tile keeps the previous frame's pixels)
+                if (threadIdx.x == 0) hdr->td_skipped = 1u;
+                return;
+            }
             const bool timed_out = render_coop_quadrant<true>(s_list, &s_coop, q, ranges, point_list, splat, W, H, gx, bg,
                                                               out_color, out_invdepth, rgb8, quad_work, final_T);
             // (cannot happen by the counters' construction; if it ever does the quadrant is truncated, and the frame says so)
@@ -830,6 +849,10 @@ __device__ __forceinline__ void render_stream_body(const uint2 *__restrict__ ran
             if (SUPER && (q & 0x80000000u) != 0u) continue;  // (a cooperative workgroup has it: the deal marks the entry)
             tile = (int)(q >> 2);
             quad = (int)(q & 3u);
+        }
+        if (dirty != nullptr && dirty[tile] != td_token) {  // (tile reuse: the previous frame's pixels stand)
+            if (lane == 0) hdr->td_skipped = 1u;
+            continue;
         }
         // half: 0 = whole quadrant, 1 = its rows 0-3 (the other half runs elsewhere), 2 = its rows 4-7
         const int half = extra ? 2 : ((split_flag != nullptr && split_flag[4 * tile + quad] != 0u) ? 1 : 0);
@@ -1036,6 +1059,8 @@ struct RenderStreamArgs {
     int coop_blocks;
     GsrHeader *hdr;             // (a cooperative quadrant whose hand-off timed out is counted there)
     int frames;                 // frames of the launch (the interleaved grid: render_stream_kernel)
+    const uint32_t *tile_dirty; // tile reuse: tiles marked with hdr->td_token are composited, the others keep the previous
+                                // frame's pixels when hdr->td_reuse says so (nullptr: every tile, every frame)
 };
 template <bool SUPER>
 __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void render_stream_kernel(
@@ -1052,7 +1077,7 @@ __global__ __launch_bounds__(GSR_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) 
     render_stream_body<SUPER>(a.ranges, a.point_list, a.splat, a.W, a.H, a.gx, a.num_tiles, a.tile_order, a.bg,
                               a.out_color, a.out_invdepth, a.final_T, a.n_contrib, a.rgb8, a.quad_work, a.num_cus,
                               a.main_blocks, a.split_flag, a.split_list, a.split_count, a.quad_work_b, a.quad_order,
-                              a.coop_list, a.coop_blocks, a.hdr, wgx);
+                              a.coop_list, a.coop_blocks, a.hdr, wgx, a.tile_dirty);
 }
 
 // Longest-first tile order for the queue (radix-fallback path; the counting path orders inside tile_starts_kernel).
@@ -1234,6 +1259,7 @@ int gsr_launch_render(int B, const GsrFrame *fr, bool order_ready, bool split_re
                 a.split_count = im.split_count;
                 a.quad_work_b = im.quad_work_b;
                 a.quad_order = use_qorder ? im.quad_order : (const uint32_t *)nullptr;
+                a.tile_dirty = (fr[k].pc && fr[k].td) ? im.tile_dirty : (const uint32_t *)nullptr;
             }
             const int row = B > 1 ? (blocks + extra + GSR_XCDS - 1) / GSR_XCDS * GSR_XCDS : blocks + extra;
 #ifndef GSR_RENDER_INTERLEAVE

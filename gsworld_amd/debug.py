@@ -110,4 +110,4 @@ def sort_state(geomBuffer: torch.Tensor) -> dict:
         check(lib().gsr_debug_sort_state(C.c_void_p(geomBuffer.data_ptr()), out,
                                          C.c_void_p(torch.cuda.current_stream(geomBuffer.device).cuda_stream)))
     return dict(blind=bool(out[0]), fresh=bool(out[1]), bad=bool(out[2]), trust=int(out[3]), buckets=int(out[4]),
-                stride=int(out[5]), coop_quads=int(out[6]), near=bool(out[7] & 1), kept_blocks=bool(out[7] & 2))
+                stride=int(out[5]), coop_quads=int(out[6]), near=bool(out[7] & 1), kept_blocks=bool(out[7] & 2), kept_tiles=bool(out[7] & 4))

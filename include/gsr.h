@@ -162,6 +162,13 @@ typedef struct GsrInputs {
  * prep_block_cached).  A fixed sensor camera over a scene in which only the robot moves recomputes the robot.  Frames are the same
  * bit for bit; the promise is the caller's: arrays changed under an unchanged version give stale blocks. */
 #define GSR_MODEL_VERSION(v) ((int32_t)(((uint32_t)(v) & 0xFFFFFFu) << 8))
+/* Bit 3 of param_space, read only beside a model version: the caller's promise that GsrOutputs.out_rgb8 still holds, byte for
+ * byte, what the previous frame on this state wrote there (nobody drew into it, nobody else rendered into it).  An inference
+ * frame whose ONLY output is out_rgb8 (out_color == out_invdepth == NULL) then leaves a 16 x 16 tile as it stands when camera,
+ * background, settings and buffer are the previous frame's and no Gaussian of a recomputed block touches the tile now or touched
+ * it then: its list holds the same records in the same order, so the compositor would write the bytes that are there
+ * (csrc/render.hip "tile reuse"; preprocess marks the tiles of every recomputed Gaussian).  Frames are the same bit for bit. */
+#define GSR_FRAME_KEPT 8
 
 typedef struct GsrOutputs {
     /* The two float images.  Both may be NULL for an inference frame (GsrSettings.forward_only on the default path) that

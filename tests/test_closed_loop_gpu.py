@@ -560,6 +560,7 @@ def test_block_cache_keeps_what_did_not_move_and_every_frame_is_the_uncached_one
             cached.capture()
             plain.capture()
         kept = {n: 0 for n in cams}
+        tiles = {n: 0 for n in cams}
         for k in range(1, steps):
             M, s = poses[k if k % 5 else k - 1]  # (every fifth step repeats the poses of the step before: nothing moved)
             got = cached.step(M, s, cameras={"wrist_cam": wrist(k)}, ensure=True)
@@ -568,6 +569,74 @@ def test_block_cache_keeps_what_did_not_move_and_every_frame_is_the_uncached_one
                 assert torch.equal(got[n], want[n]), f"captured={captured} step {k} {n}"
             for n, lane in zip(cached.names, cached.multi.lanes):
                 kept[n] += int(dbg.sort_state(lane.geom)["kept_blocks"])
+                tiles[n] += int(dbg.sort_state(lane.geom)["kept_tiles"])
             assert not any(dbg.sort_state(lane.geom)["kept_blocks"] for lane in plain.multi.lanes)
         assert kept["right_cam"] >= steps - 3, kept       # the fixed camera keeps its static blocks on (nearly) every step
         assert 0 < kept["wrist_cam"] < steps - 1, kept    # the wrist camera only while it rests
+        # ... and the compositor leaves the tiles none of the recomputed Gaussians touches (render.hip, tile reuse): the uint8
+        # frame already holds their pixels
+        assert tiles["right_cam"] >= steps - 3 and 0 < tiles["wrist_cam"] < steps - 1, tiles
+
+
+def test_tile_reuse_skips_only_what_nothing_touched_and_repaints_when_the_frame_s_inputs_change(cuda_device):
+    """GSR_FRAME_KEPT (ClosedLoopRenderer(tile_reuse=True), the default): the loop's uint8 frames are its own, and a 16 x 16
+    tile that no recomputed Gaussian touches under an unchanged camera and background is not composited again
+    (csrc/render.hip "tile reuse").  Shown from the outside by breaking the promise on purpose: a frame filled with a marker
+    byte keeps it exactly in the tiles the step did not have to draw -- everywhere else, and everywhere at all once the
+    background changes or the loop is built with ``tile_reuse=False``, the bytes are those of a loop that keeps nothing."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=300_000, seed=34)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    # (the surrogate scene scatters its 17 moving parts over the whole view and the rollout moves every one of them every
+    #  step -- hardly a tile is left then; here the arm rests and the gripper's last links and the two objects move)
+    walk = list(cl.rollout_poses(rollout, len(actors), steps=8, seed=5))
+    poses = []
+    for M, s in walk:
+        M0, s0 = walk[0][0].clone(), walk[0][1].clone()
+        M0[-4:], s0[-4:] = M[-4:], s[-4:]
+        poses.append((M0, s0))
+    MARK = 7
+    for captured in (False, True):
+        reuse = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev)
+        every = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, tile_reuse=False)
+        plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, block_cache=False)
+        loops = (reuse, every, plain)
+        for lp in loops:
+            lp.reset(*poses[0])
+            if captured:
+                lp.capture()
+        for k in (1, 2, 3):
+            for lp in loops:
+                lp.step(*poses[k], ensure=True)
+        for lp in (reuse, every):  # (the promise broken on purpose)
+            for n in cams:
+                lp.frames[n].fill_(MARK)
+        got, all_tiles, want = (lp.step(*poses[4], ensure=True) for lp in loops)
+        for n in cams:
+            assert torch.equal(all_tiles[n], want[n]), f"captured={captured} {n}: tile_reuse=False composites every tile"
+            g, w = got[n][0], want[n][0]
+            H, W = g.shape[:2]
+            tiles = lambda x: x.reshape(H // 16, 16, W // 16, 16, 3).permute(0, 2, 1, 3, 4).reshape(H // 16, W // 16, -1)  # noqa: E731
+            left = (tiles(g) == MARK).all(dim=2)
+            drawn = (tiles(g) == tiles(w)).all(dim=2)
+            assert bool((left | drawn).all()), f"captured={captured} {n}: a tile is either left whole or drawn whole"
+            # both cameras stand still: everything the arm and the objects do not cover is left (most of either frame), and
+            # what they cover is drawn
+            assert (0.4 * left.numel() if n == "right_cam" else 0) < int(left.sum()) < left.numel(), (n, int(left.sum()))
+            assert any(dbg.sort_state(lane.geom)["kept_tiles"] for lane in reuse.multi.lanes)
+        assert not any(dbg.sort_state(lane.geom)["kept_tiles"] for lane in every.multi.lanes)
+        # another background: every pixel may depend on it, every tile is drawn -- the marker is gone
+        for lp in loops:
+            lp.bg.copy_(torch.tensor([0.25, 0.5, 0.75], device=dev))
+        got, _, want = (lp.step(*poses[5], ensure=True) for lp in loops)
+        for n in cams:
+            assert torch.equal(got[n], want[n]), f"captured={captured} {n}: background changed"
+        # ... and from there on the loop keeps its promise again: frames equal while tiles are left
+        for k in (6, 7):
+            got, _, want = (lp.step(*poses[k], ensure=True) for lp in loops)
+            for n in cams:
+                assert torch.equal(got[n], want[n]), f"captured={captured} step {k} {n}"
+            assert any(dbg.sort_state(lane.geom)["kept_tiles"] for lane in reuse.multi.lanes)
