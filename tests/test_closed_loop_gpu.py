@@ -640,3 +640,54 @@ def test_tile_reuse_skips_only_what_nothing_touched_and_repaints_when_the_frame_
             for n in cams:
                 assert torch.equal(got[n], want[n]), f"captured={captured} step {k} {n}"
             assert any(dbg.sort_state(lane.geom)["kept_tiles"] for lane in reuse.multi.lanes)
+
+
+@pytest.mark.parametrize("E", [1, 2])
+def test_tile_reuse_random_rests_and_moves_give_the_frames_of_a_loop_that_keeps_nothing(cuda_device, E):
+    """A seeded soak of what the block cache and the tile reuse key on: per step a random subset of the parts moves (sometimes
+    none, sometimes all), the wrist camera rests or moves, now and then the background changes -- every frame of every
+    environment is the frame of a loop built with ``block_cache=False``, eager for the first half and under graph replay for
+    the second."""
+    import random
+
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=200_000, seed=35)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    steps = 64
+    walk = list(cl.rollout_poses(rollout, len(actors), steps=steps, seed=6, num_envs=E))
+    rng = random.Random(1234 + E)
+    K = walk[0][0].shape[-3]
+
+    def wrist(a):
+        return look_at_view([0.55 - 0.10 * math.sin(a), 0.35, 0.25 + 0.05 * math.sin(2.0 * a)], [0.35, 0.05, 0.05], [0, 0, 1],
+                            0.9715089, 0.7551448, 640, 480)
+
+    reuse = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
+    plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E, block_cache=False)
+    M, s = walk[0][0].clone(), walk[0][1].clone()
+    for lp in (reuse, plain):
+        lp.reset(M, s)
+    angle, skipped = 0.0, 0
+    for k in range(1, steps):
+        if k == steps // 2:
+            for lp in (reuse, plain):
+                lp.capture()
+        mode = rng.random()
+        moving = [] if mode < 0.2 else (range(K) if mode > 0.85 else rng.sample(range(K), rng.randint(1, 4)))
+        for p in moving:  # (the chosen parts take the rollout's pose of this step, in every environment; the others rest)
+            M[..., p, :, :], s[..., p] = walk[k][0][..., p, :, :], walk[k][1][..., p]
+        if rng.random() < 0.3:
+            angle += 0.05
+        if rng.random() < 0.08:
+            bg = torch.tensor([rng.random(), rng.random(), rng.random()], device=dev)
+            for lp in (reuse, plain):
+                lp.bg.copy_(bg)
+        got = reuse.step(M.clone(), s.clone(), cameras={"wrist_cam": wrist(angle)}, ensure=True)
+        want = plain.step(M.clone(), s.clone(), cameras={"wrist_cam": wrist(angle)}, ensure=True)
+        for n in cams:
+            assert torch.equal(got[n], want[n]), f"E={E} step {k} {n} (moving {list(moving)})"
+        skipped += sum(int(dbg.sort_state(lane.geom)["kept_tiles"]) for lane in reuse.multi.lanes)
+    assert skipped > steps // 2, skipped  # (the soak did exercise the reuse)
