@@ -168,6 +168,8 @@ fuzz)  # fuzz sweeps and soaks on the committed library -> $OUT/fuzz_and_soak.tx
     timeout 900 python tools/soak_static_scene.py 9000 inference 2>&1 | tail -1
     timeout 900 python tools/soak_moving_camera.py 600 400000 1 2>&1 | tail -1
     timeout 900 python tools/soak_moving_camera.py 300 1468850 2 2>&1 | tail -1
+    timeout 900 python tools/soak_tile_reuse.py 1200 400000 1 7 2>&1 | tail -1
+    timeout 900 python tools/soak_tile_reuse.py 400 1468850 2 8 2>&1 | tail -1
   } | cut -c1-400 | tee $OUT/fuzz_and_soak.txt
   ;;
 hostprof)  # the host's share of a policy-in-the-loop step
