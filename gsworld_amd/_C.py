@@ -212,6 +212,8 @@ def pack_batch(frames):
                 layout[0] if layout is not None else e,
                 layout[1] if (layout is not None and layout[1] is not None) else ei,
                 int(f.get("overflow_mirror") or 0)))
+        if hasattr(_ext, "StepPack"):
+            return ("pack", _ext.StepPack(packed))  # (the argument structs filled once, kept on the C++ side)
         return ("ext", packed)
     built, caps = [], (C.c_int64 * B)()
     for k, f in enumerate(frames):
@@ -229,6 +231,9 @@ def pack_batch(frames):
 def run_packed_batch(pack, device):
     """Enqueues the frames of :func:`pack_batch` on the current stream of ``device``."""
     kind, p = pack
+    if kind == "pack":
+        p.run()
+        return
     if kind == "ext":
         _ext.forward_batch(p)
         return

@@ -246,6 +246,7 @@ class ClosedLoopRenderer:
         self._graphs = None   # ... or one captured step per ring slot, each staging its slot itself (see capture())
         self._pack = None     # the step's argument pack (MultiCameraRenderer.last_pack): eager steps without the Python
         self.eager_when_ahead = True  # step(ensure=False) issues the launches one by one instead of replaying the graph
+        self.eager_when_waited = False  # ... step(ensure=True) too (A/B: the graph's one submission against eleven launches)
         self.image_size = (H, W)
 
     @staticmethod
@@ -428,8 +429,9 @@ class ClosedLoopRenderer:
             self.set_cameras(cameras)
         if self._graphs is not None and self._stale:
             self.capture()  # (device tensors arrived since the capture: their values must not be staged over)
-        if not ensure and self.eager_when_ahead and self._pack is not None and self._table is not None and \
-                self._ring_dev is not None and not self._stale and (self._graphs is not None or self._graph is None):
+        if (not ensure or self.eager_when_waited) and self.eager_when_ahead and self._pack is not None and \
+                self._table is not None and self._ring_dev is not None and not self._stale and \
+                (self._graphs is not None or self._graph is None):
             # Steps enqueued AHEAD of the device (nobody waits for this step's frames before the next is issued): the step's
             # eleven launches one by one, from the argument pack of the last eager step.  Two graph replays in a row leave the
             # device idle for ~14 us between them (kernel trace: the last kernel of one to the first of the next, however far
@@ -439,9 +441,19 @@ class ClosedLoopRenderer:
             k = self._slot_acquire()
             np.copyto(self._ring_np[k], self._host_np)
             self._dirty.clear()
-            self._launch_stage(k, int(self._stage.numel()))
-            self.multi.rerun(self._pack)
-            self._slot_release(k, False)
+            pack, caps = self._pack
+            if pack[0] == "pack":
+                # (the staging kernel and the frames' launches in ONE call into the compiled binding: csrc_torch/ext.cpp StepPack)
+                nm, ns = self.num_envs * self.K * 16, self.num_envs * self.K
+                with torch.cuda.device(self.device):
+                    pack[1].run_staged(int(self._stage.numel()), self._ring_dev[k], self._stage.data_ptr(), ns, 0, nm,
+                                       self._table.data_ptr())
+                for lane, cap in caps:
+                    lane._finish(cap)
+            else:
+                self._launch_stage(k, int(self._stage.numel()))
+                self.multi.rerun(self._pack)
+            self._slot_release(k, ensure)
         elif self._graphs is not None:
             # this step's host values travel INSIDE its graph: the whole mirror into the next pinned slot (a host copy of a
             # kilobyte), then the replay of the graph that was captured reading that slot

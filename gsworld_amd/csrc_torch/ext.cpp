@@ -224,6 +224,67 @@ void forward_batch(const py::list &frames) {
     TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
 }
 
+// ---- the argument pack of a step, kept on this side (gsworld_amd._C.pack_batch) ---------------------------------------
+// A loop that renders the SAME frames step after step (same tensors, settings and state; the per-step values live in device
+// buffers the kernels read) parsed its 39-value tuples again on every call of forward_batch: ~10 us of host per step, and in
+// the closed loop's eager route 15 us of idle device between the staging kernel and preprocess (kernel trace, round 6).  The
+// pack keeps the filled argument structs; run() is gsr_forward_batch, run_staged() gsr_stage_step + gsr_forward_batch --
+// one call from Python for everything a step enqueues.
+struct StepPack {
+    std::vector<FrameCall> calls;  // (sized once: the resize callbacks keep pointers into it)
+    std::vector<int64_t> caps;
+    std::vector<GsrSettings> st;
+    std::vector<GsrInputs> in;
+    std::vector<GsrOutputs> out;
+    std::vector<GsrBuffers> buf;
+    py::list keep;  // the tensors the raw pointers came from
+    torch::Device dev{torch::kCPU};
+
+    explicit StepPack(const py::list &frames) : keep(frames) {
+        const size_t B = frames.size();
+        TORCH_CHECK(B > 0, "StepPack: no frames");
+        calls.resize(B);
+        caps.resize(B);
+        for (size_t k = 0; k < B; k++) {
+            const py::tuple t = frames[k].cast<py::tuple>();
+            TORCH_CHECK(t.size() == 39, "StepPack: a frame is a tuple of 39 values, got ", t.size());
+            auto T = [&](int i) { return t[i].cast<torch::Tensor>(); };
+            if (k == 0) dev = T(11).device();
+            caps[k] = t[29].cast<int64_t>();
+            fill_frame(calls[k], t[0].cast<int>(), t[1].cast<int>(), t[2].cast<double>(), t[3].cast<double>(),
+                       t[4].cast<double>(), t[5].cast<int>(), t[6].cast<int>(), t[7].cast<bool>(), t[8].cast<bool>(),
+                       t[9].cast<double>(), T(10), T(11), T(12), T(13), T(14), T(15), T(16), T(17), T(18), T(19), T(20), T(21),
+                       T(22), T(23), T(24), T(25), T(26), T(27), T(28), t[30].cast<int>(), t[31].cast<std::vector<int>>(),
+                       T(32), T(33), T(34), T(35), T(36), T(37), t[38].cast<int64_t>());
+        }
+        st.resize(B); in.resize(B); out.resize(B); buf.resize(B);
+        for (size_t k = 0; k < B; k++) {
+            st[k] = calls[k].st;
+            in[k] = calls[k].in;
+            out[k] = calls[k].out;
+            buf[k] = calls[k].buf;
+        }
+    }
+    void launch(void *stream) {
+        const int rc = gsr_forward_batch((int32_t)calls.size(), st.data(), in.data(), out.data(), buf.data(), caps.data(), stream);
+        TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
+    }
+    void run() {
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        launch(current_stream(dev));
+    }
+    // gsr_stage_step (include/gsr.h: n floats from the pinned slot `src` to `dst`, K matrices packed into `table`), then the frames
+    void run_staged(int64_t n, int64_t src, int64_t dst, int64_t K, int64_t mat_off, int64_t scale_off, int64_t table) {
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+        void *stream = current_stream(dev);
+        const int rc = gsr_stage_step((int32_t)n, reinterpret_cast<const float *>((uintptr_t)src),
+                                      reinterpret_cast<float *>((uintptr_t)dst), (int32_t)K, (int32_t)mat_off,
+                                      (int32_t)scale_off, reinterpret_cast<float *>((uintptr_t)table), stream);
+        TORCH_CHECK(rc == GSR_OK, "libgsr_hip error ", rc, ": ", gsr_last_error());
+        launch(stream);
+    }
+};
+
 std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(geom.device());
     GsrFrameStats s{};
@@ -414,6 +475,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("near_plane") = GSR_NEAR_PLANE);
     m.def("forward_frame", &forward_frame);
     m.def("forward_batch", &forward_batch);
+    py::class_<StepPack>(m, "StepPack")
+        .def(py::init<const py::list &>())
+        .def("run", &StepPack::run)
+        .def("run_staged", &StepPack::run_staged);
     m.def("frame_stats", &frame_stats);
     m.def("version", []() { return std::string(gsr_version()); });
 }
