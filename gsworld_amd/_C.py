@@ -188,7 +188,9 @@ def pack_batch(frames):
     """The argument pack of :func:`forward_batch_raw` for these frames, built once: a caller that renders the SAME frames
     again and again -- same tensors, same settings, same state buffers: a closed loop whose per-step values live in device
     buffers the kernels read -- keeps it and calls :func:`run_packed_batch` per step (the per-frame Python that builds it
-    costs more host time than the step's eleven launches)."""
+    costs more host time than the step's eleven launches).  With the compiled binding the pack is a ``StepPack``: the argument
+    structs are filled ONCE, so every tensor but the three state buffers (which the resize callbacks follow) must keep its
+    storage for as long as the pack is used -- build a new pack after replacing or resizing any of them."""
     B = len(frames)
     dev = frames[0]["means3D"].device
     if _ext is not None and hasattr(_ext, "forward_batch"):
