@@ -70,28 +70,31 @@ class FrameGather:
 
     def __init__(self, height: int, width: int, batch: int = 16, device="cpu", world: int | None = None,
                  buffers: int = 1, collective: str = "gather", dst: int = 0, background: bool = False,
-                 timing: bool = False):
+                 timing: bool = False, force_collective: bool = False):
         """``background`` (host tensors only): the collective of a full batch runs on a worker thread, the CPU
         counterpart of the GPU path's side stream -- the caller goes on filling the other half and only
         :meth:`wait_reusable` / :meth:`wait_gathered` block (what the scheduling tests exercise).  ``timing``: record
         how long every collective took (:attr:`gather_ms`; HIP events on the side stream, wall clock on the host) and
-        how long callers were held in :meth:`wait_reusable` (:attr:`waits`)."""
+        how long callers were held in :meth:`wait_reusable` (:attr:`waits`).  ``force_collective``: issue the collective
+        (side stream, events, double buffering and all) even in a process group of ONE rank -- the only way a 1-GPU box can
+        put RCCL itself under this class (tools/rccl_world1.py, tests/test_distributed_gpu.py)."""
         if collective not in ("gather", "all_gather"):
             raise ValueError("collective must be 'gather' or 'all_gather'")
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.rank = dist.get_rank() if (self.world > 1 and dist.is_initialized()) else 0
+        self._multi = self.world > 1 or (bool(force_collective) and dist.is_initialized())
+        self.rank = dist.get_rank() if (self._multi and dist.is_initialized()) else 0
         self.collective = collective
         self.dst = dst
         self.batch = max(1, int(batch))
         self.buffers = max(1, int(buffers))
         self.device = torch.device(device)
         self.frames = torch.empty((self.buffers * self.batch, height, width, 3), dtype=torch.uint8, device=self.device)
-        self.receives = self.world > 1 and (collective == "all_gather" or self.rank == dst)
+        self.receives = self._multi and (collective == "all_gather" or self.rank == dst)
         self._gathered = [torch.empty((self.world * self.batch, height, width, 3), dtype=torch.uint8,
                                       device=self.device) if self.receives else self._half(b)
                           for b in range(self.buffers)]
         self.gathered = self._gathered[0]  # result of the most recent gather (this rank's own frames if it is not a receiver)
-        self.stream = torch.cuda.Stream(self.device) if (self.world > 1 and self.device.type == "cuda") else None
+        self.stream = torch.cuda.Stream(self.device) if (self._multi and self.device.type == "cuda") else None
         self._done = [None] * self.buffers  # event after the collective that last read half b
         self._done_batch = [None] * self.buffers  # ... and which batch that was
         self._last = None  # event of the most recent collective (what `gathered` waits for)
@@ -102,7 +105,7 @@ class FrameGather:
         # (step, batch waited for, seconds blocked) of the last wait_reusable calls that found a collective -- kept only
         # with timing=True, and bounded: a render loop runs for hours
         self.waits = deque(maxlen=4096)
-        self._pool = ThreadPoolExecutor(1) if (background and self.device.type != "cuda" and self.world > 1) else None
+        self._pool = ThreadPoolExecutor(1) if (background and self.device.type != "cuda" and self._multi) else None
 
     def _half(self, b: int) -> torch.Tensor:
         return self.frames if self.buffers == 1 else self.frames[b * self.batch:(b + 1) * self.batch]
@@ -195,7 +198,7 @@ class FrameGather:
             return False
         b = (i // self.batch) % self.buffers
         src, dst_buf = self._half(b), self._gathered[b]
-        if self.world > 1:
+        if self._multi:
             if self.stream is not None:
                 cur = torch.cuda.current_stream(self.device)
                 self.stream.wait_stream(cur)

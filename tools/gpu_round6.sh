@@ -12,6 +12,7 @@
 #   pmc          counters of the eight-frame step -> pmc_render.json
 #   knnssim      rocprofv3 stats of gsr_knn_dist2 at 1.47 M and gsr_ssim_forward / backward at 800 x 800
 #   dist         two ranks over gloo on the one GPU (the N > 1 record's shape)
+#   rccl1        RCCL itself under the frame gather, in a process group of one rank
 #   expacc       -DGSR_EXP_ACCURATE=1 on the eight full-size scenes of configs[3] (tools/variants/libgsr_hip.expacc.so)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -227,6 +228,9 @@ pmc)
 knnssim)
   STATS_ROWS=8 stats knn_dist2 tools/prof_knn_ssim.py knn
   STATS_ROWS=8 stats ssim tools/prof_knn_ssim.py ssim
+  ;;
+rccl1)  # RCCL under gsworld_amd.distributed in a process group of one rank (all a 1-GPU box can do)
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python tools/rccl_world1.py 24 1468850 2> $OUT/rccl_world1.err | grep "^{" | tail -1 | tee $OUT/rccl_world1.json | cut -c1-900
   ;;
 dist)
   echo "== two ranks on this GPU over gloo (the N > 1 record's shape; RCCL needs an 8-GPU node)"
