@@ -10,7 +10,7 @@ make -s -j8
 for spec in "$@"; do
   name=${spec%%:*}; extra=${spec#*:}
   /opt/rocm/bin/hipcc $FLAGS $extra -c $SRC -o /tmp/variant_$name.o
-  objs=$(ls *.o | grep -v "^${SRC%.hip}.o$" | grep -v "^render_coopspin.o$")
+  objs=$(ls *.o | grep -v "^${SRC%.hip}.o$" | grep -v "_coopspin.o$\|_expacc.o$")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libgsr_hip.$name.so $objs /tmp/variant_$name.o
   echo built $OUT/libgsr_hip.$name.so
 done

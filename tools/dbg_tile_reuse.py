@@ -1,8 +1,12 @@
 """Debug: how many tiles does the tile reuse leave, per camera and step? (marker byte trick of tests/test_closed_loop_gpu.py)"""
+import os
 import sys
+
 import torch
-from gsworld_amd import closed_loop as cl, debug as dbg, scenes
-from gsworld_amd.camera import look_at_view
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gsworld_amd import closed_loop as cl, debug as dbg, scenes  # noqa: E402
+from gsworld_amd.camera import look_at_view  # noqa: E402
 
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000

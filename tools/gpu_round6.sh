@@ -13,6 +13,8 @@
 #   knnssim      rocprofv3 stats of gsr_knn_dist2 at 1.47 M and gsr_ssim_forward / backward at 800 x 800
 #   dist         two ranks over gloo on the one GPU (the N > 1 record's shape)
 #   rccl1        RCCL itself under the frame gather, in a process group of one rank
+#   cl_waited    policy in the loop: the graph's one submission against eleven launches from the kept pack
+#   tiles        tiles the tile reuse leaves per camera and step on the surrogate
 #   expacc       -DGSR_EXP_ACCURATE=1 on the eight full-size scenes of configs[3] (tools/variants/libgsr_hip.expacc.so)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -74,6 +76,21 @@ cl_vstats)  # kernel stats of the closed-loop surrogate for every variant librar
   ;;
 test)  # some tests, with their output: TEST_K='expr' (pytest -k)
   timeout 1200 python -m pytest tests/ -x -q -m gpu -k "${TEST_K:-config}" 2>&1 | tail -${TEST_TAIL:-70}
+  ;;
+cl_waited)  # a waited-for step (policy in the loop) as one graph replay against eleven launches from the kept argument pack
+  line() { python -c "
+import json,sys
+rows=[json.loads(l) for l in sys.stdin if l.startswith('{')]
+print(' '.join(('policy' if r['policy_in_loop'] else 'ahead')+'='+str(round(r['frames_per_s'])) for r in rows))"; }
+  for rep in 1 2; do
+    for E in ${CL_ENVS:-1 2 4}; do
+      echo "E=$E graph when waited: $(CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
+      echo "E=$E eager when waited: $(CL_EAGER_WAITED=1 CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
+    done
+  done
+  ;;
+tiles)  # how many of its 1 200 tiles the tile reuse leaves per camera and step (marker-byte trick), full-size surrogate
+  timeout 300 python tools/dbg_tile_reuse.py 1468850 1 2>&1 | grep "captured=False" | tee $OUT/tile_reuse_tiles_left.txt
   ;;
 cl_env)  # the closed loop under HIP runtime knobs (what does the boundary between two graph replays cost, and why)
   for e in "X=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" "DEBUG_HIP_GRAPH_BATCH_SIZE=64" "DEBUG_HIP_FORCE_GRAPH_QUEUES=1" \
