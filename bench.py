@@ -717,6 +717,18 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
                   "policy_in_loop_frac_of_8TBs": b_step * ((ep_len + 1) / dt_policy) / 8e12,
                   "note": "B_alg = 48 N + 280 V + 64 R + 16 W H per frame (SURVEY 8d) with the reference's per-tile R, summed "
                           "over the step's two frames, x steps per second / 8 TB/s"}
+        # the step's REAL HBM traffic, from the committed counter run of the same surrogate (tools/gpu_round6.sh clpmc:
+        # 2 x FETCH_SIZE + WRITE_SIZE per kernel, one dispatch of each of the step's eleven kernels) x this run's steps per second
+        import glob as _glob
+
+        for path in sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round*",
+                                                   "pmc_closed_loop.json"))):
+            rec_ = json.load(open(path))
+            cl_alg["counters"] = {"hbm_bytes_per_step": rec_["hbm_bytes_per_step"],
+                                  "real_hbm_GBs": rec_["hbm_bytes_per_step"] * ((ep_len + 1) / dt) / 1e9,
+                                  "real_over_algorithmic": rec_["hbm_bytes_per_step"] / b_step,
+                                  "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))),
+                                  "collected": rec_.get("collected")}
     except Exception as ex:  # noqa: BLE001
         cl_alg = {"error": f"{type(ex).__name__}: {ex}"}
     # ---- the same rollout with E environments per step (the wrapper's `for i in range(self.num_envs)`, gs_world_wrapper.py:

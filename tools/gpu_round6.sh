@@ -10,6 +10,7 @@
 #   stats        kernel stats of the step's launches, one frame per launch, dense view, moving camera
 #   train        training step: stats (+ pmc with `trainpmc`)
 #   pmc          counters of the eight-frame step -> pmc_render.json
+#   clpmc        counters of the closed-loop step -> pmc_closed_loop.json
 #   knnssim      rocprofv3 stats of gsr_knn_dist2 at 1.47 M and gsr_ssim_forward / backward at 800 x 800
 #   dist         two ranks over gloo on the one GPU (the N > 1 record's shape)
 #   rccl1        RCCL itself under the frame gather, in a process group of one rank
@@ -228,6 +229,12 @@ r=json.loads(sys.stdin.readline()); print('ms_per_step %.4f host %.3f' % (r['ms_
     fi
   done
   cp /tmp/libgsr_hip.base.so gsworld_amd/libgsr_hip.so
+  ;;
+clpmc)  # counters of the closed-loop step (configs[2] surrogate, steps enqueued ahead) -> pmc_closed_loop.json
+  CL_ONLY=1,0 PMC_CMD="tools/ab_closed_loop.py 1468850 1" bash tools/gpu_pmc_train.sh round6/pmc_cl_raw > $OUT/pmc/closed_loop_step.txt 2>&1; grep -c "grid" $OUT/pmc/closed_loop_step.txt
+  python tools/pmc_train_summary.py $OUT/pmc/closed_loop_step.txt $OUT/pmc_closed_loop.json 0 "closed-loop step (configs[2] surrogate, two frames)" \
+    "render_stream,preprocess_kernel,band_,ss_,stage_step,tile_starts"
+  rm -rf gpurun_out/round6/pmc_cl_raw/p*/
   ;;
 trainpmc)
   bash tools/gpu_pmc_train.sh round6/pmc_train_raw > $OUT/pmc/train_step.txt 2>&1; grep -c "grid" $OUT/pmc/train_step.txt
