@@ -16,6 +16,7 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <cstring>
 #include <tuple>
 
 #include "../../include/gsr.h"
@@ -285,6 +286,35 @@ struct StepPack {
     }
 };
 
+// The host values of a closed-loop step (part matrices, uniform scales, camera matrices -- gsworld_amd/closed_loop.py keeps them
+// in one float32 staging vector): every (offset, tensor) pair into the host mirror, then the whole mirror into the pinned ring
+// slot the step's staging kernel will read.  One call instead of a dozen numpy copies behind as many Python-level checks:
+// with the policy in the loop the host's share of a step is on the critical path (13 -> 4 us of ~250, round 6).  Returns false
+// -- nothing written -- if a tensor is not plain host float32 or does not fit: the caller takes its general path.
+bool stage_host_values(torch::Tensor mirror, torch::Tensor slot, const py::list &segs) {
+    TORCH_CHECK(mirror.device().is_cpu() && slot.device().is_cpu() && mirror.scalar_type() == torch::kFloat32 &&
+                    slot.scalar_type() == torch::kFloat32 && mirror.is_contiguous() && slot.is_contiguous() &&
+                    mirror.numel() == slot.numel(),
+                "stage_host_values: mirror and slot must be host float32 vectors of one size");
+    const int64_t n = mirror.numel();
+    const size_t S = segs.size();
+    std::vector<std::pair<int64_t, torch::Tensor>> parsed;
+    parsed.reserve(S);
+    for (size_t k = 0; k < S; k++) {
+        const py::tuple t = segs[k].cast<py::tuple>();
+        const int64_t off = t[0].cast<int64_t>();
+        torch::Tensor src = t[1].cast<torch::Tensor>();
+        if (!src.device().is_cpu() || src.scalar_type() != torch::kFloat32 || !src.is_contiguous() || src.requires_grad() ||
+            off < 0 || off + src.numel() > n)
+            return false;
+        parsed.emplace_back(off, std::move(src));
+    }
+    float *m = mirror.data_ptr<float>();
+    for (auto &pr : parsed) std::memcpy(m + pr.first, pr.second.data_ptr<float>(), (size_t)pr.second.numel() * sizeof(float));
+    std::memcpy(slot.data_ptr<float>(), m, (size_t)n * sizeof(float));
+    return true;
+}
+
 std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(geom.device());
     GsrFrameStats s{};
@@ -475,6 +505,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("near_plane") = GSR_NEAR_PLANE);
     m.def("forward_frame", &forward_frame);
     m.def("forward_batch", &forward_batch);
+    m.def("stage_host_values", &stage_host_values);
     py::class_<StepPack>(m, "StepPack")
         .def(py::init<const py::list &>())
         .def("run", &StepPack::run)

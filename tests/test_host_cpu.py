@@ -368,3 +368,25 @@ def test_plan_query_is_the_librarys_own_decision_and_knows_the_sample_sorts_mode
 
     assert ClosedLoopRenderer._takes_permuted_model(Cam, 1_468_850)
     assert not ClosedLoopRenderer._takes_permuted_model(Cam, limit + 1)
+
+
+def test_stage_host_values_writes_mirror_and_slot_or_nothing():
+    """csrc_torch/ext.cpp stage_host_values (the closed loop's per-step host values in one call): every (offset, tensor) pair
+    lands in the mirror, the mirror in the slot; a tensor that is not plain host float32, or does not fit, leaves both
+    untouched and the caller takes its general path."""
+    import torch
+
+    from gsworld_amd import _C
+
+    if _C._ext is None or not hasattr(_C._ext, "stage_host_values"):
+        pytest.skip("compiled binding not built")
+    mirror, slot = torch.arange(40, dtype=torch.float32), torch.zeros(40)
+    a, b = torch.full((2, 4), 7.0), torch.full((3,), 9.0)
+    assert _C._ext.stage_host_values(mirror, slot, [(4, a), (30, b)])
+    want = torch.arange(40, dtype=torch.float32)
+    want[4:12], want[30:33] = 7.0, 9.0
+    assert torch.equal(mirror, want) and torch.equal(slot, want)
+    before = mirror.clone()
+    for bad in ([(4, a.double())], [(38, b)], [(-1, b)], [(0, a.t())], [(4, a), (0, torch.ones(3, requires_grad=True))]):
+        assert not _C._ext.stage_host_values(mirror, slot, bad)
+        assert torch.equal(mirror, before) and torch.equal(slot, before)

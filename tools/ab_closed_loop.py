@@ -49,6 +49,8 @@ def main():
         loop.reset(*pinned[0])
         if os.environ.get("CL_EAGER", "") != "1":  # (A/B: every step's launches issued one by one instead of a graph replay)
             loop.capture()
+        if os.environ.get("CL_NO_FAST_STAGE", "") == "1":  # (A/B: the step's host values through set_poses / set_cameras)
+            loop._stage_fn = None
         if os.environ.get("CL_EAGER_WAITED", "") == "1":  # (A/B: a waited-for step issues its launches one by one as well)
             loop.eager_when_waited = True
         for ensure in (False, True):

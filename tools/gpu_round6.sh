@@ -85,6 +85,7 @@ rows=[json.loads(l) for l in sys.stdin if l.startswith('{')]
 print(' '.join(('policy' if r['policy_in_loop'] else 'ahead')+'='+str(round(r['frames_per_s'])) for r in rows))"; }
   for rep in 1 2; do
     for E in ${CL_ENVS:-1 2 4}; do
+      echo "E=$E graph when waited, host values through set_poses / set_cameras: $(CL_NO_FAST_STAGE=1 CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
       echo "E=$E graph when waited: $(CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
       echo "E=$E eager when waited: $(CL_EAGER_WAITED=1 CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
     done
