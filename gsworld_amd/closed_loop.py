@@ -248,6 +248,11 @@ class ClosedLoopRenderer:
         self._pack = None     # the step's argument pack (MultiCameraRenderer.last_pack): eager steps without the Python
         self.eager_when_ahead = True  # step(ensure=False) issues the launches one by one instead of replaying the graph
         self._stage_fn = getattr(_C._ext, "stage_host_values", None) if _C._ext is not None else None
+        self._sync_fn = getattr(_C._ext, "sync_current_stream", None) if (_C._ext is not None and dev.type == "cuda") else None
+        self._dev_index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0)
+        self._mat_shape = tuple(self.matrices.shape)
+        self._cam_meta = {n: (self._seg[n][0], c.image_width, c.image_height, c.FoVx, c.FoVy)
+                          for n, c in zip(self.names, self.cameras)}
         self.eager_when_waited = False  # ... step(ensure=True) too (A/B: the graph's one submission against eleven launches)
         self.image_size = (H, W)
 
@@ -373,25 +378,23 @@ class ClosedLoopRenderer:
         Returns the slot, or None when anything is not of that kind (nothing written: the general path takes over)."""
         segs = []
         if matrices is not None:
-            if matrices.is_cuda or (scales is not None and scales.is_cuda) or \
-                    tuple(matrices.shape) != tuple(self.matrices.shape) or \
-                    (scales is not None and scales.numel() != self.scales.numel()):
+            # (device tensors, other dtypes, strided views: the compiled side says no and nothing is written)
+            if tuple(matrices.shape) != self._mat_shape or (scales is not None and scales.numel() != self.num_envs * self.K):
                 return None
             segs.append((0, matrices))
             if scales is not None:
                 segs.append((self.num_envs * self.K * 16, scales))
         if cameras:
             for name, cam in cameras.items():
-                if name not in self._seg or name == "poses":
+                meta = self._cam_meta.get(name)
+                if meta is None:
                     return None  # (set_cameras raises the KeyError)
-                mine = self.cameras[self.names.index(name)]
-                if (cam.image_width, cam.image_height) != (mine.image_width, mine.image_height) or \
-                        abs(cam.FoVx - mine.FoVx) > 1e-9 or abs(cam.FoVy - mine.FoVy) > 1e-9:
+                o, w, h, fx, fy = meta
+                if cam.image_width != w or cam.image_height != h or abs(cam.FoVx - fx) > 1e-9 or abs(cam.FoVy - fy) > 1e-9:
                     return None  # (set_cameras raises the ValueError)
                 wv, fp, cc = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
                 if wv.numel() != 16 or fp.numel() != 16 or cc.numel() != 3:
                     return None
-                o = self._seg[name][0]
                 segs += [(o, wv), (o + 16, fp), (o + 32, cc)]
         # (the slot is taken before the write: its last reader has finished by then)
         ring_k, ring_ev, waited = self._ring_k, list(self._ring_ev), self._ring_waited
@@ -517,7 +520,10 @@ class ClosedLoopRenderer:
             self._gpu_step()
             self._pack = self.multi.last_pack if self.fuse_transform and self._table is not None else None
         if ensure:
-            torch.cuda.current_stream(self.device).synchronize()
+            if self._sync_fn is not None:
+                self._sync_fn(self._dev_index)
+            else:
+                torch.cuda.current_stream(self.device).synchronize()
         self._check_overflow(late=not ensure)
         return self.frames
 

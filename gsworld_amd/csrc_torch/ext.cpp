@@ -315,6 +315,14 @@ bool stage_host_values(torch::Tensor mirror, torch::Tensor slot, const py::list 
     return true;
 }
 
+// hipStreamSynchronize of the device's current stream (what torch.cuda.current_stream(dev).synchronize() does, without the two
+// Python-level objects in front of it: 2.3 -> 0.6 us in front of every waited-for step's return)
+void sync_current_stream(int64_t device_index) {
+    const auto s = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)device_index);
+    py::gil_scoped_release nogil;
+    s.synchronize();
+}
+
 std::tuple<int64_t, int64_t, int64_t> frame_stats(const torch::Tensor &geom) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(geom.device());
     GsrFrameStats s{};
@@ -506,6 +514,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("forward_frame", &forward_frame);
     m.def("forward_batch", &forward_batch);
     m.def("stage_host_values", &stage_host_values);
+    m.def("sync_current_stream", &sync_current_stream);
     py::class_<StepPack>(m, "StepPack")
         .def(py::init<const py::list &>())
         .def("run", &StepPack::run)
