@@ -89,7 +89,7 @@ print(' '.join(('policy' if r['policy_in_loop'] else 'ahead')+'='+str(round(r['f
       echo "E=$E graph when waited: $(CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
       echo "E=$E eager when waited: $(CL_EAGER_WAITED=1 CL_ONLY=1 timeout 300 python tools/ab_closed_loop.py 1468850 $E 2>/dev/null | line)"
     done
-  done
+  done | tee $OUT/closed_loop_waited.txt
   ;;
 tiles)  # how many of its 1 200 tiles the tile reuse leaves per camera and step (marker-byte trick), full-size surrogate
   timeout 300 python tools/dbg_tile_reuse.py 1468850 1 2>&1 | grep "captured=False" | tee $OUT/tile_reuse_tiles_left.txt
