@@ -753,6 +753,44 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
             del lp, pe
         except Exception as ex:  # noqa: BLE001
             env_sweep[f"num_envs_{E}"] = {"error": f"{type(ex).__name__}: {ex}"}
+    # ---- a second surrogate in which the robot LOOKS like a robot (scenes.arm_tabletop_scene: the robot's Gaussians on the
+    # links of the reference's URDF at the scan pose, 8 % of the model, two objects on the table) under the SAME rollout:
+    # tabletop_scene scatters its part clusters over a 0.8 m cube that fills right_cam's view, and the rollout swings them
+    # through the whole frame -- hardly a tile stays as it was.  Not a BASELINE configuration; beside configs[2]'s surrogate.
+    arm_shaped = None
+    try:
+        raw_arm = scenes.arm_tabletop_scene(rollout["link_scan"], rollout["labels"], n=raw.num, seed=1)
+        arm_shaped = {}
+        for E in (1, 4):
+            pe = pinned if E == 1 else [(M.pin_memory(), s_.pin_memory())
+                                        for M, s_ in cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0, num_envs=E)]
+            rec = {}
+            for label, kw in (("kept", {}), ("every_tile_composited", {"tile_reuse": False}), ("nothing_kept", {"block_cache": False})):
+                lp = cl.ClosedLoopRenderer(raw_arm, parts, cams, scaled_parts=actors, device=dev, num_envs=E, **kw)
+                lp.reset(*pe[0])
+                lp.capture()
+                r_ = {}
+                for key, ensure in (("frames_per_s", False), ("policy_in_loop_frames_per_s", True)):
+                    torch.cuda.synchronize()
+                    t0a = time.perf_counter()
+                    for (M, s_), w in zip(pe, wrists):
+                        lp.step(M, s_, cameras={"wrist_cam": w}, ensure=ensure)
+                    torch.cuda.synchronize()
+                    r_[key] = (ep_len + 1) * len(cams) * E / (time.perf_counter() - t0a)
+                r_["overflow_frames"] = lp.overflow_frames()
+                if label == "kept":
+                    last = {n_: f.clone() for n_, f in lp.frames.items()}
+                else:
+                    r_["last_frames_identical_to_the_loop_that_keeps_s"] = all(torch.equal(last[n_], f) for n_, f in lp.frames.items())
+                rec[label] = r_
+                del lp
+            arm_shaped[f"num_envs_{E}"] = rec
+        arm_shaped["what"] = ("scenes.arm_tabletop_scene under the configs[2] rollout: ClosedLoopRenderer as shipped (blocks nothing "
+                              "moved in keep their records, tiles nothing touched keep their pixels), with tile_reuse=False, with "
+                              "block_cache=False; frames bit-identical between the three")
+        del raw_arm
+    except Exception as ex:  # noqa: BLE001
+        arm_shaped = {"error": f"{type(ex).__name__}: {ex}"}
     # ---- the same rollout with consecutive steps in flight (PipelinedClosedLoop, depth 3: six frames instead of two).
     # configs[2] is a RANDOM-ACTION rollout: gsworld_rand_action_tabletop.py:107-133 never looks at its observations, so
     # step k + 1 may be enqueued while step k renders; a policy that needs frame k first gets the figure above.
@@ -816,6 +854,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
         "policy_in_loop_frames_per_s": (ep_len + 1) * len(cams) / dt_policy,
         "policy_in_loop_steps_per_s": (ep_len + 1) / dt_policy,
         "environments_per_step": env_sweep,
+        "arm_shaped": arm_shaped,
         "block_cache": {"on": True, "what": "inference frames of ClosedLoopRenderer keep a block of 256 Gaussians as the previous "
                         "frame on the state computed it when settings, camera and the block's pose row are that frame's bit for "
                         "bit (GSR_MODEL_VERSION; the headline and every other figure of this line never pass a model version: "

@@ -77,6 +77,7 @@ def xarm6_rollout(path: str | None = None) -> dict:
         lab = [int(v) for v in z["labels"][i] if v >= 0]
         parts[names[i]] = lab[0] if len(lab) == 1 else lab
     return dict(parts=parts, link_now=torch.from_numpy(z["link_now"][:, keep]), link_scan=torch.from_numpy(z["link_scan"][keep]),
+                labels=torch.from_numpy(z["labels"][keep]),  # (per kept link: one or two semantic labels, -1 = none)
                 sim2gs_arm=torch.from_numpy(z["sim2gs_arm"]), link_offset=torch.from_numpy(z["link_offset"]),
                 qpos=torch.from_numpy(z["qpos"]))
 

@@ -195,6 +195,81 @@ def tabletop_scene(name: str = "xarm6_align", n: int = XARM6_ALIGN_NUM_GAUSSIANS
     return RawGaussians(xyz, dc, rest, opacity, scaling.contiguous(), rotation, semantics)
 
 
+def arm_tabletop_scene(link_scan, labels, n: int = XARM6_ALIGN_NUM_GAUSSIANS, seed: int = 1, robot_fraction: float = 0.08):
+    """A second table-top surrogate in which the robot LOOKS like a robot: the same table / background and floaters as
+    :func:`tabletop_scene` (xarm6_align), but the robot's Gaussians sit ON the xarm6's links -- capsules between consecutive
+    link frames of the reference's URDF at the scan pose (``link_scan`` (L,4,4) sim-frame poses and their ``labels``, e.g. from
+    :func:`gsworld_amd.rollouts.xarm6_rollout`: ``tests/golden/xarm6_rollout.npz``) -- and two graspable objects stand on the
+    table (labels 17, 18).  :func:`tabletop_scene` scatters its 20 part clusters over a 0.8 m cube that fills the sensor
+    camera's view, and a forward-kinematics rollout then swings those clusters through the whole frame; here an arm moves the way
+    an arm does.  ``robot_fraction`` of the Gaussians belong to the links (a real GSWorld asset: the robot scan is a small part
+    of the scene).  Not a BASELINE configuration: a datum beside configs[2]'s surrogate (bench.py ``closed_loop.arm_shaped``)."""
+    gen = torch.Generator().manual_seed(seed)
+    link_scan = torch.as_tensor(link_scan, dtype=torch.float32)
+    L = link_scan.shape[0]
+    n_rob = int(n * robot_fraction)
+    n_obj = int(n * 0.01)
+    n_flo = int(n * 0.03)
+    n_tab = n - n_rob - 2 * n_obj - n_flo
+    # table / background (as tabletop_scene)
+    xyz_t = torch.rand(n_tab, 3, generator=gen)
+    xyz_t[:, 0] = xyz_t[:, 0] * 2.0 - 0.5
+    xyz_t[:, 1] = xyz_t[:, 1] * 2.0 - 1.0
+    xyz_t[:, 2] = torch.randn(n_tab, generator=gen) * 0.003
+    ls_t = (math.log(0.01) + 0.5 * torch.randn(n_tab, 1, generator=gen)).repeat(1, 3)
+    ls_t[:, 2] += math.log(0.1)
+    q_t = torch.zeros(n_tab, 4)
+    q_t[:, 0] = 1.0
+    q_t += 0.05 * torch.randn(n_tab, 4, generator=gen)
+    # robot: link k's Gaussians along the segment from its frame to the next link's, 2.5 cm around it
+    org = link_scan[:, :3, 3]
+    nxt = torch.cat((org[1:], org[-1:] + torch.tensor([[0.0, 0.0, -0.03]])))
+    seg_len = (nxt - org).norm(dim=1) + 0.05
+    share = seg_len / seg_len.sum()
+    which = torch.multinomial(share, n_rob, replacement=True, generator=gen)
+    t = torch.rand(n_rob, 1, generator=gen)
+    xyz_r = org[which] * (1.0 - t) + nxt[which] * t + torch.randn(n_rob, 3, generator=gen) * 0.025
+    ls_r = math.log(0.004) + 0.4 * torch.randn(n_rob, 3, generator=gen)
+    q_r = torch.randn(n_rob, 4, generator=gen)
+    lab = torch.as_tensor(labels)
+    if lab.dim() == 2:  # (a link with two labels: its Gaussians carry either)
+        pick = torch.randint(0, lab.shape[1], (n_rob,), generator=gen)
+        lab_r = lab[which, pick]
+        lab_r = torch.where(lab_r < 0, lab[which, 0], lab_r)
+    else:
+        lab_r = lab[which]
+    # two objects on the table
+    obj_c = torch.tensor([[0.45, -0.15, 0.03], [0.45, 0.15, 0.03]])
+    xyz_o = obj_c.repeat_interleave(n_obj, 0) + torch.randn(2 * n_obj, 3, generator=gen) * 0.02
+    ls_o = math.log(0.003) + 0.3 * torch.randn(2 * n_obj, 3, generator=gen)
+    q_o = torch.randn(2 * n_obj, 4, generator=gen)
+    lab_o = torch.tensor([17.0, 18.0]).repeat_interleave(n_obj)
+    # floaters
+    d = torch.randn(n_flo, 3, generator=gen)
+    d = d / d.norm(dim=1, keepdim=True)
+    xyz_f = d * (2 + 4 * torch.rand(n_flo, 1, generator=gen))
+    ls_f = math.log(0.05) + 0.5 * torch.randn(n_flo, 3, generator=gen)
+    q_f = torch.randn(n_flo, 4, generator=gen)
+
+    xyz = torch.cat((xyz_t, xyz_r, xyz_o, xyz_f))
+    scaling = torch.cat((ls_t, ls_r, ls_o, ls_f))
+    rotation = torch.cat((q_t, q_r, q_o, q_f))
+    mode = torch.rand(n, 1, generator=gen) < 0.6
+    opacity = torch.where(mode, 3 + torch.randn(n, 1, generator=gen), -2 + torch.randn(n, 1, generator=gen))
+    dc, rest = _sh(gen, n)
+    semantics = torch.cat((torch.zeros(n_tab), lab_r.float(), lab_o, torch.zeros(n_flo)))[:, None]
+    perm = torch.randperm(n, generator=gen)
+    xyz, scaling, rotation, opacity, dc, rest, semantics = (
+        v[perm].contiguous() for v in (xyz, scaling, rotation, opacity, dc, rest, semantics))
+    sim2gs = torch.tensor(SIM2GS_XARM_TRANS)
+    rigid, scale, R, _ = extract_rigid_transform(sim2gs)
+    xyz = (xyz @ sim2gs[:3, :3].T + sim2gs[:3, 3]).contiguous()
+    qR = torch.tensor(_matrix_to_quat_wxyz(R.numpy()), dtype=torch.float32)
+    rotation = _quat_mul(qR.expand_as(rotation), rotation).contiguous()
+    scaling = scaling + math.log(float(scale))
+    return RawGaussians(xyz, dc, rest, opacity, scaling.contiguous(), rotation, semantics)
+
+
 def sensor_camera(name: str = "xarm6_align", width: int = 640, height: int = 480) -> ViewParams:
     """The ``right_cam`` sensor of the scene's env, pushed through the wrapper's camera conversion.
 
@@ -228,6 +303,6 @@ def training_camera(width: int = 800, height: int = 800, fov_deg: float = 60.0) 
     return identity_camera(width, height, fov_deg)
 
 
-__all__ = ["RawGaussians", "random_scene_camera_frame", "identity_camera", "tabletop_scene", "sensor_camera",
+__all__ = ["RawGaussians", "random_scene_camera_frame", "identity_camera", "tabletop_scene", "arm_tabletop_scene", "sensor_camera",
            "dense_view_camera",
            "training_camera", "SCENE_NAMES", "XARM6_ALIGN_NUM_GAUSSIANS", "look_at_view"]

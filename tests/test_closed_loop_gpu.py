@@ -691,3 +691,34 @@ def test_tile_reuse_random_rests_and_moves_give_the_frames_of_a_loop_that_keeps_
             assert torch.equal(got[n], want[n]), f"E={E} step {k} {n} (moving {list(moving)})"
         skipped += sum(int(dbg.sort_state(lane.geom)["kept_tiles"]) for lane in reuse.multi.lanes)
     assert skipped > steps // 2, skipped  # (the soak did exercise the reuse)
+
+
+def test_arm_shaped_scene_keeps_blocks_and_tiles_and_gives_the_frames_of_a_loop_that_keeps_nothing(cuda_device):
+    """scenes.arm_tabletop_scene: the robot's Gaussians on the links of the reference's URDF (the rollout fixture's scan pose),
+    two objects on the table -- under the forward-kinematics rollout an arm then moves the way an arm does, and the fixed
+    sensor camera leaves a good part of its tiles alone on every step.  Frames byte for byte those of a loop built with
+    ``block_cache=False``; one and two environments."""
+    dev = cuda_device
+    rollout = cl.xarm6_rollout()
+    raw = scenes.arm_tabletop_scene(rollout["link_scan"], rollout["labels"], n=250_000, seed=3)
+    labels = set(int(v) for v in raw.semantics.reshape(-1).unique().tolist())
+    assert labels == set(range(0, 19))  # background, the 16 link labels, the two objects
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    for E in (1, 2):
+        poses = list(cl.rollout_poses(rollout, len(actors), steps=10, seed=9, num_envs=E))
+        kept = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
+        plain = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E, block_cache=False)
+        for lp in (kept, plain):
+            lp.reset(*poses[0])
+            lp.capture()
+        left = 0
+        for k in range(1, 10):
+            got = kept.step(*poses[k], ensure=True)
+            want = plain.step(*poses[k], ensure=True)
+            for n in cams:
+                assert torch.equal(got[n], want[n]), f"E={E} step {k} {n}"
+            left += sum(int(dbg.sort_state(lane.geom)["kept_tiles"]) for lane in kept.multi.lanes)
+        assert left >= 9 * E  # (at least the fixed camera of every environment, every step)
+        assert kept.overflow_frames() == 0

@@ -22,7 +22,11 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else scenes.XARM6_ALIGN_NUM_GAUSSIANS
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     W, H = 640, 480
-    raw = scenes.tabletop_scene("xarm6_align", n=n, seed=1)
+    if os.environ.get("CL_SCENE", "") == "arm":  # (the robot's Gaussians on the URDF's links instead of scattered clusters)
+        rl = cl.xarm6_rollout()
+        raw = scenes.arm_tabletop_scene(rl["link_scan"], rl["labels"], n=n, seed=1)
+    else:
+        raw = scenes.tabletop_scene("xarm6_align", n=n, seed=1)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align", W, H),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
     rollout = cl.xarm6_rollout()
@@ -45,7 +49,9 @@ def main():
     for batched in (True, False):
         if only and batched != bool(int(only.split(",")[0])):
             continue
-        loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E)
+        loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E,
+                                     block_cache=os.environ.get("CL_NO_CACHE", "") != "1",
+                                     tile_reuse=os.environ.get("CL_NO_TILE_REUSE", "") != "1")
         loop.reset(*pinned[0])
         if os.environ.get("CL_EAGER", "") != "1":  # (A/B: every step's launches issued one by one instead of a graph replay)
             loop.capture()

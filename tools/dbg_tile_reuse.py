@@ -11,8 +11,11 @@ from gsworld_amd.camera import look_at_view  # noqa: E402
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 34
-raw = scenes.tabletop_scene("xarm6_align", n=n, seed=seed)
 rollout = cl.xarm6_rollout()
+if os.environ.get("CL_SCENE", "") == "arm":
+    raw = scenes.arm_tabletop_scene(rollout["link_scan"], rollout["labels"], n=n, seed=seed)
+else:
+    raw = scenes.tabletop_scene("xarm6_align", n=n, seed=seed)
 parts, actors = cl.xarm6_rollout_parts(rollout)
 cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
         "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
