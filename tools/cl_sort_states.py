@@ -16,7 +16,11 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else scenes.XARM6_ALIGN_NUM_GAUSSIANS
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 W, H = 640, 480
-raw = scenes.tabletop_scene("xarm6_align", n=n, seed=1)
+if os.environ.get("CL_SCENE", "") == "arm":  # (the arm-shaped surrogate: scenes.arm_tabletop_scene)
+    _r = cl.xarm6_rollout()
+    raw = scenes.arm_tabletop_scene(_r["link_scan"], _r["labels"], n=n, seed=1)
+else:
+    raw = scenes.tabletop_scene("xarm6_align", n=n, seed=1)
 cams = {"right_cam": scenes.sensor_camera("xarm6_align", W, H),
         "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, W, H)}
 rollout = cl.xarm6_rollout()
