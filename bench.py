@@ -734,7 +734,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
     # ---- the same rollout with E environments per step (the wrapper's `for i in range(self.num_envs)`, gs_world_wrapper.py:
     # 241-242): E x 2 frames per gsr_forward_batch call, environment e playing the trajectory 17 e steps ahead
     env_sweep = {}
-    for E in (2, 4):
+    for E in (2, 4, 8):
         try:
             lp = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
             pe = [(M.pin_memory(), s_.pin_memory()) for M, s_ in cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0, num_envs=E)]
@@ -748,7 +748,8 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
                     lp.step(M, s_, cameras={"wrist_cam": w}, ensure=ensure)
                 torch.cuda.synchronize()
                 rec[label] = (ep_len + 1) * len(cams) * E / (time.perf_counter() - t0e)
-            rec["frames_per_launch"], rec["overflow_frames"] = E * len(cams), lp.overflow_frames()
+            rec["frames_per_launch"], rec["overflow_frames"] = min(E * len(cams), lp.multi.set_frames), lp.overflow_frames()
+            rec["sets_per_step"] = -(-E * len(cams) // lp.multi.set_frames)  # (each on a stream of its own, up to three)
             env_sweep[f"num_envs_{E}"] = rec
             del lp, pe
         except Exception as ex:  # noqa: BLE001
@@ -761,7 +762,7 @@ def secondary_measurements(args, dev, raw, name, model, laid, bg, group_streams=
     try:
         raw_arm = scenes.arm_tabletop_scene(rollout["link_scan"], rollout["labels"], n=raw.num, seed=1)
         arm_shaped = {}
-        for E in (1, 4):
+        for E in (1, 4, 8):
             pe = pinned if E == 1 else [(M.pin_memory(), s_.pin_memory())
                                         for M, s_ in cl.rollout_poses(rollout, len(actors), steps=ep_len + 1, seed=0, num_envs=E)]
             rec = {}

@@ -172,6 +172,9 @@ def _frame_structs(settings: GsrSettings, background, means3D, colors, opacity, 
     return settings, inp, out, buf, cbs
 
 
+MAX_FRAMES_PER_LAUNCH = 8  # include/gsr.h GSR_MAX_FRAMES_PER_LAUNCH
+
+
 def forward_batch_raw(frames, device=None):
     """B frames of one step through gsr_forward_batch: one set of launches whose grids span the frames (include/gsr.h;
     GSWorld's per-step double loop over cameras and environments, gs_world_wrapper.py:238-267).  ``frames``: a list of

@@ -310,6 +310,8 @@ class MultiCameraRenderer:
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(num_cameras)] if not self.batched else []
         self._set_streams: list = []  # (batched: one per image size beyond the first, created when a step has several)
+        self.max_set_streams = 3      # sets of ONE image size in flight at once (more than `set_frames` frames per step)
+        self.set_frames = _C.MAX_FRAMES_PER_LAUNCH  # frames per set of launches
         self.last_pack = None
 
     def rerun(self, pack_caps) -> None:
@@ -371,21 +373,32 @@ class MultiCameraRenderer:
             sets: dict = {}
             for call in calls:
                 sets.setdefault((call["settings"].image_height, call["settings"].image_width), []).append(call)
+            # ... and more frames of one size than one set of launches takes (include/gsr.h GSR_MAX_FRAMES_PER_LAUNCH = 8: five or
+            # more environments with two cameras) are several sets as well: gsr_forward_batch would run them one after the other
+            # on one stream, where two or three in flight fill the latency-bound stages of each other (the headline's
+            # arrangement: one stream 12.8 k, three 15.0 k frames/s).  Up to `max_set_streams` streams, sets dealt in turn.
+            chunks = []
+            for group in sets.values():
+                for i in range(0, len(group), self.set_frames):
+                    chunks.append(group[i:i + self.set_frames])
             with torch.cuda.device(self.device):
-                if len(sets) == 1:
+                if len(chunks) == 1 or (len(sets) == 1 and self.max_set_streams <= 1):
                     pack = _C.pack_batch(calls)
                     _C.run_packed_batch(pack, self.device)
                     if len(calls) == len(self.lanes):
                         self.last_pack = (pack, caps)
                 else:
                     cur = torch.cuda.current_stream(self.device)
-                    while len(self._set_streams) < len(sets):
+                    n_st = min(len(chunks), max(1, self.max_set_streams)) if len(sets) == 1 else len(chunks)
+                    while len(self._set_streams) < n_st:
                         self._set_streams.append(torch.cuda.Stream(self.device))
-                    for st, group in zip(self._set_streams, sets.values()):
+                    used = self._set_streams[:n_st]
+                    for st in used:
                         st.wait_stream(cur)
-                        with torch.cuda.stream(st):
+                    for i, group in enumerate(chunks):
+                        with torch.cuda.stream(used[i % n_st]):
                             _C.forward_batch_raw(group, device=self.device)
-                    for st, _ in zip(self._set_streams, sets):
+                    for st in used:
                         cur.wait_stream(st)
             for lane, cap in caps:
                 lane._finish(cap)

@@ -722,3 +722,32 @@ def test_arm_shaped_scene_keeps_blocks_and_tiles_and_gives_the_frames_of_a_loop_
             left += sum(int(dbg.sort_state(lane.geom)["kept_tiles"]) for lane in kept.multi.lanes)
         assert left >= 9 * E  # (at least the fixed camera of every environment, every step)
         assert kept.overflow_frames() == 0
+
+
+def test_steps_of_eight_frames_and_more_go_as_sets_on_streams_of_their_own(cuda_device):
+    """Four environments and more (eight frames per step) are rendered as at least two sets of launches in flight at once
+    (ClosedLoopRenderer -> MultiCameraRenderer.set_frames / max_set_streams).  Same frames as one set after the other on one
+    stream, eager and under graph replay; five environments = two sets of five."""
+    dev = cuda_device
+    raw = scenes.tabletop_scene("xarm6_align", n=120_000, seed=37)
+    rollout = cl.xarm6_rollout()
+    parts, actors = cl.xarm6_rollout_parts(rollout)
+    cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
+            "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
+    for E, per_set in ((4, 4), (5, 5), (9, 8)):
+        poses = list(cl.rollout_poses(rollout, len(actors), steps=6, seed=10, num_envs=E))
+        sets = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
+        one = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
+        assert sets.multi.set_frames == per_set
+        one.multi.max_set_streams, one.multi.set_frames = 1, 8
+        for lp in (sets, one):
+            lp.reset(*poses[0])
+        for k in range(1, 6):
+            if k == 3:
+                for lp in (sets, one):
+                    lp.capture()
+            got = sets.step(*poses[k], ensure=True)
+            want = one.step(*poses[k], ensure=True)
+            for n in cams:
+                assert torch.equal(got[n], want[n]), f"E={E} step {k} {n}"
+        assert sets.overflow_frames() == one.overflow_frames() == 0

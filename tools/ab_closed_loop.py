@@ -52,6 +52,10 @@ def main():
         loop = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, batched=batched, num_envs=E,
                                      block_cache=os.environ.get("CL_NO_CACHE", "") != "1",
                                      tile_reuse=os.environ.get("CL_NO_TILE_REUSE", "") != "1")
+        if os.environ.get("CL_SET_STREAMS"):  # (A/B: sets of one image size in flight at once when a step has more than 8 frames)
+            loop.multi.max_set_streams = int(os.environ["CL_SET_STREAMS"])
+        if os.environ.get("CL_SET_FRAMES"):
+            loop.multi.set_frames = int(os.environ["CL_SET_FRAMES"])
         loop.reset(*pinned[0])
         if os.environ.get("CL_EAGER", "") != "1":  # (A/B: every step's launches issued one by one instead of a graph replay)
             loop.capture()
