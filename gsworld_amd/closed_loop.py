@@ -163,13 +163,13 @@ class ClosedLoopRenderer:
         self.multi = MultiCameraRenderer(lanes, dev, forward_only=True, want_radii=False, want_float=not no_float, growth=growth,
                                          min_capacity=(2 * int(self.xyz.shape[0]) if min_capacity is None else int(min_capacity)),
                                          bound_capacity=bool(bound_capacity), overflow_mirror=True, batched=batched)
-        # Eight frames and more per step (four environments with two cameras) go as at least TWO sets of launches on streams of
+        # Six frames and more per step (three environments with two cameras) go as at least TWO sets of launches on streams of
         # their own (MultiCameraRenderer: up to three in flight), at most eight frames each: the latency-bound stages of one
         # set are filled by the other's.  Same box, configs[2]'s surrogate / the arm-shaped one, frames/s enqueued ahead:
         # 4 environments 14.0 -> 14.6 k / 17.8 -> 18.0 k (policy in the loop 13.5 -> 14.1 / 16.8 -> 17.5), 8 environments
         # 14.2 -> 16.5 k / 17.9 -> 21.4 k, 16 environments 14.1 -> 16.9 k / 17.3 -> 22.0 k.  Fewer frames stay one set (two
         # environments as 2 + 2: 11.6 -> 11.4 k).
-        if lanes >= 8:
+        if lanes >= 6:  # (three environments as 3 + 3 frames: 12.95 -> 13.2 k, policy in the loop 12.4 -> 12.8 k)
             self.multi.set_frames = min(8, (lanes + 1) // 2)
         self.recovered_steps = 0      # steps re-rendered because a lane had overflowed (see step())
         self.late_overflow_frames = 0  # overflowed frames that were only noticed after their step had been returned

@@ -725,7 +725,7 @@ def test_arm_shaped_scene_keeps_blocks_and_tiles_and_gives_the_frames_of_a_loop_
 
 
 def test_steps_of_eight_frames_and_more_go_as_sets_on_streams_of_their_own(cuda_device):
-    """Four environments and more (eight frames per step) are rendered as at least two sets of launches in flight at once
+    """Three environments and more (six frames per step) are rendered as at least two sets of launches in flight at once
     (ClosedLoopRenderer -> MultiCameraRenderer.set_frames / max_set_streams).  Same frames as one set after the other on one
     stream, eager and under graph replay; five environments = two sets of five."""
     dev = cuda_device
@@ -734,7 +734,7 @@ def test_steps_of_eight_frames_and_more_go_as_sets_on_streams_of_their_own(cuda_
     parts, actors = cl.xarm6_rollout_parts(rollout)
     cams = {"right_cam": scenes.sensor_camera("xarm6_align"),
             "wrist_cam": look_at_view([0.55, 0.35, 0.25], [0.35, 0.05, 0.05], [0, 0, 1], 0.9715089, 0.7551448, 640, 480)}
-    for E, per_set in ((4, 4), (5, 5), (9, 8)):
+    for E, per_set in ((3, 3), (4, 4), (5, 5), (9, 8)):
         poses = list(cl.rollout_poses(rollout, len(actors), steps=6, seed=10, num_envs=E))
         sets = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
         one = cl.ClosedLoopRenderer(raw, parts, cams, scaled_parts=actors, device=dev, num_envs=E)
