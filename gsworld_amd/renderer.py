@@ -304,7 +304,11 @@ class MultiCameraRenderer:
         caller's stream whose grids span the frames (include/gsr.h; up to 8 frames per set) -- instead of one complete
         pipeline per frame on its own HIP stream.  Same kernels, disjoint state: the frames are bit-identical either
         way.  Frames that cannot share launches (the exact-mode frame that sizes a lane, A/B selectors) run one after
-        the other on the caller's stream.  ``False``: the stream-per-frame path of rounds 2-4."""
+        the other on the caller's stream.  ``False``: the stream-per-frame path of rounds 2-4.
+        Attributes a caller may set before the first :meth:`render`: ``set_frames`` (frames per set of launches, default and
+        maximum 8 = ``GSR_MAX_FRAMES_PER_LAUNCH``) and ``max_set_streams`` (sets of one image size in flight at once, default
+        4): a step with more frames than ``set_frames`` goes as several sets on streams of their own, forked from and joined
+        to the caller's stream (capturable); ``max_set_streams = 1`` runs them one after the other in one call."""
         self.device = torch.device(device)
         self.batched = bool(batched)
         self.lanes = [FrameRenderer(self.device, **renderer_kw) for _ in range(num_cameras)]
