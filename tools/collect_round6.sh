@@ -11,7 +11,7 @@ for f in bench_default.json bench_driver_flags.json bench_two_ranks_gloo.json; d
 done
 cp $S/kernel_stats_*.csv $D/ 2>/dev/null || true
 cp $S/pmc/*.txt $D/pmc/ 2>/dev/null || true
-for f in config5_gradient_bound.txt exp_parity_base.json exp_parity_expacc.json pmc_train_step.json pmc_closed_loop.json headline_variants.txt closed_loop_same_box.txt closed_loop_step_sequence.txt closed_loop_waited.txt rccl_world1.json tile_reuse_tiles_left.txt fuzz_and_soak.txt host_step_profile.txt train_step_sequence.txt; do [ -f $S/$f ] && cp $S/$f $D/ || true; done
+for f in config5_gradient_bound.txt exp_parity_base.json exp_parity_expacc.json pmc_train_step.json pmc_closed_loop.json headline_variants.txt closed_loop_same_box.txt closed_loop_step_sequence.txt closed_loop_waited.txt rccl_world1.json tile_reuse_tiles_left.txt host_step_profile.txt train_step_sequence.txt; do [ -f $S/$f ] && cp $S/$f $D/ || true; done
 if [ -f $S/pmc_render.json ]; then
   want=$(sha256sum gsworld_amd/csrc/render.hip | cut -c1-16)
   have=$(python -c "import json; print(json.load(open('$S/pmc_render.json'))['render_hip_sha16'])")
